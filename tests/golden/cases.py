@@ -1,0 +1,88 @@
+"""Golden-vector case list for the lz4-mt hot path.
+
+Inputs are *defined* here by deterministic generators, so only the expected outputs of the
+reference need to be stored (manifest.json + streams/*.lz4mt, written by gen_golden.py from the
+reference's own lib/lz4-mt_*.c built under oracle/_ref).
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import helpers as H  # noqa: E402
+
+_tools = None
+
+
+def tools():
+    global _tools
+    if _tools is None:
+        so = os.path.join(H.ROOT, "zstdmt_amd", "lib", "libzmt_tools.so")
+        if not os.path.exists(so):
+            import subprocess
+            os.makedirs(os.path.dirname(so), exist_ok=True)
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-pthread",
+                                   os.path.join(H.ROOT, "zstdmt_amd/csrc/tools/gen_text.c"),
+                                   "-o", so, "-lm"])
+        t = C.CDLL(so)
+        t.zmt_gen_text.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int]
+        t.zmt_gen_random.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+        _tools = t
+    return _tools
+
+
+def text(n, seed=20260926, offset=0):
+    buf = C.create_string_buffer(max(n, 1))
+    assert tools().zmt_gen_text(buf, n, seed, offset, 4) == 0
+    return buf.raw[:n]
+
+
+def rnd(n, seed=1):
+    buf = C.create_string_buffer(max(n, 1))
+    tools().zmt_gen_random(buf, n, seed)
+    return buf.raw[:n]
+
+
+def rep(unit: bytes, n: int) -> bytes:
+    return (unit * (n // len(unit) + 1))[:n]
+
+
+K = 1024
+CH = 128 * K
+
+# name -> (chunk size, input thunk)
+CASES = {
+    "empty":              (CH, lambda: b""),
+    "hello_5":            (CH, lambda: b"hello"),
+    "abc_12":             (CH, lambda: b"abcabcabcabc"),
+    "abc_13":             (CH, lambda: b"abcabcabcabca"),
+    "text_100":           (CH, lambda: text(100)),
+    "text_64k":           (CH, lambda: text(64 * K)),
+    "text_64k_p1":        (CH, lambda: text(64 * K + 1)),
+    "text_64k_p20":       (CH, lambda: text(64 * K + 20)),
+    "text_128k":          (CH, lambda: text(CH)),
+    "text_3x128k_p100":   (CH, lambda: text(3 * CH + 100)),
+    "lcg_128k":           (CH, lambda: H.lcg(CH, 1)),
+    "zeros_128k":         (CH, lambda: bytes(CH)),
+    "zeros_70000":        (CH, lambda: bytes(70000)),
+    "zeros_262149":       (CH, lambda: bytes(262149)),
+    "A64k_B64k":          (CH, lambda: b"A" * 65536 + b"B" * 65536),
+    "period_300":         (CH, lambda: rep(H.lcg(300, 1), CH)),
+    "period_65535":       (CH, lambda: rep(H.lcg(65535, 1), CH)),
+    "period_65536":       (CH, lambda: rep(H.lcg(65536, 1), CH)),
+    "mixed_rnd_zero_rnd": (CH, lambda: H.lcg(40000, 1) + bytes(60000) + H.lcg(31072, 7)),
+    "mixed_text_rnd":     (CH, lambda: text(50000) + rnd(30000, 3) + text(51072, offset=65536)),
+    "text_1m_chunk1m":    (1024 * K, lambda: text(1024 * K)),
+    "text_300k_chunk64k": (64 * K, lambda: text(300 * K)),
+    "text_200k_chunk100000": (100000, lambda: text(200 * K)),
+    "rnd_512k_chunk256k": (256 * K, lambda: rnd(512 * K, 9)),
+    "lowentropy_128k":    (CH, lambda: bytes(b & 0x03 | 0x40 for b in rnd(CH, 5))),
+}
+
+# SURVEY.md Appendix C known-answer streams (full hex dumps published there)
+KNOWN_HEX = {
+    "empty": "502a4d18040000000f00000004224d186440a700000000055dcc02",
+    "hello_5": "502a4d18040000002000000004224d186c4005000000000000002c0500008068656c6c6f00000000f97700fb",
+    "abc_12": "502a4d18040000002700000004224d186c400c000000000000003b0c000080616263616263616263616263000000003366e641",
+    "abc_13": "502a4d18040000002800000004224d186c400d00000000000000ce0d0000806162636162636162636162636100000000fabc9f1a",
+}

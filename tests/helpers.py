@@ -1,0 +1,227 @@
+"""Shared test plumbing: ctypes bindings for the oracle (CPU restatement) and, when it has been
+built in this container, the reference's own lz4-mt sources (oracle/_ref/liblz4mt_ref.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/.
+"""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import threading
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "liblz4mt_ref.so")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+_oracle = None
+_ref = None
+
+
+def build_oracle():
+    """(Re)build liboracle.so if missing or stale.  Building the checker is not using it."""
+    src = os.path.join(ORACLE_DIR, "lz4_oracle.c")
+    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        lib = C.CDLL(build_oracle())
+        sz, p8 = C.c_size_t, C.c_char_p
+        lib.zo_xxh32.restype = C.c_uint32
+        lib.zo_xxh32.argtypes = [p8, sz, C.c_uint32]
+        lib.zo_lz4f_bound.restype = sz
+        lib.zo_lz4f_bound.argtypes = [sz]
+        for name in ("zo_lz4f_compress", "zo_lz4f_decompress"):
+            f = getattr(lib, name)
+            f.restype = sz
+            f.argtypes = [p8, sz, C.c_void_p, sz]
+        lib.zo_lz4mt_compress_bound.restype = sz
+        lib.zo_lz4mt_compress_bound.argtypes = [sz, sz]
+        lib.zo_lz4mt_compress.restype = sz
+        lib.zo_lz4mt_compress.argtypes = [C.c_void_p, sz, sz, C.c_void_p, sz]
+        lib.zo_lz4mt_decompress.restype = sz
+        lib.zo_lz4mt_decompress.argtypes = [C.c_void_p, sz, C.c_void_p, sz]
+        lib.zo_lz4mt_compress_mt.restype = sz
+        lib.zo_lz4mt_compress_mt.argtypes = [C.c_void_p, sz, sz, C.c_void_p, sz, C.c_int]
+        lib.zo_lz4mt_decompress_mt.restype = sz
+        lib.zo_lz4mt_decompress_mt.argtypes = [C.c_void_p, sz, C.c_void_p, sz, C.c_int]
+        _oracle = lib
+    return _oracle
+
+
+SIZE_ERR = C.c_size_t(-1).value
+
+
+def oracle_compress(data: bytes, chunk: int) -> bytes:
+    lib = oracle()
+    cap = lib.zo_lz4mt_compress_bound(len(data), chunk)
+    out = C.create_string_buffer(cap)
+    n = lib.zo_lz4mt_compress(data, len(data), chunk, out, cap)
+    assert n != SIZE_ERR
+    return out.raw[:n]
+
+
+def oracle_decompress(stream: bytes, cap: int):
+    """Returns bytes, or None on malformed input."""
+    lib = oracle()
+    out = C.create_string_buffer(max(cap, 1))
+    n = lib.zo_lz4mt_decompress(stream, len(stream), out, cap)
+    if n in (SIZE_ERR, SIZE_ERR - 1):
+        return None
+    return out.raw[:n]
+
+
+def oracle_frame_compress(data: bytes) -> bytes:
+    lib = oracle()
+    cap = lib.zo_lz4f_bound(len(data))
+    out = C.create_string_buffer(cap)
+    n = lib.zo_lz4f_compress(data, len(data), out, cap)
+    assert n != SIZE_ERR
+    return out.raw[:n]
+
+
+# ----------------------------------------------------------------------------------------------
+# The reference itself (only where oracle/_ref has been built: this container, or shipped .so)
+# ----------------------------------------------------------------------------------------------
+class RefBuffer(C.Structure):  # LZ4MT_Buffer, /root/reference/lib/lz4-mt.h:67-71
+    _fields_ = [("buf", C.c_void_p), ("size", C.c_size_t), ("allocated", C.c_size_t)]
+
+
+RD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(RefBuffer))
+
+
+class RefRdWr(C.Structure):  # LZ4MT_RdWr_t, /root/reference/lib/lz4-mt.h:84-89
+    _fields_ = [("fn_read", RD_FN), ("arg_read", C.c_void_p),
+                ("fn_write", RD_FN), ("arg_write", C.c_void_p)]
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def bind_lz4mt(lib):
+    """Attach prototypes for the LZ4MT_* ABI (shared by the reference .so and our own library)."""
+    vp, sz = C.c_void_p, C.c_size_t
+    lib.LZ4MT_createCCtx.restype = vp
+    lib.LZ4MT_createCCtx.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.LZ4MT_compressCCtx.restype = sz
+    lib.LZ4MT_compressCCtx.argtypes = [vp, C.POINTER(RefRdWr)]
+    lib.LZ4MT_freeCCtx.argtypes = [vp]
+    lib.LZ4MT_freeCCtx.restype = None
+    lib.LZ4MT_createDCtx.restype = vp
+    lib.LZ4MT_createDCtx.argtypes = [C.c_int, C.c_int]
+    lib.LZ4MT_decompressDCtx.restype = sz
+    lib.LZ4MT_decompressDCtx.argtypes = [vp, C.POINTER(RefRdWr)]
+    lib.LZ4MT_freeDCtx.argtypes = [vp]
+    lib.LZ4MT_freeDCtx.restype = None
+    for n in ("GetFramesCCtx", "GetInsizeCCtx", "GetOutsizeCCtx",
+              "GetFramesDCtx", "GetInsizeDCtx", "GetOutsizeDCtx"):
+        f = getattr(lib, "LZ4MT_" + n)
+        f.restype = sz
+        f.argtypes = [vp]
+    lib.LZ4MT_isError.restype = C.c_uint
+    lib.LZ4MT_isError.argtypes = [sz]
+    lib.LZ4MT_getErrorString.restype = C.c_char_p
+    lib.LZ4MT_getErrorString.argtypes = [sz]
+    return lib
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        _ref = bind_lz4mt(C.CDLL(REF_SO))
+    return _ref
+
+
+class MemIO:
+    """In-memory fn_read / fn_write pair obeying the callback protocol of lib/README.md:19-24.
+    Records every request so tests can assert the read/write pattern."""
+
+    def __init__(self, data: bytes, fail_read_at=None, fail_write_at=None, read_rv=-1, write_rv=-1):
+        self.data = data
+        self.pos = 0
+        self.out = []
+        self.reads = []
+        self.writes = []
+        self.lock = threading.Lock()
+        self.fail_read_at = fail_read_at
+        self.fail_write_at = fail_write_at
+        self.read_rv = read_rv
+        self.write_rv = write_rv
+        self._rd = RD_FN(self._read)
+        self._wr = RD_FN(self._write)
+        self.rdwr = RefRdWr(self._rd, None, self._wr, None)
+
+    def _read(self, _arg, bufp):
+        b = bufp.contents
+        with self.lock:
+            if self.fail_read_at is not None and len(self.reads) >= self.fail_read_at:
+                return self.read_rv
+            want = b.size
+            n = min(want, len(self.data) - self.pos)
+            if n:
+                C.memmove(b.buf, self.data[self.pos:self.pos + n], n)
+            self.pos += n
+            b.size = n
+            self.reads.append((want, n))
+        return 0
+
+    def _write(self, _arg, bufp):
+        b = bufp.contents
+        with self.lock:
+            if self.fail_write_at is not None and len(self.writes) >= self.fail_write_at:
+                return self.write_rv
+            self.out.append(C.string_at(b.buf, b.size))
+            self.writes.append(b.size)
+        return 0
+
+    def result(self) -> bytes:
+        return b"".join(self.out)
+
+
+def lz4mt_compress_via(lib, data: bytes, chunk: int, threads: int = 1, level: int = 1):
+    """Run <lib>.LZ4MT_compressCCtx over in-memory callbacks; returns (rv, stream, io, stats)."""
+    io = MemIO(data)
+    ctx = lib.LZ4MT_createCCtx(threads, level, chunk)
+    assert ctx
+    rv = lib.LZ4MT_compressCCtx(ctx, C.byref(io.rdwr))
+    stats = (lib.LZ4MT_GetFramesCCtx(ctx), lib.LZ4MT_GetInsizeCCtx(ctx),
+             lib.LZ4MT_GetOutsizeCCtx(ctx))
+    lib.LZ4MT_freeCCtx(ctx)
+    return rv, io.result(), io, stats
+
+
+def lz4mt_decompress_via(lib, stream: bytes, threads: int = 1, inputsize: int = 0):
+    io = MemIO(stream)
+    ctx = lib.LZ4MT_createDCtx(threads, inputsize)
+    assert ctx
+    rv = lib.LZ4MT_decompressDCtx(ctx, C.byref(io.rdwr))
+    stats = (lib.LZ4MT_GetFramesDCtx(ctx), lib.LZ4MT_GetInsizeDCtx(ctx),
+             lib.LZ4MT_GetOutsizeDCtx(ctx))
+    lib.LZ4MT_freeDCtx(ctx)
+    return rv, io.result(), io, stats
+
+
+# ----------------------------------------------------------------------------------------------
+# Deterministic input generators
+# ----------------------------------------------------------------------------------------------
+def lcg(n: int, seed: int) -> bytes:
+    """x = x*6364136223846793005 + 1442695040888963407 mod 2^64; byte = x >> 56."""
+    import numpy as np
+    out = np.empty(n, dtype=np.uint8)
+    x = seed & 0xFFFFFFFFFFFFFFFF
+    a, c, m = 6364136223846793005, 1442695040888963407, (1 << 64) - 1
+    for i in range(n):
+        x = (x * a + c) & m
+        out[i] = x >> 56
+    return out.tobytes()
+
+
+def sha256(b: bytes) -> str:
+    return hashlib.sha256(b).hexdigest()

@@ -1,0 +1,116 @@
+"""Pin the oracle (CPU restatement) to the reference: committed golden vectors produced by the
+reference's own lz4-mt sources (tests/golden/gen_golden.py) and SURVEY.md Appendix C answers."""
+import json
+import os
+
+import pytest
+
+import helpers as H
+from cases import CASES, KNOWN_HEX
+
+with open(os.path.join(H.GOLDEN_DIR, "manifest.json")) as _f:
+    MAN = json.load(_f)["cases"]
+
+
+def golden_stream(name):
+    e = MAN[name]
+    if "out_hex" in e:
+        return bytes.fromhex(e["out_hex"])
+    if "out_file" in e:
+        with open(os.path.join(H.GOLDEN_DIR, e["out_file"]), "rb") as f:
+            return f.read()
+    return None
+
+
+def test_case_list_matches_manifest():
+    assert set(CASES) == set(MAN)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_compress_matches_reference(name):
+    chunk, thunk = CASES[name]
+    data = thunk()
+    e = MAN[name]
+    assert len(data) == e["in_len"] and H.sha256(data) == e["in_sha256"], "input generator drifted"
+    s = H.oracle_compress(data, chunk)
+    assert len(s) == e["out_len"]
+    assert H.sha256(s) == e["out_sha256"]
+    g = golden_stream(name)
+    if g is not None:
+        assert s == g
+    # stats the reference reported (SURVEY 8b "Stats")
+    assert e["outsize"] == len(s) and e["insize"] == len(data)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_decompress_golden(name):
+    chunk, thunk = CASES[name]
+    data = thunk()
+    g = golden_stream(name)
+    if g is None:
+        g = H.oracle_compress(data, chunk)
+        assert H.sha256(g) == MAN[name]["out_sha256"]
+    back = H.oracle_decompress(g, max(len(data), 65536))
+    assert back == data
+
+
+@pytest.mark.parametrize("name", sorted(KNOWN_HEX))
+def test_survey_known_answers(name):
+    chunk, thunk = CASES[name]
+    assert H.oracle_compress(thunk(), chunk).hex() == KNOWN_HEX[name]
+
+
+def test_frame_bound():
+    lib = H.oracle()
+    assert lib.zo_lz4f_bound(131072) == 131107      # SURVEY section 8 config arithmetic
+    assert lib.zo_lz4f_bound(4 << 20) == 4194587
+    assert lib.zo_lz4f_bound(0) == 27
+
+
+def test_xxh32_vectors():
+    lib = H.oracle()
+    # published XXH32 test vectors (xxHash spec) + cross-check with the python xxhash module
+    assert lib.zo_xxh32(b"", 0, 0) == 0x02CC5D05
+    import xxhash
+    for n in (1, 3, 4, 15, 16, 17, 31, 32, 33, 100, 4096, 65537):
+        d = H.lcg(n, n)
+        assert lib.zo_xxh32(d, n, 0) == xxhash.xxh32(d, seed=0).intdigest()
+        assert lib.zo_xxh32(d, n, 77) == xxhash.xxh32(d, seed=77).intdigest()
+
+
+@pytest.mark.parametrize("mutate", ["magic", "hc", "blocksize", "checksum", "truncate", "trailing",
+                                    "skipmagic", "skiplen", "offset0"])
+def test_oracle_rejects_corrupt(mutate):
+    data = CASES["text_128k"][1]()
+    s = bytearray(H.oracle_compress(data, 128 * 1024))
+    if mutate == "magic":
+        s[12] ^= 1
+    elif mutate == "hc":
+        s[12 + 14] ^= 0x10
+    elif mutate == "blocksize":
+        s[12 + 15 + 2] ^= 0x40
+    elif mutate == "checksum":
+        s[-1] ^= 0x80
+    elif mutate == "truncate":
+        s = s[:-5]
+    elif mutate == "trailing":
+        s[8] += 1
+        s += b"\0"
+    elif mutate == "skipmagic":
+        s[0] ^= 1
+    elif mutate == "skiplen":
+        s[4] = 8
+    elif mutate == "offset0":
+        # first sequence's offset -> 0 (invalid): token at block start
+        p = 12 + 15 + 4
+        lit = s[p] >> 4
+        q = p + 1
+        if lit == 15:
+            while s[q] == 255:
+                lit += 255
+                q += 1
+            lit += s[q]
+            q += 1
+        s[q + lit] = 0
+        s[q + lit + 1] = 0
+    assert H.oracle_decompress(bytes(s), len(data)) is None

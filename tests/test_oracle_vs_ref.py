@@ -1,0 +1,80 @@
+"""Live cross-check of the oracle against the reference's own lz4-mt code (oracle/_ref), where
+that has been built (this container; the .so also travels to the GPU box).  Skipped otherwise --
+the committed golden vectors (test_oracle_golden.py) are the portable pin."""
+import random
+
+import pytest
+
+import helpers as H
+from cases import rnd, text
+
+pytestmark = pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built")
+
+
+def _mix(rng, n):
+    """Borderline-compressible soup: exercises the stored-vs-compressed bail-out points."""
+    out = bytearray()
+    while len(out) < n:
+        k = rng.choice([0, 1, 2, 3, 4])
+        m = rng.randrange(1, 5000)
+        if k == 0:
+            out += rnd(m, rng.randrange(1 << 30))
+        elif k == 1:
+            out += bytes([rng.randrange(256)]) * m
+        elif k == 2:
+            out += text(m, seed=rng.randrange(1 << 30))
+        elif k == 3:
+            unit = rnd(rng.randrange(1, 40), rng.randrange(1 << 30))
+            out += (unit * (m // len(unit) + 1))[:m]
+        else:
+            back = rng.randrange(1, len(out) + 1) if out else 0
+            if back:
+                start = len(out) - back
+                out += out[start:start + m]
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_compress_bit_exact(seed):
+    rng = random.Random(seed)
+    n = rng.choice([0, 1, 11, 12, 13, 14, 65535, 65536, 65537, 65548, 131071, 131072, 200000,
+                    rng.randrange(1, 400000)])
+    chunk = rng.choice([65536, 131072, 131072, 100000, 262144, 1 << 20])
+    data = _mix(rng, n)
+    rv, s_ref, _, _ = H.lz4mt_compress_via(H.ref(), data, chunk, threads=rng.choice([1, 3]))
+    assert rv == 0
+    assert H.oracle_compress(data, chunk) == s_ref
+    rv, back, _, _ = H.lz4mt_decompress_via(H.ref(), s_ref, threads=2)
+    assert rv == 0 and back == data
+    assert H.oracle_decompress(s_ref, max(n, 65536)) == data
+
+
+@pytest.mark.parametrize("frac", [0.93, 0.97, 0.99, 0.995, 1.0])
+def test_borderline_blocks(frac):
+    """Blocks whose LZ4 size lands around len-1: the capacity checks decide stored vs compressed."""
+    rng = random.Random(int(frac * 1000))
+    n = 131072
+    k = int(n * frac)
+    data = bytearray(rnd(n, 42))
+    # sprinkle short repeats so the encoder saves a few bytes here and there
+    for _ in range((n - k) // 6):
+        p = rng.randrange(100, n - 16)
+        q = rng.randrange(0, p - 8)
+        data[p:p + 8] = data[q:q + 8]
+    data = bytes(data)
+    rv, s_ref, _, _ = H.lz4mt_compress_via(H.ref(), data, 131072, threads=1)
+    assert rv == 0 and H.oracle_compress(data, 131072) == s_ref
+
+
+def test_mt_variants_agree():
+    data = text(1 << 20) + rnd(100000, 2) + bytes(300000)
+    s = H.oracle_compress(data, 131072)
+    import ctypes as C
+    lib = H.oracle()
+    cap = lib.zo_lz4mt_compress_bound(len(data), 131072)
+    out = C.create_string_buffer(cap)
+    n = lib.zo_lz4mt_compress_mt(data, len(data), 131072, out, cap, 4)
+    assert out.raw[:n] == s
+    back = C.create_string_buffer(len(data))
+    m = lib.zo_lz4mt_decompress_mt(s, len(s), back, len(data), 4)
+    assert m == len(data) and back.raw == data
