@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""bench.py -- lz4-mt hot path on MI355X: compress + decompress of the synthetic enwik-style buffer.
+
+Workload (BASELINE.json configs[1]): lz4-mt level 1, 8 GiB enwik-style synthetic text per GPU,
+128 KiB chunks (65 536 chunks -> 65 536 records).  One "step" = one full pass of the hot path over
+that buffer, inputs already resident in HBM:
+
+    compress_batch (XXH32 of every chunk + bit-exact LZ4 frame encode into per-chunk slots)
+    -> compact (scan of record sizes + ordered pack into the MT stream)
+    -> probe_sizes (content-size fields + scan)
+    -> decompress_batch (frame decode + XXH32 content-checksum verification)
+
+value = uncompressed MB (1e6 B) round-tripped per second, whole job (all ranks).  Per-direction
+rates, per-kernel HIP-event times and the HBM roofline of the kernels are carried alongside.
+
+Multi-GPU: chunks are independent, so each rank takes its own 8 GiB shard (weak scaling); the only
+exchange is the all-gather of per-rank stream sizes that gives every rank its offset in the final
+stream (frame reassembly); `--gather` additionally times the RCCL gather of the compressed
+segments to rank 0 (reported separately).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK = 8.0e12        # B/s, MI355X spec (MI355X_MICROARCH.md)
+HBM_COPY = 6.29e12       # measured float4 copy ceiling, same guide
+SEED = 20260926
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gib", type=float, default=8.0, help="uncompressed GiB per GPU")
+    ap.add_argument("--chunk", type=int, default=131072)
+    ap.add_argument("--dec-variant", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-mib", type=int, default=2048, help="cpu_baseline sample size")
+    ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of segments")
+    ap.add_argument("--verify", action="store_true", help="download and compare the round trip")
+    return ap.parse_args()
+
+
+def tools():
+    t = C.CDLL(os.path.join(ROOT, "zstdmt_amd", "lib", "libzmt_tools.so"))
+    t.zmt_gen_text.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int]
+    return t
+
+
+def cpu_baseline(args):
+    """oracle/_ref (reference sources + liblz4) if present, else the oracle port; bounded sample."""
+    exe = os.path.join(ROOT, "oracle", "cpu_bench")
+    ref = os.path.join(ROOT, "oracle", "_ref", "liblz4mt_ref.so")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "cpu_bench"],
+                              stdout=subprocess.DEVNULL)
+    cores = os.cpu_count() or 1
+    threads = min(cores, 128)   # LZ4MT_THREAD_MAX, lib/lz4-mt.h:28
+    kind = "reference" if os.path.exists(ref) else "port"
+    n = args.cpu_mib << 20
+    try:
+        out = subprocess.check_output([exe, kind, ref if kind == "reference" else "-", str(n),
+                                       str(args.chunk), str(threads), str(SEED)], timeout=600)
+        r = json.loads(out)
+    except Exception as e:  # report, never hide
+        return {"value": None, "unit": "MB/s", "cores": threads, "kind": kind, "error": repr(e)}
+    return {"value": r["roundtrip_MBps"], "unit": "MB/s", "cores": threads, "kind": kind,
+            "compress_MBps": r["compress_MBps"], "decompress_MBps": r["decompress_MBps"],
+            "host_cpus": cores,
+            "sample": f"{args.cpu_mib} MiB of the same synthetic text, {args.chunk}-byte chunks, "
+                      f"LZ4MT_compressCCtx+LZ4MT_decompressDCtx with memcpy callbacks, T={threads}"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        dist = dist_
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import zstdmt_amd as z
+    eng = z.Engine(local)
+    L, h = eng.L, eng.h
+    eng.set_variant("lz4_dec", args.dec_variant)
+    eng.set_variant("profile", 1)
+
+    n = int(args.gib * (1 << 30)) // args.chunk * args.chunk
+    chunk = args.chunk
+    nrec = eng.record_count(n, chunk)
+    stride = eng.slot_stride(chunk)
+
+    # ---- synthetic input, generated on the host in 256 MiB pieces, uploaded once ----
+    d_in = eng.alloc(n + 64)
+    piece = 256 << 20
+    hbuf = np.empty(min(piece, n), np.uint8)
+    T = tools()
+    gen_threads = max(1, (os.cpu_count() or 1) // max(1, world))
+    t0 = time.time()
+    for off in range(0, n, piece):
+        m = min(piece, n - off)
+        # each rank generates a different part of the (conceptually world*n byte) corpus
+        T.zmt_gen_text(hbuf.ctypes.data, m, SEED, rank * n + off, gen_threads)
+        eng._ck(L.gpumt_memcpy_h2d(h, d_in.ptr + off, hbuf.ctypes.data, m, 0), "h2d")
+        eng.sync(0)
+    gen_s = time.time() - t0
+
+    d_slots = eng.alloc(nrec * stride)
+    d_rl = eng.alloc(nrec * 4)
+    d_ro = eng.alloc((nrec + 1) * 8)
+    d_stream = eng.alloc(nrec * stride)       # worst case
+    d_ol = eng.alloc(nrec * 4)
+    d_oo = eng.alloc((nrec + 1) * 8)
+    d_st = eng.alloc(nrec * 4)
+    d_out = eng.alloc(n + 64)
+
+    def step():
+        eng.timer_start(1)
+        eng.lz4_compress(d_in, n, chunk, d_slots, stride, d_rl)
+        eng.timer_stop(1)
+        eng.timer_start(2)
+        eng.lz4_compact(d_slots, stride, d_rl, nrec, d_stream, d_ro)
+        eng.timer_stop(2)
+        eng.timer_start(3)
+        eng.lz4_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo)
+        eng.lz4_decompress(d_stream, d_ro, d_rl, nrec, d_out, d_oo, d_ol, d_st)
+        eng.timer_stop(3)
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            dist.barrier()
+        eng.sync()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        eng.sync(0)
+        # slots 1-3: API-level legs; 8..13: individual kernels (profile mode)
+        for name, slot in (("compress", 1), ("compact", 2), ("decompress", 3),
+                           ("k_xxh32_c", 8), ("k_lz4_enc", 9), ("k_scan_compact", 10),
+                           ("k_lz4_dec", 11), ("k_xxh32_d", 12)):
+            acc[name] = acc.get(name, 0.0) + eng.timer_ms(slot)
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tw = torch.tensor([wall], device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+
+    ms = {k: v / args.steps for k, v in acc.items()}
+    total_c = int(eng.download(d_ro, 8, np.uint64, offset=nrec * 8)[0])
+    status = eng.download(d_st, nrec * 4, np.uint32)
+    bad = int((status != 0).sum())
+
+    # ---- frame reassembly across ranks: sizes all-gather (-> offsets), optional bulk gather ----
+    gather_ms = None
+    seg_off = 0
+    if dist is not None:
+        import torch
+        sizes = torch.zeros(world, dtype=torch.int64, device="cuda")
+        mine = torch.tensor([total_c], dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(sizes, mine)
+        seg_off = int(sizes[:rank].sum().item())
+        if args.gather:
+            gather_ms = rccl_gather(eng, dist, d_stream, sizes.tolist(), rank, world)
+
+    ok = True
+    if args.verify:
+        a = eng.download(d_in, n)
+        b = eng.download(d_out, n)
+        ok = bool((a == b).all())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    U = float(n)
+    Cb = float(total_c)
+    alg = U + Cb                              # algorithmic bytes either direction
+    t_c = (ms["compress"] + ms["compact"]) * 1e-3
+    t_d = ms["decompress"] * 1e-3
+    kern = {}
+    for k, byt in (("k_xxh32_c", U), ("k_lz4_enc", U + Cb), ("k_scan_compact", 2 * Cb),
+                   ("k_lz4_dec", U + Cb), ("k_xxh32_d", U)):
+        t = ms[k] * 1e-3
+        kern[k] = {"ms": round(ms[k], 4), "alg_bytes": byt,
+                   "GBps": round(byt / t / 1e9, 2) if t > 0 else None}
+    dom = max(("k_lz4_enc", "k_lz4_dec", "k_xxh32_c", "k_xxh32_d", "k_scan_compact"),
+              key=lambda k: ms[k])
+
+    def roof(k):
+        t = ms[k] * 1e-3
+        a = kern[k]["alg_bytes"] / t / 1e9
+        return {"kernel": {"k_lz4_enc": "zmt_lz4_enc_kernel", "k_lz4_dec": "zmt_lz4_dec",
+                           "k_xxh32_c": "zmt_xxh32_kernel", "k_xxh32_d": "zmt_xxh32_kernel",
+                           "k_scan_compact": "zmt_compact_kernel"}[k],
+                "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(a * 1e9 / HBM_PEAK, 5), "frac_of_copy_ceiling": round(a * 1e9 / HBM_COPY, 5),
+                "alg_bytes_per_launch": kern[k]["alg_bytes"], "avg_launch_ms": round(ms[k], 4),
+                "traffic": None}
+
+    step_s = wall / args.steps
+    res = {
+        "metric": "MB/s compress+decompress, 8 GiB synthetic, lz4-mt; % HBM roofline",
+        "value": round(world * U / 1e6 / step_s, 1),
+        "unit": "MB/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(step_s * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"lz4-mt -1, {args.gib:g} GiB enwik-style synthetic per GPU, "
+                               f"{chunk // 1024} KiB chunks, device-resident compress+decompress",
+                   "chunk": chunk, "records_per_gpu": nrec, "level": 1,
+                   "ratio": round(U / Cb, 4), "dec_variant": args.dec_variant,
+                   "parallelism": f"chunk-sharded x{world}"},
+        "compress_MBps": round(world * U / 1e6 / t_c, 1),
+        "decompress_MBps": round(world * U / 1e6 / t_d, 1),
+        "roofline": roof(dom),
+        "roofline_decompress": roof("k_lz4_dec"),
+        "roofline_decompress_path": {
+            "what": "decode + XXH32 verify kernels together", "achieved": round(alg / t_d / 1e9, 2),
+            "unit": "GB/s", "frac": round(alg / t_d / HBM_PEAK, 5)},
+        "kernels": kern,
+        "decode_errors": bad, "roundtrip_verified": ok if args.verify else None,
+        "gen_s": round(gen_s, 2), "device": eng.name,
+        "segment_offset_rank0": seg_off, "gather_ms": gather_ms,
+    }
+    if not args.no_cpu:
+        res["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def rccl_gather(eng, dist, d_stream, sizes, rank, world):
+    """gatherv of the per-rank compressed segments to rank 0 over RCCL (send/recv), timed."""
+    import torch
+    t = torch.cuda
+    total = int(sum(sizes))
+    mine = int(sizes[rank])
+    # torch tensors for RCCL: stage the segment through a torch-owned buffer (D2D copy, untimed)
+    seg = torch.empty(mine, dtype=torch.uint8, device="cuda")
+    eng._ck(eng.L.gpumt_memcpy_d2d(eng.h, seg.data_ptr(), d_stream.ptr, mine, 0), "d2d")
+    eng.sync(0)
+    full = torch.empty(total if rank == 0 else 1, dtype=torch.uint8, device="cuda")
+    dist.barrier()
+    t.synchronize()
+    t0 = time.perf_counter()
+    if rank == 0:
+        off = 0
+        reqs = []
+        for r in range(world):
+            if r == 0:
+                full[:mine].copy_(seg)
+            else:
+                reqs.append(dist.irecv(full[off:off + int(sizes[r])], src=r))
+            off += int(sizes[r])
+        for q in reqs:
+            q.wait()
+    else:
+        dist.send(seg, dst=0)
+    t.synchronize()
+    dist.barrier()
+    return round((time.perf_counter() - t0) * 1e3, 3)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+/*
+ * gpumt.h -- C ABI of the MI355X device engine that replaces zstdmt's per-chunk codec dispatch.
+ *
+ * This is the *internal* boundary the reference does not have (last row):
+ * the host library behind LZ4MT_* (include/lz4-mt.h) hands batches of chunks / records to the GPU
+ * through these calls, exactly where the reference's worker threads call into liblz4:
+ *
+ *   gpumt_lz4_compress_batch   replaces  LZ4F_compressFrame    @ lib/lz4-mt_compress.c:281  (C2)
+ *                                        + header emit          @ lib/lz4-mt_compress.c:294-298 (F5)
+ *   gpumt_lz4_slot_stride      replaces  LZ4F_compressFrameBound@ lib/lz4-mt_compress.c:232,244 (C1)
+ *   gpumt_lz4_compact          replaces  pt_write ordering      @ lib/lz4-mt_compress.c:178-205 (F4)
+ *   gpumt_lz4_decompress_batch replaces  LZ4F_decompress        @ lib/lz4-mt_decompress.c:349-362 (C3)
+ *                                        + size probe           @ lib/lz4-mt_decompress.c:329-334 (F10)
+ *
+ * Plain C types only: opaque handle, device pointers as void*, sizes as integers.  Nothing here
+ * falls back to the CPU: every entry point returns GPUMT_E_NODEVICE/E_HIP when the HIP runtime or
+ * the gfx950 device is unavailable.
+ *
+ * All device pointers must come from gpumt_malloc() of the same handle (or any allocation of the
+ * same HIP device).  "stream" arguments are small integers 0..GPUMT_NSTREAMS-1 naming the
+ * handle's own HIP streams (0 = compute, 1 = H2D, 2 = D2H in the host pipeline).
+ */
+#ifndef GPUMT_H
+#define GPUMT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPUMT_NSTREAMS 4
+
+enum {
+	GPUMT_OK = 0,
+	GPUMT_E_NODEVICE = -1, /* no HIP device / runtime */
+	GPUMT_E_HIP = -2,      /* a HIP call failed; see gpumt_last_error() */
+	GPUMT_E_ARG = -3,
+	GPUMT_E_NOMEM = -4
+};
+
+/* per-record status words written by gpumt_lz4_decompress_batch (0 = frame decoded and verified) */
+enum {
+	GPUMT_ST_OK = 0,
+	GPUMT_ST_BAD_RECORD = 1,   /* skippable header wrong (magic / len != 4 / csize)      -> data_error  */
+	GPUMT_ST_BAD_FRAME = 2,    /* LZ4F magic / version / reserved bits / header checksum -> compression_library */
+	GPUMT_ST_BAD_BLOCK = 3,    /* malformed block (overrun, zero offset, offset too far)  */
+	GPUMT_ST_SIZE_MISMATCH = 4,/* decoded bytes != content-size field                     */
+	GPUMT_ST_BAD_CHECKSUM = 5, /* XXH32 content checksum mismatch                         */
+	GPUMT_ST_TRAILING = 6,     /* record longer than the frame it carries -> frame_decompress */
+	GPUMT_ST_UNSUPPORTED = 7   /* valid LZ4F feature the device path does not decode (block checksum, dictID) */
+};
+
+typedef struct gpumt_ctx gpumt_ctx;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int  gpumt_device_count(void);
+int  gpumt_open(int device, gpumt_ctx **out);
+void gpumt_close(gpumt_ctx *h);
+const char *gpumt_last_error(gpumt_ctx *h);
+const char *gpumt_device_name(gpumt_ctx *h);
+
+/* ---- memory / transfers / sync ------------------------------------------------------------ */
+void *gpumt_malloc(gpumt_ctx *h, size_t bytes);
+void  gpumt_free(gpumt_ctx *h, void *dptr);
+void *gpumt_host_alloc(gpumt_ctx *h, size_t bytes);          /* pinned */
+void  gpumt_host_free(gpumt_ctx *h, void *hptr);
+int   gpumt_memcpy_h2d(gpumt_ctx *h, void *dst, const void *src, size_t n, int stream);
+int   gpumt_memcpy_d2h(gpumt_ctx *h, void *dst, const void *src, size_t n, int stream);
+int   gpumt_memcpy_d2d(gpumt_ctx *h, void *dst, const void *src, size_t n, int stream);
+int   gpumt_memset(gpumt_ctx *h, void *dst, int byte, size_t n, int stream);
+int   gpumt_stream_sync(gpumt_ctx *h, int stream);
+int   gpumt_device_sync(gpumt_ctx *h);
+/* make `waiter` wait (on device) for everything queued so far on `signaler` */
+int   gpumt_stream_wait(gpumt_ctx *h, int waiter, int signaler);
+/* raw hipStream_t of a stream index, for callers that interoperate (e.g. RCCL via torch) */
+void *gpumt_stream_handle(gpumt_ctx *h, int stream);
+
+/* ---- HIP-event timing on the handle's streams (bench.py's roofline leg) -------------------- */
+int   gpumt_timer_start(gpumt_ctx *h, int slot, int stream);   /* slot 0..15 */
+int   gpumt_timer_stop(gpumt_ctx *h, int slot, int stream);
+int   gpumt_timer_ms(gpumt_ctx *h, int slot, float *ms);       /* syncs on the stop event */
+
+/* ---- LZ4 (lz4-mt level 1..2 = LZ4 "fast", acceleration 1) ---------------------------------- */
+
+/* Bytes one record can occupy: 12 + LZ4F_compressFrameBound(chunk), rounded up to 256. */
+size_t gpumt_lz4_slot_stride(size_t chunk);
+
+/* Number of records the reference emits for n input bytes (>= 1: empty input -> one empty frame). */
+size_t gpumt_lz4_record_count(size_t n, size_t chunk);
+
+/*
+ * Compress d_in[0..n) as consecutive chunks of `chunk` bytes (last one ragged).  Record i
+ * (12-byte skippable header + one LZ4 frame, byte-identical to the reference's output for that
+ * chunk) is written at d_slots + i*slot_stride and its length to d_rec_len[i].
+ * Uses internal scratch of 4 bytes per chunk for the XXH32 content checksums.
+ */
+int gpumt_lz4_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk,
+			     void *d_slots, size_t slot_stride, uint32_t *d_rec_len, int stream);
+
+/*
+ * Ordered concatenation: d_rec_off[i] = sum of d_rec_len[0..i), d_rec_off[nrec] = total, and the
+ * records are packed into d_stream at those offsets (the MT stream, ready for fn_write / D2H).
+ */
+int gpumt_lz4_compact(gpumt_ctx *h, const void *d_slots, size_t slot_stride,
+		      const uint32_t *d_rec_len, size_t nrec, void *d_stream,
+		      uint64_t *d_rec_off, int stream);
+
+/*
+ * For records located at d_stream + d_rec_off[i] (length d_rec_len[i], including the 12-byte
+ * skippable header) read each frame's content-size field and produce d_out_len[i] and the
+ * exclusive scan d_out_off[0..nrec] (what pt_decompress does per record at :333-334).
+ */
+int gpumt_lz4_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
+			  const uint32_t *d_rec_len, size_t nrec, uint32_t *d_out_len,
+			  uint64_t *d_out_off, int stream);
+
+/*
+ * Decode nrec records.  Record i's content goes to d_out + d_out_off[i] and must be exactly
+ * d_out_len[i] bytes; header, block structure, content size and XXH32 content checksum are
+ * verified.  d_status[i] receives a GPUMT_ST_* code.
+ */
+int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
+			       const uint32_t *d_rec_len, size_t nrec, void *d_out,
+			       const uint64_t *d_out_off, const uint32_t *d_out_len,
+			       uint32_t *d_status, int stream);
+
+/* XXH32 (seed 0) of n items: item i = d_base + d_off[i], d_len[i] bytes -> d_hash[i]. */
+int gpumt_xxh32_batch(gpumt_ctx *h, const void *d_base, const uint64_t *d_off,
+		      const uint32_t *d_len, size_t n, uint32_t *d_hash, int stream);
+
+/* Kernel-variant selector for A/B measurements (0 = default). Returns previous value. */
+int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,88 @@
+/*
+ * emu_api.cpp -- TEST HARNESS ONLY.  C entry points that run the repo's HIP kernels (compiled as
+ * host C++ with -DZMT_EMU) under the fiber harness, mirroring the gpumt_* batch calls so the same
+ * python parity checks can drive either.  Host pointers stand in for device pointers.
+ */
+#include "emu_runtime.h"
+
+#include <algorithm>
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+extern "C" {
+void zmt_xxh32_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, const u32 *, const u32 *, u32 *);
+void zmt_lz4_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
+void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u32 *);
+void zmt_lz4_dec_batch(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u32 *);
+void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
+void zmt_scan_kernel(const u32 *, u32, u64 *);
+void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
+}
+
+using emu::dim3;
+
+extern "C" {
+
+size_t emu_lz4_slot_stride(size_t chunk)
+{
+	size_t full = chunk / 65536, part = chunk % 65536;
+	size_t b = 12 + 19 + 4 * (full + (part ? 1 : 0)) + chunk + 8;
+	return (b + 255) & ~(size_t)255;
+}
+
+void emu_xxh32_batch(const u8 *base, const u64 *off, const u32 *len, u32 n, u32 *out)
+{
+	emu::launch(dim3{(n * 4 + 255) / 256, 1, 1}, dim3{256, 1, 1},
+		    [=]() { zmt_xxh32_kernel(base, off, len, n, out, nullptr, nullptr, nullptr); });
+}
+
+void emu_lz4_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len)
+{
+	u32 nrec = n ? (u32)((n + chunk - 1) / chunk) : 1;
+	std::vector<u64> off(nrec);
+	std::vector<u32> len(nrec), chk(nrec);
+	for (u32 i = 0; i < nrec; i++) {
+		off[i] = (u64)i * chunk;
+		len[i] = (u32)std::min<u64>(chunk, n - off[i]);
+	}
+	emu_xxh32_batch(in, off.data(), len.data(), nrec, chk.data());
+	const u32 *chkp = chk.data();
+	emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
+		    [=]() { zmt_lz4_enc_kernel(in, n, chunk, nrec, slots, stride, rec_len, chkp); });
+}
+
+void emu_lz4_compact(const u8 *slots, u64 stride, const u32 *rec_len, u32 nrec, u8 *stream, u64 *rec_off)
+{
+	emu::launch(dim3{1, 1, 1}, dim3{1024, 1, 1}, [=]() { zmt_scan_kernel(rec_len, nrec, rec_off); });
+	emu::launch(dim3{nrec, 1, 1}, dim3{256, 1, 1},
+		    [=]() { zmt_compact_kernel(slots, stride, rec_len, rec_off, nrec, stream); });
+}
+
+void emu_lz4_probe_sizes(const u8 *stream, const u64 *rec_off, const u32 *rec_len, u32 nrec,
+			 u32 *out_len, u64 *out_off)
+{
+	emu::launch(dim3{(nrec + 255) / 256, 1, 1}, dim3{256, 1, 1},
+		    [=]() { zmt_probe_kernel(stream, rec_off, rec_len, nrec, out_len); });
+	emu::launch(dim3{1, 1, 1}, dim3{1024, 1, 1}, [=]() { zmt_scan_kernel(out_len, nrec, out_off); });
+}
+
+void emu_lz4_decompress_batch(int variant, const u8 *stream, const u64 *rec_off, const u32 *rec_len,
+			      u32 nrec, u8 *out, const u64 *out_off, const u32 *out_len, u32 *status)
+{
+	std::vector<u32> ce(nrec), cv(nrec);
+	u32 *cep = ce.data(), *cvp = cv.data();
+	if (variant == 1)
+		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
+			zmt_lz4_dec_serial(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp);
+		});
+	else
+		emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{256, 1, 1}, [=]() {
+			zmt_lz4_dec_batch(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp);
+		});
+	emu::launch(dim3{(nrec * 4 + 255) / 256, 1, 1}, dim3{256, 1, 1},
+		    [=]() { zmt_xxh32_kernel(out, out_off, out_len, nrec, nullptr, cep, cvp, status); });
+}
+
+} /* extern "C" */

@@ -1,0 +1,87 @@
+"""Drive the fiber-emulated kernels (tests/emu/libzmt_emu.so) with the same call shapes as the
+gpumt_* device API, on numpy host buffers.  TEST HARNESS ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import helpers as H
+
+EMU_DIR = os.path.join(H.ROOT, "tests", "emu")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", EMU_DIR], stdout=subprocess.DEVNULL)
+        L = C.CDLL(os.path.join(EMU_DIR, "libzmt_emu.so"))
+        L.emu_lz4_slot_stride.restype = C.c_size_t
+        L.emu_lz4_slot_stride.argtypes = [C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def xxh32_batch(buf: np.ndarray, off: np.ndarray, length: np.ndarray) -> np.ndarray:
+    n = len(off)
+    out = np.zeros(n, np.uint32)
+    lib().emu_xxh32_batch(_p(buf), _p(off.astype(np.uint64)), _p(length.astype(np.uint32)),
+                          C.c_uint32(n), _p(out))
+    return out
+
+
+def compress(data: bytes, chunk: int):
+    """-> (stream bytes, rec_off[n+1], rec_len[n])"""
+    L = lib()
+    n = len(data)
+    nrec = max(1, (n + chunk - 1) // chunk)
+    stride = L.emu_lz4_slot_stride(chunk)
+    inp = np.frombuffer(data + b"\0" * 16, np.uint8).copy()   # slack: hash reads 8 bytes
+    slots = np.full(nrec * stride, 0xEE, np.uint8)
+    rec_len = np.zeros(nrec, np.uint32)
+    L.emu_lz4_compress_batch(_p(inp), C.c_uint64(n), C.c_uint32(chunk), _p(slots),
+                             C.c_uint64(stride), _p(rec_len))
+    rec_off = np.zeros(nrec + 1, np.uint64)
+    stream = np.full(int(rec_len.sum()) + 16, 0xDD, np.uint8)
+    L.emu_lz4_compact(_p(slots), C.c_uint64(stride), _p(rec_len), C.c_uint32(nrec), _p(stream),
+                      _p(rec_off))
+    total = int(rec_off[nrec])
+    return stream[:total].tobytes(), rec_off, rec_len
+
+
+def walk_records(stream: bytes):
+    """Host-side header walk (what pt_read does): -> rec_off[n], rec_len[n] or None if malformed"""
+    import struct
+    offs, lens = [], []
+    i = 0
+    while i < len(stream):
+        if len(stream) - i < 12:
+            return None
+        c = struct.unpack_from("<I", stream, i + 8)[0]
+        offs.append(i)
+        lens.append(min(12 + c, len(stream) - i))
+        i += 12 + c
+    return np.array(offs, np.uint64), np.array(lens, np.uint32)
+
+
+def decompress(stream: bytes, variant: int = 0, rec=None):
+    """-> (content bytes, status[n])"""
+    L = lib()
+    ro, rl = rec if rec is not None else walk_records(stream)
+    nrec = len(ro)
+    sbuf = np.frombuffer(stream + b"\0" * 64, np.uint8).copy()
+    out_len = np.zeros(nrec, np.uint32)
+    out_off = np.zeros(nrec + 1, np.uint64)
+    L.emu_lz4_probe_sizes(_p(sbuf), _p(ro), _p(rl), C.c_uint32(nrec), _p(out_len), _p(out_off))
+    total = int(out_off[nrec])
+    out = np.full(total + 64, 0xCC, np.uint8)
+    status = np.full(nrec, 99, np.uint32)
+    L.emu_lz4_decompress_batch(C.c_int(variant), _p(sbuf), _p(ro), _p(rl), C.c_uint32(nrec), _p(out),
+                               _p(out_off), _p(out_len), _p(status))
+    assert (out[total:] == 0xCC).all(), "decoder wrote past the end of its output"
+    return out[:total].tobytes(), status

@@ -1,0 +1,60 @@
+"""The C-ABI library loads and exports every symbol include/*.h declares (no GPU compute here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import helpers as H
+
+
+def _declared(header):
+    txt = open(os.path.join(H.ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:gpumt|LZ4MT)_[A-Za-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    from zstdmt_amd._native import lib_path
+    if not os.path.exists(lib_path()):
+        import __graft_entry__ as g
+        g.build()
+    return C.CDLL(lib_path())
+
+
+@pytest.mark.parametrize("header", [h for h in ("gpumt.h", "lz4-mt.h")
+                                    if os.path.exists(os.path.join(H.ROOT, "include", h))])
+def test_exports(native, header):
+    names = _declared(header)
+    assert len(names) >= 10
+    missing = [n for n in names if not hasattr(native, n)]
+    assert not missing, missing
+
+
+def test_binding_table_matches_header(native):
+    from zstdmt_amd._native import GPUMT_SYMBOLS
+    assert sorted(GPUMT_SYMBOLS) == _declared("gpumt.h")
+
+
+def test_pure_helpers(native):
+    native.gpumt_lz4_slot_stride.restype = C.c_size_t
+    native.gpumt_lz4_slot_stride.argtypes = [C.c_size_t]
+    native.gpumt_lz4_record_count.restype = C.c_size_t
+    native.gpumt_lz4_record_count.argtypes = [C.c_size_t, C.c_size_t]
+    # 12 + LZ4F_compressFrameBound(chunk), rounded to 256
+    assert native.gpumt_lz4_slot_stride(131072) == (131119 + 255) // 256 * 256
+    assert native.gpumt_lz4_slot_stride(4 << 20) == (4194599 + 255) // 256 * 256
+    assert native.gpumt_lz4_record_count(0, 131072) == 1
+    assert native.gpumt_lz4_record_count(131072, 131072) == 1
+    assert native.gpumt_lz4_record_count(131073, 131072) == 2
+
+
+def test_no_device_fails_loudly(native):
+    """Without a GPU the engine must refuse to open -- never fall back to a CPU path."""
+    native.gpumt_device_count.restype = C.c_int
+    if native.gpumt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    import zstdmt_amd as z
+    with pytest.raises(z.NativeError):
+        z.Engine(0)

@@ -1,0 +1,163 @@
+"""Parity tests proper: the HIP path, through the C ABI (include/gpumt.h), against the oracle and
+the committed golden vectors.  Bit-exact for frames, byte-exact for decoded content."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from cases import CASES, KNOWN_HEX, rnd, text
+
+pytestmark = pytest.mark.gpu
+
+# decoder kernel variants under test (include/gpumt.h gpumt_set_variant "lz4_dec")
+VARIANTS = [1]
+
+with open(os.path.join(H.GOLDEN_DIR, "manifest.json")) as _f:
+    MAN = json.load(_f)["cases"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import zstdmt_amd as z
+    e = z.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_compress_golden(eng, name):
+    chunk, thunk = CASES[name]
+    data = thunk()
+    stream, rec_off, rec_len = eng.compress_bytes(data, chunk)
+    e = MAN[name]
+    assert len(stream) == e["out_len"]
+    assert H.sha256(stream) == e["out_sha256"]
+    assert len(rec_len) == e["frames"]
+    if name in KNOWN_HEX:
+        assert stream.hex() == KNOWN_HEX[name]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_decompress_golden(eng, name, variant):
+    chunk, thunk = CASES[name]
+    data = thunk()
+    stream = H.oracle_compress(data, chunk)
+    assert H.sha256(stream) == MAN[name]["out_sha256"]
+    import emu_driver as E
+    ro, rl = E.walk_records(stream)
+    eng.set_variant("lz4_dec", variant)
+    try:
+        out, status = eng.decompress_bytes(stream, ro, rl)
+    finally:
+        eng.set_variant("lz4_dec", 0)
+    assert status.tolist() == [0] * len(status)
+    assert out == data
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_vs_oracle(eng, seed):
+    import random
+    from test_oracle_vs_ref import _mix
+    rng = random.Random(1000 + seed)
+    n = rng.randrange(1, 3_000_000)
+    chunk = rng.choice([65536, 131072, 131072, 100000, 262144, 1 << 20])
+    data = _mix(rng, n)
+    want = H.oracle_compress(data, chunk)
+    stream, ro, rl = eng.compress_bytes(data, chunk)
+    assert stream == want
+    for variant in VARIANTS:
+        eng.set_variant("lz4_dec", variant)
+        out, status = eng.decompress_bytes(stream, ro, rl)
+        eng.set_variant("lz4_dec", 0)
+        assert not status.any() and out == data
+
+
+def test_config1_random_64m(eng):
+    """BASELINE config 1 shape: 64 MiB of PRNG bytes, default 4 MiB chunks -> 16 frames of 64 stored
+    blocks; output = input + 16*(12+15+64*4+4+4) bytes."""
+    data = rnd(64 << 20, 7)
+    stream, ro, rl = eng.compress_bytes(data, 4 << 20)
+    assert len(rl) == 16 and len(stream) == (64 << 20) + 4656
+    assert stream == H.oracle_compress(data, 4 << 20)
+    out, status = eng.decompress_bytes(stream, ro, rl)
+    assert not status.any() and out == data
+
+
+def test_text_256m_roundtrip_and_checksum_of_checksums(eng):
+    """Larger-than-oracle-friendly size: size-independent properties (round trip; per-chunk XXH32
+    of the decoded data equals the checksum each frame carries) + oracle spot-check of 4 chunks."""
+    n = 256 << 20
+    data = text(n)
+    stream, ro, rl = eng.compress_bytes(data, 131072)
+    out, status = eng.decompress_bytes(stream, ro, rl)
+    assert not status.any()
+    assert out == data
+    for i in (0, 1, 1000, len(rl) - 1):
+        rec = stream[int(ro[i]):int(ro[i]) + int(rl[i])]
+        assert rec == H.oracle_compress(data[i * 131072:(i + 1) * 131072], 131072)
+
+
+@pytest.mark.parametrize("mutate,code", [("magic", 2), ("hc", 2), ("blocksize", 3), ("checksum", 5),
+                                         ("skipmagic", 1), ("skiplen", 1), ("offset0", 3),
+                                         ("csize", 4)])
+def test_corrupt_streams_rejected(eng, mutate, code):
+    data = text(131072)
+    s = bytearray(H.oracle_compress(data, 131072))
+    if mutate == "magic":
+        s[12] ^= 1
+    elif mutate == "hc":
+        s[12 + 14] ^= 0x10
+    elif mutate == "blocksize":
+        s[12 + 15 + 2] ^= 0x40
+    elif mutate == "checksum":
+        s[-1] ^= 0x80
+    elif mutate == "skipmagic":
+        s[0] ^= 1
+    elif mutate == "skiplen":
+        s[4] = 8
+    elif mutate == "csize":
+        pass
+    elif mutate == "offset0":
+        p = 12 + 15 + 4
+        lit = s[p] >> 4
+        q = p + 1
+        if lit == 15:
+            while s[q] == 255:
+                lit += 255
+                q += 1
+            lit += s[q]
+            q += 1
+        s[q + lit] = 0
+        s[q + lit + 1] = 0
+    ro = np.array([0], np.uint64)
+    rl = np.array([len(s)], np.uint32)
+    if mutate == "csize":
+        # claim one byte less than the frame really holds, with a valid header checksum
+        import xxhash
+        s[12 + 6] = (s[12 + 6] - 1) & 0xFF
+        s[12 + 14] = (xxhash.xxh32(bytes(s[12 + 4:12 + 14]), seed=0).intdigest() >> 8) & 0xFF
+    for variant in VARIANTS:
+        eng.set_variant("lz4_dec", variant)
+        out, status = eng.decompress_bytes(bytes(s), ro, rl)
+        eng.set_variant("lz4_dec", 0)
+        assert status.tolist() == [code], (variant, status)
+    assert H.oracle_decompress(bytes(s), 131072) is None   # the oracle rejects it too
+
+
+def test_xxh32_batch(eng):
+    import xxhash
+    import ctypes as C
+    lens = [0, 1, 15, 16, 17, 100, 4096, 65537, 131072]
+    blobs = [H.lcg(n, n + 1) for n in lens]
+    buf = b"".join(blobs)
+    off = np.cumsum([0] + lens[:-1]).astype(np.uint64)
+    d_buf = eng.upload(buf)
+    d_off = eng.upload(off)
+    d_len = eng.upload(np.array(lens, np.uint32))
+    d_h = eng.alloc(len(lens) * 4)
+    eng._ck(eng.L.gpumt_xxh32_batch(eng.h, d_buf.ptr, d_off.ptr, d_len.ptr, len(lens), d_h.ptr, 0), "xxh")
+    got = eng.download(d_h, len(lens) * 4, np.uint32).tolist()
+    assert got == [xxhash.xxh32(b, seed=0).intdigest() for b in blobs]

@@ -1,0 +1,447 @@
+/*
+ * gpumt.hip -- C-ABI shim between the plain-C host engine and the gfx950 kernels (include/gpumt.h).
+ * Owns the HIP device, four streams, timing events and per-handle scratch; launches the kernels.
+ * There is deliberately no CPU fallback anywhere in this file.
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../../include/gpumt.h"
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+extern "C" {
+__global__ void zmt_xxh32_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, const u32 *,
+				 const u32 *, u32 *);
+__global__ void zmt_lz4_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
+__global__ void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
+				   const u32 *, u32 *, u32 *, u32 *);
+__global__ void zmt_lz4_dec_batch(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
+				  const u32 *, u32 *, u32 *, u32 *);
+__global__ void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
+__global__ void zmt_scan_kernel(const u32 *, u32, u64 *);
+__global__ void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
+__global__ void zmt_iota_kernel(u64 *, u32 *, u64, u64, u32);
+}
+
+#define NTIMERS 16
+
+struct gpumt_ctx {
+	int device;
+	hipStream_t st[GPUMT_NSTREAMS];
+	hipEvent_t t0[NTIMERS], t1[NTIMERS];
+	hipEvent_t xev;
+	/* scratch, grown on demand (never shrinks) */
+	void *scratch[2];        /* [0] compress side, [1] decompress side */
+	size_t scratch_bytes[2];
+	int dec_variant;
+	int profile; /* record events in timer slots 8.. around individual kernels */
+	char err[256];
+	char name[128];
+};
+
+static int fail(gpumt_ctx *h, hipError_t e, const char *what)
+{
+	if (h)
+		snprintf(h->err, sizeof h->err, "%s: %s", what, hipGetErrorString(e));
+	return GPUMT_E_HIP;
+}
+#define CK(call)                                                                                   \
+	do {                                                                                       \
+		hipError_t e_ = (call);                                                            \
+		if (e_ != hipSuccess)                                                              \
+			return fail(h, e_, #call);                                                 \
+	} while (0)
+
+#define PROF0(slot)                                                                               \
+	do {                                                                                       \
+		if (h->profile)                                                                    \
+			(void)hipEventRecord(h->t0[slot], h->st[s]);                               \
+	} while (0)
+#define PROF1(slot)                                                                               \
+	do {                                                                                       \
+		if (h->profile)                                                                    \
+			(void)hipEventRecord(h->t1[slot], h->st[s]);                               \
+	} while (0)
+
+static int use(gpumt_ctx *h)
+{
+	CK(hipSetDevice(h->device));
+	return GPUMT_OK;
+}
+
+static int want_scratch(gpumt_ctx *h, int k, size_t bytes)
+{
+	if (bytes <= h->scratch_bytes[k])
+		return GPUMT_OK;
+	if (h->scratch[k]) {
+		CK(hipDeviceSynchronize());
+		CK(hipFree(h->scratch[k]));
+		h->scratch[k] = NULL;
+		h->scratch_bytes[k] = 0;
+	}
+	bytes = (bytes + 0xFFFFF) & ~(size_t)0xFFFFF;
+	CK(hipMalloc(&h->scratch[k], bytes));
+	h->scratch_bytes[k] = bytes;
+	return GPUMT_OK;
+}
+
+extern "C" {
+
+int gpumt_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+		return 0;
+	return n;
+}
+
+int gpumt_open(int device, gpumt_ctx **out)
+{
+	int n = 0;
+	gpumt_ctx *h;
+	if (!out)
+		return GPUMT_E_ARG;
+	*out = NULL;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+		return GPUMT_E_NODEVICE;
+	h = (gpumt_ctx *)calloc(1, sizeof *h);
+	if (!h)
+		return GPUMT_E_NOMEM;
+	h->device = device;
+	{
+		hipDeviceProp_t p;
+		hipError_t e = hipSetDevice(device);
+		if (e == hipSuccess)
+			e = hipGetDeviceProperties(&p, device);
+		if (e != hipSuccess) {
+			free(h);
+			return GPUMT_E_NODEVICE;
+		}
+		snprintf(h->name, sizeof h->name, "%s (%s, %d CUs)", p.name, p.gcnArchName,
+			 p.multiProcessorCount);
+		if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
+			/* kernels are built for gfx950 only */
+			free(h);
+			return GPUMT_E_NODEVICE;
+		}
+	}
+	for (int i = 0; i < GPUMT_NSTREAMS; i++)
+		if (hipStreamCreateWithFlags(&h->st[i], hipStreamNonBlocking) != hipSuccess) {
+			free(h);
+			return GPUMT_E_HIP;
+		}
+	for (int i = 0; i < NTIMERS; i++) {
+		(void)hipEventCreate(&h->t0[i]);
+		(void)hipEventCreate(&h->t1[i]);
+	}
+	(void)hipEventCreateWithFlags(&h->xev, hipEventDisableTiming);
+	*out = h;
+	return GPUMT_OK;
+}
+
+void gpumt_close(gpumt_ctx *h)
+{
+	if (!h)
+		return;
+	(void)hipSetDevice(h->device);
+	(void)hipDeviceSynchronize();
+	for (int k = 0; k < 2; k++)
+		if (h->scratch[k])
+			(void)hipFree(h->scratch[k]);
+	for (int i = 0; i < NTIMERS; i++) {
+		(void)hipEventDestroy(h->t0[i]);
+		(void)hipEventDestroy(h->t1[i]);
+	}
+	(void)hipEventDestroy(h->xev);
+	for (int i = 0; i < GPUMT_NSTREAMS; i++)
+		(void)hipStreamDestroy(h->st[i]);
+	free(h);
+}
+
+const char *gpumt_last_error(gpumt_ctx *h) { return h ? h->err : "no handle"; }
+const char *gpumt_device_name(gpumt_ctx *h) { return h ? h->name : ""; }
+
+void *gpumt_malloc(gpumt_ctx *h, size_t bytes)
+{
+	void *p = NULL;
+	if (!h || use(h))
+		return NULL;
+	if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess)
+		return NULL;
+	return p;
+}
+void gpumt_free(gpumt_ctx *h, void *p)
+{
+	if (h && p && !use(h))
+		(void)hipFree(p);
+}
+void *gpumt_host_alloc(gpumt_ctx *h, size_t bytes)
+{
+	void *p = NULL;
+	if (!h || use(h))
+		return NULL;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+		return NULL;
+	return p;
+}
+void gpumt_host_free(gpumt_ctx *h, void *p)
+{
+	if (h && p && !use(h))
+		(void)hipHostFree(p);
+}
+
+#define STREAM_OK(s) ((s) >= 0 && (s) < GPUMT_NSTREAMS)
+
+int gpumt_memcpy_h2d(gpumt_ctx *h, void *dst, const void *src, size_t n, int s)
+{
+	if (!h || !STREAM_OK(s))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, h->st[s]));
+	return GPUMT_OK;
+}
+int gpumt_memcpy_d2h(gpumt_ctx *h, void *dst, const void *src, size_t n, int s)
+{
+	if (!h || !STREAM_OK(s))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, h->st[s]));
+	return GPUMT_OK;
+}
+int gpumt_memcpy_d2d(gpumt_ctx *h, void *dst, const void *src, size_t n, int s)
+{
+	if (!h || !STREAM_OK(s))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, h->st[s]));
+	return GPUMT_OK;
+}
+int gpumt_memset(gpumt_ctx *h, void *dst, int byte, size_t n, int s)
+{
+	if (!h || !STREAM_OK(s))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipMemsetAsync(dst, byte, n, h->st[s]));
+	return GPUMT_OK;
+}
+int gpumt_stream_sync(gpumt_ctx *h, int s)
+{
+	if (!h || !STREAM_OK(s))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipStreamSynchronize(h->st[s]));
+	return GPUMT_OK;
+}
+int gpumt_device_sync(gpumt_ctx *h)
+{
+	if (!h)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipDeviceSynchronize());
+	return GPUMT_OK;
+}
+int gpumt_stream_wait(gpumt_ctx *h, int waiter, int signaler)
+{
+	hipEvent_t ev;
+	if (!h || !STREAM_OK(waiter) || !STREAM_OK(signaler))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	/* a fresh event per edge: edges may be in flight concurrently */
+	CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+	CK(hipEventRecord(ev, h->st[signaler]));
+	CK(hipStreamWaitEvent(h->st[waiter], ev, 0));
+	CK(hipEventDestroy(ev)); /* destruction is deferred until the event completes */
+	return GPUMT_OK;
+}
+void *gpumt_stream_handle(gpumt_ctx *h, int s)
+{
+	return (h && STREAM_OK(s)) ? (void *)h->st[s] : NULL;
+}
+
+int gpumt_timer_start(gpumt_ctx *h, int slot, int s)
+{
+	if (!h || slot < 0 || slot >= NTIMERS || !STREAM_OK(s))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipEventRecord(h->t0[slot], h->st[s]));
+	return GPUMT_OK;
+}
+int gpumt_timer_stop(gpumt_ctx *h, int slot, int s)
+{
+	if (!h || slot < 0 || slot >= NTIMERS || !STREAM_OK(s))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipEventRecord(h->t1[slot], h->st[s]));
+	return GPUMT_OK;
+}
+int gpumt_timer_ms(gpumt_ctx *h, int slot, float *ms)
+{
+	if (!h || slot < 0 || slot >= NTIMERS || !ms)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipEventSynchronize(h->t1[slot]));
+	CK(hipEventElapsedTime(ms, h->t0[slot], h->t1[slot]));
+	return GPUMT_OK;
+}
+
+/* ------------------------------------------------------------------------------- LZ4 */
+size_t gpumt_lz4_slot_stride(size_t chunk)
+{
+	size_t full = chunk / 65536, part = chunk % 65536;
+	size_t b = 12 + 19 + 4 * (full + (part ? 1 : 0)) + chunk + 8;
+	return (b + 255) & ~(size_t)255;
+}
+
+size_t gpumt_lz4_record_count(size_t n, size_t chunk)
+{
+	if (!chunk)
+		return 0;
+	return n ? (n + chunk - 1) / chunk : 1;
+}
+
+int gpumt_xxh32_batch(gpumt_ctx *h, const void *d_base, const uint64_t *d_off,
+		      const uint32_t *d_len, size_t n, uint32_t *d_hash, int s)
+{
+	if (!h || !STREAM_OK(s) || n > 0x3FFFFFFFu)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	if (!n)
+		return GPUMT_OK;
+	hipLaunchKernelGGL(zmt_xxh32_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0,
+			   h->st[s], (const u8 *)d_base, d_off, d_len, (u32)n, d_hash,
+			   (const u32 *)NULL, (const u32 *)NULL, (u32 *)NULL);
+	CK(hipGetLastError());
+	return GPUMT_OK;
+}
+
+int gpumt_lz4_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk,
+			     void *d_slots, size_t slot_stride, uint32_t *d_rec_len, int s)
+{
+	size_t nrec = gpumt_lz4_record_count(n, chunk);
+	if (!h || !STREAM_OK(s) || chunk == 0 || chunk > 0x40000000u || nrec > 0x3FFFFFFFu ||
+	    slot_stride < gpumt_lz4_slot_stride(chunk))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	/* scratch: off[nrec] u64 | len[nrec] u32 | chk[nrec] u32 */
+	if (want_scratch(h, 0, nrec * 16))
+		return GPUMT_E_HIP;
+	u64 *off = (u64 *)h->scratch[0];
+	u32 *len = (u32 *)(off + nrec);
+	u32 *chk = len + nrec;
+	hipLaunchKernelGGL(zmt_iota_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0,
+			   h->st[s], off, len, (u64)n, (u64)chunk, (u32)nrec);
+	PROF0(8);
+	hipLaunchKernelGGL(zmt_xxh32_kernel, dim3((unsigned)((nrec * 4 + 255) / 256)), dim3(256), 0,
+			   h->st[s], (const u8 *)d_in, (const u64 *)off, (const u32 *)len, (u32)nrec,
+			   chk, (const u32 *)NULL, (const u32 *)NULL, (u32 *)NULL);
+	PROF1(8);
+	PROF0(9);
+	hipLaunchKernelGGL(zmt_lz4_enc_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
+			   (const u8 *)d_in, (u64)n, (u32)chunk, (u32)nrec, (u8 *)d_slots,
+			   (u64)slot_stride, d_rec_len, (const u32 *)chk);
+	PROF1(9);
+	CK(hipGetLastError());
+	return GPUMT_OK;
+}
+
+int gpumt_lz4_compact(gpumt_ctx *h, const void *d_slots, size_t slot_stride,
+		      const uint32_t *d_rec_len, size_t nrec, void *d_stream, uint64_t *d_rec_off,
+		      int s)
+{
+	if (!h || !STREAM_OK(s) || nrec == 0 || nrec > 0x3FFFFFFFu)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	PROF0(10);
+	hipLaunchKernelGGL(zmt_scan_kernel, dim3(1), dim3(1024), 0, h->st[s], d_rec_len, (u32)nrec,
+			   d_rec_off);
+	hipLaunchKernelGGL(zmt_compact_kernel, dim3((unsigned)nrec), dim3(256), 0, h->st[s],
+			   (const u8 *)d_slots, (u64)slot_stride, d_rec_len,
+			   (const u64 *)d_rec_off, (u32)nrec, (u8 *)d_stream);
+	PROF1(10);
+	CK(hipGetLastError());
+	return GPUMT_OK;
+}
+
+int gpumt_lz4_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
+			  const uint32_t *d_rec_len, size_t nrec, uint32_t *d_out_len,
+			  uint64_t *d_out_off, int s)
+{
+	if (!h || !STREAM_OK(s) || nrec == 0 || nrec > 0x3FFFFFFFu)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	hipLaunchKernelGGL(zmt_probe_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0,
+			   h->st[s], (const u8 *)d_stream, d_rec_off, d_rec_len, (u32)nrec,
+			   d_out_len);
+	hipLaunchKernelGGL(zmt_scan_kernel, dim3(1), dim3(1024), 0, h->st[s],
+			   (const u32 *)d_out_len, (u32)nrec, d_out_off);
+	CK(hipGetLastError());
+	return GPUMT_OK;
+}
+
+int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
+			       const uint32_t *d_rec_len, size_t nrec, void *d_out,
+			       const uint64_t *d_out_off, const uint32_t *d_out_len,
+			       uint32_t *d_status, int s)
+{
+	if (!h || !STREAM_OK(s) || nrec == 0 || nrec > 0x3FFFFFFFu)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	if (want_scratch(h, 1, nrec * 8))
+		return GPUMT_E_HIP;
+	u32 *ce = (u32 *)h->scratch[1], *cv = ce + nrec;
+	PROF0(11);
+	if (h->dec_variant == 1)
+		hipLaunchKernelGGL(zmt_lz4_dec_serial, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
+				   (const u8 *)d_stream, d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out,
+				   d_out_off, d_out_len, d_status, ce, cv);
+	else
+		hipLaunchKernelGGL(zmt_lz4_dec_batch, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0,
+				   h->st[s], (const u8 *)d_stream, d_rec_off, d_rec_len, (u32)nrec,
+				   (u8 *)d_out, d_out_off, d_out_len, d_status, ce, cv);
+	PROF1(11);
+	PROF0(12);
+	hipLaunchKernelGGL(zmt_xxh32_kernel, dim3((unsigned)((nrec * 4 + 255) / 256)), dim3(256), 0,
+			   h->st[s], (const u8 *)d_out, d_out_off, d_out_len, (u32)nrec, (u32 *)NULL,
+			   (const u32 *)ce, (const u32 *)cv, d_status);
+	PROF1(12);
+	CK(hipGetLastError());
+	return GPUMT_OK;
+}
+
+int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
+{
+	int prev = -1;
+	if (!h || !what)
+		return -1;
+	if (!strcmp(what, "lz4_dec")) {
+		prev = h->dec_variant;
+		h->dec_variant = variant;
+	} else if (!strcmp(what, "profile")) {
+		prev = h->profile;
+		h->profile = variant;
+	}
+	return prev;
+}
+
+} /* extern "C" */

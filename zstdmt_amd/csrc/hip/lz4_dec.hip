@@ -1,0 +1,220 @@
+/*
+ * lz4_dec.hip -- LZ4 frame decoder, one wave per record (= one chunk).
+ *
+ * Replaces, per record, LZ4F_decompress (call site /root/reference/lib/lz4-mt_decompress.c:349-362)
+ * together with the record checks of pt_read (:229-236): skippable magic and length, LZ4F magic /
+ * version / reserved bits / header checksum, block walk (stored or LZ4 block with the chunk's
+ * earlier output as prefix -- linked blocks), end mark, content size.  The XXH32 content checksum
+ * is extracted here and verified by zmt_xxh32_kernel over the decoded bytes.
+ *
+ * Variant "serial" (this file, kernel zmt_lz4_dec_serial): the token stream is walked
+ * wave-uniformly, the 64 lanes cooperate on each literal run and each match (byte i of the copy
+ * is lane i mod 64).  Overlapping matches (offset < length) read the pattern's first period, so a
+ * copy never depends on bytes written by the same sequence.  Output is written straight to HBM;
+ * match sources are read back through L1/L2 (same wave, program order).
+ */
+#include "lz4_common.h"
+
+/* order this wave's earlier global stores before its later global loads */
+static __device__ __forceinline__ void wave_mem_fence()
+{
+#ifdef ZMT_EMU
+	wv_sync();
+#else
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
+
+/*
+ * Decode one LZ4 block [src, src+slen) appending at out[opos...]; matches may reach back to
+ * out[low].  Returns new opos or 0xFFFFFFFF on malformed input.  limit = highest legal opos.
+ */
+static __device__ u32 decode_block_serial(const u8 *src, u32 slen, u8 *out, u32 opos, u32 low,
+					  u32 limit, int lane)
+{
+	u32 ip = 0;
+	if (slen == 0)
+		return 0xFFFFFFFFu;
+	for (;;) {
+		u32 tok, lit, ml, off;
+		if (ip >= slen)
+			return 0xFFFFFFFFu;
+		tok = uld8(src + ip++);
+		lit = tok >> 4;
+		if (lit == 15) {
+			u32 b;
+			do {
+				if (ip >= slen)
+					return 0xFFFFFFFFu;
+				b = uld8(src + ip++);
+				lit += b;
+			} while (b == 255);
+		}
+		if (slen - ip < lit || limit - opos < lit)
+			return 0xFFFFFFFFu;
+		wave_copy(out + opos, src + ip, lit, lane);
+		ip += lit;
+		opos += lit;
+		if (ip == slen)
+			return opos;
+		if (slen - ip < 2)
+			return 0xFFFFFFFFu;
+		off = uld16(src + ip);
+		ip += 2;
+		ml = tok & 15;
+		if (ml == 15) {
+			u32 b;
+			do {
+				if (ip >= slen)
+					return 0xFFFFFFFFu;
+				b = uld8(src + ip++);
+				ml += b;
+			} while (b == 255);
+		}
+		ml += 4;
+		if (off == 0 || off > opos - low || limit - opos < ml)
+			return 0xFFFFFFFFu;
+		wave_mem_fence();
+		{
+			const u8 *m = out + opos - off;
+			u8 *d = out + opos;
+			if (off >= ml) {
+				for (u32 i = (u32)lane; i < ml; i += 64)
+					d[i] = m[i];
+			} else {
+				/* periodic fill: byte i of the match equals byte i mod off of the source */
+				for (u32 i = (u32)lane; i < ml; i += 64)
+					d[i] = m[i % off];
+			}
+		}
+		opos += ml;
+	}
+}
+
+struct FrameInfo {
+	u32 hdr;       /* header bytes */
+	u32 blkmax;
+	u32 has_csize, has_ccheck, indep;
+	u64 csize;
+};
+
+/* wave-uniform parse + validation of the LZ4F frame header at f[0..flen) */
+static __device__ u32 parse_frame_header(const u8 *f, u32 flen, FrameInfo &fi)
+{
+	u32 flg, bd, hdr;
+	if (flen < 7 || uld32(f) != ZMT_LZ4F_MAGIC)
+		return ST_BAD_FRAME;
+	flg = uld8(f + 4);
+	bd = uld8(f + 5);
+	if ((flg >> 6) != 1 || (flg & 0x02) || (bd & 0x8F) || (bd >> 4) < 4)
+		return ST_BAD_FRAME;
+	if ((flg & 0x10) || (flg & 0x01))
+		return ST_UNSUPPORTED; /* block checksums / dictID: valid LZ4F, never emitted by lz4-mt */
+	fi.indep = (flg >> 5) & 1;
+	fi.has_csize = (flg >> 3) & 1;
+	fi.has_ccheck = (flg >> 2) & 1;
+	fi.blkmax = 1u << (8 + 2 * (bd >> 4));
+	hdr = 7 + (fi.has_csize ? 8 : 0);
+	if (flen < hdr)
+		return ST_BAD_FRAME;
+	{
+		u8 d[10];
+		for (u32 i = 0; i < hdr - 5; i++)
+			d[i] = (u8)uld8(f + 4 + i);
+		if (uld8(f + hdr - 1) != ((xxh32_short(d, hdr - 5) >> 8) & 0xFF))
+			return ST_BAD_FRAME;
+	}
+	fi.csize = fi.has_csize ? ((u64)uld32(f + 6) | (u64)uld32(f + 10) << 32) : 0;
+	fi.hdr = hdr;
+	return ST_OK;
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+zmt_lz4_dec_serial(const u8 *__restrict__ stream, const u64 *__restrict__ rec_off,
+		   const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
+		   const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
+		   u32 *__restrict__ status, u32 *__restrict__ chk_expect,
+		   u32 *__restrict__ chk_valid)
+{
+	const u32 rec = blockIdx.x;
+	const int lane = wv_lane();
+	if (rec >= nrec)
+		return;
+	const u8 *r = stream + rec_off[rec];
+	const u32 rlen = rec_len[rec];
+	u8 *out = out_base + out_off[rec];
+	const u32 cap = out_len[rec];
+	u32 st = ST_OK, opos = 0, ip, flen;
+	FrameInfo fi;
+
+	if (lane == 0) {
+		chk_valid[rec] = 0;
+		chk_expect[rec] = 0;
+	}
+	if (rlen < 12 || uld32(r) != ZMT_SKIP_MAGIC || uld32(r + 4) != 4 ||
+	    uld32(r + 8) != rlen - 12) {
+		st = ST_BAD_RECORD;
+		goto done;
+	}
+	flen = rlen - 12;
+	r += 12;
+	st = parse_frame_header(r, flen, fi);
+	if (st != ST_OK)
+		goto done;
+	ip = fi.hdr;
+	for (;;) {
+		u32 bh, bsz;
+		if (flen - ip < 4) {
+			st = ST_BAD_BLOCK;
+			goto done;
+		}
+		bh = uld32(r + ip);
+		ip += 4;
+		if (bh == 0)
+			break;
+		bsz = bh & 0x7FFFFFFFu;
+		if (bsz > fi.blkmax || flen - ip < bsz) {
+			st = ST_BAD_BLOCK;
+			goto done;
+		}
+		if (bh & 0x80000000u) {
+			if (cap - opos < bsz) {
+				st = ST_BAD_BLOCK;
+				goto done;
+			}
+			wave_copy(out + opos, r + ip, bsz, lane);
+			opos += bsz;
+		} else {
+			u32 room = cap - opos < fi.blkmax ? cap - opos : fi.blkmax;
+			u32 np = decode_block_serial(r + ip, bsz, out, opos, fi.indep ? opos : 0,
+						     opos + room, lane);
+			if (np == 0xFFFFFFFFu) {
+				st = ST_BAD_BLOCK;
+				goto done;
+			}
+			opos = np;
+		}
+		ip += bsz;
+	}
+	if ((fi.has_csize && fi.csize != (u64)opos) || opos != cap) {
+		st = ST_SIZE_MISMATCH;
+		goto done;
+	}
+	if (fi.has_ccheck) {
+		if (flen - ip < 4) {
+			st = ST_BAD_BLOCK;
+			goto done;
+		}
+		if (lane == 0) {
+			chk_expect[rec] = ld32u(r + ip);
+			chk_valid[rec] = 1;
+		}
+		ip += 4;
+	}
+	if (ip != flen)
+		st = ST_TRAILING;
+done:
+	if (lane == 0)
+		status[rec] = st;
+}

@@ -1,0 +1,144 @@
+/*
+ * wave.h -- wave64 cross-lane primitives used by the gfx950 kernels.
+ *
+ * All cross-lane operations are used in wave-uniform control flow only.  wv_sync() orders one
+ * lane's LDS/global stores before another lane's later loads inside the same wave (the hardware
+ * issues a wave's DS and VMEM operations in order; the fence keeps the compiler from moving them).
+ *
+ * ZMT_EMU selects the host fiber harness of tests/emu (test infrastructure, never shipped).
+ */
+#ifndef ZMT_WAVE_H
+#define ZMT_WAVE_H
+
+#include <stdint.h>
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#ifdef ZMT_EMU
+/* ------------------------------------------------------------------ host fiber harness */
+#include "emu_runtime.h"
+
+static inline int wv_lane() { return (int)(emu::tid() & 63); }
+static inline void wv_sync() { emu::wave_barrier(); }
+
+static inline u64 wv_xchg_(u64 v, int src)
+{
+	emu::Block *b = emu::g_blk;
+	unsigned base = emu::tid() & ~63u;
+	b->slot[emu::tid()] = v;
+	emu::wave_barrier();
+	u64 r = b->slot[base + ((unsigned)src & 63)];
+	emu::wave_barrier();
+	return r;
+}
+static inline u32 wv_shfl(u32 v, int src) { return (u32)wv_xchg_(v, src); }
+static inline u32 wv_readlane(u32 v, int lane) { return (u32)wv_xchg_(v, lane); }
+/* uniform code: every lane already holds the value; the strict mode checks that claim */
+#ifdef ZMT_EMU_STRICT
+static inline u32 wv_readfirst(u32 v)
+{
+	u32 r = (u32)wv_xchg_(v, 0);
+	if (r != v) {
+		fprintf(stderr, "emu: readfirstlane on a non-uniform value\n");
+		abort();
+	}
+	return r;
+}
+#else
+static inline u32 wv_readfirst(u32 v) { return v; }
+#endif
+static inline u64 wv_ballot(bool p)
+{
+	emu::Block *b = emu::g_blk;
+	unsigned base = emu::tid() & ~63u;
+	b->slot[emu::tid()] = p ? 1 : 0;
+	emu::wave_barrier();
+	u64 m = 0;
+	for (unsigned i = 0; i < emu::wave_size_of(emu::tid() / 64); i++)
+		m |= (u64)(b->slot[base + i] & 1) << i;
+	emu::wave_barrier();
+	return m;
+}
+static inline int wv_popc(u64 m) { return __builtin_popcountll(m); }
+static inline int wv_ffs(u64 m) { return __builtin_ffsll((long long)m); } /* 1-based, 0 if none */
+static inline void wv_sleep() {}
+#define ZMT_UNROLL
+
+#else
+/* ------------------------------------------------------------------------------ gfx950 */
+#include <hip/hip_runtime.h>
+
+static __device__ __forceinline__ int wv_lane() { return (int)__lane_id(); }
+static __device__ __forceinline__ void wv_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+static __device__ __forceinline__ u32 wv_shfl(u32 v, int src)
+{
+	return (u32)__builtin_amdgcn_ds_bpermute(src << 2, (int)v);
+}
+/* lane must be wave-uniform */
+static __device__ __forceinline__ u32 wv_readlane(u32 v, int lane)
+{
+	return (u32)__builtin_amdgcn_readlane((int)v, lane);
+}
+static __device__ __forceinline__ u32 wv_readfirst(u32 v)
+{
+	return (u32)__builtin_amdgcn_readfirstlane((int)v);
+}
+static __device__ __forceinline__ u64 wv_ballot(bool p) { return __ballot(p); }
+static __device__ __forceinline__ int wv_popc(u64 m) { return __popcll(m); }
+static __device__ __forceinline__ int wv_ffs(u64 m) { return __ffsll((unsigned long long)m); }
+static __device__ __forceinline__ void wv_sleep() { __builtin_amdgcn_s_sleep(2); }
+#define ZMT_UNROLL _Pragma("unroll")
+#endif
+
+/* ---------------------------------------------------------------- shared by both builds */
+static __device__ __forceinline__ bool wv_any(bool p) { return wv_ballot(p) != 0; }
+static __device__ __forceinline__ bool wv_all(bool p) { return wv_ballot(!p) == 0; }
+
+/* inclusive prefix sum over the 64 lanes */
+static __device__ __forceinline__ u32 wv_scan_incl(u32 v)
+{
+	int l = wv_lane();
+	ZMT_UNROLL
+	for (int d = 1; d < 64; d <<= 1) {
+		u32 o = wv_shfl(v, l - d);
+		if (l >= d)
+			v += o;
+	}
+	return v;
+}
+
+/* unaligned little-endian accesses (gfx950 global memory handles misaligned dwords natively) */
+static __device__ __forceinline__ u32 ld32u(const u8 *p)
+{
+	u32 v;
+	__builtin_memcpy(&v, p, 4);
+	return v;
+}
+static __device__ __forceinline__ u64 ld64u(const u8 *p)
+{
+	u64 v;
+	__builtin_memcpy(&v, p, 8);
+	return v;
+}
+static __device__ __forceinline__ u32 ld16u(const u8 *p)
+{
+	u16 v;
+	__builtin_memcpy(&v, p, 2);
+	return v;
+}
+static __device__ __forceinline__ void st32u(u8 *p, u32 v) { __builtin_memcpy(p, &v, 4); }
+static __device__ __forceinline__ void st16u(u8 *p, u32 v)
+{
+	u16 w = (u16)v;
+	__builtin_memcpy(p, &w, 2);
+}
+
+#endif

@@ -1,0 +1,176 @@
+"""Thin object wrapper over the gpumt_* C ABI (include/gpumt.h) for tests and bench.py.
+
+Device buffers are plain integers (device pointers) owned by the Engine; numpy arrays are only
+used to stage host data.  Every call that fails raises NativeError with the HIP error text.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._native import NativeError, lib
+
+ST_NAMES = {0: "ok", 1: "bad_record", 2: "bad_frame", 3: "bad_block", 4: "size_mismatch",
+            5: "bad_checksum", 6: "trailing", 7: "unsupported"}
+
+
+class DevBuf:
+    __slots__ = ("ptr", "nbytes", "eng")
+
+    def __init__(self, eng, nbytes):
+        self.eng = eng
+        self.nbytes = int(nbytes)
+        self.ptr = lib().gpumt_malloc(eng.h, self.nbytes)
+        if not self.ptr:
+            raise NativeError(f"gpumt_malloc({nbytes}) failed")
+
+    def free(self):
+        if self.ptr:
+            lib().gpumt_free(self.eng.h, self.ptr)
+            self.ptr = None
+
+    def at(self, byte_off):
+        return C.c_void_p(self.ptr + int(byte_off))
+
+
+class Engine:
+    """One HIP device. `Engine(0)` raises NativeError when no gfx950 GPU is usable."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.gpumt_open(device, C.byref(h))
+        if rc != 0:
+            raise NativeError(f"gpumt_open({device}) failed with {rc} (no gfx950 device / HIP runtime)")
+        self.h = h
+        self.name = self.L.gpumt_device_name(h).decode()
+
+    def close(self):
+        if self.h:
+            self.L.gpumt_close(self.h)
+            self.h = None
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise NativeError(f"{what} -> {rc}: {self.L.gpumt_last_error(self.h).decode()}")
+
+    def alloc(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    def upload(self, arr, stream=0, slack=64):
+        """numpy array / bytes -> new device buffer (+slack bytes so 8-byte hash reads stay inside)"""
+        a = np.frombuffer(arr, np.uint8) if isinstance(arr, (bytes, bytearray)) else arr
+        a = np.ascontiguousarray(a)
+        d = self.alloc(a.nbytes + slack)
+        if a.nbytes:
+            self._ck(self.L.gpumt_memcpy_h2d(self.h, d.ptr, a.ctypes.data, a.nbytes, stream), "h2d")
+            self.sync(stream)
+        return d
+
+    def download(self, d, nbytes, dtype=np.uint8, offset=0, stream=0):
+        out = np.empty(int(nbytes), np.uint8)
+        if nbytes:
+            self._ck(self.L.gpumt_memcpy_d2h(self.h, out.ctypes.data, d.ptr + int(offset), int(nbytes),
+                                             stream), "d2h")
+            self.sync(stream)
+        return out.view(dtype)
+
+    def sync(self, stream=None):
+        if stream is None:
+            self._ck(self.L.gpumt_device_sync(self.h), "device_sync")
+        else:
+            self._ck(self.L.gpumt_stream_sync(self.h, stream), "stream_sync")
+
+    def timer_start(self, slot, stream=0):
+        self._ck(self.L.gpumt_timer_start(self.h, slot, stream), "timer_start")
+
+    def timer_stop(self, slot, stream=0):
+        self._ck(self.L.gpumt_timer_stop(self.h, slot, stream), "timer_stop")
+
+    def timer_ms(self, slot):
+        ms = C.c_float()
+        self._ck(self.L.gpumt_timer_ms(self.h, slot, C.byref(ms)), "timer_ms")
+        return ms.value
+
+    def set_variant(self, what, v):
+        return self.L.gpumt_set_variant(self.h, what.encode(), v)
+
+    # ---- LZ4, device-resident ----------------------------------------------------------------
+    def slot_stride(self, chunk):
+        return self.L.gpumt_lz4_slot_stride(chunk)
+
+    def record_count(self, n, chunk):
+        return self.L.gpumt_lz4_record_count(n, chunk)
+
+    def lz4_compress(self, d_in, n, chunk, d_slots, stride, d_rec_len, stream=0):
+        self._ck(self.L.gpumt_lz4_compress_batch(self.h, d_in.ptr, n, chunk, d_slots.ptr, stride,
+                                                 d_rec_len.ptr, stream), "lz4_compress_batch")
+
+    def lz4_compact(self, d_slots, stride, d_rec_len, nrec, d_stream, d_rec_off, stream=0):
+        self._ck(self.L.gpumt_lz4_compact(self.h, d_slots.ptr, stride, d_rec_len.ptr, nrec,
+                                          d_stream.ptr, d_rec_off.ptr, stream), "lz4_compact")
+
+    def lz4_probe(self, d_stream, d_rec_off, d_rec_len, nrec, d_out_len, d_out_off, stream=0):
+        self._ck(self.L.gpumt_lz4_probe_sizes(self.h, d_stream.ptr, d_rec_off.ptr, d_rec_len.ptr, nrec,
+                                              d_out_len.ptr, d_out_off.ptr, stream), "lz4_probe_sizes")
+
+    def lz4_decompress(self, d_stream, d_rec_off, d_rec_len, nrec, d_out, d_out_off, d_out_len,
+                       d_status, stream=0):
+        self._ck(self.L.gpumt_lz4_decompress_batch(self.h, d_stream.ptr, d_rec_off.ptr, d_rec_len.ptr,
+                                                   nrec, d_out.ptr, d_out_off.ptr, d_out_len.ptr,
+                                                   d_status.ptr, stream), "lz4_decompress_batch")
+
+    # ---- convenience round trips on host bytes (tests) ----------------------------------------
+    def compress_bytes(self, data: bytes, chunk: int):
+        """-> (stream bytes, rec_off[n+1] u64, rec_len[n] u32)"""
+        n = len(data)
+        nrec = self.record_count(n, chunk)
+        stride = self.slot_stride(chunk)
+        d_in = self.upload(data)
+        d_slots = self.alloc(nrec * stride)
+        d_len = self.alloc(nrec * 4)
+        d_off = self.alloc((nrec + 1) * 8)
+        try:
+            self.lz4_compress(d_in, n, chunk, d_slots, stride, d_len)
+            rec_len = self.download(d_len, nrec * 4, np.uint32)
+            total = int(rec_len.astype(np.uint64).sum())
+            d_stream = self.alloc(total + 64)
+            try:
+                self.lz4_compact(d_slots, stride, d_len, nrec, d_stream, d_off)
+                rec_off = self.download(d_off, (nrec + 1) * 8, np.uint64)
+                assert int(rec_off[nrec]) == total
+                stream = self.download(d_stream, total).tobytes()
+            finally:
+                d_stream.free()
+        finally:
+            for b in (d_in, d_slots, d_len, d_off):
+                b.free()
+        return stream, rec_off, rec_len
+
+    def decompress_bytes(self, stream: bytes, rec_off, rec_len):
+        """-> (content bytes, status[n])"""
+        nrec = len(rec_len)
+        d_stream = self.upload(stream)
+        d_ro = self.upload(np.asarray(rec_off, np.uint64)[:nrec].copy())
+        d_rl = self.upload(np.asarray(rec_len, np.uint32).copy())
+        d_ol = self.alloc(nrec * 4)
+        d_oo = self.alloc((nrec + 1) * 8)
+        d_st = self.alloc(nrec * 4)
+        try:
+            self.lz4_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo)
+            out_off = self.download(d_oo, (nrec + 1) * 8, np.uint64)
+            total = int(out_off[nrec])
+            d_out = self.alloc(total + 64)
+            try:
+                lib().gpumt_memset(self.h, d_out.ptr, 0xCC, total + 64, 0)
+                self.lz4_decompress(d_stream, d_ro, d_rl, nrec, d_out, d_oo, d_ol, d_st)
+                status = self.download(d_st, nrec * 4, np.uint32)
+                raw = self.download(d_out, total + 64)
+                assert (raw[total:] == 0xCC).all(), "decoder wrote past the end of its output"
+                out = raw[:total].tobytes()
+            finally:
+                d_out.free()
+        finally:
+            for b in (d_stream, d_ro, d_rl, d_ol, d_oo, d_st):
+                b.free()
+        return out, status
