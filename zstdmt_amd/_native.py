@@ -57,7 +57,7 @@ def lib():
                 f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         try:
-            L = C.CDLL(p, mode=C.RTLD_GLOBAL)
+            L = C.CDLL(p)
         except OSError as e:
             raise NativeError(f"cannot load {p}: {e}") from e
         for name, (res, args) in GPUMT_SYMBOLS.items():
