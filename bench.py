@@ -138,7 +138,7 @@ def main():
         eng.timer_stop(2)
         eng.timer_start(3)
         eng.lz4_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo)
-        eng.lz4_decompress(d_stream, d_ro, d_rl, nrec, d_out, d_oo, d_ol, d_st)
+        eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st)
         eng.timer_stop(3)
 
     def barrier():

@@ -120,15 +120,21 @@ int gpumt_lz4_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d_
  * Decode nrec records.  Record i's content goes to d_out + d_out_off[i] and must be exactly
  * d_out_len[i] bytes; header, block structure, content size and XXH32 content checksum are
  * verified.  d_status[i] receives a GPUMT_ST_* code.
+ * stream_bytes / out_bytes: upper bounds of the bytes spanned by the records in d_stream and by
+ * their contents in d_out (they size the internal token-list scratch, about 0.7 x stream_bytes).
  */
-int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
-			       const uint32_t *d_rec_len, size_t nrec, void *d_out,
-			       const uint64_t *d_out_off, const uint32_t *d_out_len,
-			       uint32_t *d_status, int stream);
+int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream_bytes,
+			       const uint64_t *d_rec_off, const uint32_t *d_rec_len, size_t nrec,
+			       void *d_out, size_t out_bytes, const uint64_t *d_out_off,
+			       const uint32_t *d_out_len, uint32_t *d_status, int stream);
 
 /* XXH32 (seed 0) of n items: item i = d_base + d_off[i], d_len[i] bytes -> d_hash[i]. */
 int gpumt_xxh32_batch(gpumt_ctx *h, const void *d_base, const uint64_t *d_off,
 		      const uint32_t *d_len, size_t n, uint32_t *d_hash, int stream);
+
+/* Developer aid: read-and-clear the 16 phase-cycle counters filled by the profiling decoder
+ * (gpumt_set_variant("lz4_dec", 2)). */
+int gpumt_debug_counters(gpumt_ctx *h, unsigned long long *dst, int n);
 
 /* Kernel-variant selector for A/B measurements (0 = default). Returns previous value. */
 int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant);

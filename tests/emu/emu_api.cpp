@@ -14,7 +14,11 @@ typedef uint64_t u64;
 extern "C" {
 void zmt_xxh32_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, const u32 *, const u32 *, u32 *);
 void zmt_lz4_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
-void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u32 *);
+void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u32 *, u32);
+void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
+void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
+void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *, u32 *, unsigned long long *, u32);
+void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, const u32 *, u32 *);
 void zmt_lz4_dec_batch(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u32 *);
 void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 void zmt_scan_kernel(const u32 *, u32, u64 *);
@@ -68,19 +72,50 @@ void emu_lz4_probe_sizes(const u8 *stream, const u64 *rec_off, const u32 *rec_le
 	emu::launch(dim3{1, 1, 1}, dim3{1024, 1, 1}, [=]() { zmt_scan_kernel(out_len, nrec, out_off); });
 }
 
-void emu_lz4_decompress_batch(int variant, const u8 *stream, const u64 *rec_off, const u32 *rec_len,
-			      u32 nrec, u8 *out, const u64 *out_off, const u32 *out_len, u32 *status)
+void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, const u64 *rec_off,
+			      const u32 *rec_len, u32 nrec, u8 *out, u64 out_bytes, const u64 *out_off,
+			      const u32 *out_len, u32 *status)
 {
 	std::vector<u32> ce(nrec), cv(nrec);
 	u32 *cep = ce.data(), *cvp = cv.data();
-	if (variant == 1)
+	if (variant == 1) {
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
-			zmt_lz4_dec_serial(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp);
+			zmt_lz4_dec_serial(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp, 0xFFFFFFFFu);
 		});
-	else
+	} else if (variant == 2) {
 		emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{256, 1, 1}, [=]() {
 			zmt_lz4_dec_batch(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp);
 		});
+	} else {
+		size_t nblk_max = out_bytes / 65536 + nrec + 1;
+		size_t ntok_max = stream_bytes / 3 + 128 * nblk_max + 256;
+		std::vector<u32> est(nrec), rnb(nrec), rfl(nrec), bcs(nblk_max, 0xFFFFFFFFu), bnt(nblk_max), bol(nblk_max), bix(ntok_max / 64 + 2);
+		std::vector<u64> blk0(nrec + 1), bco(nblk_max);
+		std::vector<uint16_t> tok(ntok_max);
+		u32 *estp = est.data(), *rnbp = rnb.data(), *rflp = rfl.data(), *bcsp = bcs.data(), *bntp = bnt.data(), *bolp = bol.data(), *bixp = bix.data();
+		u64 *blk0p = blk0.data(), *bcop = bco.data();
+		uint16_t *tokp = tok.data();
+		emu::launch(dim3{(nrec + 255) / 256, 1, 1}, dim3{256, 1, 1}, [=]() { zmt_dec_nblk_kernel(out_len, nrec, estp); });
+		emu::launch(dim3{1, 1, 1}, dim3{1024, 1, 1}, [=]() { zmt_scan_kernel(estp, nrec, blk0p); });
+		emu::launch(dim3{(nrec + 255) / 256, 1, 1}, dim3{256, 1, 1}, [=]() {
+			zmt_dec_frames_kernel(stream, rec_off, rec_len, nrec, out_len, blk0p, bcop, bcsp, rnbp, rflp, status, cep, cvp);
+		});
+		emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
+			zmt_dec_parse_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bixp, bntp, bolp, nullptr, 0);
+		});
+		if (getenv("ZMT_EMU_DEBUG")) {
+			for (size_t b = 0; b < blk0[nrec]; b++)
+				fprintf(stderr, "blk %zu coff=%llu csize=%x ntok=%u olen=%u\n", b, (unsigned long long)bco[b], bcs[b], bnt[b], bol[b]);
+			for (u32 r = 0; r < nrec; r++)
+				fprintf(stderr, "rec %u status=%u nblk=%u\n", r, status[r], rnb[r]);
+		}
+		emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{256, 1, 1}, [=]() {
+			zmt_dec_copy_kernel(stream, stream_bytes, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bixp, bntp, bolp, status);
+		});
+		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
+			zmt_lz4_dec_serial(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp, 100u);
+		});
+	}
 	emu::launch(dim3{(nrec * 4 + 255) / 256, 1, 1}, dim3{256, 1, 1},
 		    [=]() { zmt_xxh32_kernel(out, out_off, out_len, nrec, nullptr, cep, cvp, status); });
 }

@@ -81,7 +81,8 @@ def decompress(stream: bytes, variant: int = 0, rec=None):
     total = int(out_off[nrec])
     out = np.full(total + 64, 0xCC, np.uint8)
     status = np.full(nrec, 99, np.uint32)
-    L.emu_lz4_decompress_batch(C.c_int(variant), _p(sbuf), _p(ro), _p(rl), C.c_uint32(nrec), _p(out),
-                               _p(out_off), _p(out_len), _p(status))
+    L.emu_lz4_decompress_batch(C.c_int(variant), _p(sbuf), C.c_uint64(len(stream)), _p(ro), _p(rl),
+                               C.c_uint32(nrec), _p(out), C.c_uint64(total), _p(out_off), _p(out_len),
+                               _p(status))
     assert (out[total:] == 0xCC).all(), "decoder wrote past the end of its output"
     return out[:total].tobytes(), status

@@ -36,7 +36,7 @@ def test_emu_compress_bit_exact(name):
     assert H.sha256(stream) == MAN[name]["out_sha256"]
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("name", SMALL)
 def test_emu_decompress(name, variant):
     chunk, thunk = CASES[name]

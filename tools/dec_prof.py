@@ -1,0 +1,63 @@
+"""Per-phase cycle profile of the batch decoder (developer tool)."""
+import sys, os, ctypes as C, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import zstdmt_amd as z
+gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "2", "3"])]
+eng = z.Engine(0); L, h = eng.L, eng.h
+T = C.CDLL(os.path.join(ROOT, "zstdmt_amd", "lib", "libzmt_tools.so"))
+T.zmt_gen_text.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int]
+chunk = 131072
+n = int(gib * (1 << 30)) // chunk * chunk
+nrec = n // chunk; stride = eng.slot_stride(chunk)
+hb = np.empty(n, np.uint8); T.zmt_gen_text(hb.ctypes.data, n, 20260926, 0, 32)
+d_in = eng.upload(hb)
+d_slots = eng.alloc(nrec * stride); d_rl = eng.alloc(nrec * 4); d_ro = eng.alloc((nrec + 1) * 8)
+d_stream = eng.alloc(nrec * stride); d_ol = eng.alloc(nrec * 4); d_oo = eng.alloc((nrec + 1) * 8)
+d_st = eng.alloc(nrec * 4); d_out = eng.alloc(n + 64)
+eng.lz4_compress(d_in, n, chunk, d_slots, stride, d_rl)
+eng.lz4_compact(d_slots, stride, d_rl, nrec, d_stream, d_ro)
+eng.lz4_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo)
+eng.sync()
+names = ["stage", "spec", "walk", "decode+scan+classify", "literals", "fence+far", "rounds", "flush", "slowpath", "batches", "seqs", "total"]
+for v in variants:
+    eng.set_variant("lz4_dec", v)
+    eng.set_variant("profile", 1)
+    for rep in range(2):
+        cnt = (C.c_ulonglong * 16)()
+        L.gpumt_debug_counters(h, cnt, 16)
+        eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st)
+        eng.sync()
+        ms = eng.timer_ms(11)
+    st = eng.download(d_st, nrec * 4, np.uint32)
+    ok = bool((eng.download(d_out, n) == hb).all())
+    print(f"variant {v}: kernel {ms:.3f} ms  ({n/1e6/ms:.1f} GB/s out)  errors={int((st!=0).sum())} data_ok={ok}")
+    if v == 0:
+        for xf in ([int(x) for x in os.environ.get("K2X", "0").split(",")] if os.environ.get("K2PROF") else []):
+            eng.set_variant("k2x", xf)
+            eng.set_variant("profile", 2)
+            cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
+            eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
+            L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); w = max(c[6], 1); st_ = max(c[4], 1)
+            print(f"   K2 prof xflags={xf}: parse_ms={eng.timer_ms(14):.3f} waves={c[6]} steps/wave={c[4]/w:.0f} cycles/step total={c[0]/st_:.0f} refill={c[1]/st_:.0f} token={c[2]/st_:.0f} drain={c[3]/st_:.0f} slowloads/step={c[5]/st_:.2f}")
+            eng.set_variant("profile", 1); eng.set_variant("k2x", 0)
+        if os.environ.get("K3PROF"):
+            eng.set_variant("profile", 3)
+            cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
+            eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
+            L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); nbat = nrec * 2 * 86
+            nm = ["fields", "scan+cuts+reserve", "far-issue", "literals", "far-commit", "rounds", "flush", "loop/other"]
+            print("   K3 prof (cycles per ~batch): " + ", ".join(f"{nm[i]}={c[i]/nbat:.0f}" for i in range(8)) + f" total={c[8]/nbat:.0f}")
+            eng.set_variant("profile", 1)
+        print("   split: frames %.3f ms, parse %.3f ms, copy %.3f ms, xxh %.3f ms" % (eng.timer_ms(13), eng.timer_ms(14), eng.timer_ms(15), eng.timer_ms(12)))
+    if v == 3:
+        L.gpumt_debug_counters(h, cnt, 16)
+        c = list(cnt)
+        nb = max(c[9], 1)
+        print(f"  batches={c[9]} seqs/batch={c[10]/nb:.1f} waves={nrec}")
+        tot = c[11]
+        for i in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+            print(f"  {names[i]:22s} {c[i]/nb:9.0f} cyc/batch  {100*c[i]/tot:5.1f}%")
+        print(f"  {'total/wave':22s} {tot/nrec:9.0f} cycles; per batch {tot/nb:.0f}")

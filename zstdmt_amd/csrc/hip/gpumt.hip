@@ -12,6 +12,7 @@
 #include "../../../include/gpumt.h"
 
 typedef uint8_t u8;
+typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
@@ -20,9 +21,22 @@ __global__ void zmt_xxh32_kernel(const u8 *, const u64 *, const u32 *, u32, u32 
 				 const u32 *, u32 *);
 __global__ void zmt_lz4_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
 __global__ void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
-				   const u32 *, u32 *, u32 *, u32 *);
+				   const u32 *, u32 *, u32 *, u32 *, u32);
+__global__ void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
+__global__ void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *,
+				      const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
+__global__ void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *,
+				     u32 *, u32 *, u32 *, unsigned long long *, u32);
+__global__ void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
+				    const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
+				    const u32 *, const u32 *, const u32 *, u32 *);
+__global__ void zmt_dec_copy_kernel_prof(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
+					 const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
+					 const u32 *, const u32 *, const u32 *, u32 *, unsigned long long *);
 __global__ void zmt_lz4_dec_batch(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
 				  const u32 *, u32 *, u32 *, u32 *);
+__global__ void zmt_lz4_dec_batch_prof(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
+				       const u32 *, u32 *, u32 *, u32 *, unsigned long long *);
 __global__ void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 __global__ void zmt_scan_kernel(const u32 *, u32, u64 *);
 __global__ void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
@@ -40,6 +54,8 @@ struct gpumt_ctx {
 	void *scratch[2];        /* [0] compress side, [1] decompress side */
 	size_t scratch_bytes[2];
 	int dec_variant;
+	unsigned long long *d_prof; /* 16 phase counters of the profiling decoder */
+	int xflags;  /* experiment switches of the parse kernel (developer) */
 	int profile; /* record events in timer slots 8.. around individual kernels */
 	char err[256];
 	char name[128];
@@ -398,35 +414,124 @@ int gpumt_lz4_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d_
 	return GPUMT_OK;
 }
 
-int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
-			       const uint32_t *d_rec_len, size_t nrec, void *d_out,
-			       const uint64_t *d_out_off, const uint32_t *d_out_len,
-			       uint32_t *d_status, int s)
+int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream_bytes,
+			       const uint64_t *d_rec_off, const uint32_t *d_rec_len, size_t nrec,
+			       void *d_out, size_t out_bytes, const uint64_t *d_out_off,
+			       const uint32_t *d_out_len, uint32_t *d_status, int s)
 {
 	if (!h || !STREAM_OK(s) || nrec == 0 || nrec > 0x3FFFFFFFu)
 		return GPUMT_E_ARG;
 	if (use(h))
 		return GPUMT_E_HIP;
-	if (want_scratch(h, 1, nrec * 8))
+	const u32 n = (u32)nrec;
+	const unsigned g256 = (unsigned)((nrec + 255) / 256);
+	/* scratch carve-up (all offsets 16-byte aligned) */
+	const size_t nblk_max = out_bytes / 65536 + nrec + 1;
+	const size_t ntok_max = stream_bytes / 3 + 128 * nblk_max + 256;
+	size_t off = 0;
+#define CARVE(var, type, count)                                                                    \
+	size_t var##_o = off;                                                                      \
+	off += (((size_t)(count) * sizeof(type)) + 15) & ~(size_t)15;
+	CARVE(ce, u32, nrec)
+	CARVE(cv, u32, nrec)
+	CARVE(est, u32, nrec)
+	CARVE(blk0, u64, nrec + 1)
+	CARVE(rnb, u32, nrec)
+	CARVE(rfl, u32, nrec)
+	CARVE(bco, u64, nblk_max)
+	CARVE(bcs, u32, nblk_max)
+	CARVE(bnt, u32, nblk_max)
+	CARVE(bol, u32, nblk_max)
+	CARVE(bix, u32, ntok_max / 64 + 2)
+	CARVE(tok, u16, ntok_max)
+#undef CARVE
+	const bool split = (h->dec_variant == 0);
+	if (h->profile >= 2 && !h->d_prof) {
+		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
+		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
+	}
+	if (want_scratch(h, 1, split ? off : nrec * 8 + 32))
 		return GPUMT_E_HIP;
-	u32 *ce = (u32 *)h->scratch[1], *cv = ce + nrec;
+	u8 *sc = (u8 *)h->scratch[1];
+	u32 *ce = (u32 *)(sc + ce_o), *cv = (u32 *)(sc + cv_o);
 	PROF0(11);
-	if (h->dec_variant == 1)
-		hipLaunchKernelGGL(zmt_lz4_dec_serial, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
-				   (const u8 *)d_stream, d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out,
-				   d_out_off, d_out_len, d_status, ce, cv);
-	else
+	if (split) {
+		u32 *est = (u32 *)(sc + est_o), *rnb = (u32 *)(sc + rnb_o), *rfl = (u32 *)(sc + rfl_o);
+		u64 *blk0 = (u64 *)(sc + blk0_o), *bco = (u64 *)(sc + bco_o);
+		u32 *bcs = (u32 *)(sc + bcs_o), *bnt = (u32 *)(sc + bnt_o), *bol = (u32 *)(sc + bol_o);
+		u32 *bix = (u32 *)(sc + bix_o);
+		u16 *tok = (u16 *)(sc + tok_o);
+		PROF0(13);
+		hipLaunchKernelGGL(zmt_dec_nblk_kernel, dim3(g256), dim3(256), 0, h->st[s], d_out_len, n, est);
+		hipLaunchKernelGGL(zmt_scan_kernel, dim3(1), dim3(1024), 0, h->st[s], (const u32 *)est, n, blk0);
+		hipLaunchKernelGGL(zmt_dec_frames_kernel, dim3(g256), dim3(256), 0, h->st[s],
+				   (const u8 *)d_stream, d_rec_off, d_rec_len, n, d_out_len,
+				   (const u64 *)blk0, bco, bcs, rnb, rfl, d_status, ce, cv);
+		PROF1(13);
+		PROF0(14);
+		hipLaunchKernelGGL(zmt_dec_parse_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
+				   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
+				   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bix, bnt, bol,
+				   h->profile == 2 ? h->d_prof : (unsigned long long *)NULL, (u32)h->xflags);
+		PROF1(14);
+		PROF0(15);
+		if (h->profile == 3)
+			hipLaunchKernelGGL(zmt_dec_copy_kernel_prof, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0,
+					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, n, (u8 *)d_out,
+					   d_out_off, d_out_len, (const u64 *)blk0, (const u64 *)bco,
+					   (const u32 *)bcs, (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok,
+					   (const u32 *)bix, (const u32 *)bnt, (const u32 *)bol, d_status, h->d_prof);
+		else
+			hipLaunchKernelGGL(zmt_dec_copy_kernel, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0,
+					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, n, (u8 *)d_out,
+					   d_out_off, d_out_len, (const u64 *)blk0, (const u64 *)bco,
+					   (const u32 *)bcs, (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok,
+					   (const u32 *)bix, (const u32 *)bnt, (const u32 *)bol, d_status);
+		PROF1(15);
+		/* records the fast path does not cover (block size > 64 KiB, odd block counts) */
+		hipLaunchKernelGGL(zmt_lz4_dec_serial, dim3(n), dim3(64), 0, h->st[s], (const u8 *)d_stream,
+				   d_rec_off, d_rec_len, n, (u8 *)d_out, d_out_off, d_out_len, d_status, ce,
+				   cv, 100u);
+	} else if (h->dec_variant == 3) {
+		if (!h->d_prof)
+			CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
+		hipLaunchKernelGGL(zmt_lz4_dec_batch_prof, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0,
+				   h->st[s], (const u8 *)d_stream, d_rec_off, d_rec_len, n, (u8 *)d_out,
+				   d_out_off, d_out_len, d_status, ce, cv, h->d_prof);
+	} else if (h->dec_variant == 1) {
+		hipLaunchKernelGGL(zmt_lz4_dec_serial, dim3(n), dim3(64), 0, h->st[s], (const u8 *)d_stream,
+				   d_rec_off, d_rec_len, n, (u8 *)d_out, d_out_off, d_out_len, d_status, ce,
+				   cv, 0xFFFFFFFFu);
+	} else {
 		hipLaunchKernelGGL(zmt_lz4_dec_batch, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0,
-				   h->st[s], (const u8 *)d_stream, d_rec_off, d_rec_len, (u32)nrec,
-				   (u8 *)d_out, d_out_off, d_out_len, d_status, ce, cv);
+				   h->st[s], (const u8 *)d_stream, d_rec_off, d_rec_len, n, (u8 *)d_out,
+				   d_out_off, d_out_len, d_status, ce, cv);
+	}
 	PROF1(11);
 	PROF0(12);
 	hipLaunchKernelGGL(zmt_xxh32_kernel, dim3((unsigned)((nrec * 4 + 255) / 256)), dim3(256), 0,
-			   h->st[s], (const u8 *)d_out, d_out_off, d_out_len, (u32)nrec, (u32 *)NULL,
+			   h->st[s], (const u8 *)d_out, d_out_off, d_out_len, n, (u32 *)NULL,
 			   (const u32 *)ce, (const u32 *)cv, d_status);
 	PROF1(12);
 	CK(hipGetLastError());
 	return GPUMT_OK;
+}
+
+/* read (and clear) the phase counters of the profiling decoder; returns count written */
+int gpumt_debug_counters(gpumt_ctx *h, unsigned long long *dst, int n)
+{
+	if (!h || !dst || n < 16)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	if (!h->d_prof) {
+		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
+		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
+	}
+	CK(hipDeviceSynchronize());
+	CK(hipMemcpy(dst, h->d_prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
+	return 16;
 }
 
 int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
@@ -437,6 +542,9 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	if (!strcmp(what, "lz4_dec")) {
 		prev = h->dec_variant;
 		h->dec_variant = variant;
+	} else if (!strcmp(what, "k2x")) {
+		prev = h->xflags;
+		h->xflags = variant;
 	} else if (!strcmp(what, "profile")) {
 		prev = h->profile;
 		h->profile = variant;

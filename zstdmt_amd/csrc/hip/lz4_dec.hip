@@ -87,11 +87,14 @@ zmt_lz4_dec_serial(const u8 *__restrict__ stream, const u64 *__restrict__ rec_of
 		   const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
 		   const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
 		   u32 *__restrict__ status, u32 *__restrict__ chk_expect,
-		   u32 *__restrict__ chk_valid)
+		   u32 *__restrict__ chk_valid, u32 only_status)
 {
 	const u32 rec = blockIdx.x;
 	const int lane = wv_lane();
 	if (rec >= nrec)
+		return;
+	/* clean-up pass of the split decoder: only records it flagged for this kernel */
+	if (only_status != 0xFFFFFFFFu && wv_readfirst(status[rec]) != only_status)
 		return;
 	const u8 *r = stream + rec_off[rec];
 	const u32 rlen = rec_len[rec];

@@ -64,6 +64,8 @@ static inline u64 wv_ballot(bool p)
 }
 static inline int wv_popc(u64 m) { return __builtin_popcountll(m); }
 static inline int wv_ffs(u64 m) { return __builtin_ffsll((long long)m); } /* 1-based, 0 if none */
+/* number of set bits of m below this lane */
+static inline u32 wv_mbcnt(u64 m) { return (u32)__builtin_popcountll(m & ((1ull << wv_lane()) - 1)); }
 static inline void wv_sleep() {}
 #define ZMT_UNROLL
 
@@ -94,6 +96,10 @@ static __device__ __forceinline__ u32 wv_readfirst(u32 v)
 static __device__ __forceinline__ u64 wv_ballot(bool p) { return __ballot(p); }
 static __device__ __forceinline__ int wv_popc(u64 m) { return __popcll(m); }
 static __device__ __forceinline__ int wv_ffs(u64 m) { return __ffsll((unsigned long long)m); }
+static __device__ __forceinline__ u32 wv_mbcnt(u64 m)
+{
+	return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0));
+}
 static __device__ __forceinline__ void wv_sleep() { __builtin_amdgcn_s_sleep(2); }
 #define ZMT_UNROLL _Pragma("unroll")
 #endif
@@ -103,10 +109,10 @@ static __device__ __forceinline__ bool wv_any(bool p) { return wv_ballot(p) != 0
 static __device__ __forceinline__ bool wv_all(bool p) { return wv_ballot(!p) == 0; }
 
 /* inclusive prefix sum over the 64 lanes */
-static __device__ __forceinline__ u32 wv_scan_incl(u32 v)
+#ifdef ZMT_EMU
+static inline u32 wv_scan_incl(u32 v)
 {
 	int l = wv_lane();
-	ZMT_UNROLL
 	for (int d = 1; d < 64; d <<= 1) {
 		u32 o = wv_shfl(v, l - d);
 		if (l >= d)
@@ -114,6 +120,20 @@ static __device__ __forceinline__ u32 wv_scan_incl(u32 v)
 	}
 	return v;
 }
+#else
+/* DPP row shifts inside each 16-lane row, then row broadcasts (gfx9 row_bcast15 / row_bcast31);
+ * lanes a shift has no source for keep the `old` operand, 0 */
+static __device__ __forceinline__ u32 wv_scan_incl(u32 v)
+{
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); /* row_bcast:15 -> rows 1,3 */
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); /* row_bcast:31 -> rows 2,3 */
+	return v;
+}
+#endif
 
 /* unaligned little-endian accesses (gfx950 global memory handles misaligned dwords natively) */
 static __device__ __forceinline__ u32 ld32u(const u8 *p)

@@ -114,10 +114,11 @@ class Engine:
         self._ck(self.L.gpumt_lz4_probe_sizes(self.h, d_stream.ptr, d_rec_off.ptr, d_rec_len.ptr, nrec,
                                               d_out_len.ptr, d_out_off.ptr, stream), "lz4_probe_sizes")
 
-    def lz4_decompress(self, d_stream, d_rec_off, d_rec_len, nrec, d_out, d_out_off, d_out_len,
-                       d_status, stream=0):
-        self._ck(self.L.gpumt_lz4_decompress_batch(self.h, d_stream.ptr, d_rec_off.ptr, d_rec_len.ptr,
-                                                   nrec, d_out.ptr, d_out_off.ptr, d_out_len.ptr,
+    def lz4_decompress(self, d_stream, stream_bytes, d_rec_off, d_rec_len, nrec, d_out, out_bytes,
+                       d_out_off, d_out_len, d_status, stream=0):
+        self._ck(self.L.gpumt_lz4_decompress_batch(self.h, d_stream.ptr, int(stream_bytes),
+                                                   d_rec_off.ptr, d_rec_len.ptr, nrec, d_out.ptr,
+                                                   int(out_bytes), d_out_off.ptr, d_out_len.ptr,
                                                    d_status.ptr, stream), "lz4_decompress_batch")
 
     # ---- convenience round trips on host bytes (tests) ----------------------------------------
@@ -163,7 +164,7 @@ class Engine:
             d_out = self.alloc(total + 64)
             try:
                 lib().gpumt_memset(self.h, d_out.ptr, 0xCC, total + 64, 0)
-                self.lz4_decompress(d_stream, d_ro, d_rl, nrec, d_out, d_oo, d_ol, d_st)
+                self.lz4_decompress(d_stream, len(stream), d_ro, d_rl, nrec, d_out, total, d_oo, d_ol, d_st)
                 status = self.download(d_st, nrec * 4, np.uint32)
                 raw = self.download(d_out, total + 64)
                 assert (raw[total:] == 0xCC).all(), "decoder wrote past the end of its output"
