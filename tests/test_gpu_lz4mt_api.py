@@ -1,0 +1,166 @@
+"""The drop-in boundary: LZ4MT_* of libzstdmt_amd.so (include/lz4-mt.h) driven through the same
+callback protocol as the reference (lib/lz4-mt.h), checked against the golden vectors, the oracle
+and -- where oracle/_ref is present -- the reference library itself, call for call."""
+import ctypes as C
+import json
+import os
+
+import pytest
+
+import helpers as H
+from cases import CASES, rnd, text
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(H.GOLDEN_DIR, "manifest.json")) as _f:
+    MAN = json.load(_f)["cases"]
+
+ERR = lambda e: C.c_size_t(-e).value  # noqa: E731  (size_t)-enum
+E_MEM, E_READ, E_WRITE, E_DATA, E_FC, E_FD, E_PARAM, E_LIB, E_CANCEL = range(1, 10)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from zstdmt_amd._native import lib_path
+    return H.bind_lz4mt(C.CDLL(lib_path()))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_compress_matches_reference_golden(lib, name):
+    chunk, thunk = CASES[name]
+    data = thunk()
+    rv, stream, io, stats = H.lz4mt_compress_via(lib, data, chunk, threads=4, level=1)
+    e = MAN[name]
+    assert rv == 0
+    assert len(stream) == e["out_len"] and H.sha256(stream) == e["out_sha256"]
+    # statistics as the reference reports them (frames written, bytes read, bytes written)
+    assert stats == (e["frames"], e["insize"], e["outsize"])
+    # one fn_read of exactly `inputsize` per chunk (+ the terminating empty read), one fn_write
+    # per record, in order
+    assert all(want == chunk for want, _ in io.reads)
+    assert len(io.writes) == e["frames"]
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_decompress_golden(lib, name):
+    chunk, thunk = CASES[name]
+    data = thunk()
+    stream = H.oracle_compress(data, chunk)
+    rv, out, io, stats = H.lz4mt_decompress_via(lib, stream, threads=2)
+    e = MAN[name]
+    assert rv == 0 and out == data
+    assert stats == (e["frames"], e["d_insize"], e["d_outsize"])
+    # read pattern of pt_read: 4-byte sniff, 8-byte rest of the first header, payload, then
+    # 12-byte headers + payloads, then the empty read that signals EOF
+    wants = [w for w, _ in io.reads]
+    assert wants[0] == 4 and wants[1] == 8
+    assert wants[-1] == 12 and io.reads[-1][1] == 0
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", ["empty", "hello_5", "text_3x128k_p100", "zeros_262149",
+                                  "text_300k_chunk64k", "rnd_512k_chunk256k"])
+def test_callback_trace_equals_reference(lib, name):
+    """Same requests, same sizes, same order as the reference library (T=1: deterministic)."""
+    chunk, thunk = CASES[name]
+    data = thunk()
+    ref = H.ref()
+    rv_r, s_r, io_r, st_r = H.lz4mt_compress_via(ref, data, chunk, threads=1)
+    rv_o, s_o, io_o, st_o = H.lz4mt_compress_via(lib, data, chunk, threads=1)
+    assert (rv_o, s_o, st_o) == (rv_r, s_r, st_r)
+    assert io_o.reads == io_r.reads and io_o.writes == io_r.writes
+    rv_r, d_r, io_r, st_r = H.lz4mt_decompress_via(ref, s_r, threads=1)
+    rv_o, d_o, io_o, st_o = H.lz4mt_decompress_via(lib, s_r, threads=1)
+    assert (rv_o, d_o, st_o) == (rv_r, d_r, st_r)
+    assert io_o.reads == io_r.reads and io_o.writes == io_r.writes
+
+
+def test_large_pipeline_many_batches(lib):
+    """> 2 device batches each way (64 MiB per batch): exercises the double-buffered pipeline."""
+    data = text(200 << 20)
+    rv, stream, io, stats = H.lz4mt_compress_via(lib, data, 131072, threads=8)
+    assert rv == 0 and stats[0] == 1600
+    for i in (0, 511, 512, 1599):   # batch boundaries included
+        off = sum(io.writes[:i])
+        assert stream[off:off + io.writes[i]] == H.oracle_compress(data[i * 131072:(i + 1) * 131072], 131072)
+    rv, out, _, dstats = H.lz4mt_decompress_via(lib, stream, threads=8)
+    assert rv == 0 and out == data and dstats[0] == 1600
+
+
+def test_config1_default_chunk(lib):
+    """BASELINE config 1 through the API: inputsize 0 -> 4 MiB chunks, 64 MiB of PRNG bytes."""
+    data = rnd(64 << 20, 7)
+    rv, stream, io, stats = H.lz4mt_compress_via(lib, data, 0, threads=4)
+    assert rv == 0 and stats == (16, 64 << 20, (64 << 20) + 4656)
+    assert all(w == 4 << 20 for w, _ in io.reads)
+    rv, out, _, _ = H.lz4mt_decompress_via(lib, stream, threads=4)
+    assert rv == 0 and out == data
+
+
+def test_create_argument_checks(lib):
+    assert not lib.LZ4MT_createCCtx(0, 1, 0)
+    assert not lib.LZ4MT_createCCtx(129, 1, 0)
+    assert not lib.LZ4MT_createCCtx(1, 0, 0)
+    assert not lib.LZ4MT_createCCtx(1, 13, 0)
+    assert not lib.LZ4MT_createDCtx(0, 0)
+    assert not lib.LZ4MT_createDCtx(129, 0)
+    io = H.MemIO(b"x")
+    assert lib.LZ4MT_compressCCtx(None, C.byref(io.rdwr)) == ERR(E_PARAM)
+    assert lib.LZ4MT_decompressDCtx(None, C.byref(io.rdwr)) == ERR(E_PARAM)
+    # LZ4HC levels: context is created, compression reports the parameter as unsupported
+    rv, _, _, _ = H.lz4mt_compress_via(lib, b"abc", 131072, threads=1, level=3)
+    assert rv == ERR(E_PARAM) and lib.LZ4MT_isError(rv)
+    assert lib.LZ4MT_getErrorString(rv) == b"Compression parameter is out of bound"
+    assert not lib.LZ4MT_isError(0)
+
+
+@pytest.mark.parametrize("rv_cb,code", [(-1, E_READ), (-2, E_CANCEL), (-3, E_MEM), (-7, E_READ)])
+def test_read_failures(lib, rv_cb, code):
+    data = text(400000)
+    io = H.MemIO(data, fail_read_at=2, read_rv=rv_cb)
+    ctx = lib.LZ4MT_createCCtx(2, 1, 131072)
+    assert lib.LZ4MT_compressCCtx(ctx, C.byref(io.rdwr)) == ERR(code)
+    lib.LZ4MT_freeCCtx(ctx)
+    stream = H.oracle_compress(data, 131072)
+    io = H.MemIO(stream, fail_read_at=3, read_rv=rv_cb)
+    ctx = lib.LZ4MT_createDCtx(2, 0)
+    assert lib.LZ4MT_decompressDCtx(ctx, C.byref(io.rdwr)) == ERR(code)
+    lib.LZ4MT_freeDCtx(ctx)
+
+
+def test_write_failure_maps_like_reference(lib):
+    """The reference routes write failures through mt_error(): -1 surfaces as read_fail."""
+    data = text(400000)
+    io = H.MemIO(data, fail_write_at=1, write_rv=-1)
+    ctx = lib.LZ4MT_createCCtx(2, 1, 131072)
+    assert lib.LZ4MT_compressCCtx(ctx, C.byref(io.rdwr)) == ERR(E_READ)
+    lib.LZ4MT_freeCCtx(ctx)
+
+
+@pytest.mark.parametrize("mutate,code", [("badmagic", E_DATA), ("notlz4", E_DATA), ("skiplen", E_DATA),
+                                         ("truncated", E_DATA), ("frame", E_LIB), ("checksum", E_LIB),
+                                         ("secondmagic", E_DATA), ("plainlz4", E_FD)])
+def test_decompress_errors(lib, mutate, code):
+    data = text(300000)
+    s = bytearray(H.oracle_compress(data, 131072))
+    if mutate == "badmagic":
+        s[0] ^= 1                      # neither skippable nor LZ4F magic
+    elif mutate == "notlz4":
+        s[:4] = b"\x28\xb5\x2f\xfd"    # a zstd magic
+    elif mutate == "skiplen":
+        s[4] = 8
+    elif mutate == "truncated":
+        s = s[:-10]
+    elif mutate == "frame":
+        s[12] ^= 1                     # LZ4F magic inside the first record
+    elif mutate == "checksum":
+        s[-1] ^= 0x40
+    elif mutate == "secondmagic":
+        import struct
+        c0 = struct.unpack_from("<I", s, 8)[0]
+        s[12 + c0] ^= 1                # skippable magic of the second record
+    elif mutate == "plainlz4":
+        s = s[12:]                     # a bare LZ4 frame: reference falls back to st_decompress
+    rv, out, _, _ = H.lz4mt_decompress_via(lib, bytes(s), threads=2)
+    assert rv == ERR(code), (rv, lib.LZ4MT_getErrorString(rv))
+    assert lib.LZ4MT_isError(rv)

@@ -1,0 +1,592 @@
+/*
+ * lz4mt_engine.c -- the host side of lz4-mt on MI355X: LZ4MT_* (include/lz4-mt.h) over gpumt_*.
+ *
+ * Replaces the pthread worker pool of the reference (lib/lz4-mt_compress.c:207-353,
+ * lib/lz4-mt_decompress.c:165-567): instead of T threads each pulling one chunk through the codec,
+ * one host thread moves *batches* of chunks through a three-stage device pipeline
+ *
+ *        fn_read -> pinned in[s]  --H2D (stream 1)-->  kernels (stream 0)  --D2H (stream 2)-->
+ *        pinned out[s] -> fn_write
+ *
+ * with two slots s, so that reading batch i+1 and writing batch i-1 overlap the kernels of
+ * batch i.  Callback-visible behaviour follows the reference: compress issues one fn_read of
+ * exactly `inputsize` bytes per chunk and one fn_write per record, in input order; decompress
+ * reads 4, then 8|12 header bytes and the payload per record, and writes one chunk per call.
+ * This file is plain C and never includes a HIP header.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gpumt.h"
+#include "lz4-mt.h"
+
+#define BATCH_BYTES ((size_t)64 << 20) /* uncompressed bytes per device batch (target) */
+#define BATCH_MAXREC 8192
+
+size_t lz4mt_errcode;
+
+/* ------------------------------------------------------------------ errors (lz4-mt_common.c) */
+unsigned LZ4MT_isError(size_t code)
+{
+	return code > ERROR(maxCode);
+}
+
+const char *LZ4MT_getErrorString(size_t code)
+{
+	static const char *const names[] = {
+		"No error detected",
+		"Allocation error : not enough memory",
+		"Read failure",
+		"Write failure",
+		"Malformed input",
+		"Could not compress frame at once",
+		"Could not decompress frame at once",
+		"Compression parameter is out of bound",
+		"Compression library reports failure",
+		"Unspecified lz4mt error code", /* canceled has no text in the reference either */
+	};
+	static const char *const codec[] = {
+		"", "device: malformed record header", "device: bad LZ4 frame header",
+		"device: malformed LZ4 block", "device: content size mismatch",
+		"device: content checksum mismatch", "device: trailing bytes after frame",
+		"device: unsupported LZ4 frame feature",
+	};
+	size_t idx = (size_t)0 - code;
+	/* like the reference, a pending codec-level error takes precedence */
+	if (lz4mt_errcode >= 1 && lz4mt_errcode <= 7 && idx == LZ4MT_error_compression_library)
+		return codec[lz4mt_errcode];
+	if (idx < LZ4MT_error_canceled)
+		return names[idx];
+	return names[9];
+}
+
+/* callback return value -> library error (reference mt_error, lz4-mt_compress.c:161-173; note
+ * that write failures go through the same mapping and so surface as read_fail) */
+static size_t mt_error(int rv)
+{
+	switch (rv) {
+	case -1:
+		return ERROR(read_fail);
+	case -2:
+		return ERROR(canceled);
+	case -3:
+		return ERROR(memory_allocation);
+	}
+	return ERROR(read_fail);
+}
+
+static uint32_t rd32(const uint8_t *p)
+{
+	return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+static uint64_t rd64(const uint8_t *p)
+{
+	return (uint64_t)rd32(p) | (uint64_t)rd32(p + 4) << 32;
+}
+
+/* a device buffer + pinned mirror that only ever grows */
+typedef struct {
+	void *d;
+	void *h;
+	size_t cap;
+} dbuf;
+
+static int dbuf_want(gpumt_ctx *g, dbuf *b, size_t bytes, int pinned, int device)
+{
+	if (bytes <= b->cap)
+		return 0;
+	gpumt_device_sync(g);
+	if (b->d)
+		gpumt_free(g, b->d);
+	if (b->h)
+		gpumt_host_free(g, b->h);
+	b->d = b->h = NULL;
+	b->cap = 0;
+	bytes += bytes / 8 + 4096;
+	if (device && !(b->d = gpumt_malloc(g, bytes)))
+		return -1;
+	if (pinned && !(b->h = gpumt_host_alloc(g, bytes)))
+		return -1;
+	b->cap = bytes;
+	return 0;
+}
+static void dbuf_free(gpumt_ctx *g, dbuf *b)
+{
+	if (b->d)
+		gpumt_free(g, b->d);
+	if (b->h)
+		gpumt_host_free(g, b->h);
+	memset(b, 0, sizeof *b);
+}
+
+/* =================================================================== compression ============ */
+struct cslot {
+	dbuf in;      /* chunk data, H2D                       */
+	dbuf slots;   /* device only: per-chunk records        */
+	dbuf stream;  /* packed records, D2H                   */
+	dbuf meta;    /* rec_len[n] u32 | pad | rec_off[n+1] u64, D2H */
+	size_t n;     /* bytes in the batch                    */
+	size_t nrec;
+};
+
+struct LZ4MT_CCtx_s {
+	int level, threads, inputsize;
+	size_t insize, outsize, curframe, frames;
+	gpumt_ctx *gpu;
+	struct cslot s[2];
+};
+
+LZ4MT_CCtx *LZ4MT_createCCtx(int threads, int level, int inputsize)
+{
+	LZ4MT_CCtx *ctx;
+	if (threads < 1 || threads > LZ4MT_THREAD_MAX)
+		return NULL;
+	if (level < LZ4MT_LEVEL_MIN || level > LZ4MT_LEVEL_MAX)
+		return NULL;
+	if (inputsize < 0)
+		return NULL;
+	ctx = (LZ4MT_CCtx *)calloc(1, sizeof *ctx);
+	if (!ctx)
+		return NULL;
+	ctx->level = level;
+	ctx->threads = threads;
+	ctx->inputsize = inputsize ? inputsize : 1024 * 1024 * 4; /* lz4-mt_compress.c:111-114 */
+	if (gpumt_open(0, &ctx->gpu) != GPUMT_OK) {
+		free(ctx); /* no device: fail loudly, there is no CPU path */
+		return NULL;
+	}
+	return ctx;
+}
+
+void LZ4MT_freeCCtx(LZ4MT_CCtx *ctx)
+{
+	if (!ctx)
+		return;
+	for (int i = 0; i < 2; i++) {
+		dbuf_free(ctx->gpu, &ctx->s[i].in);
+		dbuf_free(ctx->gpu, &ctx->s[i].slots);
+		dbuf_free(ctx->gpu, &ctx->s[i].stream);
+		dbuf_free(ctx->gpu, &ctx->s[i].meta);
+	}
+	gpumt_close(ctx->gpu);
+	free(ctx);
+}
+
+size_t LZ4MT_GetFramesCCtx(LZ4MT_CCtx *ctx) { return ctx ? ctx->curframe : 0; }
+size_t LZ4MT_GetInsizeCCtx(LZ4MT_CCtx *ctx) { return ctx ? ctx->insize : 0; }
+size_t LZ4MT_GetOutsizeCCtx(LZ4MT_CCtx *ctx) { return ctx ? ctx->outsize : 0; }
+
+/*
+ * Fill slot s with up to `maxrec` chunks.  Returns 0, or an error code; *eof is set when the
+ * input is exhausted.  A short (non-zero) read is a short chunk and closes the batch, exactly
+ * one fn_read per chunk as in pt_compress (lz4-mt_compress.c:256-277).
+ */
+static size_t c_read_batch(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *io, struct cslot *s, size_t maxrec, int *eof)
+{
+	const size_t chunk = (size_t)ctx->inputsize;
+	s->n = 0;
+	s->nrec = 0;
+	while (s->nrec < maxrec) {
+		LZ4MT_Buffer b;
+		int rv;
+		b.buf = (uint8_t *)s->in.h + s->n;
+		b.size = chunk;
+		b.allocated = chunk;
+		rv = io->fn_read(io->arg_read, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		if (b.size == 0 && ctx->frames > 0) {
+			*eof = 1;
+			break;
+		}
+		if (b.size > chunk)
+			return ERROR(read_fail);
+		ctx->insize += b.size;
+		ctx->frames++;
+		s->n += b.size;
+		s->nrec++;
+		if (b.size < chunk)
+			break; /* ragged chunk (or the empty first read, which still yields one empty
+				* frame): it must be the last one of this device batch; reading goes on
+				* with the next batch, as the reference's loop does */
+	}
+	return 0;
+}
+
+static size_t c_launch(LZ4MT_CCtx *ctx, struct cslot *s)
+{
+	gpumt_ctx *g = ctx->gpu;
+	const size_t chunk = (size_t)ctx->inputsize;
+	const size_t stride = gpumt_lz4_slot_stride(chunk);
+	uint32_t *d_len = (uint32_t *)s->meta.d;
+	uint64_t *d_off = (uint64_t *)((uint8_t *)s->meta.d + ((s->nrec * 4 + 15) & ~(size_t)15));
+	int rc = 0;
+	if (s->n)
+		rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, s->n, 1);
+	rc |= gpumt_stream_wait(g, 0, 1);
+	rc |= gpumt_lz4_compress_batch(g, s->in.d, s->n, chunk, s->slots.d, stride, d_len, 0);
+	rc |= gpumt_lz4_compact(g, s->slots.d, stride, d_len, s->nrec, s->stream.d, d_off, 0);
+	rc |= gpumt_stream_wait(g, 2, 0);
+	rc |= gpumt_memcpy_d2h(g, s->meta.h, s->meta.d, ((s->nrec * 4 + 15) & ~(size_t)15) + (s->nrec + 1) * 8, 2);
+	return rc ? ERROR(compression_library) : 0;
+}
+
+static size_t c_finish(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *io, struct cslot *s)
+{
+	gpumt_ctx *g = ctx->gpu;
+	const uint32_t *len = (const uint32_t *)s->meta.h;
+	const uint64_t *off = (const uint64_t *)((const uint8_t *)s->meta.h + ((s->nrec * 4 + 15) & ~(size_t)15));
+	size_t total;
+	if (gpumt_stream_sync(g, 2))
+		return ERROR(compression_library);
+	total = (size_t)off[s->nrec];
+	if (total > s->stream.cap)
+		return ERROR(frame_compress);
+	if (gpumt_memcpy_d2h(g, s->stream.h, s->stream.d, total, 2) || gpumt_stream_sync(g, 2))
+		return ERROR(compression_library);
+	for (size_t i = 0; i < s->nrec; i++) { /* pt_write: strictly in frame order */
+		LZ4MT_Buffer b;
+		int rv;
+		b.buf = (uint8_t *)s->stream.h + off[i];
+		b.size = len[i];
+		b.allocated = len[i];
+		rv = io->fn_write(io->arg_write, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		ctx->outsize += len[i];
+		ctx->curframe++;
+	}
+	return 0;
+}
+
+size_t LZ4MT_compressCCtx(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *rdwr)
+{
+	size_t chunk, stride, maxrec, err = 0;
+	int eof = 0, cur = 0, have_prev = 0;
+
+	if (!ctx)
+		return ERROR(compressionParameter_unsupported); /* lz4-mt_compress.c:317-318 */
+	if (ctx->level > 2)
+		return ERROR(compressionParameter_unsupported); /* LZ4HC: not on the device yet */
+	chunk = (size_t)ctx->inputsize;
+	stride = gpumt_lz4_slot_stride(chunk);
+	maxrec = BATCH_BYTES / chunk;
+	if (maxrec < 1)
+		maxrec = 1;
+	if (maxrec > BATCH_MAXREC)
+		maxrec = BATCH_MAXREC;
+	for (int i = 0; i < 2; i++) {
+		struct cslot *s = &ctx->s[i];
+		if (dbuf_want(ctx->gpu, &s->in, maxrec * chunk + 64, 1, 1) ||
+		    dbuf_want(ctx->gpu, &s->slots, maxrec * stride, 0, 1) ||
+		    dbuf_want(ctx->gpu, &s->stream, maxrec * stride, 1, 1) ||
+		    dbuf_want(ctx->gpu, &s->meta, maxrec * 12 + 64, 1, 1))
+			return ERROR(memory_allocation);
+	}
+	/* the reference keeps its counters across calls; so do we */
+	while (!eof) {
+		struct cslot *s = &ctx->s[cur];
+		err = c_read_batch(ctx, rdwr, s, maxrec, &eof);
+		if (err)
+			break;
+		if (s->nrec) {
+			err = c_launch(ctx, s);
+			if (err)
+				break;
+		}
+		if (have_prev) {
+			err = c_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
+			have_prev = 0;
+			if (err)
+				break;
+		}
+		if (s->nrec) {
+			have_prev = 1;
+			cur ^= 1;
+		}
+	}
+	if (!err && have_prev)
+		err = c_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
+	gpumt_device_sync(ctx->gpu);
+	return err;
+}
+
+/* ================================================================= decompression ============ */
+struct dslot {
+	dbuf in;     /* record bytes (headers included), H2D                                  */
+	dbuf meta;   /* rec_off u64[n] | out_off u64[n+1] | rec_len u32[n] | out_len u32[n], H2D */
+	dbuf status; /* u32[n], D2H                                                           */
+	dbuf out;    /* decoded chunks, D2H                                                   */
+	size_t nrec, in_bytes, out_bytes;
+};
+
+struct LZ4MT_DCtx_s {
+	int threads, inputsize;
+	size_t insize, outsize, curframe, frames;
+	gpumt_ctx *gpu;
+	struct dslot s[2];
+	/* a record header read ahead of its batch */
+	int have_hdr;
+	uint32_t hdr_csize;
+};
+
+LZ4MT_DCtx *LZ4MT_createDCtx(int threads, int inputsize)
+{
+	LZ4MT_DCtx *ctx;
+	if (threads < 1 || threads > LZ4MT_THREAD_MAX)
+		return NULL;
+	ctx = (LZ4MT_DCtx *)calloc(1, sizeof *ctx);
+	if (!ctx)
+		return NULL;
+	ctx->threads = threads;
+	ctx->inputsize = inputsize ? inputsize : 1024 + 1024 * 4; /* sic, lz4-mt_decompress.c:115 */
+	if (gpumt_open(0, &ctx->gpu) != GPUMT_OK) {
+		free(ctx);
+		return NULL;
+	}
+	return ctx;
+}
+
+void LZ4MT_freeDCtx(LZ4MT_DCtx *ctx)
+{
+	if (!ctx)
+		return;
+	for (int i = 0; i < 2; i++) {
+		dbuf_free(ctx->gpu, &ctx->s[i].in);
+		dbuf_free(ctx->gpu, &ctx->s[i].meta);
+		dbuf_free(ctx->gpu, &ctx->s[i].status);
+		dbuf_free(ctx->gpu, &ctx->s[i].out);
+	}
+	gpumt_close(ctx->gpu);
+	free(ctx);
+}
+
+size_t LZ4MT_GetFramesDCtx(LZ4MT_DCtx *ctx) { return ctx ? ctx->curframe : 0; }
+size_t LZ4MT_GetInsizeDCtx(LZ4MT_DCtx *ctx) { return ctx ? ctx->insize : 0; }
+size_t LZ4MT_GetOutsizeDCtx(LZ4MT_DCtx *ctx) { return ctx ? ctx->outsize : 0; }
+
+#define D_META_BYTES(n) ((n) * 8 + ((n) + 1) * 8 + (n) * 4 + (n) * 4 + 64)
+
+/* host view of a slot's meta arrays (capacity BATCH_MAXREC) */
+static uint64_t *m_rec_off(struct dslot *s, int dev) { return (uint64_t *)(dev ? s->meta.d : s->meta.h); }
+static uint64_t *m_out_off(struct dslot *s, int dev) { return m_rec_off(s, dev) + BATCH_MAXREC; }
+static uint32_t *m_rec_len(struct dslot *s, int dev) { return (uint32_t *)(m_out_off(s, dev) + BATCH_MAXREC + 1); }
+static uint32_t *m_out_len(struct dslot *s, int dev) { return m_rec_len(s, dev) + BATCH_MAXREC; }
+
+/* read one record header (pt_read, lz4-mt_decompress.c:192-236): 0 = ok, *csize set; eof flagged */
+static size_t d_read_header(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, uint32_t *csize, int *eof)
+{
+	uint8_t hb[12];
+	LZ4MT_Buffer b;
+	int rv;
+	if (ctx->frames == 0) { /* magic already consumed by the sniff */
+		b.buf = hb + 4;
+		b.size = 8;
+		b.allocated = 8;
+		rv = io->fn_read(io->arg_read, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		if (b.size != 8)
+			return ERROR(read_fail);
+	} else {
+		b.buf = hb;
+		b.size = 12;
+		b.allocated = 12;
+		rv = io->fn_read(io->arg_read, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		if (b.size == 0) {
+			*eof = 1;
+			return 0;
+		}
+		if (b.size != 12)
+			return ERROR(read_fail);
+		if (rd32(hb) != LZ4FMT_MAGIC_SKIPPABLE)
+			return ERROR(data_error);
+	}
+	if (rd32(hb + 4) != 4)
+		return ERROR(data_error);
+	ctx->insize += 12;
+	*csize = rd32(hb + 8);
+	return 0;
+}
+
+static size_t d_read_batch(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, struct dslot *s, int *eof)
+{
+	s->nrec = 0;
+	s->in_bytes = 0;
+	s->out_bytes = 0;
+	while (s->nrec < BATCH_MAXREC) {
+		uint32_t csize;
+		uint64_t osz = 0;
+		uint8_t *rec;
+		LZ4MT_Buffer b;
+		size_t err;
+		int rv;
+		if (ctx->have_hdr) {
+			csize = ctx->hdr_csize;
+		} else {
+			err = d_read_header(ctx, io, &csize, eof);
+			if (err)
+				return err;
+			if (*eof)
+				break;
+		}
+		/* close the batch when it is full; the header just read waits for the next one */
+		if (s->nrec && (s->in_bytes + 12 + (size_t)csize > s->in.cap - 64 || s->out_bytes >= BATCH_BYTES)) {
+			ctx->have_hdr = 1;
+			ctx->hdr_csize = csize;
+			break;
+		}
+		ctx->have_hdr = 0;
+		if (s->in_bytes + 12 + (size_t)csize + 64 > s->in.cap) {
+			/* a single record larger than the slot: grow (nothing is in flight in this slot) */
+			dbuf old = s->in;
+			memset(&s->in, 0, sizeof s->in);
+			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + 12 + (size_t)csize + 64, 1, 1))
+				return ERROR(memory_allocation);
+			memcpy(s->in.h, old.h, s->in_bytes);
+			dbuf_free(ctx->gpu, &old);
+		}
+		rec = (uint8_t *)s->in.h + s->in_bytes;
+		/* rebuild the 12-byte header in front of the payload: the device checks it too */
+		rec[0] = 0x50; rec[1] = 0x2A; rec[2] = 0x4D; rec[3] = 0x18;
+		rec[4] = 4; rec[5] = rec[6] = rec[7] = 0;
+		rec[8] = (uint8_t)csize; rec[9] = (uint8_t)(csize >> 8);
+		rec[10] = (uint8_t)(csize >> 16); rec[11] = (uint8_t)(csize >> 24);
+		b.buf = rec + 12;
+		b.size = csize;
+		b.allocated = csize;
+		rv = io->fn_read(io->arg_read, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		if (b.size != csize)
+			return ERROR(data_error); /* "needed more bytes" */
+		ctx->insize += csize;
+		ctx->frames++;
+		/* output size = LE64 at payload+6 (lz4-mt_decompress.c:333-334); frames that carry no
+		 * content size (only the empty frame is written that way) decode to nothing */
+		if (csize >= 15 && (rec[12 + 4] & 0x08))
+			osz = rd64(rec + 12 + 6);
+		if (osz > 0xFFFFFFFFull)
+			return ERROR(data_error);
+		m_rec_off(s, 0)[s->nrec] = s->in_bytes;
+		m_rec_len(s, 0)[s->nrec] = 12 + csize;
+		m_out_off(s, 0)[s->nrec] = s->out_bytes;
+		m_out_len(s, 0)[s->nrec] = (uint32_t)osz;
+		s->in_bytes += 12 + (size_t)csize;
+		s->out_bytes += (size_t)osz;
+		s->nrec++;
+	}
+	m_out_off(s, 0)[s->nrec] = s->out_bytes;
+	return 0;
+}
+
+static size_t d_launch(LZ4MT_DCtx *ctx, struct dslot *s)
+{
+	gpumt_ctx *g = ctx->gpu;
+	int rc = 0;
+	if (dbuf_want(g, &s->out, s->out_bytes + 64, 1, 1) || dbuf_want(g, &s->status, s->nrec * 4 + 64, 1, 1))
+		return ERROR(memory_allocation);
+	rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, s->in_bytes, 1);
+	rc |= gpumt_memcpy_h2d(g, s->meta.d, s->meta.h, D_META_BYTES(BATCH_MAXREC), 1);
+	rc |= gpumt_stream_wait(g, 0, 1);
+	rc |= gpumt_lz4_decompress_batch(g, s->in.d, s->in_bytes, m_rec_off(s, 1), m_rec_len(s, 1), s->nrec,
+					 s->out.d, s->out_bytes, m_out_off(s, 1), m_out_len(s, 1),
+					 (uint32_t *)s->status.d, 0);
+	rc |= gpumt_stream_wait(g, 2, 0);
+	rc |= gpumt_memcpy_d2h(g, s->status.h, s->status.d, s->nrec * 4, 2);
+	if (s->out_bytes)
+		rc |= gpumt_memcpy_d2h(g, s->out.h, s->out.d, s->out_bytes, 2);
+	return rc ? ERROR(compression_library) : 0;
+}
+
+static size_t d_finish(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, struct dslot *s)
+{
+	const uint32_t *st = (const uint32_t *)s->status.h;
+	if (gpumt_stream_sync(ctx->gpu, 2))
+		return ERROR(compression_library);
+	for (size_t i = 0; i < s->nrec; i++) {
+		LZ4MT_Buffer b;
+		int rv;
+		if (st[i] != GPUMT_ST_OK) {
+			/* pt_decompress: LZ4F error -> compression_library (code kept in the global),
+			 * frame not consumed exactly -> frame_decompress (lz4-mt_decompress.c:353-362) */
+			if (st[i] == GPUMT_ST_BAD_RECORD)
+				return ERROR(data_error);
+			if (st[i] == GPUMT_ST_TRAILING)
+				return ERROR(frame_decompress);
+			lz4mt_errcode = st[i];
+			return ERROR(compression_library);
+		}
+		b.buf = (uint8_t *)s->out.h + m_out_off(s, 0)[i];
+		b.size = m_out_len(s, 0)[i];
+		b.allocated = b.size;
+		rv = io->fn_write(io->arg_write, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		ctx->outsize += b.size;
+		ctx->curframe++;
+	}
+	return 0;
+}
+
+size_t LZ4MT_decompressDCtx(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *rdwr)
+{
+	uint8_t magic[4];
+	LZ4MT_Buffer b;
+	size_t err = 0;
+	int rv, eof = 0, cur = 0, have_prev = 0;
+
+	if (!ctx)
+		return ERROR(compressionParameter_unsupported); /* lz4-mt_decompress.c:493-494 */
+	/* sniff: 4 bytes (lz4-mt_decompress.c:503-520) */
+	b.buf = magic;
+	b.size = 4;
+	b.allocated = 4;
+	rv = rdwr->fn_read(rdwr->arg_read, &b);
+	if (rv != 0)
+		return mt_error(rv);
+	if (b.size != 4)
+		return ERROR(data_error);
+	if (rd32(magic) != LZ4FMT_MAGIC_SKIPPABLE) {
+		if (rd32(magic) != LZ4FMT_MAGICNUMBER)
+			return ERROR(data_error);
+		/* plain .lz4 stream: the reference decodes it single-threaded (st_decompress, :391-483);
+		 * not on the device path yet -- see INTEGRATION.md */
+		return ERROR(frame_decompress);
+	}
+	for (int i = 0; i < 2; i++) {
+		struct dslot *s = &ctx->s[i];
+		if (dbuf_want(ctx->gpu, &s->in, BATCH_BYTES + (BATCH_BYTES >> 2), 1, 1) ||
+		    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1))
+			return ERROR(memory_allocation);
+	}
+	ctx->have_hdr = 0;
+	while (!eof) {
+		struct dslot *s = &ctx->s[cur];
+		err = d_read_batch(ctx, rdwr, s, &eof);
+		if (err)
+			break;
+		if (s->nrec) {
+			err = d_launch(ctx, s);
+			if (err)
+				break;
+		}
+		if (have_prev) {
+			err = d_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
+			have_prev = 0;
+			if (err)
+				break;
+		}
+		if (s->nrec) {
+			have_prev = 1;
+			cur ^= 1;
+		}
+	}
+	if (!err && have_prev)
+		err = d_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
+	gpumt_device_sync(ctx->gpu);
+	return err;
+}
