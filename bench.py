@@ -158,7 +158,8 @@ def main():
         # slots 1-3: API-level legs; 8..13: individual kernels (profile mode)
         for name, slot in (("compress", 1), ("compact", 2), ("decompress", 3),
                            ("k_xxh32_c", 8), ("k_lz4_enc", 9), ("k_scan_compact", 10),
-                           ("k_lz4_dec", 11), ("k_xxh32_d", 12)):
+                           ("k_lz4_dec", 11), ("k_xxh32_d", 12), ("k_dec_frames", 13),
+                           ("k_dec_parse", 14), ("k_dec_copy", 15)):
             acc[name] = acc.get(name, 0.0) + eng.timer_ms(slot)
     barrier()
     wall = time.perf_counter() - t0
@@ -177,13 +178,10 @@ def main():
     gather_ms = None
     seg_off = 0
     if dist is not None:
-        import torch
-        sizes = torch.zeros(world, dtype=torch.int64, device="cuda")
-        mine = torch.tensor([total_c], dtype=torch.int64, device="cuda")
-        dist.all_gather_into_tensor(sizes, mine)
-        seg_off = int(sizes[:rank].sum().item())
+        from zstdmt_amd.shard import exchange_segment_sizes
+        sizes, seg_off = exchange_segment_sizes(total_c, device="cuda")
         if args.gather:
-            gather_ms = rccl_gather(eng, dist, d_stream, sizes.tolist(), rank, world)
+            gather_ms = rccl_gather(eng, dist, d_stream, sizes, rank, world)
 
     ok = True
     if args.verify:
@@ -202,24 +200,37 @@ def main():
     t_c = (ms["compress"] + ms["compact"]) * 1e-3
     t_d = ms["decompress"] * 1e-3
     kern = {}
+    split = args.dec_variant == 0
+    ntok_bytes = 0.0   # token list written by the parse kernel and read by the copy kernel
     for k, byt in (("k_xxh32_c", U), ("k_lz4_enc", U + Cb), ("k_scan_compact", 2 * Cb),
-                   ("k_lz4_dec", U + Cb), ("k_xxh32_d", U)):
+                   ("k_lz4_dec", U + Cb), ("k_xxh32_d", U), ("k_dec_frames", 0.0),
+                   ("k_dec_parse", Cb), ("k_dec_copy", U + Cb)):
+        if k.startswith("k_dec_") and not split:
+            continue
         t = ms[k] * 1e-3
         kern[k] = {"ms": round(ms[k], 4), "alg_bytes": byt,
                    "GBps": round(byt / t / 1e9, 2) if t > 0 else None}
     dom = max(("k_lz4_enc", "k_lz4_dec", "k_xxh32_c", "k_xxh32_d", "k_scan_compact"),
               key=lambda k: ms[k])
+    traffic = {}
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tf):
+        with open(tf) as f:
+            traffic = json.load(f).get("per_launch_bytes_8gib", {})
 
     def roof(k):
         t = ms[k] * 1e-3
         a = kern[k]["alg_bytes"] / t / 1e9
-        return {"kernel": {"k_lz4_enc": "zmt_lz4_enc_kernel", "k_lz4_dec": "zmt_lz4_dec",
-                           "k_xxh32_c": "zmt_xxh32_kernel", "k_xxh32_d": "zmt_xxh32_kernel",
-                           "k_scan_compact": "zmt_compact_kernel"}[k],
+        kname = {"k_lz4_enc": "zmt_lz4_enc_kernel",
+                 "k_lz4_dec": ("zmt_dec_frames+parse+copy_kernel" if split else "zmt_lz4_dec_*"),
+                 "k_xxh32_c": "zmt_xxh32_kernel", "k_xxh32_d": "zmt_xxh32_kernel",
+                 "k_scan_compact": "zmt_compact_kernel", "k_dec_copy": "zmt_dec_copy_kernel",
+                 "k_dec_parse": "zmt_dec_parse_kernel"}[k]
+        return {"kernel": kname,
                 "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(a * 1e9 / HBM_PEAK, 5), "frac_of_copy_ceiling": round(a * 1e9 / HBM_COPY, 5),
                 "alg_bytes_per_launch": kern[k]["alg_bytes"], "avg_launch_ms": round(ms[k], 4),
-                "traffic": None}
+                "traffic": (traffic.get(kname) if abs(args.gib - 8.0) < 1e-9 else None)}
 
     step_s = wall / args.steps
     res = {
@@ -239,6 +250,7 @@ def main():
         "decompress_MBps": round(world * U / 1e6 / t_d, 1),
         "roofline": roof(dom),
         "roofline_decompress": roof("k_lz4_dec"),
+        "roofline_decompress_copy_kernel": roof("k_dec_copy") if split else None,
         "roofline_decompress_path": {
             "what": "decode + XXH32 verify kernels together", "achieved": round(alg / t_d / 1e9, 2),
             "unit": "GB/s", "frac": round(alg / t_d / HBM_PEAK, 5)},
@@ -255,33 +267,19 @@ def main():
 
 
 def rccl_gather(eng, dist, d_stream, sizes, rank, world):
-    """gatherv of the per-rank compressed segments to rank 0 over RCCL (send/recv), timed."""
+    """gatherv of the per-rank compressed segments to rank 0 over RCCL (zstdmt_amd.shard), timed."""
     import torch
-    t = torch.cuda
-    total = int(sum(sizes))
+    from zstdmt_amd.shard import gather_segments
     mine = int(sizes[rank])
-    # torch tensors for RCCL: stage the segment through a torch-owned buffer (D2D copy, untimed)
+    # RCCL wants torch tensors: stage the segment into a torch-owned buffer (D2D copy, untimed)
     seg = torch.empty(mine, dtype=torch.uint8, device="cuda")
     eng._ck(eng.L.gpumt_memcpy_d2d(eng.h, seg.data_ptr(), d_stream.ptr, mine, 0), "d2d")
     eng.sync(0)
-    full = torch.empty(total if rank == 0 else 1, dtype=torch.uint8, device="cuda")
     dist.barrier()
-    t.synchronize()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if rank == 0:
-        off = 0
-        reqs = []
-        for r in range(world):
-            if r == 0:
-                full[:mine].copy_(seg)
-            else:
-                reqs.append(dist.irecv(full[off:off + int(sizes[r])], src=r))
-            off += int(sizes[r])
-        for q in reqs:
-            q.wait()
-    else:
-        dist.send(seg, dst=0)
-    t.synchronize()
+    gather_segments(seg, sizes, dst=0)
+    torch.cuda.synchronize()
     dist.barrier()
     return round((time.perf_counter() - t0) * 1e3, 3)
 
