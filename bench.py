@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--gib", type=float, default=8.0, help="uncompressed GiB per GPU")
     ap.add_argument("--chunk", type=int, default=131072)
     ap.add_argument("--dec-variant", type=int, default=0)
+    ap.add_argument("--enc-variant", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-mib", type=int, default=2048, help="cpu_baseline sample size")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of segments")
@@ -98,6 +99,7 @@ def main():
     eng = z.Engine(local)
     L, h = eng.L, eng.h
     eng.set_variant("lz4_dec", args.dec_variant)
+    eng.set_variant("lz4_enc", args.enc_variant)
     eng.set_variant("profile", 1)
 
     n = int(args.gib * (1 << 30)) // args.chunk * args.chunk

@@ -89,9 +89,10 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 	} else {
 		size_t nblk_max = out_bytes / 65536 + nrec + 1;
 		size_t ntok_max = stream_bytes / 3 + 128 * nblk_max + 256;
-		std::vector<u32> est(nrec), rnb(nrec), rfl(nrec), bcs(nblk_max, 0xFFFFFFFFu), bnt(nblk_max), bol(nblk_max), bix(ntok_max / 64 + 2);
-		std::vector<u64> blk0(nrec + 1), bco(nblk_max);
-		std::vector<uint16_t> tok(ntok_max);
+		/* scratch starts as garbage, like device memory */
+		std::vector<u32> est(nrec, 0xA5A5A5A5u), rnb(nrec, 0xA5A5A5A5u), rfl(nrec, 0xA5A5A5A5u), bcs(nblk_max, 0x00A5A5A5u), bnt(nblk_max, 0xA5A5A5A5u), bol(nblk_max, 0xA5A5A5A5u), bix(ntok_max / 64 + 2, 0xA5A5A5A5u);
+		std::vector<u64> blk0(nrec + 1, 0xA5A5A5A5A5A5A5A5ull), bco(nblk_max, 0x00A5A5A5A5A5A5A5ull);
+		std::vector<uint16_t> tok(ntok_max, 0xA5A5);
 		u32 *estp = est.data(), *rnbp = rnb.data(), *rflp = rfl.data(), *bcsp = bcs.data(), *bntp = bnt.data(), *bolp = bol.data(), *bixp = bix.data();
 		u64 *blk0p = blk0.data(), *bcop = bco.data();
 		uint16_t *tokp = tok.data();

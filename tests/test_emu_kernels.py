@@ -45,3 +45,43 @@ def test_emu_decompress(name, variant):
     out, status = E.decompress(stream, variant)
     assert status.tolist() == [0] * len(status)
     assert out == data
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("mutate,code", [("magic", 2), ("hc", 2), ("blocksize", 3), ("checksum", 5),
+                                         ("skipmagic", 1), ("skiplen", 1), ("offset0", 3)])
+def test_emu_corrupt_streams(mutate, code, variant):
+    """Same corruptions as tests/test_gpu_lz4.py, on the fiber harness (scratch starts as garbage)."""
+    data = text(131072) + text(70000, seed=5)
+    s = bytearray(H.oracle_compress(data, 131072))
+    if mutate == "magic":
+        s[12] ^= 1
+    elif mutate == "hc":
+        s[12 + 14] ^= 0x10
+    elif mutate == "blocksize":
+        s[12 + 15 + 2] ^= 0x40
+    elif mutate == "checksum":
+        import struct
+        c0 = struct.unpack_from("<I", s, 8)[0]
+        s[12 + c0 - 1] ^= 0x80
+    elif mutate == "skipmagic":
+        s[0] ^= 1
+    elif mutate == "skiplen":
+        s[4] = 8
+    elif mutate == "offset0":
+        p = 12 + 15 + 4
+        lit = s[p] >> 4
+        q = p + 1
+        if lit == 15:
+            while s[q] == 255:
+                lit += 255
+                q += 1
+            lit += s[q]
+            q += 1
+        s[q + lit] = 0
+        s[q + lit + 1] = 0
+    good = H.oracle_compress(data, 131072)
+    rec = E.walk_records(good)   # record boundaries of the uncorrupted stream
+    out, status = E.decompress(bytes(s), variant, rec=rec)
+    assert status.tolist() == [code, 0]
+    assert out[131072:] == data[131072:]   # the healthy record still decodes

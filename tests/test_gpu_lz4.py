@@ -26,11 +26,16 @@ def eng():
     e.close()
 
 
+@pytest.mark.parametrize("enc", [0, 1])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_compress_golden(eng, name):
+def test_compress_golden(eng, name, enc):
     chunk, thunk = CASES[name]
     data = thunk()
-    stream, rec_off, rec_len = eng.compress_bytes(data, chunk)
+    eng.set_variant("lz4_enc", enc)
+    try:
+        stream, rec_off, rec_len = eng.compress_bytes(data, chunk)
+    finally:
+        eng.set_variant("lz4_enc", 0)
     e = MAN[name]
     assert len(stream) == e["out_len"]
     assert H.sha256(stream) == e["out_sha256"]
@@ -57,12 +62,13 @@ def test_decompress_golden(eng, name, variant):
     assert out == data
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(12))
 def test_fuzz_vs_oracle(eng, seed):
     import random
     from test_oracle_vs_ref import _mix
     rng = random.Random(1000 + seed)
     n = rng.randrange(1, 3_000_000)
+    eng.set_variant("lz4_enc", seed & 1)
     chunk = rng.choice([65536, 131072, 131072, 100000, 262144, 1 << 20])
     data = _mix(rng, n)
     want = H.oracle_compress(data, chunk)
@@ -73,6 +79,7 @@ def test_fuzz_vs_oracle(eng, seed):
         out, status = eng.decompress_bytes(stream, ro, rl)
         eng.set_variant("lz4_dec", 0)
         assert not status.any() and out == data
+    eng.set_variant("lz4_enc", 0)
 
 
 def test_config1_random_64m(eng):

@@ -20,6 +20,7 @@ extern "C" {
 __global__ void zmt_xxh32_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, const u32 *,
 				 const u32 *, u32 *);
 __global__ void zmt_lz4_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
+__global__ void zmt_lz4_enc_v1_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
 __global__ void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
 				   const u32 *, u32 *, u32 *, u32 *, u32);
 __global__ void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
@@ -54,6 +55,7 @@ struct gpumt_ctx {
 	void *scratch[2];        /* [0] compress side, [1] decompress side */
 	size_t scratch_bytes[2];
 	int dec_variant;
+	int enc_variant; /* 0 = batched probes (default), 1 = one probe at a time */
 	unsigned long long *d_prof; /* 16 phase counters of the profiling decoder */
 	int xflags;  /* experiment switches of the parse kernel (developer) */
 	int profile; /* record events in timer slots 8.. around individual kernels */
@@ -370,9 +372,14 @@ int gpumt_lz4_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t ch
 			   chk, (const u32 *)NULL, (const u32 *)NULL, (u32 *)NULL);
 	PROF1(8);
 	PROF0(9);
-	hipLaunchKernelGGL(zmt_lz4_enc_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
-			   (const u8 *)d_in, (u64)n, (u32)chunk, (u32)nrec, (u8 *)d_slots,
-			   (u64)slot_stride, d_rec_len, (const u32 *)chk);
+	if (h->enc_variant == 1)
+		hipLaunchKernelGGL(zmt_lz4_enc_v1_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
+				   (const u8 *)d_in, (u64)n, (u32)chunk, (u32)nrec, (u8 *)d_slots,
+				   (u64)slot_stride, d_rec_len, (const u32 *)chk);
+	else
+		hipLaunchKernelGGL(zmt_lz4_enc_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
+				   (const u8 *)d_in, (u64)n, (u32)chunk, (u32)nrec, (u8 *)d_slots,
+				   (u64)slot_stride, d_rec_len, (const u32 *)chk);
 	PROF1(9);
 	CK(hipGetLastError());
 	return GPUMT_OK;
@@ -542,6 +549,9 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	if (!strcmp(what, "lz4_dec")) {
 		prev = h->dec_variant;
 		h->dec_variant = variant;
+	} else if (!strcmp(what, "lz4_enc")) {
+		prev = h->enc_variant;
+		h->enc_variant = variant;
 	} else if (!strcmp(what, "k2x")) {
 		prev = h->xflags;
 		h->xflags = variant;

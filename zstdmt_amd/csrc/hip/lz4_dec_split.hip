@@ -86,6 +86,10 @@ zmt_dec_frames_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 	chk_expect[rec] = 0;
 	rec_nblk[rec] = 0;
 	rec_flags[rec] = 0;
+	/* every slot of this record in the block table must be defined for the parse kernel, also
+	 * when the record is rejected below */
+	for (u32 i = 0; i < nb_max; i++)
+		blk_csize[b0 + i] = BLK_EMPTY;
 	if (rlen < 12 || ld32u(r) != ZMT_SKIP_MAGIC || ld32u(r + 4) != 4 || ld32u(r + 8) != rlen - 12) {
 		status[rec] = ST_BAD_RECORD;
 		return;
@@ -170,8 +174,9 @@ zmt_dec_frames_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 		if (st == ST_OK && ip != flen)
 			st = ST_TRAILING;
 	}
-	for (u32 i = nb; i < nb_max; i++)
-		blk_csize[b0 + i] = BLK_EMPTY;
+	if (st != ST_OK)
+		for (u32 i = 0; i < nb; i++)
+			blk_csize[b0 + i] = BLK_EMPTY; /* rejected record: nothing to parse */
 	rec_nblk[rec] = nb;
 	rec_flags[rec] = indep;
 	status[rec] = st;
