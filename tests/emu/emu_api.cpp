@@ -14,6 +14,10 @@ typedef uint64_t u64;
 extern "C" {
 void zmt_xxh32_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, const u32 *, const u32 *, u32 *);
 void zmt_lz4_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
+void zmt_lz4_enc_v1_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
+void zmt_lz4_enc3_u16_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
+void zmt_lz4_enc3_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
+void zmt_lz4_enc3_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
 void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u32 *, u32);
 void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
@@ -42,6 +46,9 @@ void emu_xxh32_batch(const u8 *base, const u64 *off, const u32 *len, u32 n, u32 
 		    [=]() { zmt_xxh32_kernel(base, off, len, n, out, nullptr, nullptr, nullptr); });
 }
 
+static int g_enc_variant = 0;
+void emu_set_enc_variant(int v) { g_enc_variant = v; }
+
 void emu_lz4_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len)
 {
 	u32 nrec = n ? (u32)((n + chunk - 1) / chunk) : 1;
@@ -53,8 +60,25 @@ void emu_lz4_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 strid
 	}
 	emu_xxh32_batch(in, off.data(), len.data(), nrec, chk.data());
 	const u32 *chkp = chk.data();
-	emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
-		    [=]() { zmt_lz4_enc_kernel(in, n, chunk, nrec, slots, stride, rec_len, chkp); });
+	if (g_enc_variant == 1) {
+		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
+			    [=]() { zmt_lz4_enc_v1_kernel(in, n, chunk, nrec, slots, stride, rec_len, chkp); });
+	} else if (g_enc_variant == 2) {
+		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
+			    [=]() { zmt_lz4_enc_kernel(in, n, chunk, nrec, slots, stride, rec_len, chkp); });
+	} else if (chunk <= 65536) {
+		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
+			    [=]() { zmt_lz4_enc3_u16_kernel(in, n, chunk, 0, nrec, slots, stride, rec_len, chkp, nullptr); });
+	} else {
+		if (chunk <= 131072)
+			emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
+				    [=]() { zmt_lz4_enc3_p17_kernel(in, n, chunk, 0, nrec, slots, stride, rec_len, chkp, nullptr); });
+		else
+			emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
+				    [=]() { zmt_lz4_enc3_u32_kernel(in, n, chunk, 0, nrec, slots, stride, rec_len, chkp, nullptr); });
+		emu::launch(dim3{1, 1, 1}, dim3{64, 1, 1},
+			    [=]() { zmt_lz4_enc3_u16_kernel(in, n, chunk, nrec - 1, nrec, slots, stride, rec_len, chkp, nullptr); });
+	}
 }
 
 void emu_lz4_compact(const u8 *slots, u64 stride, const u32 *rec_len, u32 nrec, u8 *stream, u64 *rec_off)

@@ -35,9 +35,10 @@ def xxh32_batch(buf: np.ndarray, off: np.ndarray, length: np.ndarray) -> np.ndar
     return out
 
 
-def compress(data: bytes, chunk: int):
-    """-> (stream bytes, rec_off[n+1], rec_len[n])"""
+def compress(data: bytes, chunk: int, variant: int = 0):
+    """-> (stream bytes, rec_off[n+1], rec_len[n]); variant 0 = v3 (default), 1 = v1, 2 = v2"""
     L = lib()
+    L.emu_set_enc_variant(C.c_int(variant))
     n = len(data)
     nrec = max(1, (n + chunk - 1) // chunk)
     stride = L.emu_lz4_slot_stride(chunk)

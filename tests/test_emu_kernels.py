@@ -27,11 +27,14 @@ def test_emu_xxh32():
     assert got.tolist() == want
 
 
-@pytest.mark.parametrize("name", SMALL)
-def test_emu_compress_bit_exact(name):
+ENC_SUBSET = ["empty", "hello_5", "abc_13", "text_64k_p20", "zeros_70000", "period_65535", "mixed_text_rnd"]
+
+
+@pytest.mark.parametrize("variant,name", [(0, n) for n in SMALL] + [(v, n) for v in (1, 2) for n in ENC_SUBSET])
+def test_emu_compress_bit_exact(name, variant):
     chunk, thunk = CASES[name]
     data = thunk()
-    stream, rec_off, rec_len = E.compress(data, chunk)
+    stream, rec_off, rec_len = E.compress(data, chunk, variant)
     assert len(stream) == MAN[name]["out_len"]
     assert H.sha256(stream) == MAN[name]["out_sha256"]
 

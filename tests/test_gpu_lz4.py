@@ -26,7 +26,7 @@ def eng():
     e.close()
 
 
-@pytest.mark.parametrize("enc", [0, 1])
+@pytest.mark.parametrize("enc", [0, 1, 2])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_compress_golden(eng, name, enc):
     chunk, thunk = CASES[name]
@@ -68,7 +68,7 @@ def test_fuzz_vs_oracle(eng, seed):
     from test_oracle_vs_ref import _mix
     rng = random.Random(1000 + seed)
     n = rng.randrange(1, 3_000_000)
-    eng.set_variant("lz4_enc", seed & 1)
+    eng.set_variant("lz4_enc", seed % 3)
     chunk = rng.choice([65536, 131072, 131072, 100000, 262144, 1 << 20])
     data = _mix(rng, n)
     want = H.oracle_compress(data, chunk)

@@ -23,7 +23,7 @@ for seed in range(n0,n1):
             t[b:b+l]=t[a:a+l] if rng.random()<0.7 else bytes([rng.randrange(256)])*l
         data=bytes(t)
     want=H.oracle_compress(data,chunk)
-    got,_,_=E.compress(data,chunk)
+    got,_,_=E.compress(data,chunk,0)
     ok = got==want
     print(seed,kind,n,chunk,"OK" if ok else "FAIL",len(got),len(want),flush=True)
     if not ok:

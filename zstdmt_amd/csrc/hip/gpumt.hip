@@ -21,6 +21,12 @@ __global__ void zmt_xxh32_kernel(const u8 *, const u64 *, const u32 *, u32, u32 
 				 const u32 *, u32 *);
 __global__ void zmt_lz4_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
 __global__ void zmt_lz4_enc_v1_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
+__global__ void zmt_lz4_enc3_u16_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
+					unsigned long long *);
+__global__ void zmt_lz4_enc3_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
+					unsigned long long *);
+__global__ void zmt_lz4_enc3_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
+					unsigned long long *);
 __global__ void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
 				   const u32 *, u32 *, u32 *, u32 *, u32);
 __global__ void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
@@ -55,7 +61,7 @@ struct gpumt_ctx {
 	void *scratch[2];        /* [0] compress side, [1] decompress side */
 	size_t scratch_bytes[2];
 	int dec_variant;
-	int enc_variant; /* 0 = batched probes (default), 1 = one probe at a time */
+	int enc_variant; /* 0 = v3 (LDS input ring, small batches, 17-bit table), 1 = v1, 2 = v2 */
 	unsigned long long *d_prof; /* 16 phase counters of the profiling decoder */
 	int xflags;  /* experiment switches of the parse kernel (developer) */
 	int profile; /* record events in timer slots 8.. around individual kernels */
@@ -372,14 +378,43 @@ int gpumt_lz4_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t ch
 			   chk, (const u32 *)NULL, (const u32 *)NULL, (u32 *)NULL);
 	PROF1(8);
 	PROF0(9);
-	if (h->enc_variant == 1)
+	unsigned long long *eprof = NULL;
+	if (h->profile == 4) {
+		if (!h->d_prof) {
+			CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
+			CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
+		}
+		eprof = h->d_prof;
+	}
+	if (h->enc_variant == 1) {
 		hipLaunchKernelGGL(zmt_lz4_enc_v1_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
 				   (const u8 *)d_in, (u64)n, (u32)chunk, (u32)nrec, (u8 *)d_slots,
 				   (u64)slot_stride, d_rec_len, (const u32 *)chk);
-	else
+	} else if (h->enc_variant == 2) {
 		hipLaunchKernelGGL(zmt_lz4_enc_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
 				   (const u8 *)d_in, (u64)n, (u32)chunk, (u32)nrec, (u8 *)d_slots,
 				   (u64)slot_stride, d_rec_len, (const u32 *)chk);
+	} else if (chunk <= 65536) {
+		/* every record is a single independent block: byU16 table */
+		hipLaunchKernelGGL(zmt_lz4_enc3_u16_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
+				   (const u8 *)d_in, (u64)n, (u32)chunk, 0u, (u32)nrec, (u8 *)d_slots,
+				   (u64)slot_stride, d_rec_len, (const u32 *)chk, eprof);
+	} else {
+		/* linked-block records; the ragged last record may be <= 64 KiB and then belongs to the
+		 * byU16 kernel (each kernel skips records of the other kind) */
+		if (chunk <= 131072)
+			hipLaunchKernelGGL(zmt_lz4_enc3_p17_kernel, dim3((unsigned)nrec), dim3(64),
+					   (size_t)h->xflags /* developer: dynamic-LDS padding = occupancy knob */, h->st[s],
+					   (const u8 *)d_in, (u64)n, (u32)chunk, 0u, (u32)nrec, (u8 *)d_slots,
+					   (u64)slot_stride, d_rec_len, (const u32 *)chk, eprof);
+		else
+			hipLaunchKernelGGL(zmt_lz4_enc3_u32_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
+					   (const u8 *)d_in, (u64)n, (u32)chunk, 0u, (u32)nrec, (u8 *)d_slots,
+					   (u64)slot_stride, d_rec_len, (const u32 *)chk, eprof);
+		hipLaunchKernelGGL(zmt_lz4_enc3_u16_kernel, dim3(1), dim3(64), 0, h->st[s], (const u8 *)d_in,
+				   (u64)n, (u32)chunk, (u32)(nrec - 1), (u32)nrec, (u8 *)d_slots,
+				   (u64)slot_stride, d_rec_len, (const u32 *)chk, (unsigned long long *)NULL);
+	}
 	PROF1(9);
 	CK(hipGetLastError());
 	return GPUMT_OK;

@@ -1,0 +1,544 @@
+/*
+ * lz4_enc3.hip -- LZ4 frame encoder v3 (default): same bit-exact greedy parse as lz4_enc.hip
+ * (reference call site /root/reference/lib/lz4-mt_compress.c:281), rebuilt
+ * around what the MI355X measurements say is expensive: dependent global loads and wide gathers.
+ *
+ *  - The chunk's input is streamed through a 2 KiB LDS ring (1 KiB coalesced refills), so hashing,
+ *    the ip side of catch-up / match counting, the re-match test and literal sources are LDS reads.
+ *  - The search evaluates the reference's probe sequence in batches of 16, 16, 32, 64, 64, ...
+ *    lanes (lane j = probe kbase + j).  Most matches sit within the first 16 probes, so the one
+ *    candidate gather per batch usually touches <= 16 cache lines.  In-batch duplicate hashes
+ *    are detected exactly (LDS atomic-or bitmap) and resolved by a readlane loop only when present.
+ *  - One cooperative fetch of [match-32, match+96) then serves catch-up (backward) and the match
+ *    length (forward) for the common case; longer runs continue 64 bytes at a time.
+ *  - For chunks <= 128 KiB the 4096-entry table stores 17-bit positions as u16 + one bit
+ *    (8.5 KiB instead of 16 KiB), which lets 12 chunk-waves share a CU's LDS instead of 8.
+ *
+ * Table modes: T_U16  single block <= 64 KiB (byU16: 8192 x u16, 13-bit hash of 4 bytes)
+ *              T_P17  linked blocks, chunk <= 128 KiB (byU32 semantics, 17-bit entries)
+ *              T_U32  linked blocks, any chunk size (4096 x u32)
+ */
+#include "lz4_common.h"
+
+#define MINMATCH 4u
+#define MFLIMIT 12u
+#define LASTLITERALS 5u
+#define DIST_MAX 65535u
+#define IRING 2048u /* input ring bytes (power of two) */
+#define IMIRROR 16u
+
+enum { T_U16 = 0, T_P17 = 1, T_U32 = 2 };
+
+#ifdef ZMT_EMU
+static inline u32 lds_or(u32 *p, u32 v)
+{
+	u32 o = *p;
+	*p = o | v;
+	return o;
+}
+static inline u32 lds_and(u32 *p, u32 v)
+{
+	u32 o = *p;
+	*p = o & v;
+	return o;
+}
+#else
+static __device__ __forceinline__ u32 lds_or(u32 *p, u32 v) { return atomicOr(p, v); }
+static __device__ __forceinline__ u32 lds_and(u32 *p, u32 v) { return atomicAnd(p, v); }
+#endif
+
+template <int TM> static __device__ __forceinline__ u32 hash3(u64 x)
+{
+	if (TM == T_U16)
+		return ((u32)x * 2654435761u) >> 19;
+	return (u32)(((x << 24) * 889523592379ULL) >> 52);
+}
+
+/* ---- hash table, three storage layouts; `lo` is the main array, `hi` the 17th bits (T_P17) ---- */
+template <int TM> static __device__ __forceinline__ u32 t_read(const u32 *lo, const u32 *hi, u32 h)
+{
+	if (TM == T_U32)
+		return lo[h];
+	u32 v = ((const u16 *)lo)[h];
+	if (TM == T_P17)
+		v |= ((hi[h >> 5] >> (h & 31)) & 1) << 16;
+	return v;
+}
+/* per-lane store; several lanes may hit different entries of one hi word -> atomics there */
+template <int TM> static __device__ __forceinline__ void t_write(u32 *lo, u32 *hi, u32 h, u32 v)
+{
+	if (TM == T_U32) {
+		lo[h] = v;
+		return;
+	}
+	((u16 *)lo)[h] = (u16)v;
+	if (TM == T_P17) {
+		if (v >> 16)
+			lds_or(&hi[h >> 5], 1u << (h & 31));
+		else
+			lds_and(&hi[h >> 5], ~(1u << (h & 31)));
+	}
+}
+
+/* probe k of a search that starts at ip: position and the gap to probe k+1 (see lz4_enc.hip) */
+static __device__ __forceinline__ u32 probe_pos3(u32 ip, u32 k, u32 *gap)
+{
+	if (k <= 64) {
+		*gap = 1;
+		return ip + k;
+	}
+	const u32 t = k - 65, q = t >> 6, r = t & 63;
+	*gap = q + 2;
+	return ip + 65 + 64 * (q * (q + 3) / 2) + (q + 2) * r;
+}
+
+static __device__ __forceinline__ u32 put_len_ext3(u8 *op, u32 rem, int lane)
+{
+	u32 n255 = rem / 255;
+	for (u32 i = (u32)lane; i < n255; i += 64)
+		op[i] = 255;
+	if (lane == 0)
+		op[n255] = (u8)(rem - n255 * 255);
+	return n255 + 1;
+}
+
+/* ---- input ring: ring[p & (IRING-1)] = chunk[p] for p in [rhi - IRING, rhi) ---- */
+struct InRing {
+	u8 *ring;
+	const u8 *chunk;
+	u32 rlo;     /* ring is valid for chunk positions [max(rlo, rhi - IRING), rhi) */
+	u32 rhi;     /* end of what has been loaded (multiple of 1024) */
+	u32 limit;   /* never load at or beyond this chunk position (readable bytes of the input) */
+	u8 *mwin;    /* 128-byte window of the match side: mwin[i] = chunk[mbase + i] */
+	u32 mbase;
+	u64 pc[8];   /* phase cycle counters (profiling build of the kernel only) */
+	u64 tq;
+	bool prof;
+};
+#ifndef ZMT_EMU
+#define EPC(R, i) do { if ((R).prof) { u64 t_ = (u64)clock64(); (R).pc[i] += t_ - (R).tq; (R).tq = t_; } } while (0)
+#else
+#define EPC(R, i) do { } while (0)
+#endif
+
+/* make [pos, pos + 1024) (clipped to the input) resident */
+static __device__ __forceinline__ void ring_want(InRing &R, u32 pos, int lane)
+{
+	const u32 want_hi = pos + 1024;
+	if (want_hi > R.rhi + 2 * IRING) {
+		/* far jump (long literal run): restart the ring at the new position */
+		R.rhi = pos & ~1023u;
+		R.rlo = R.rhi;
+	}
+	while (R.rhi < want_hi && R.rhi < R.limit) {
+		const u32 p = R.rhi + 16u * (u32)lane;
+		u64 a = 0, b = 0;
+		if (p + 16 <= R.limit) {
+			a = ld64u(R.chunk + p);
+			b = ld64u(R.chunk + p + 8);
+		} else {
+			for (u32 k = 0; k < 8; k++) {
+				if (p + k < R.limit)
+					a |= (u64)R.chunk[p + k] << (8 * k);
+				if (p + 8 + k < R.limit)
+					b |= (u64)R.chunk[p + 8 + k] << (8 * k);
+			}
+		}
+		wv_sync();
+		u8 *d = R.ring + (p & (IRING - 1));
+		*(u64 *)d = a;
+		*(u64 *)(d + 8) = b;
+		if ((p & (IRING - 1)) == 0) { /* mirror: multi-byte reads never wrap */
+			*(u64 *)(R.ring + IRING) = a;
+			*(u64 *)(R.ring + IRING + 8) = b;
+		}
+		wv_sync();
+		R.rhi += 1024;
+	}
+}
+/* is chunk[p .. p+n) readable from the ring? (n <= IMIRROR beyond a wrap) */
+static __device__ __forceinline__ bool ring_has(const InRing &R, u32 p, u32 n)
+{
+	return p >= R.rlo && p + IRING >= R.rhi && p + n <= R.rhi;
+}
+static __device__ __forceinline__ u64 in_ld64(const InRing &R, u32 p)
+{
+	return ring_has(R, p, 8) ? ld64u(R.ring + (p & (IRING - 1))) : ld64u(R.chunk + p);
+}
+static __device__ __forceinline__ u32 in_ld8(const InRing &R, u32 p)
+{
+	return ring_has(R, p, 1) ? (u32)R.ring[p & (IRING - 1)] : (u32)R.chunk[p];
+}
+
+/* fetch chunk[m-32 .. m+96) (clipped at 0) into the match window: one global round trip that
+ * serves the re-match test, catch-up (<= 32 bytes back) and the match count (<= 64 forward) */
+#define MWIN 128u
+static __device__ __forceinline__ void mwin_fetch(InRing &R, u32 m, int lane)
+{
+	const u32 base = m >= 32 ? m - 32 : 0;
+	const u32 p = base + 2u * (u32)lane;
+	u32 v = 0;
+	if (p + 2 <= R.limit)
+		v = ld16u(R.chunk + p);
+	else if (p < R.limit)
+		v = R.chunk[p];
+	wv_sync();
+	*(u16 *)(R.mwin + 2u * (u32)lane) = (u16)v;
+	wv_sync();
+	R.mbase = base;
+}
+/* chunk[p] of the match side: window when inside, else memory */
+static __device__ __forceinline__ u32 m_ld8(const InRing &R, u32 p)
+{
+	return (p >= R.mbase && p < R.mbase + MWIN) ? (u32)R.mwin[p - R.mbase] : (u32)R.chunk[p];
+}
+
+/* cooperative literal copy chunk[a .. a+n) -> d, from the ring when it is there */
+static __device__ __forceinline__ void copy_literals(const InRing &R, u8 *d, u32 a, u32 n, int lane)
+{
+	if (n <= 256 && ring_has(R, a, n)) {
+		for (u32 i = (u32)lane; i < n; i += 64)
+			d[i] = R.ring[(a + i) & (IRING - 1)];
+	} else {
+		wave_copy(d, R.chunk + a, n, lane);
+	}
+}
+
+template <int TM>
+static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, u32 pos, u32 len, u8 *dst,
+				    u32 cap, int lane)
+{
+	const u8 *chunk = R.chunk;
+	const u32 iend = pos + len;
+	const u32 mflimit_p1 = iend - MFLIMIT + 1;
+	const u32 matchlimit = iend - LASTLITERALS;
+	const u32 low = (TM == T_U16) ? pos : 0;
+	u32 ip = pos, anchor = pos, op = 0;
+	u32 match = 0, token = 0, tokhi = 0;
+
+	if (len < MFLIMIT + 1)
+		goto last_literals;
+
+	ring_want(R, ip, lane);
+	{
+		const u64 x = wv_readfirst((u32)in_ld64(R, ip)) | (u64)wv_readfirst((u32)(in_ld64(R, ip) >> 32)) << 32;
+		if (lane == 0)
+			t_write<TM>(tlo, thi, hash3<TM>(TM == T_U16 ? (u64)(u32)x : x), ip);
+	}
+	ip++;
+
+	for (;;) {
+		/* ---------------- search ---------------- */
+		{
+			const u32 ip0 = ip;
+			bool found = false;
+			u32 kbase = 0, bsz = 16;
+			for (u32 batch = 0;; batch++) {
+				u32 gap;
+				const u32 cur = probe_pos3(ip0, kbase + (u32)lane, &gap);
+				const bool valid = (u32)lane < bsz && cur + gap <= mflimit_p1;
+				const u32 cur0 = wv_readlane(cur, 0); /* first probe of the batch */
+				const u64 vm = wv_ballot(valid);
+				if (vm == 0)
+					goto last_literals;
+				EPC(R, 7);
+				ring_want(R, cur0, lane);
+				const u64 x = valid ? in_ld64(R, cur) : 0;
+				const u32 h = hash3<TM>(TM == T_U16 ? (u64)(u32)x : x);
+				wv_sync();
+				u32 cand = valid ? t_read<TM>(tlo, thi, h) : 0;
+				u32 prev_dup = 64, next_dup = 64;
+				{
+					bool d = false;
+					if (valid)
+						d = (lds_or(&bitmap[h >> 5], 1u << (h & 31)) >> (h & 31)) & 1;
+					const bool any_dup = wv_any(d);
+					wv_sync();
+					if (valid)
+						bitmap[h >> 5] = 0;
+					if (any_dup) {
+						for (u32 i = 0; i < bsz; i++) {
+							const u32 hi_ = wv_readlane(h, (int)i);
+							const bool vi = (vm >> i) & 1;
+							if (vi && valid && hi_ == h) {
+								if (i < (u32)lane)
+									prev_dup = i;
+								else if (i > (u32)lane && next_dup == 64)
+									next_dup = i;
+							}
+						}
+					}
+				}
+				{
+					const u32 pc = wv_shfl(cur, (int)(prev_dup & 63));
+					const u32 p4 = wv_shfl((u32)x, (int)(prev_dup & 63));
+					if (prev_dup < 64)
+						cand = pc;
+					const bool dist_ok = (TM == T_U16) || cand + DIST_MAX >= cur;
+					EPC(R, 0);
+					const u32 c4 = (valid && dist_ok && prev_dup == 64) ? ld32u(chunk + cand) : p4;
+					const bool m = valid && dist_ok && c4 == (u32)x;
+					const u64 mm = wv_ballot(m);
+					const u32 nvalid = (u32)wv_popc(vm);
+					const u32 jstar = mm ? (u32)wv_ffs(mm) - 1 : 64;
+					const u32 ninsert = mm ? jstar + 1 : nvalid;
+					if ((u32)lane < ninsert && !(next_dup < ninsert))
+						t_write<TM>(tlo, thi, h, cur);
+					wv_sync();
+					EPC(R, 1);
+					if (R.prof) R.pc[6] += 1;
+					if (mm) {
+						ip = wv_readlane(cur, (int)jstar);
+						match = wv_readlane(cand, (int)jstar);
+						found = true;
+						break;
+					}
+					if (nvalid < bsz)
+						goto last_literals;
+				}
+				kbase += bsz;
+				bsz = (batch == 0) ? 16 : (batch == 1 ? 32 : 64);
+			}
+			if (!found)
+				goto last_literals;
+		}
+		mwin_fetch(R, match, lane);
+		/* ---------------- catch up (cooperative backward compare) ---------------- */
+		{
+			/* backward */
+			for (;;) {
+				u32 room = ip - anchor;
+				if (match - low < room)
+					room = match - low;
+				if (room == 0)
+					break;
+				const u32 n = room < 64 ? room : 64;
+				bool eq = false;
+				if ((u32)lane < n)
+					eq = in_ld8(R, ip - 1 - (u32)lane) == m_ld8(R, match - 1 - (u32)lane);
+				const u64 ne = ~wv_ballot(eq);
+				const u32 run = ne ? (u32)wv_ffs(ne) - 1 : 64;
+				const u32 take = run < n ? run : n;
+				ip -= take;
+				match -= take;
+				if (take < 64)
+					break;
+			}
+		}
+		EPC(R, 2);
+		{
+			u32 lit = ip - anchor;
+			token = op++;
+			if (op + lit + (2 + 1 + LASTLITERALS) + lit / 255 > cap)
+				return 0;
+			tokhi = (lit >= 15 ? 15u : lit) << 4;
+			if (lit >= 15)
+				op += put_len_ext3(dst + op, lit - 15, lane);
+			copy_literals(R, dst + op, anchor, lit, lane);
+			op += lit;
+		}
+		EPC(R, 3);
+		for (;;) { /* next_match */
+			u32 mc;
+			if (lane == 0)
+				st16u(dst + op, ip - match);
+			op += 2;
+			{
+				/* forward count, 64 bytes per step; ip side from the ring */
+				const u32 limit = matchlimit - (ip + MINMATCH);
+				u32 base = 0;
+				ring_want(R, ip, lane);
+				for (;;) {
+					const u32 i = base + (u32)lane;
+					bool stop = true;
+					if (i < limit)
+						stop = in_ld8(R, ip + MINMATCH + i) != m_ld8(R, match + MINMATCH + i);
+					const u64 sm = wv_ballot(stop);
+					if (sm) {
+						mc = base + (u32)wv_ffs(sm) - 1;
+						break;
+					}
+					base += 64;
+					ring_want(R, ip + MINMATCH + base, lane);
+				}
+			}
+			EPC(R, 4);
+			ip += mc + MINMATCH;
+			if (op + (1 + LASTLITERALS) + (mc + 240) / 255 > cap)
+				return 0;
+			if (lane == 0)
+				dst[token] = (u8)(tokhi | (mc >= 15 ? 15u : mc));
+			if (mc >= 15)
+				op += put_len_ext3(dst + op, mc - 15, lane);
+			anchor = ip;
+			if (ip >= mflimit_p1)
+				goto block_done;
+			ring_want(R, ip, lane);
+			{
+				/* T[h(ip-2)] = ip-2, then the immediate re-match test at ip */
+				const u64 x2 = wv_readfirst((u32)in_ld64(R, ip - 2)) |
+					       (u64)wv_readfirst((u32)(in_ld64(R, ip - 2) >> 32)) << 32;
+				const u64 x0 = wv_readfirst((u32)in_ld64(R, ip)) |
+					       (u64)wv_readfirst((u32)(in_ld64(R, ip) >> 32)) << 32;
+				const u32 h2 = hash3<TM>(TM == T_U16 ? (u64)(u32)x2 : x2);
+				const u32 h0 = hash3<TM>(TM == T_U16 ? (u64)(u32)x0 : x0);
+				wv_sync();
+				if (lane == 0)
+					t_write<TM>(tlo, thi, h2, ip - 2);
+				wv_sync();
+				const u32 midx = wv_readfirst(t_read<TM>(tlo, thi, h0));
+				wv_sync();
+				if (lane == 0)
+					t_write<TM>(tlo, thi, h0, ip);
+				match = midx;
+				bool rm = (TM == T_U16) || midx + DIST_MAX >= ip;
+				if (rm) {
+					/* one fetch: the 4-byte test now, the match count right after */
+					mwin_fetch(R, match, lane);
+					const u32 o = match - R.mbase;
+					rm = wv_readfirst(ld32u(R.mwin + o)) == (u32)x0;
+				}
+				EPC(R, 5);
+				if (rm) {
+					token = op++;
+					tokhi = 0;
+					continue;
+				}
+			}
+			break;
+		}
+		ip++;
+	}
+block_done:
+last_literals:
+	{
+		u32 run = iend - anchor;
+		if (op + run + 1 + (run + 255 - 15) / 255 > cap)
+			return 0;
+		if (run >= 15) {
+			if (lane == 0)
+				dst[op] = 15 << 4;
+			op++;
+			op += put_len_ext3(dst + op, run - 15, lane);
+		} else {
+			if (lane == 0)
+				dst[op] = (u8)(run << 4);
+			op++;
+		}
+		copy_literals(R, dst + op, anchor, run, lane);
+		op += run;
+	}
+	return op;
+}
+
+template <int TM>
+static __device__ __forceinline__ void enc3_body(u32 *tlo, u32 *thi, u32 *bitmap, u8 *ring, u8 *mwin,
+						  const u8 *__restrict__ in, u64 n, u32 chunk, u32 rec0, u32 nrec,
+						  u8 *__restrict__ slots, u64 slot_stride,
+						  u32 *__restrict__ rec_len, const u32 *__restrict__ chk,
+						  unsigned long long *prof)
+{
+	const u32 rec = rec0 + blockIdx.x;
+	const int lane = wv_lane();
+	if (rec >= nrec)
+		return;
+	const u64 start = (u64)rec * chunk;
+	const u32 len = (u32)((n - start) < (u64)chunk ? (n - start) : (u64)chunk);
+	/* a record of <= 64 KiB is a single independent block with the byU16 table: it belongs to the
+	 * T_U16 kernel (launched for the ragged last record), everything longer to the linked-block
+	 * kernels */
+	if ((TM == T_U16) != (len <= ZMT_BLOCK))
+		return;
+	const u8 *src = in + start;
+	u8 *dst = slots + (u64)rec * slot_stride;
+	const u32 hdr = len ? 15 : 7;
+	u32 op = 12 + hdr;
+
+	if (lane == 0) {
+		u8 d[10];
+		st32u(dst, ZMT_SKIP_MAGIC);
+		st32u(dst + 4, 4);
+		st32u(dst + 12, ZMT_LZ4F_MAGIC);
+		d[0] = (u8)(0x40 | (TM == T_U16 ? 0x20 : 0) | (len ? 0x08 : 0) | 0x04);
+		d[1] = 0x40;
+		for (int i = 0; i < 8; i++)
+			d[2 + i] = (i < 4) ? (u8)(len >> (8 * i)) : 0;
+		for (u32 i = 0; i < hdr - 5; i++)
+			dst[16 + i] = d[i];
+		dst[12 + hdr - 1] = (u8)(xxh32_short(d, hdr - 5) >> 8);
+	}
+	const u32 tab_words = (TM == T_P17) ? 2048 : 4096;
+	for (u32 i = (u32)lane; i < tab_words; i += 64)
+		tlo[i] = 0;
+	for (u32 i = (u32)lane; i < 128; i += 64) {
+		bitmap[i] = 0;
+		bitmap[i + 128] = 0;
+		if (TM == T_P17)
+			thi[i] = 0;
+	}
+	wv_sync();
+
+	InRing R;
+	R.ring = ring;
+	R.mwin = mwin;
+	R.mbase = 0;
+	R.chunk = src;
+	R.rhi = 0;
+	R.rlo = 0;
+	R.prof = prof != nullptr;
+	for (int i = 0; i < 8; i++)
+		R.pc[i] = 0;
+#ifndef ZMT_EMU
+	R.tq = R.prof ? (u64)clock64() : 0;
+	const u64 t_begin = R.tq;
+#endif
+	/* the input buffer carries >= 8 readable bytes after its end (hash reads); never go further */
+	R.limit = (u32)((n - start) < (u64)chunk + 8 ? (n - start) + 8 : (u64)chunk + 8);
+
+	for (u32 pos = 0; pos < len; pos += ZMT_BLOCK) {
+		u32 blen = len - pos < ZMT_BLOCK ? len - pos : ZMT_BLOCK;
+		u32 c = encode_block3<TM>(tlo, thi, bitmap, R, pos, blen, dst + op + 4, blen - 1, lane);
+		u32 bh = c;
+		if (c == 0) {
+			wave_copy(dst + op + 4, src + pos, blen, lane);
+			c = blen;
+			bh = blen | 0x80000000u;
+		}
+		if (lane == 0)
+			st32u(dst + op, bh);
+		op += 4 + c;
+	}
+	if (lane == 0) {
+		st32u(dst + op, 0);
+		st32u(dst + op + 4, chk[rec]);
+		st32u(dst + 8, op + 8 - 12);
+		rec_len[rec] = op + 8;
+	}
+#ifndef ZMT_EMU
+	if (R.prof && lane == 0) {
+		for (int i = 0; i < 8; i++)
+			atomicAdd(prof + i, (unsigned long long)R.pc[i]);
+		atomicAdd(prof + 8, (unsigned long long)((u64)clock64() - t_begin));
+		atomicAdd(prof + 9, 1ull);
+	}
+#endif
+}
+
+#define ENC3_KERNEL(NAME, TM, TABBYTES)                                                            \
+	extern "C" __global__ void __launch_bounds__(64)                                            \
+	NAME(const u8 *__restrict__ in, u64 n, u32 chunk, u32 rec0, u32 nrec,                       \
+	     u8 *__restrict__ slots, u64 slot_stride, u32 *__restrict__ rec_len,                   \
+	     const u32 *__restrict__ chk, unsigned long long *prof)                                \
+	{                                                                                          \
+		__shared__ __attribute__((aligned(16))) u32 tlo[(TABBYTES) / 4];                   \
+		__shared__ u32 thi[128];                                                           \
+		__shared__ u32 bitmap[256];                                                        \
+		__shared__ __attribute__((aligned(16))) u8 ring[IRING + IMIRROR];                  \
+		__shared__ __attribute__((aligned(16))) u8 mwin[MWIN + 16];                        \
+		enc3_body<TM>(tlo, thi, bitmap, ring, mwin, in, n, chunk, rec0, nrec, slots,       \
+			      slot_stride, rec_len, chk, prof);                                                     \
+	}
+
+ENC3_KERNEL(zmt_lz4_enc3_u16_kernel, T_U16, 16384)
+ENC3_KERNEL(zmt_lz4_enc3_p17_kernel, T_P17, 8192)
+ENC3_KERNEL(zmt_lz4_enc3_u32_kernel, T_U32, 16384)
