@@ -88,11 +88,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
+        # launched by torch.distributed.run: one process per GPU, RCCL ("nccl") process group.
+        # torch must be imported BEFORE the native library so both share one HIP runtime.
         import torch
         import torch.distributed as dist_
         dist = dist_
         torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import zstdmt_amd as z

@@ -122,6 +122,8 @@ int gpumt_lz4_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d_
  * verified.  d_status[i] receives a GPUMT_ST_* code.
  * stream_bytes / out_bytes: upper bounds of the bytes spanned by the records in d_stream and by
  * their contents in d_out (they size the internal token-list scratch, about 0.7 x stream_bytes).
+ * The d_stream allocation must extend at least 256 readable bytes past stream_bytes: the parse
+ * kernel fetches whole aligned 128-byte lines (their contents past the last record are ignored).
  */
 int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream_bytes,
 			       const uint64_t *d_rec_off, const uint32_t *d_rec_len, size_t nrec,

@@ -75,7 +75,7 @@ def decompress(stream: bytes, variant: int = 0, rec=None):
     L = lib()
     ro, rl = rec if rec is not None else walk_records(stream)
     nrec = len(ro)
-    sbuf = np.frombuffer(stream + b"\0" * 64, np.uint8).copy()
+    sbuf = np.frombuffer(stream + b"\0" * 512, np.uint8).copy()
     out_len = np.zeros(nrec, np.uint32)
     out_off = np.zeros(nrec + 1, np.uint64)
     L.emu_lz4_probe_sizes(_p(sbuf), _p(ro), _p(rl), C.c_uint32(nrec), _p(out_len), _p(out_off))

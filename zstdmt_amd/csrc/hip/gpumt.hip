@@ -210,7 +210,9 @@ void *gpumt_host_alloc(gpumt_ctx *h, size_t bytes)
 	void *p = NULL;
 	if (!h || use(h))
 		return NULL;
-	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+	/* non-coherent = CPU-cached pinned memory: the callbacks memcpy in and out of it at full host
+	 * speed; visibility is established by the stream synchronisation the engine does anyway */
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocNonCoherent) != hipSuccess)
 		return NULL;
 	return p;
 }

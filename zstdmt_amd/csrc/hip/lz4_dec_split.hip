@@ -202,10 +202,18 @@ zmt_dec_frames_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 #else
 #define KT() 0ull
 #endif
-#define P_RING 256u
-#define P_UNIT 64u   /* refill granule */
-#define P_RSTRIDE 272u /* row stride of the input rings: 16-byte aligned, spreads banks */
+#define P_RING 384u  /* three 128-byte units per lane */
+#define P_UNIT 128u  /* refill granule: one aligned line of the stream */
+typedef u32 v4u __attribute__((vector_size(16)));
+#define P_RSTRIDE 400u /* row stride of the input rings: 384 + 16-byte mirror */
 #define P_TSTRIDE 136u /* row stride of the token tile (64 x u16 + pad) */
+
+/* ring offset of g-coordinate g for a lane whose ring lap starts at rb (0 <= g - rb < 2 * P_RING) */
+static __device__ __forceinline__ u32 ring_off(u32 g, u32 rb)
+{
+	const u32 d = g - rb;
+	return d < P_RING ? d : d - P_RING;
+}
 
 extern "C" __global__ void __launch_bounds__(64)
 zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
@@ -245,122 +253,136 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 		}
 		return;
 	}
-	const u8 *const sbase = stream + cmin;
-	const u32 crel = (u32)(coff - cmin); /* this lane's block, relative to sbase */
 	const u32 trel = (u32)(tbase - tmin);
-	const u64 lim16 = stream_bytes >= 16 ? stream_bytes - 16 : 0;
 	const u8 *src = stream + coff;
 	u8 *const myring = ring_lds + (u32)lane * P_RSTRIDE;
 	u16 *const mytile = (u16 *)(tile_lds + (u32)lane * P_TSTRIDE);
 
 	u32 pos = 0, opos = 0, n = 0;
-	u32 rhi = 0;   /* ring holds block positions [rhi - P_RING, rhi) (what has landed in LDS) */
-	u32 rreq = 0;  /* ... and [rhi, rreq) is in flight */
-	u32 pend_rhi = 0;
-	u64 pendm = 0; /* lanes with a piece in flight (wave-uniform) */
-	u64 px[4], py[4];
-	for (int i = 0; i < 4; i++)
-		px[i] = py[i] = 0;
+	/* ring bookkeeping in "g" coordinates: g = boff + block position = stream offset - abase,
+	 * abase = the wave's first block start rounded down to 128, so g % 128 is the position inside
+	 * a memory line.  ring[g & 255] holds byte g for g in [ghi - 256, ghi); [ghi, greq) is in flight */
+	const u64 abase = cmin & ~127ull;
+	const u32 boff = (u32)(coff - abase);
+	u32 ghi = boff & ~(P_UNIT - 1), greq = ghi;
+	u32 rb = ghi;  /* g-coordinate of ring offset 0 of the current lap */
+	u32 pend_g = 0, pend_off = 0;
+	u64 pendm = 0; /* lanes with a unit in flight (wave-uniform) */
+	v4u pv[8];
+	for (int i = 0; i < 8; i++)
+		pv[i] = (v4u){0, 0, 0, 0};
 	u32 bx_pending = 0;
 	bool ok = true, done = !parse;
-	const int grp = lane >> 2, piece = lane & 3;   /* refill: 4 lanes per 64-byte piece */
-	const int dgrp = lane >> 3, dpiece = lane & 7; /* tile drain: 8 lanes per 128-byte row */
+	const int dgrp = lane >> 3, dpiece = lane & 7; /* refill and tile drain: 8 lanes per 128-byte line */
 
 	u64 c_refill = 0, c_token = 0, c_drain = 0, c_slow = 0, c_ext = 0, t_begin = KT();
+	u64 c_t1 = 0, c_t2 = 0, c_t3 = 0;
 	for (u32 step = 0;; step++) {
 		u64 tk0 = KT();
-		/* ---------------- top up the rings (every 4 steps) ----------------
-		 * 64-byte pieces, four lanes per piece (16 B each): one load instruction serves 16
-		 * blocks.  Software-pipelined: pieces requested in one round are loaded into registers
-		 * and land in LDS at the start of the next round, so nobody waits for HBM; a piece is
-		 * requested while the lane still has up to 192 unparsed bytes in its ring. */
-		if ((step & 3) == 0) {
+		/* ---------------- top up the rings (every 8 steps) ----------------
+		 * Refill unit = one 128-byte line of the stream, aligned in *global* memory, fetched by
+		 * eight lanes with one 16-byte load each: a load instruction serves 8 blocks and touches
+		 * 8 lines (the texture path costs per line, not per byte).  Software-pipelined: units
+		 * requested in one round land in LDS at the start of the next round. */
+		if ((step & 7) == 0 || step < 4) { /* start-up: three back-to-back rounds fill the ring */
 			if (pendm) {
 				wv_sync();
 				ZMT_UNROLL
-				for (int i = 0; i < 4; i++) {
-					const int r = 16 * i + grp;
-					const u32 r_rhi = wv_shfl(pend_rhi, r);
+				for (int i = 0; i < 8; i++) {
+					const int r = 8 * i + dgrp;
+					const u32 ro = wv_shfl(pend_off, r);
 					if ((pendm >> r) & 1) {
-						const u32 ro = r_rhi & (P_RING - 1);
-						u8 *d = ring_lds + (u32)r * P_RSTRIDE + ro + 16u * (u32)piece;
-						*(u64 *)d = px[i];
-						*(u64 *)(d + 8) = py[i];
-						if (ro == 0 && piece == 0) {
-							/* mirror of the first 16 bytes after the end: dword reads never wrap */
-							*(u64 *)(d + P_RING) = px[i];
-							*(u64 *)(d + P_RING + 8) = py[i];
-						}
+						u8 *d = ring_lds + (u32)r * P_RSTRIDE + ro + 16u * (u32)dpiece;
+						*(v4u *)d = pv[i];
+						if (ro == 0 && dpiece == 0)
+							*(v4u *)(d + P_RING) = pv[i]; /* mirror: dword reads never wrap */
 					}
 				}
 				wv_sync();
 				if ((pendm >> lane) & 1)
-					rhi = pend_rhi + P_UNIT;
+					ghi = pend_g + P_UNIT;
 			}
-			if (!done && pos >= rreq)
-				rhi = rreq = pos & ~(P_UNIT - 1); /* long jump: restart the ring at the parse position */
-			/* the slot to be overwritten holds [rreq-256, rreq-192): already parsed? */
-			const bool need = !done && rreq < cs && rreq <= pos + (P_RING - P_UNIT);
+			const u32 gp0 = boff + pos;
+			if (!done && gp0 >= greq)
+				ghi = greq = rb = gp0 & ~(P_UNIT - 1); /* long jump: restart the ring at the parse position */
+			while (gp0 - rb >= P_RING)
+				rb += P_RING; /* the parse position entered the next lap */
+			/* the slot to be overwritten holds [greq-384, greq-256): already parsed? */
+			const bool need = !done && greq < boff + cs && greq <= gp0 + (P_RING - P_UNIT);
 			pendm = wv_ballot(need);
-			pend_rhi = rreq;
+			pend_g = greq;
+			pend_off = ring_off(greq, rb);
 			if (pendm) {
 				ZMT_UNROLL
-				for (int i = 0; i < 4; i++) {
-					const int r = 16 * i + grp;
-					const u32 r_src = wv_shfl(crel + rreq, r);
-					px[i] = 0;
-					py[i] = 0;
+				for (int i = 0; i < 8; i++) {
+					const int r = 8 * i + dgrp;
+					const u32 r_g = wv_shfl(greq, r);
+					v4u v = {0, 0, 0, 0};
 					if (((pendm >> r) & 1) && !(xflags & 2)) {
-						const u64 a = cmin + r_src + 16u * (u32)piece;
-						if (a <= lim16 && stream_bytes >= 16) {
-							px[i] = ld64u(stream + a);
-							py[i] = ld64u(stream + a + 8);
-						} else {
-							/* the stream's last bytes: never read past its end */
-							for (u32 k = 0; k < 8; k++) {
-								if (a + k < stream_bytes)
-									px[i] |= (u64)stream[a + k] << (8 * k);
-								if (a + 8 + k < stream_bytes)
-									py[i] |= (u64)stream[a + 8 + k] << (8 * k);
-							}
-						}
+						/* 16-byte aligned; may run up to 127 bytes past stream_bytes: the stream
+						 * allocation carries that slack (include/gpumt.h) */
+						v = *(const v4u *)(stream + abase + r_g + 16u * (u32)dpiece);
 					}
+					pv[i] = v;
 				}
 				if (need)
-					rreq += P_UNIT;
+					greq += P_UNIT;
 			}
 		}
 		{ u64 t_ = KT(); c_refill += t_ - tk0; tk0 = t_; }
-		/* ---------------- one token per lane ---------------- */
+		/* ---------------- one token per lane ----------------
+		 * Fast path, branch-free: two dependent LDS dword reads (token + first literal-length
+		 * byte; offset + first match-length byte).  Anything else -- bytes not in the ring yet,
+		 * a 255 continuation byte, the block's last sequence, malformed input -- sends that lane
+		 * through the generic path below (rare after start-up, and then only those lanes). */
 		u32 my_pos = pos, my_opos = opos;
 		bool emit = false;
+		bool slow = false;
 		if (!done) {
-			u32 w;
-			if ((xflags & 1) || (pos + 4 <= rhi && pos + P_RING >= rhi))
-				w = ld32u(myring + (pos & (P_RING - 1))); /* may run into the mirror */
-			else {
-				w = ld32u(src + pos); /* not in the ring: record always has >= 4 bytes after a block */
-				c_slow++;
-			}
+			const u32 gp = boff + pos;
+			const bool in1 = gp + 4 <= ghi && gp + P_RING >= ghi;
+			const u32 w = ld32u(myring + (in1 ? ring_off(gp, rb) : 0)); /* may run into the mirror */
 			const u32 tokb = w & 255;
-			u32 lit = tokb >> 4, h = pos + 1;
+			const bool lx = (tokb >> 4) == 15;
+			const u32 b1 = (w >> 8) & 255;
+			const u32 lit = (tokb >> 4) + (lx ? b1 : 0);
+			const u32 lend = pos + 1 + (lx ? 1 : 0) + lit;
+			const u32 g2 = boff + lend;
+			const bool in2 = g2 + 4 <= ghi && g2 + P_RING >= ghi;
+			const u32 w2 = ld32u(myring + (in2 ? ring_off(g2, rb) : 0));
+			{ u64 t_ = KT(); c_t1 += t_ - tk0; tk0 = t_; }
+			const bool mx = (tokb & 15) == 15;
+			const u32 b2 = (w2 >> 16) & 255;
+			const u32 ml = (tokb & 15) + (mx ? b2 : 0);
+			const u32 m = lend + 2 + (mx ? 1 : 0);
+			/* fast path valid: both reads in the ring, no 255 continuation, a match follows
+			 * and a further token follows the match (m < cs) */
+			slow = !in1 || !in2 || (lx && b1 == 255) || (mx && b2 == 255) || m >= cs ||
+			       opos + lit + ml + 4 > ZMT_BLOCK;
+			if (!slow) {
+				emit = true;
+				opos += lit + ml + 4;
+				pos = m;
+			}
+			{ u64 t_ = KT(); c_t2 += t_ - tk0; tk0 = t_; }
+		}
+		if (slow) {
+			/* generic path (same arithmetic as the serial decoder), from global memory */
+			c_slow++;
+			u32 tokb = src[pos], lit = tokb >> 4, h = pos + 1;
 			if (lit == 15) {
-				u32 b = (w >> 8) & 255;
-				if (h >= cs)
-					ok = false;
-				h++;
-				lit += b;
-				while (ok && b == 255) {
+				u32 b;
+				do {
 					if (h >= cs) {
 						ok = false;
 						break;
 					}
 					b = src[h++];
 					lit += b;
-				}
+				} while (b == 255);
 			}
 			const u32 lend = h + lit;
-			if (lend > cs || lend < h)
+			if (ok && (lend > cs || lend < h))
 				ok = false;
 			if (ok) {
 				emit = true;
@@ -378,11 +400,7 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 								ok = false;
 								break;
 							}
-							if (m < rhi && m + P_RING >= rhi)
-								b = myring[m & (P_RING - 1)];
-							else
-								b = src[m];
-							m++;
+							b = src[m++];
 							ml += b;
 						} while (b == 255);
 					}
@@ -392,16 +410,12 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 					pos = m;
 				}
 			}
-#if defined(ZMT_EMU) && defined(ZMT_EMU_TRACE)
-			if (!ok)
-				fprintf(stderr, "parse fail gb=%u step=%u pos=%u my_pos=%u lit=%u lend=%u cs=%u opos=%u rhi=%u w=%08x\n",
-					gb, step, pos, my_pos, lit, lend, cs, opos, rhi, w);
-#endif
 			if (!ok) {
 				done = true;
 				emit = false;
 			}
 		}
+		{ u64 t_ = KT(); c_t3 += t_ - tk0; tk0 = t_; }
 		if (emit) {
 			mytile[n & 63] = (u16)my_pos;
 			if ((n & 63) == 0)
@@ -448,6 +462,9 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 					atomicAdd(prof + 4, (unsigned long long)(step + 1));
 					atomicAdd(prof + 5, (unsigned long long)slow_all);
 					atomicAdd(prof + 6, 1ull);
+					atomicAdd(prof + 10, (unsigned long long)c_t1);
+					atomicAdd(prof + 11, (unsigned long long)c_t2);
+					atomicAdd(prof + 12, (unsigned long long)c_t3);
 				}
 			}
 #endif

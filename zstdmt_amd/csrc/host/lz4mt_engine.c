@@ -21,7 +21,15 @@
 #include "gpumt.h"
 #include "lz4-mt.h"
 
-#define BATCH_BYTES ((size_t)64 << 20) /* uncompressed bytes per device batch (target) */
+/*
+ * Device batches.  The kernels are latency-bound per chunk (a wave per chunk / per record), so a
+ * batch should hold thousands of chunks to fill 256 CUs; pinned host memory on the other hand costs
+ * ~0.3 s per GiB to allocate and free (measured, tools/ubench/hostalloc.hip).  Batches therefore
+ * start at 64 MiB (small inputs stay cheap) and grow to 256 MiB; the buffers live as long as the
+ * context, so repeated calls on one context do not pay for them again.
+ */
+#define BATCH_MIN ((size_t)64 << 20)
+#define BATCH_BYTES ((size_t)256 << 20)
 #define BATCH_MAXREC 8192
 
 size_t lz4mt_errcode;
@@ -271,22 +279,28 @@ size_t LZ4MT_compressCCtx(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *rdwr)
 		return ERROR(compressionParameter_unsupported); /* LZ4HC: not on the device yet */
 	chunk = (size_t)ctx->inputsize;
 	stride = gpumt_lz4_slot_stride(chunk);
-	maxrec = BATCH_BYTES / chunk;
+	maxrec = BATCH_MIN / chunk;
 	if (maxrec < 1)
 		maxrec = 1;
-	if (maxrec > BATCH_MAXREC)
-		maxrec = BATCH_MAXREC;
-	for (int i = 0; i < 2; i++) {
-		struct cslot *s = &ctx->s[i];
-		if (dbuf_want(ctx->gpu, &s->in, maxrec * chunk + 64, 1, 1) ||
-		    dbuf_want(ctx->gpu, &s->slots, maxrec * stride, 0, 1) ||
-		    dbuf_want(ctx->gpu, &s->stream, maxrec * stride, 1, 1) ||
-		    dbuf_want(ctx->gpu, &s->meta, maxrec * 12 + 64, 1, 1))
-			return ERROR(memory_allocation);
-	}
 	/* the reference keeps its counters across calls; so do we */
 	while (!eof) {
 		struct cslot *s = &ctx->s[cur];
+		size_t lim = BATCH_BYTES / chunk;
+		if (lim < 1)
+			lim = 1;
+		if (lim > BATCH_MAXREC)
+			lim = BATCH_MAXREC;
+		if (maxrec > lim)
+			maxrec = lim;
+		/* (re)size this slot for the current batch size; it is idle: its previous batch was
+		 * finished two iterations ago */
+		if (dbuf_want(ctx->gpu, &s->in, maxrec * chunk + 512, 1, 1) ||
+		    dbuf_want(ctx->gpu, &s->slots, maxrec * stride, 0, 1) ||
+		    dbuf_want(ctx->gpu, &s->stream, maxrec * stride + 512, 1, 1) ||
+		    dbuf_want(ctx->gpu, &s->meta, maxrec * 12 + 64, 1, 1)) {
+			err = ERROR(memory_allocation);
+			break;
+		}
 		err = c_read_batch(ctx, rdwr, s, maxrec, &eof);
 		if (err)
 			break;
@@ -305,6 +319,7 @@ size_t LZ4MT_compressCCtx(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *rdwr)
 			have_prev = 1;
 			cur ^= 1;
 		}
+		maxrec *= 4;
 	}
 	if (!err && have_prev)
 		err = c_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
@@ -323,6 +338,7 @@ struct dslot {
 
 struct LZ4MT_DCtx_s {
 	int threads, inputsize;
+	size_t budget; /* output bytes per device batch, grows from BATCH_MIN to BATCH_BYTES */
 	size_t insize, outsize, curframe, frames;
 	gpumt_ctx *gpu;
 	struct dslot s[2];
@@ -434,17 +450,17 @@ static size_t d_read_batch(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, struct dslot *s, i
 				break;
 		}
 		/* close the batch when it is full; the header just read waits for the next one */
-		if (s->nrec && (s->in_bytes + 12 + (size_t)csize > s->in.cap - 64 || s->out_bytes >= BATCH_BYTES)) {
+		if (s->nrec && (s->in_bytes + 12 + (size_t)csize > s->in.cap - 512 || s->out_bytes >= ctx->budget)) {
 			ctx->have_hdr = 1;
 			ctx->hdr_csize = csize;
 			break;
 		}
 		ctx->have_hdr = 0;
-		if (s->in_bytes + 12 + (size_t)csize + 64 > s->in.cap) {
+		if (s->in_bytes + 12 + (size_t)csize + 512 > s->in.cap) {
 			/* a single record larger than the slot: grow (nothing is in flight in this slot) */
 			dbuf old = s->in;
 			memset(&s->in, 0, sizeof s->in);
-			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + 12 + (size_t)csize + 64, 1, 1))
+			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + 12 + (size_t)csize + 512, 1, 1))
 				return ERROR(memory_allocation);
 			memcpy(s->in.h, old.h, s->in_bytes);
 			dbuf_free(ctx->gpu, &old);
@@ -557,15 +573,17 @@ size_t LZ4MT_decompressDCtx(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *rdwr)
 		 * not on the device path yet -- see INTEGRATION.md */
 		return ERROR(frame_decompress);
 	}
-	for (int i = 0; i < 2; i++) {
-		struct dslot *s = &ctx->s[i];
-		if (dbuf_want(ctx->gpu, &s->in, BATCH_BYTES + (BATCH_BYTES >> 2), 1, 1) ||
-		    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1))
-			return ERROR(memory_allocation);
-	}
 	ctx->have_hdr = 0;
+	ctx->budget = BATCH_MIN;
 	while (!eof) {
 		struct dslot *s = &ctx->s[cur];
+		/* input slot sized for the batch budget (compressed data is never larger than that plus
+		 * per-record overhead); the slot is idle here */
+		if (dbuf_want(ctx->gpu, &s->in, ctx->budget + (ctx->budget >> 3) + 4096, 1, 1) ||
+		    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1)) {
+			err = ERROR(memory_allocation);
+			break;
+		}
 		err = d_read_batch(ctx, rdwr, s, &eof);
 		if (err)
 			break;
@@ -584,6 +602,8 @@ size_t LZ4MT_decompressDCtx(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *rdwr)
 			have_prev = 1;
 			cur ^= 1;
 		}
+		if (ctx->budget < BATCH_BYTES)
+			ctx->budget *= 4;
 	}
 	if (!err && have_prev)
 		err = d_finish(ctx, rdwr, &ctx->s[cur ^ 1]);

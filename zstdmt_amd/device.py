@@ -57,8 +57,9 @@ class Engine:
     def alloc(self, nbytes):
         return DevBuf(self, nbytes)
 
-    def upload(self, arr, stream=0, slack=64):
-        """numpy array / bytes -> new device buffer (+slack bytes so 8-byte hash reads stay inside)"""
+    def upload(self, arr, stream=0, slack=256):
+        """numpy array / bytes -> new device buffer (+slack: 8-byte hash reads of the encoder and the
+        128-byte line fetches of the decoder's parse kernel stay inside the allocation)"""
         a = np.frombuffer(arr, np.uint8) if isinstance(arr, (bytes, bytearray)) else arr
         a = np.ascontiguousarray(a)
         d = self.alloc(a.nbytes + slack)
