@@ -226,7 +226,9 @@ def main():
     def roof(k):
         t = ms[k] * 1e-3
         a = kern[k]["alg_bytes"] / t / 1e9
-        kname = {"k_lz4_enc": "zmt_lz4_enc_kernel",
+        kname = {"k_lz4_enc": {0: "zmt_lz4_enc3_p17_kernel" if 65536 < chunk <= 131072 else
+                                   ("zmt_lz4_enc3_u16_kernel" if chunk <= 65536 else "zmt_lz4_enc3_u32_kernel"),
+                               1: "zmt_lz4_enc_v1_kernel", 2: "zmt_lz4_enc_kernel"}[args.enc_variant],
                  "k_lz4_dec": ("zmt_dec_frames+parse+copy_kernel" if split else "zmt_lz4_dec_*"),
                  "k_xxh32_c": "zmt_xxh32_kernel", "k_xxh32_d": "zmt_xxh32_kernel",
                  "k_scan_compact": "zmt_compact_kernel", "k_dec_copy": "zmt_dec_copy_kernel",

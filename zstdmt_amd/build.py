@@ -19,6 +19,7 @@ OBJDIR = os.path.join(HERE, "build")
 HIP_SRCS = ["xxh32.hip", "lz4_enc.hip", "lz4_enc3.hip", "lz4_dec.hip", "lz4_dec_batch.hip", "lz4_dec_split.hip", "pack.hip", "gpumt.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+HIPFLAGS += os.environ.get("ZMT_HIPFLAGS", "").split()   # developer: -D overrides for A/B builds
 CFLAGS = ["-O2", "-g", "-std=gnu11", "-fPIC", "-pthread", "-Wall", "-Wextra",
           "-I" + os.path.join(ROOT, "include")]
 

@@ -29,8 +29,12 @@
 #include "lz4_common.h"
 #include "lz4_frame.h"
 
-#define WIN 8192u
-#define WIN_KEEP 4096u
+#ifndef WIN
+#define WIN 8192u      /* LDS output window per wave */
+#endif
+#ifndef WIN_KEEP
+#define WIN_KEEP 4096u /* history kept when the window slides */
+#endif
 #define CAP_LEN 64u
 #define SPAN_MAX 2048u
 #define CSTAGE 1024u /* compressed bytes staged in LDS per batch */
@@ -549,10 +553,8 @@ static __device__ __forceinline__ void flush_to(CopyState &st, const u8 *win, u8
 	st.flushed = upto;
 }
 
-static __device__ __forceinline__ void win_reserve(CopyState &st, u8 *win, u32 end, int lane)
+static __device__ __forceinline__ void win_slide(CopyState &st, u8 *win, int lane)
 {
-	if (end - st.wbase <= WIN)
-		return;
 	u32 nb = st.opos > WIN_KEEP ? (st.opos - WIN_KEEP) & ~15u : 0;
 	if (nb < st.wbase)
 		nb = st.wbase;
@@ -577,6 +579,11 @@ static __device__ __forceinline__ void win_reserve(CopyState &st, u8 *win, u32 e
 	}
 	wv_sync();
 	st.wbase = nb;
+}
+static __device__ __forceinline__ void win_reserve(CopyState &st, u8 *win, u32 end, int lane)
+{
+	if (end - st.wbase > WIN)
+		win_slide(st, win, lane);
 }
 
 /* cooperative copy of one long sequence straight to global memory (fields are wave-uniform) */
@@ -731,39 +738,58 @@ copy_body(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_bas
 			 * (ordinary) sequence lies inside it, else straight from global memory ---- */
 			u32 lit = 0, ml = 0, off = 1, lsrc = 0;
 			const u32 qr = q - cs0;
-			const bool staged = qr + 80 <= CSTAGE;
+			bool staged = qr + 80 <= CSTAGE;
 			{
-				const u32 w = staged ? ld32u(cb + qr) : (act0 ? ld32u(src + q) : 0);
+				/* fast path, branch-free: two LDS dword reads; a 255 continuation byte or a
+				 * sequence outside the staged window takes the generic path (rare) */
+				const u32 w = ld32u(cb + (staged ? qr : 0));
 				const u32 tokb = w & 255;
-				u32 l_ = tokb >> 4, h = q + 1;
-				if (l_ == 15) {
-					u32 b = (w >> 8) & 255;
-					h++;
-					l_ += b;
-					while (b == 255) { /* K2 validated the chain */
-						b = src[h++];
-						l_ += b;
-					}
-				}
+				const bool lx = (tokb >> 4) == 15;
+				const u32 b1 = (w >> 8) & 255;
+				const u32 l_ = (tokb >> 4) + (lx ? b1 : 0);
+				const u32 h = q + 1 + (lx ? 1 : 0);
 				const u32 lend = h + l_;
-				if (act0) {
+				const bool st2 = staged && lend - cs0 + 4 <= CSTAGE;
+				const u32 w2 = ld32u(cb + (st2 ? lend - cs0 : 0));
+				const bool mx = (tokb & 15) == 15;
+				const u32 b2 = (w2 >> 16) & 255;
+				const bool fast = staged && !(lx && b1 == 255) && (is_last || (st2 && !(mx && b2 == 255)));
+				if (act0 && fast) {
 					lit = l_;
 					lsrc = h;
 					if (!is_last) {
-						const bool st2 = staged && lend - cs0 + 4 <= CSTAGE;
-						const u32 w2 = st2 ? ld32u(cb + (lend - cs0)) : ld32u(src + lend);
 						off = w2 & 0xFFFF;
-						ml = tokb & 15;
+						ml = (tokb & 15) + (mx ? b2 : 0) + 4;
+					}
+				}
+				if (act0 && !fast) {
+					/* generic: straight from global memory (K2 validated the chain) */
+					const u32 tk = src[q];
+					u32 l2 = tk >> 4, h2 = q + 1;
+					if (l2 == 15) {
+						u32 b;
+						do {
+							b = src[h2++];
+							l2 += b;
+						} while (b == 255);
+					}
+					lit = l2;
+					lsrc = h2;
+					if (!is_last) {
+						u32 m = h2 + l2;
+						off = ld16u(src + m);
+						m += 2;
+						ml = tk & 15;
 						if (ml == 15) {
-							u32 m = lend + 3, b = (w2 >> 16) & 255;
-							ml += b;
-							while (b == 255) {
+							u32 b;
+							do {
 								b = src[m++];
 								ml += b;
-							}
+							} while (b == 255);
 						}
 						ml += 4;
 					}
+					staged = false; /* literals of this sequence come from global memory too */
 				}
 			}
 			PC(0);
@@ -827,11 +853,13 @@ copy_body(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_bas
 							st.fenced = st.flushed;
 						}
 						if (wv_any(far_plain)) {
-							u32 mx = 0;
-							for (u32 t = 1; t <= 8; t++)
-								if (wv_any(far_plain && ml > 8 * (t - 1)))
-									mx = t;
-							far_trips = mx;
+							/* widest far match in 8-byte units (1..8), by bisection on ballots */
+							const u32 tr = far_plain ? (ml + 7) >> 3 : 0;
+							u32 mxt = wv_any(tr > 4) ? 4 : 0;
+							mxt += wv_any(tr > mxt + 2) ? 2 : 0;
+							mxt += wv_any(tr > mxt + 1) ? 1 : 0;
+							mxt += wv_any(tr > mxt) ? 1 : 0;
+							far_trips = mxt;
 							const u8 *g = out + src_pos;
 							ZMT_UNROLL
 							for (u32 t = 0; t < 8; t++) {
