@@ -24,7 +24,10 @@
 #define MFLIMIT 12u
 #define LASTLITERALS 5u
 #define DIST_MAX 65535u
-#define IRING 2048u /* input ring bytes (power of two) */
+#ifndef IRING
+#define IRING 2048u /* input ring bytes (power of two): look-ahead + recent history that serves near candidates */
+#endif
+#define IPIECE 512u /* refill granule: 8 bytes per lane */
 #define IMIRROR 16u
 
 enum { T_U16 = 0, T_P17 = 1, T_U32 = 2 };
@@ -107,7 +110,7 @@ struct InRing {
 	u8 *ring;
 	const u8 *chunk;
 	u32 rlo;     /* ring is valid for chunk positions [max(rlo, rhi - IRING), rhi) */
-	u32 rhi;     /* end of what has been loaded (multiple of 1024) */
+	u32 rhi;     /* end of what has been loaded (multiple of IPIECE) */
 	u32 limit;   /* never load at or beyond this chunk position (readable bytes of the input) */
 	u8 *mwin;    /* 128-byte window of the match side: mwin[i] = chunk[mbase + i] */
 	u32 mbase;
@@ -121,39 +124,32 @@ struct InRing {
 #define EPC(R, i) do { } while (0)
 #endif
 
-/* make [pos, pos + 1024) (clipped to the input) resident */
+/* make [pos, pos + IPIECE) (clipped to the input) resident */
 static __device__ __forceinline__ void ring_want(InRing &R, u32 pos, int lane)
 {
-	const u32 want_hi = pos + 1024;
+	const u32 want_hi = pos + IPIECE;
 	if (want_hi > R.rhi + 2 * IRING) {
 		/* far jump (long literal run): restart the ring at the new position */
-		R.rhi = pos & ~1023u;
+		R.rhi = pos & ~(IPIECE - 1);
 		R.rlo = R.rhi;
 	}
 	while (R.rhi < want_hi && R.rhi < R.limit) {
-		const u32 p = R.rhi + 16u * (u32)lane;
-		u64 a = 0, b = 0;
-		if (p + 16 <= R.limit) {
+		const u32 p = R.rhi + 8u * (u32)lane;
+		u64 a = 0;
+		if (p + 8 <= R.limit) {
 			a = ld64u(R.chunk + p);
-			b = ld64u(R.chunk + p + 8);
 		} else {
-			for (u32 k = 0; k < 8; k++) {
+			for (u32 k = 0; k < 8; k++)
 				if (p + k < R.limit)
 					a |= (u64)R.chunk[p + k] << (8 * k);
-				if (p + 8 + k < R.limit)
-					b |= (u64)R.chunk[p + 8 + k] << (8 * k);
-			}
 		}
 		wv_sync();
 		u8 *d = R.ring + (p & (IRING - 1));
 		*(u64 *)d = a;
-		*(u64 *)(d + 8) = b;
-		if ((p & (IRING - 1)) == 0) { /* mirror: multi-byte reads never wrap */
-			*(u64 *)(R.ring + IRING) = a;
-			*(u64 *)(R.ring + IRING + 8) = b;
-		}
+		if ((p & (IRING - 1)) < IMIRROR) /* mirror: multi-byte reads never wrap */
+			*(u64 *)(d + IRING) = a;
 		wv_sync();
-		R.rhi += 1024;
+		R.rhi += IPIECE;
 	}
 }
 /* is chunk[p .. p+n) readable from the ring? (n <= IMIRROR beyond a wrap) */
@@ -187,10 +183,23 @@ static __device__ __forceinline__ void mwin_fetch(InRing &R, u32 m, int lane)
 	wv_sync();
 	R.mbase = base;
 }
-/* chunk[p] of the match side: window when inside, else memory */
+/* make the match side around m readable from LDS: nothing to do when the input ring still holds
+ * [m-64, m+132), else one global fetch into the window (wave-uniform decision) */
+static __device__ __forceinline__ void mside_prepare(InRing &R, u32 m, int lane)
+{
+	const u32 lo = m >= 64 ? m - 64 : 0;
+	if (ring_has(R, lo, m + 132 - lo)) {
+		R.mbase = 0xFFFFFFFFu; /* window unused: m_ld8 goes to the ring */
+		return;
+	}
+	mwin_fetch(R, m, lane);
+}
+/* chunk[p] of the match side: ring, else window, else memory */
 static __device__ __forceinline__ u32 m_ld8(const InRing &R, u32 p)
 {
-	return (p >= R.mbase && p < R.mbase + MWIN) ? (u32)R.mwin[p - R.mbase] : (u32)R.chunk[p];
+	if (ring_has(R, p, 1))
+		return (u32)R.ring[p & (IRING - 1)];
+	return (p >= R.mbase && p - R.mbase < MWIN) ? (u32)R.mwin[p - R.mbase] : (u32)R.chunk[p];
 }
 
 /* cooperative literal copy chunk[a .. a+n) -> d, from the ring when it is there */
@@ -276,7 +285,9 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						cand = pc;
 					const bool dist_ok = (TM == T_U16) || cand + DIST_MAX >= cur;
 					EPC(R, 0);
-					const u32 c4 = (valid && dist_ok && prev_dup == 64) ? ld32u(chunk + cand) : p4;
+					u32 c4 = p4;
+					if (valid && dist_ok && prev_dup == 64) /* recent candidates come from the ring */
+						c4 = ring_has(R, cand, 4) ? ld32u(R.ring + (cand & (IRING - 1))) : ld32u(chunk + cand);
 					const bool m = valid && dist_ok && c4 == (u32)x;
 					const u64 mm = wv_ballot(m);
 					const u32 nvalid = (u32)wv_popc(vm);
@@ -302,28 +313,74 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			if (!found)
 				goto last_literals;
 		}
-		mwin_fetch(R, match, lane);
-		/* ---------------- catch up (cooperative backward compare) ---------------- */
+		/* ---------------- extend the match both ways in one step ----------------
+		 * The match side is readable from LDS either way: from the input ring when the candidate
+		 * is recent, else from the 128-byte window fetched from global memory.  Backward
+		 * (catch-up) and forward (match length) compares are independent -- the forward count
+		 * from the probe position is the same whatever the catch-up finds -- so both LDS reads
+		 * are in flight together. */
+		u32 fwd; /* equal bytes following the 4 that matched at ip */
 		{
-			/* backward */
-			for (;;) {
-				u32 room = ip - anchor;
-				if (match - low < room)
-					room = match - low;
-				if (room == 0)
-					break;
-				const u32 n = room < 64 ? room : 64;
-				bool eq = false;
-				if ((u32)lane < n)
-					eq = in_ld8(R, ip - 1 - (u32)lane) == m_ld8(R, match - 1 - (u32)lane);
-				const u64 ne = ~wv_ballot(eq);
-				const u32 run = ne ? (u32)wv_ffs(ne) - 1 : 64;
-				const u32 take = run < n ? run : n;
-				ip -= take;
-				match -= take;
-				if (take < 64)
-					break;
+			mside_prepare(R, match, lane);
+			u32 room = ip - anchor;
+			if (match - low < room)
+				room = match - low;
+			const u32 nb = room < 64 ? room : 64;
+			const u32 flimit = matchlimit - (ip + MINMATCH);
+			bool eqb = false, stopf = true;
+			if ((u32)lane < nb)
+				eqb = in_ld8(R, ip - 1 - (u32)lane) == m_ld8(R, match - 1 - (u32)lane);
+			if ((u32)lane < flimit)
+				stopf = in_ld8(R, ip + MINMATCH + (u32)lane) != m_ld8(R, match + MINMATCH + (u32)lane);
+			const u64 neb = ~wv_ballot(eqb);
+			const u64 smf = wv_ballot(stopf);
+			u32 back = neb ? (u32)wv_ffs(neb) - 1 : 64;
+			if (back > nb)
+				back = nb;
+			fwd = smf ? (u32)wv_ffs(smf) - 1 : 64;
+			if (back == 64) { /* rare: catch-up continues beyond 64 bytes */
+				u32 ip2 = ip - 64, m2 = match - 64;
+				for (;;) {
+					u32 r2 = ip2 - anchor;
+					if (m2 - low < r2)
+						r2 = m2 - low;
+					if (r2 == 0)
+						break;
+					const u32 n2 = r2 < 64 ? r2 : 64;
+					bool e2 = false;
+					if ((u32)lane < n2)
+						e2 = in_ld8(R, ip2 - 1 - (u32)lane) == m_ld8(R, m2 - 1 - (u32)lane);
+					const u64 ne2 = ~wv_ballot(e2);
+					u32 t2 = ne2 ? (u32)wv_ffs(ne2) - 1 : 64;
+					if (t2 > n2)
+						t2 = n2;
+					ip2 -= t2;
+					m2 -= t2;
+					back += t2;
+					if (t2 < 64)
+						break;
+				}
 			}
+			if (!smf) { /* rare: the match runs on beyond 64 bytes */
+				u32 base = 64;
+				for (;;) {
+					ring_want(R, ip + MINMATCH + base, lane);
+					const u32 i2 = base + (u32)lane;
+					bool st2 = true;
+					if (i2 < flimit)
+						st2 = in_ld8(R, ip + MINMATCH + i2) != m_ld8(R, match + MINMATCH + i2);
+					const u64 sm2 = wv_ballot(st2);
+					if (sm2) {
+						fwd = base + (u32)wv_ffs(sm2) - 1;
+						break;
+					}
+					base += 64;
+				}
+			}
+			/* after catch-up the match starts `back` bytes earlier; its code length grows by that */
+			ip -= back;
+			match -= back;
+			fwd += back;
 		}
 		EPC(R, 2);
 		{
@@ -338,31 +395,11 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			op += lit;
 		}
 		EPC(R, 3);
-		for (;;) { /* next_match */
-			u32 mc;
+		for (;;) { /* next_match: ip, match, fwd (= match length - 4) are set */
+			const u32 mc = fwd;
 			if (lane == 0)
 				st16u(dst + op, ip - match);
 			op += 2;
-			{
-				/* forward count, 64 bytes per step; ip side from the ring */
-				const u32 limit = matchlimit - (ip + MINMATCH);
-				u32 base = 0;
-				ring_want(R, ip, lane);
-				for (;;) {
-					const u32 i = base + (u32)lane;
-					bool stop = true;
-					if (i < limit)
-						stop = in_ld8(R, ip + MINMATCH + i) != m_ld8(R, match + MINMATCH + i);
-					const u64 sm = wv_ballot(stop);
-					if (sm) {
-						mc = base + (u32)wv_ffs(sm) - 1;
-						break;
-					}
-					base += 64;
-					ring_want(R, ip + MINMATCH + base, lane);
-				}
-			}
-			EPC(R, 4);
 			ip += mc + MINMATCH;
 			if (op + (1 + LASTLITERALS) + (mc + 240) / 255 > cap)
 				return 0;
@@ -371,6 +408,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			if (mc >= 15)
 				op += put_len_ext3(dst + op, mc - 15, lane);
 			anchor = ip;
+			EPC(R, 4);
 			if (ip >= mflimit_p1)
 				goto block_done;
 			ring_want(R, ip, lane);
@@ -382,21 +420,48 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					       (u64)wv_readfirst((u32)(in_ld64(R, ip) >> 32)) << 32;
 				const u32 h2 = hash3<TM>(TM == T_U16 ? (u64)(u32)x2 : x2);
 				const u32 h0 = hash3<TM>(TM == T_U16 ? (u64)(u32)x0 : x0);
+				/* reference order: insert ip-2, look up ip, insert ip.  The lookup is issued first
+				 * (one LDS round trip instead of two); if both hashes collide the entry just
+				 * inserted is the answer */
 				wv_sync();
-				if (lane == 0)
+				u32 midx = wv_readfirst(t_read<TM>(tlo, thi, h0));
+				if (h2 == h0)
+					midx = ip - 2;
+				wv_sync();
+				if (lane == 0) {
 					t_write<TM>(tlo, thi, h2, ip - 2);
-				wv_sync();
-				const u32 midx = wv_readfirst(t_read<TM>(tlo, thi, h0));
-				wv_sync();
-				if (lane == 0)
 					t_write<TM>(tlo, thi, h0, ip);
+				}
 				match = midx;
 				bool rm = (TM == T_U16) || midx + DIST_MAX >= ip;
 				if (rm) {
-					/* one fetch: the 4-byte test now, the match count right after */
-					mwin_fetch(R, match, lane);
-					const u32 o = match - R.mbase;
-					rm = wv_readfirst(ld32u(R.mwin + o)) == (u32)x0;
+					/* the 4-byte test and the match count are one compare: equal prefix of
+					 * chunk[ip...] and chunk[match...], 64 bytes per step */
+					mside_prepare(R, match, lane);
+					const u32 lim = matchlimit - ip; /* > 4: ip < mflimit+1 */
+					bool stp = true;
+					if ((u32)lane < lim)
+						stp = in_ld8(R, ip + (u32)lane) != m_ld8(R, match + (u32)lane);
+					const u64 sm = wv_ballot(stp);
+					u32 eqn = sm ? (u32)wv_ffs(sm) - 1 : 64;
+					rm = eqn >= MINMATCH;
+					if (rm && !sm) { /* rare: more than 64 equal bytes */
+						u32 base = 64;
+						for (;;) {
+							ring_want(R, ip + base, lane);
+							const u32 i2 = base + (u32)lane;
+							bool st2 = true;
+							if (i2 < lim)
+								st2 = in_ld8(R, ip + i2) != m_ld8(R, match + i2);
+							const u64 sm2 = wv_ballot(st2);
+							if (sm2) {
+								eqn = base + (u32)wv_ffs(sm2) - 1;
+								break;
+							}
+							base += 64;
+						}
+					}
+					fwd = eqn - MINMATCH;
 				}
 				EPC(R, 5);
 				if (rm) {
@@ -472,7 +537,8 @@ static __device__ __forceinline__ void enc3_body(u32 *tlo, u32 *thi, u32 *bitmap
 		tlo[i] = 0;
 	for (u32 i = (u32)lane; i < 128; i += 64) {
 		bitmap[i] = 0;
-		bitmap[i + 128] = 0;
+		if (TM == T_U16)
+			bitmap[i + 128] = 0;
 		if (TM == T_P17)
 			thi[i] = 0;
 	}
@@ -532,7 +598,7 @@ static __device__ __forceinline__ void enc3_body(u32 *tlo, u32 *thi, u32 *bitmap
 	{                                                                                          \
 		__shared__ __attribute__((aligned(16))) u32 tlo[(TABBYTES) / 4];                   \
 		__shared__ u32 thi[128];                                                           \
-		__shared__ u32 bitmap[256];                                                        \
+		__shared__ u32 bitmap[(TM) == T_U16 ? 256 : 128];                                  \
 		__shared__ __attribute__((aligned(16))) u8 ring[IRING + IMIRROR];                  \
 		__shared__ __attribute__((aligned(16))) u8 mwin[MWIN + 16];                        \
 		enc3_body<TM>(tlo, thi, bitmap, ring, mwin, in, n, chunk, rec0, nrec, slots,       \
