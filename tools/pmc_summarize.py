@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Fold gpurun_out/prof_{stats,fetch,write} (written by tools/profile_round.sh) into profiles/.
+
+  profiles/rNN_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (newest run, largest file = the bench process)
+  profiles/pmc_traffic.json       per-launch HBM bytes of every kernel: FETCH_SIZE x2 (gfx950 correction,
+                                  MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB units
+  profiles/rNN_bench_8gib_1gpu.json  the bench line of the same run
+"""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+go = os.path.join(root, "gpurun_out")
+
+
+def biggest(pattern):
+    files = glob.glob(os.path.join(go, pattern), recursive=True)
+    # several processes write files (rocprofv3 wraps python and its children): keep the ones of the
+    # newest run, and among those the largest
+    if not files:
+        return None
+    newest = max(os.path.getmtime(f) for f in files)
+    files = [f for f in files if newest - os.path.getmtime(f) < 120]
+    return max(files, key=os.path.getsize)
+
+
+def counter_avg(path):
+    tot, n = defaultdict(float), defaultdict(int)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            tot[row["Kernel_Name"]] += float(row["Counter_Value"])
+            n[row["Kernel_Name"]] += 1
+    return {k: tot[k] / n[k] for k in tot}
+
+
+stats = biggest("prof_stats/**/*_kernel_stats.csv")
+shutil.copy(stats, os.path.join(root, "profiles", f"{rnd}_kernel_stats.csv"))
+fetch = counter_avg(biggest("prof_fetch/**/*_counter_collection.csv"))
+write = counter_avg(biggest("prof_write/**/*_counter_collection.csv"))
+detail, per = [], {}
+for k in sorted(set(fetch) | set(write)):
+    fb = fetch.get(k, 0.0) * 1024 * 2
+    wb = write.get(k, 0.0) * 1024
+    detail.append({"kernel": k, "FETCH_SIZE_KiB_raw": fetch.get(k, 0.0), "WRITE_SIZE_KiB_raw": write.get(k, 0.0),
+                   "fetch_bytes_corrected": fb, "write_bytes": wb})
+    per[k] = int(fb + wb)
+out = {
+    "_what": "HBM-side traffic per launch of each kernel at the bench workload (8 GiB, 128 KiB chunks, 1 GPU), "
+             "from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; units KiB)",
+    "_correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B -> doubled (MI355X_MICROARCH.md, HBM "
+                   "section). Calibrated on zmt_xxh32_kernel, which reads exactly 8 GiB (raw x 1024 = 0.508 x "
+                   "8.59e9 B); WRITE_SIZE calibrated on zmt_compact_kernel (writes the compacted stream once), taken as is",
+    "_command": "bash tools/profile_round.sh  (rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- "
+                "python bench.py --steps 1 --warmup 0 --no-cpu, and the same with WRITE_SIZE)",
+    "per_launch_bytes_8gib": per,
+    "detail": detail,
+}
+json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
+line = open(os.path.join(go, "bench_default.json")).read().strip().splitlines()[-1]
+json.dump(json.loads(line), open(os.path.join(root, "profiles", f"{rnd}_bench_8gib_1gpu.json"), "w"), indent=1)
+print(open(stats).read())
+for d in detail:
+    print(d["kernel"], f'{d["fetch_bytes_corrected"]/1e9:.2f} GB fetched, {d["write_bytes"]/1e9:.2f} GB written')

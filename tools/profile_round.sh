@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): the default bench line, the rocprofv3 kernel-trace summary of the
+# same command, and the two separate PMC passes (FETCH_SIZE, WRITE_SIZE).  Everything lands under
+# gpurun_out/; tools/pmc_summarize.py turns it into the files committed under profiles/.
+#   gpurun --timeout 900 -- 'bash tools/profile_round.sh'
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out
+rm -rf $O/prof_stats $O/prof_fetch $O/prof_write
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- \
+    python bench.py --steps 2 --warmup 1 --no-cpu > $O/bench_prof.json 2> $O/prof_stats.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch -- \
+    python bench.py --steps 1 --warmup 0 --no-cpu > $O/bench_fetch.json 2> $O/prof_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -- \
+    python bench.py --steps 1 --warmup 0 --no-cpu > $O/bench_write.json 2> $O/prof_write.err
+cat $O/bench_default.json

@@ -683,25 +683,17 @@ copy_body(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_bas
 		 */
 		const u16 *tk = tok + tbase;
 		const u32 *bx = bidx + (tbase >> 6);
-		const u64 avail = stream_bytes - coff; /* readable bytes from src */
 #define TOK_LOAD(T0) (((T0) + (u32)lane < ntok) ? (u32)tk[(T0) + lane] : 0u)
 #define STAGE_LOAD(CS0, A, B)                                                                     \
 	do {                                                                                       \
-		const u64 o_ = (u64)(CS0) + 16u * (u32)lane;                                       \
+		/* may run up to 31 bytes past the block, hence past stream_bytes: the stream      \
+		 * allocation carries 256 bytes of slack (include/gpumt.h) */                       \
+		const u32 o_ = (CS0) + 16u * (u32)lane;                                            \
 		(A) = 0;                                                                           \
 		(B) = 0;                                                                           \
-		if (o_ < (u64)cs + 8) {                                                            \
-			if (o_ + 16 <= avail) {                                                    \
-				(A) = ld64u(src + o_);                                             \
-				(B) = ld64u(src + o_ + 8);                                         \
-			} else {                                                                   \
-				for (u32 k_ = 0; k_ < 8; k_++) {                                   \
-					if (o_ + k_ < avail)                                       \
-						(A) |= (u64)src[o_ + k_] << (8 * k_);              \
-					if (o_ + 8 + k_ < avail)                                   \
-						(B) |= (u64)src[o_ + 8 + k_] << (8 * k_);          \
-				}                                                                  \
-			}                                                                          \
+		if (o_ < cs + 8) {                                                                 \
+			(A) = ld64u(src + o_);                                                     \
+			(B) = ld64u(src + o_ + 8);                                                 \
 		}                                                                                  \
 	} while (0)
 		u32 q_cur = TOK_LOAD(0), q_nxt = TOK_LOAD(64);
