@@ -93,6 +93,24 @@ size_t zo_lz4mt_compress_mt(const uint8_t *src, size_t n, size_t chunk, uint8_t 
 size_t zo_lz4mt_decompress_mt(const uint8_t *src, size_t slen, uint8_t *dst, size_t cap,
 			      int threads);
 
+/* ---- zstd-mt decode path (zstd_oracle.c; restates RFC 8878 + lib/zstd-mt_decompress.c) ------ */
+#define ZO_ZSTD_MAGIC    0xFD2FB528u            /* lib/zstd-mt.h:33 (MAGICNUMBER_MAX) */
+#define ZO_ZSTD_UNKNOWN  0xFFFFFFFFFFFFFFFFull  /* frame carries no content size */
+#define ZO_ZSTD_ERROR    0xFFFFFFFFFFFFFFFEull  /* not a zstd frame header */
+
+uint64_t zo_xxh64(const void *data, size_t len, uint64_t seed);
+
+/* Frame_Content_Size of a zstd frame header, ZO_ZSTD_UNKNOWN or ZO_ZSTD_ERROR. */
+uint64_t zo_zstd_frame_content_size(const uint8_t *frame, size_t slen);
+
+/* Decode one zstd frame (no dictionary).  Returns content bytes or (size_t)-1; *consumed (may be
+ * NULL) receives the frame's length in src. */
+size_t zo_zstd_decompress_frame(const uint8_t *src, size_t slen, uint8_t *dst, size_t cap,
+				size_t *consumed);
+
+/* Whole zstd-mt stream ("pzstd style" records, what lib/zstd-mt_compress.c:296-302 writes). */
+size_t zo_zstdmt_decompress(const uint8_t *src, size_t slen, uint8_t *dst, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,3 +86,32 @@ KNOWN_HEX = {
     "abc_12": "502a4d18040000002700000004224d186c400c000000000000003b0c000080616263616263616263616263000000003366e641",
     "abc_13": "502a4d18040000002800000004224d186c400d00000000000000ce0d0000806162636162636162636162636100000000fabc9f1a",
 }
+
+
+# ---- zstd-mt decoder inputs: name -> (level, chunk size (0 = the level's default), input thunk) ----
+# Streams are written by the reference build (gen_golden_zstd.py); the cases cover raw / RLE /
+# compressed blocks, Huffman literals with direct and FSE-compressed weights, 1 and 4 streams,
+# treeless blocks, predefined / RLE / compressed / repeat sequence tables, repeat offsets, long
+# offsets and lengths, multi-block frames and multi-frame streams.
+ZCASES = {
+    "z_empty":        (1, 0, lambda: b""),
+    "z_hello":        (1, 0, lambda: b"hello world, hello world, hello!"),
+    "z_text_100":     (1, 0, lambda: text(100)),
+    "z_text_3000":    (3, 0, lambda: text(3000, 5)),
+    "z_text_64k_l1":  (1, 0, lambda: text(64 * K)),
+    "z_text_200k_l1": (1, 0, lambda: text(200 * K, 7)),
+    "z_text_200k_l5": (5, 0, lambda: text(200 * K, 7)),
+    "z_text_200k_l19": (19, 0, lambda: text(200 * K, 7)),
+    "z_text_3x128k":  (1, CH, lambda: text(3 * CH + 100, 11)),
+    "z_text_1m_l1":   (1, 0, lambda: text(1024 * K + 77, 3)),
+    "z_random_100k":  (1, 0, lambda: rnd(100000, 3)),
+    "z_zeros_300k":   (1, 0, lambda: bytes(300000)),
+    "z_zeros_chunks": (3, CH, lambda: bytes(300000)),
+    "z_period_300":   (1, 0, lambda: rep(rnd(300, 9), 200000)),
+    "z_period_65537": (2, 0, lambda: rep(rnd(65537, 4), 400000)),
+    "z_lowentropy":   (1, 0, lambda: bytes(b & 3 for b in rnd(150000, 12))),
+    "z_two_symbols":  (4, 0, lambda: bytes(65 + (b & 1) for b in rnd(70000, 13))),
+    "z_mixed":        (1, 0, lambda: text(50000, 4) + bytes(70000) + rnd(3000, 5) + text(200000, 6)),
+    "z_mixed_l9":     (9, 0, lambda: text(50000, 4) + bytes(70000) + rnd(3000, 5) + text(200000, 6)),
+    "z_allbytes":     (1, 0, lambda: bytes(range(256)) * 300 + text(40000, 8)),
+}

@@ -13,16 +13,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "liblz4mt_ref.so")
+ZREF_SO = os.path.join(ORACLE_DIR, "_ref", "libzstdmt_ref.so")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 _oracle = None
 _ref = None
+_zref = None
 
 
 def build_oracle():
     """(Re)build liboracle.so if missing or stale.  Building the checker is not using it."""
-    src = os.path.join(ORACLE_DIR, "lz4_oracle.c")
-    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("lz4_oracle.c", "zstd_oracle.c", "zmt_oracle.h")]
+    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < max(map(os.path.getmtime, srcs)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"],
                               stdout=subprocess.DEVNULL)
     return ORACLE_SO
@@ -51,6 +53,14 @@ def oracle():
         lib.zo_lz4mt_compress_mt.argtypes = [C.c_void_p, sz, sz, C.c_void_p, sz, C.c_int]
         lib.zo_lz4mt_decompress_mt.restype = sz
         lib.zo_lz4mt_decompress_mt.argtypes = [C.c_void_p, sz, C.c_void_p, sz, C.c_int]
+        lib.zo_xxh64.restype = C.c_uint64
+        lib.zo_xxh64.argtypes = [p8, sz, C.c_uint64]
+        lib.zo_zstd_frame_content_size.restype = C.c_uint64
+        lib.zo_zstd_frame_content_size.argtypes = [p8, sz]
+        lib.zo_zstd_decompress_frame.restype = sz
+        lib.zo_zstd_decompress_frame.argtypes = [p8, sz, C.c_void_p, sz, C.POINTER(sz)]
+        lib.zo_zstdmt_decompress.restype = sz
+        lib.zo_zstdmt_decompress.argtypes = [p8, sz, C.c_void_p, sz]
         _oracle = lib
     return _oracle
 
@@ -105,9 +115,23 @@ def have_ref():
     return os.path.exists(REF_SO)
 
 
-def bind_lz4mt(lib):
-    """Attach prototypes for the LZ4MT_* ABI (shared by the reference .so and our own library)."""
+def bind_lz4mt(lib, pfx="LZ4MT_"):
+    """Attach prototypes for the LZ4MT_* (or ZSTDCB_*: same shapes, lib/zstd-mt.h:115-205) ABI,
+    shared by the reference .so and our own library."""
     vp, sz = C.c_void_p, C.c_size_t
+    if pfx != "LZ4MT_":
+        for n, (res, args) in {
+            "createCCtx": (vp, [C.c_int, C.c_int, C.c_int]), "compressCCtx": (sz, [vp, C.POINTER(RefRdWr)]),
+            "freeCCtx": (None, [vp]), "createDCtx": (vp, [C.c_int, C.c_int]),
+            "decompressDCtx": (sz, [vp, C.POINTER(RefRdWr)]), "freeDCtx": (None, [vp]),
+            "GetFramesCCtx": (sz, [vp]), "GetInsizeCCtx": (sz, [vp]), "GetOutsizeCCtx": (sz, [vp]),
+            "GetFramesDCtx": (sz, [vp]), "GetInsizeDCtx": (sz, [vp]), "GetOutsizeDCtx": (sz, [vp]),
+            "isError": (C.c_uint, [sz]), "getErrorString": (C.c_char_p, [sz]),
+        }.items():
+            f = getattr(lib, pfx + n)
+            f.restype = res
+            f.argtypes = args
+        return lib
     lib.LZ4MT_createCCtx.restype = vp
     lib.LZ4MT_createCCtx.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.LZ4MT_compressCCtx.restype = sz
@@ -137,6 +161,18 @@ def ref():
     if _ref is None:
         _ref = bind_lz4mt(C.CDLL(REF_SO))
     return _ref
+
+
+def have_zref():
+    return os.path.exists(ZREF_SO)
+
+
+def zref():
+    """The reference's zstd-mt library (lib/zstd-mt_*.c + the image's libzstd 1.4.9)."""
+    global _zref
+    if _zref is None:
+        _zref = bind_lz4mt(C.CDLL(ZREF_SO), "ZSTDCB_")
+    return _zref
 
 
 class MemIO:
@@ -185,27 +221,42 @@ class MemIO:
         return b"".join(self.out)
 
 
-def lz4mt_compress_via(lib, data: bytes, chunk: int, threads: int = 1, level: int = 1):
-    """Run <lib>.LZ4MT_compressCCtx over in-memory callbacks; returns (rv, stream, io, stats)."""
+def lz4mt_compress_via(lib, data: bytes, chunk: int, threads: int = 1, level: int = 1, pfx="LZ4MT_"):
+    """Run <lib>.<pfx>compressCCtx over in-memory callbacks; returns (rv, stream, io, stats)."""
+    g = lambda n: getattr(lib, pfx + n)
     io = MemIO(data)
-    ctx = lib.LZ4MT_createCCtx(threads, level, chunk)
+    ctx = g("createCCtx")(threads, level, chunk)
     assert ctx
-    rv = lib.LZ4MT_compressCCtx(ctx, C.byref(io.rdwr))
-    stats = (lib.LZ4MT_GetFramesCCtx(ctx), lib.LZ4MT_GetInsizeCCtx(ctx),
-             lib.LZ4MT_GetOutsizeCCtx(ctx))
-    lib.LZ4MT_freeCCtx(ctx)
+    rv = g("compressCCtx")(ctx, C.byref(io.rdwr))
+    stats = (g("GetFramesCCtx")(ctx), g("GetInsizeCCtx")(ctx), g("GetOutsizeCCtx")(ctx))
+    g("freeCCtx")(ctx)
     return rv, io.result(), io, stats
 
 
-def lz4mt_decompress_via(lib, stream: bytes, threads: int = 1, inputsize: int = 0):
+def lz4mt_decompress_via(lib, stream: bytes, threads: int = 1, inputsize: int = 0, pfx="LZ4MT_"):
+    g = lambda n: getattr(lib, pfx + n)
     io = MemIO(stream)
-    ctx = lib.LZ4MT_createDCtx(threads, inputsize)
+    ctx = g("createDCtx")(threads, inputsize)
     assert ctx
-    rv = lib.LZ4MT_decompressDCtx(ctx, C.byref(io.rdwr))
-    stats = (lib.LZ4MT_GetFramesDCtx(ctx), lib.LZ4MT_GetInsizeDCtx(ctx),
-             lib.LZ4MT_GetOutsizeDCtx(ctx))
-    lib.LZ4MT_freeDCtx(ctx)
+    rv = g("decompressDCtx")(ctx, C.byref(io.rdwr))
+    stats = (g("GetFramesDCtx")(ctx), g("GetInsizeDCtx")(ctx), g("GetOutsizeDCtx")(ctx))
+    g("freeDCtx")(ctx)
     return rv, io.result(), io, stats
+
+
+def zstdmt_compress_via(lib, data, chunk, threads=1, level=1):
+    return lz4mt_compress_via(lib, data, chunk, threads, level, pfx="ZSTDCB_")
+
+
+def zstdmt_decompress_via(lib, stream, threads=2, inputsize=0):
+    return lz4mt_decompress_via(lib, stream, threads, inputsize, pfx="ZSTDCB_")
+
+
+def oracle_zstdmt_decompress(stream: bytes, cap: int):
+    lib = oracle()
+    out = C.create_string_buffer(max(cap, 1))
+    n = lib.zo_zstdmt_decompress(stream, len(stream), out, cap)
+    return None if n == SIZE_ERR else out.raw[:n]
 
 
 # ----------------------------------------------------------------------------------------------
