@@ -130,6 +130,27 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 			       void *d_out, size_t out_bytes, const uint64_t *d_out_off,
 			       const uint32_t *d_out_len, uint32_t *d_status, int stream);
 
+/* ---- zstd-mt records (12-byte skippable header + one zstd frame, lib/zstd-mt_compress.c:296-302) ----
+ *
+ * gpumt_zstd_probe_sizes: d_out_len[i] = Frame_Content_Size of record i, d_out_off = exclusive
+ * scan, d_status[i] = GPUMT_ST_OK or why the record cannot be decoded on the device (bad record /
+ * frame header, or GPUMT_ST_UNSUPPORTED for frames without a content size -- zstd-mt always writes
+ * one, it compresses each chunk with one-shot ZSTD_compress, :285).
+ *
+ * gpumt_zstd_decompress_batch: decode the records whose d_status is GPUMT_ST_OK (replaces
+ * ZSTD_decompressStream at lib/zstd-mt_decompress.c:464): raw / RLE / compressed blocks, Huffman
+ * literals, FSE sequence tables of every mode, repeat offsets; no dictionaries; frames with an
+ * XXH64 content checksum report GPUMT_ST_UNSUPPORTED.  Same d_stream slack rule as above.
+ * Internal scratch: 128 KiB + 256 B of literals per record.
+ */
+int gpumt_zstd_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
+			   const uint32_t *d_rec_len, size_t nrec, uint32_t *d_out_len,
+			   uint64_t *d_out_off, uint32_t *d_status, int stream);
+int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream_bytes,
+				const uint64_t *d_rec_off, const uint32_t *d_rec_len, size_t nrec,
+				void *d_out, size_t out_bytes, const uint64_t *d_out_off,
+				const uint32_t *d_out_len, uint32_t *d_status, int stream);
+
 /* XXH32 (seed 0) of n items: item i = d_base + d_off[i], d_len[i] bytes -> d_hash[i]. */
 int gpumt_xxh32_batch(gpumt_ctx *h, const void *d_base, const uint64_t *d_off,
 		      const uint32_t *d_len, size_t n, uint32_t *d_hash, int stream);

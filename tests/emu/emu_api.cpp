@@ -27,6 +27,8 @@ void zmt_lz4_dec_batch(const u8 *, const u64 *, const u32 *, u32, u8 *, const u6
 void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 void zmt_scan_kernel(const u32 *, u32, u64 *);
 void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
+void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u8 *, u32 *);
+void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
 }
 
 using emu::dim3;
@@ -143,6 +145,24 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 	}
 	emu::launch(dim3{(nrec * 4 + 255) / 256, 1, 1}, dim3{256, 1, 1},
 		    [=]() { zmt_xxh32_kernel(out, out_off, out_len, nrec, nullptr, cep, cvp, status); });
+}
+
+
+/* zstd: probe (content sizes + status), then wave-per-record decode; literal scratch starts as garbage */
+void emu_zstd_probe(const u8 *stream, const u64 *rec_off, const u32 *rec_len, u32 nrec, u32 *out_len, u32 *status)
+{
+	emu::launch(dim3{(nrec + 255) / 256, 1, 1}, dim3{256, 1, 1},
+		    [=]() { zmt_zstd_probe_kernel(stream, rec_off, rec_len, nrec, out_len, status); });
+}
+
+void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *rec_off, const u32 *rec_len,
+			       u32 nrec, u8 *out, const u64 *out_off, const u32 *out_len, u32 *status)
+{
+	std::vector<u8> lit((size_t)nrec * (131072 + 256), 0xA5);
+	u8 *litp = lit.data();
+	emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
+		zmt_zstd_dec_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status);
+	});
 }
 
 } /* extern "C" */

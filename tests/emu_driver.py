@@ -87,3 +87,23 @@ def decompress(stream: bytes, variant: int = 0, rec=None):
                                _p(status))
     assert (out[total:] == 0xCC).all(), "decoder wrote past the end of its output"
     return out[:total].tobytes(), status
+
+
+def zstd_decompress(stream: bytes, rec=None):
+    """zstd-mt stream -> (content bytes, status[n]) through the emulated probe + decode kernels"""
+    L = lib()
+    ro, rl = rec if rec is not None else walk_records(stream)
+    nrec = len(ro)
+    pad = b"\xEE" * 300          # the device contract: 256 readable bytes past the stream
+    sbuf = np.frombuffer(stream + pad, np.uint8).copy()
+    out_len = np.zeros(nrec, np.uint32)
+    status = np.full(nrec, 99, np.uint32)
+    L.emu_zstd_probe(_p(sbuf), _p(ro), _p(rl), C.c_uint32(nrec), _p(out_len), _p(status))
+    out_off = np.zeros(nrec + 1, np.uint64)
+    out_off[1:] = np.cumsum(out_len.astype(np.uint64))
+    total = int(out_off[nrec])
+    out = np.full(total + 64, 0xCC, np.uint8)
+    L.emu_zstd_decompress_batch(_p(sbuf), C.c_uint64(len(stream)), _p(ro), _p(rl), C.c_uint32(nrec),
+                                _p(out), _p(out_off), _p(out_len), _p(status))
+    assert (out[total:] == 0xCC).all(), "decoder wrote past the end of its output"
+    return out[:total].tobytes(), status

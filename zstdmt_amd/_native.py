@@ -43,6 +43,8 @@ GPUMT_SYMBOLS = {
     "gpumt_lz4_compact": (_i, [_vp, _vp, _sz, _u32p, _sz, _vp, _u64p, _i]),
     "gpumt_lz4_probe_sizes": (_i, [_vp, _vp, _u64p, _u32p, _sz, _u32p, _u64p, _i]),
     "gpumt_lz4_decompress_batch": (_i, [_vp, _vp, _sz, _u64p, _u32p, _sz, _vp, _sz, _u64p, _u32p, _u32p, _i]),
+    "gpumt_zstd_probe_sizes": (_i, [_vp, _vp, _u64p, _u32p, _sz, _u32p, _u64p, _u32p, _i]),
+    "gpumt_zstd_decompress_batch": (_i, [_vp, _vp, _sz, _u64p, _u32p, _sz, _vp, _sz, _u64p, _u32p, _u32p, _i]),
     "gpumt_xxh32_batch": (_i, [_vp, _vp, _u64p, _u32p, _sz, _u32p, _i]),
     "gpumt_set_variant": (_i, [_vp, C.c_char_p, _i]),
     "gpumt_debug_counters": (_i, [_vp, _vp, _i]),

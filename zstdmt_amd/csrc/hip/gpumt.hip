@@ -37,6 +37,9 @@ __global__ void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, 
 __global__ void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
 				    const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 				    const u32 *, const u32 *, const u32 *, u32 *);
+__global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
+				    const u32 *, u8 *, u32 *);
+__global__ void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
 __global__ void zmt_dec_copy_kernel_prof(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
 					 const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 					 const u32 *, const u32 *, const u32 *, u32 *, unsigned long long *);
@@ -557,6 +560,45 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 			   h->st[s], (const u8 *)d_out, d_out_off, d_out_len, n, (u32 *)NULL,
 			   (const u32 *)ce, (const u32 *)cv, d_status);
 	PROF1(12);
+	CK(hipGetLastError());
+	return GPUMT_OK;
+}
+
+/* ------------------------------------------------------------------ zstd */
+int gpumt_zstd_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
+			   const uint32_t *d_rec_len, size_t nrec, uint32_t *d_out_len,
+			   uint64_t *d_out_off, uint32_t *d_status, int s)
+{
+	if (!h || !STREAM_OK(s) || nrec == 0 || nrec > 0x3FFFFFFFu)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	hipLaunchKernelGGL(zmt_zstd_probe_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0,
+			   h->st[s], (const u8 *)d_stream, d_rec_off, d_rec_len, (u32)nrec, d_out_len,
+			   d_status);
+	hipLaunchKernelGGL(zmt_scan_kernel, dim3(1), dim3(1024), 0, h->st[s],
+			   (const u32 *)d_out_len, (u32)nrec, d_out_off);
+	CK(hipGetLastError());
+	return GPUMT_OK;
+}
+
+int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream_bytes,
+				const uint64_t *d_rec_off, const uint32_t *d_rec_len, size_t nrec,
+				void *d_out, size_t out_bytes, const uint64_t *d_out_off,
+				const uint32_t *d_out_len, uint32_t *d_status, int s)
+{
+	(void)out_bytes;
+	if (!h || !STREAM_OK(s) || nrec == 0 || nrec > 0x3FFFFFFFu)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	if (want_scratch(h, 1, nrec * (size_t)(131072 + 256)))
+		return GPUMT_E_HIP;
+	PROF0(11);
+	hipLaunchKernelGGL(zmt_zstd_dec_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
+			   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
+			   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status);
+	PROF1(11);
 	CK(hipGetLastError());
 	return GPUMT_OK;
 }

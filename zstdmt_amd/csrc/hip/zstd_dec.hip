@@ -1,0 +1,1077 @@
+/*
+ * zstd_dec.hip -- zstd frame decoder for gfx950, one wave per record.
+ *
+ * Replaces ZSTD_decompressStream as called per record by the reference
+ * (/root/reference/lib/zstd-mt_decompress.c:464, one frame per 12-byte skippable record, :300-369).
+ * Format: RFC 8878 -- raw / RLE / compressed blocks, Huffman literals (direct or FSE-compressed
+ * weights, 1 or 4 streams, treeless), FSE sequence tables (predefined / RLE / compressed /
+ * repeat), repeat offsets.  No dictionaries.
+ *
+ * Work split inside the wave (the format is a chain of serial bitstreams, so lanes are used where
+ * the format offers independent streams and for all byte moving):
+ *   - every header / table description is staged into LDS with one coalesced load and parsed there;
+ *   - Huffman literals: the 4 streams decode on 4 lanes from 256-byte LDS windows that the wave
+ *     refills cooperatively every 128 symbols; decoded literals go to a per-record scratch in HBM;
+ *   - FSE tables: the three tables of a block are built on three lanes at once;
+ *   - sequences: lane 0 walks the FSE bitstream from a 1 KiB LDS window, 64 sequences at a time;
+ *     the wave then executes the 64 sequences in parallel: prefix sums give output and literal
+ *     positions, every lane copies its own literals and match (8-byte unaligned global accesses),
+ *     matches that read this batch's own output resolve in watermark rounds, long copies are
+ *     done by the whole wave.
+ */
+#include "lz4_common.h"
+#include "lz4_frame.h"
+
+#define ZMT_ZSTD_MAGIC 0xFD2FB528u
+#define Z_BLOCK_MAX 131072u
+#define Z_LITSLOT (Z_BLOCK_MAX + 256u) /* literal scratch per record (include/gpumt.h) */
+#define Z_STAGE 1024u
+#define Z_CAP 64u /* longer literal runs / matches are copied by the whole wave */
+
+struct ZLds {
+	u16 huf[2048];  /* sym | nbits << 8 */
+	u32 ll[512], of[256], ml[512]; /* sym | nbits << 8 | base << 16 */
+	u8 below[16];   /* stage[-16..0): 8-byte reads may start below the window */
+	u8 stage[Z_STAGE + 16];
+	u32 sq_ll[64], sq_ml[64], sq_off[64];
+	u8 w[256];
+	short norm[3][64];
+	u16 next[3][64];
+	u32 misc[16];
+};
+
+enum { ZM_ERR = 0, ZM_A, ZM_B, ZM_C, ZM_D, ZM_E, ZM_F, ZM_G, ZM_H };
+
+static __device__ __forceinline__ void st64g(u8 *p, u64 v) { __builtin_memcpy(p, &v, 8); }
+static __device__ __forceinline__ int hb32(u32 v) { return 31 - __builtin_clz(v); }
+
+/* ------------------------------------------------------------------ staging */
+/* stage[0..n) <- src[rel .. rel+n), n multiple of 16, n <= 1024.  Bytes below `floor_rel`
+ * (relative to src) are stored as zeros; [lo_ok, hi_ok) is what may be read from memory at all. */
+static __device__ __forceinline__ void stage_load(u8 *stage, const u8 *src, long rel, u32 n, long floor_rel,
+						  const u8 *lo_ok, const u8 *hi_ok, int lane)
+{
+	const u32 o = 16u * (u32)lane;
+	if (o < n) {
+		const long r = rel + (long)o;
+		const u8 *p = src + r;
+		u64 a = 0, b = 0;
+		if (r >= floor_rel && p >= lo_ok && p + 16 <= hi_ok) {
+			a = ld64u(p);
+			b = ld64u(p + 8);
+		} else {
+			for (int k = 0; k < 8; k++) {
+				if (r + k >= floor_rel && p + k >= lo_ok && p + k < hi_ok)
+					a |= (u64)p[k] << (8 * k);
+				if (r + 8 + k >= floor_rel && p + 8 + k >= lo_ok && p + 8 + k < hi_ok)
+					b |= (u64)p[8 + k] << (8 * k);
+			}
+		}
+		*(u64 *)(stage + o) = a;
+		*(u64 *)(stage + o + 8) = b;
+	}
+}
+
+/* ------------------------------------------------------------------ FSE (one lane) */
+/* forward bit reader over LDS bytes (table descriptions) */
+struct FwdBits {
+	const u8 *p;
+	u32 len, bit;
+};
+static __device__ __forceinline__ u32 fwd_peek(const FwdBits &b, int n)
+{
+	const u32 byte = b.bit >> 3;
+	u64 v = 0;
+	for (u32 i = 0; i < 5; i++)
+		if (byte + i < b.len)
+			v |= (u64)b.p[byte + i] << (8 * i);
+	return (u32)(v >> (b.bit & 7)) & ((1u << n) - 1);
+}
+
+/* RFC 8878 4.1.1 table description -> norm[]; returns bytes used or -1 */
+static __device__ int fse_read_ncount(const u8 *p, u32 len, short *norm, int max_sym, int max_log,
+				      int *nsym_out, int *log_out)
+{
+	FwdBits b = {p, len, 0};
+	if (len < 1)
+		return -1;
+	const int log = (int)fwd_peek(b, 4) + 5;
+	b.bit += 4;
+	if (log > max_log)
+		return -1;
+	int remaining = (1 << log) + 1, threshold = 1 << log, nbits = log + 1, sym = 0;
+	bool prev0 = false;
+	for (int i = 0; i < max_sym; i++)
+		norm[i] = 0;
+	while (remaining > 1 && sym < max_sym) {
+		if (prev0) {
+			for (;;) {
+				const int r = (int)fwd_peek(b, 2);
+				b.bit += 2;
+				sym += r;
+				if (r != 3)
+					break;
+				if (b.bit > 8 * len)
+					return -1;
+			}
+			if (sym >= max_sym)
+				return -1;
+			prev0 = false;
+			continue;
+		}
+		const int max = (2 * threshold - 1) - remaining;
+		const u32 v = fwd_peek(b, nbits);
+		int count;
+		if ((int)(v & (u32)(threshold - 1)) < max) {
+			count = (int)(v & (u32)(threshold - 1));
+			b.bit += (u32)(nbits - 1);
+		} else {
+			count = (int)(v & (u32)(2 * threshold - 1));
+			if (count >= threshold)
+				count -= max;
+			b.bit += (u32)nbits;
+		}
+		count--;
+		remaining -= count < 0 ? -count : count;
+		norm[sym++] = (short)count;
+		prev0 = (count == 0);
+		while (remaining < threshold) {
+			nbits--;
+			threshold >>= 1;
+		}
+	}
+	if (remaining != 1 || (b.bit + 7) / 8 > len)
+		return -1;
+	*nsym_out = sym;
+	*log_out = log;
+	return (int)((b.bit + 7) / 8);
+}
+
+/* spread + number the cells (serial, one lane per table); returns 0 or -1 */
+static __device__ int fse_build(u32 *cell, const short *norm, int nsym, int log, u16 *next)
+{
+	const u32 size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+	u32 high = size - 1, pos = 0;
+	for (int s = 0; s < nsym; s++) {
+		if (norm[s] == -1) {
+			cell[high--] = (u32)s;
+			next[s] = 1;
+		} else {
+			next[s] = (u16)norm[s];
+		}
+	}
+	for (int s = 0; s < nsym; s++) {
+		const int c = norm[s];
+		for (int i = 0; i < c; i++) {
+			cell[pos] = (u32)s;
+			do
+				pos = (pos + step) & mask;
+			while (pos > high);
+		}
+	}
+	if (pos != 0)
+		return -1;
+	for (u32 u = 0; u < size; u++) {
+		const u32 s = cell[u];
+		const u32 x = next[s]++;
+		const u32 nb = (u32)(log - hb32(x));
+		cell[u] = s | nb << 8 | (((x << nb) - size) & 0xFFFFu) << 16;
+	}
+	return 0;
+}
+
+/* ------------------------------------------------------------------ constants */
+__device__ static const short Z_LL_DEF[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+					       2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__device__ static const short Z_OF_DEF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+					       1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+__device__ static const short Z_ML_DEF[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+					       1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+					       1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__device__ static const u32 Z_LL_BASE[36] = {0,  1,  2,   3,   4,   5,    6,    7,    8,    9,     10,    11,
+					      12, 13, 14,  15,  16,  18,   20,   22,   24,   28,    32,    40,
+					      48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+__device__ static const u8 Z_LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,  0,  0,  0,  1,  1,
+					     1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__device__ static const u32 Z_ML_BASE[53] = {3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16,
+					      17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30,
+					      31, 32, 33, 34, 35, 37, 39, 41, 43, 47, 51, 59, 67, 83,
+					      99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+__device__ static const u8 Z_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,  0,  0,  0,
+					     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  1,  1,  1,  1,
+					     2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+
+/* ------------------------------------------------------------------ Huffman */
+/* Tree description at d[0..len) (LDS) -> lds.w[0..nw] incl. the implied last weight; sets *log.
+ * One lane.  Returns bytes consumed or -1.  `cells` is 64 words of scratch. */
+static __device__ int huf_read_weights(const u8 *d, u32 len, u8 *w, int *nw_out, int *log_out, u32 *cells,
+				       short *norm, u16 *next)
+{
+	int nw = 0, used;
+	if (len < 1)
+		return -1;
+	const int hb = d[0];
+	if (hb >= 128) {
+		nw = hb - 127;
+		const int bytes = (nw + 1) / 2;
+		if ((u32)(1 + bytes) > len)
+			return -1;
+		for (int i = 0; i < nw; i++)
+			w[i] = (i & 1) ? (d[1 + i / 2] & 15) : (d[1 + i / 2] >> 4);
+		used = 1 + bytes;
+	} else {
+		if ((u32)(1 + hb) > len || hb < 1)
+			return -1;
+		int nsym, log;
+		const int u = fse_read_ncount(d + 1, (u32)hb, norm, 13, 6, &nsym, &log);
+		if (u < 0 || u >= hb || fse_build(cells, norm, nsym, log, next))
+			return -1;
+		/* backward bitstream, two interleaved states (RFC 8878 4.2.1.2) */
+		const u8 *bs = d + 1 + u;
+		const int blen = hb - u;
+		if (bs[blen - 1] == 0)
+			return -1;
+		int pos = 8 * (blen - 1) + hb32(bs[blen - 1]);
+#define WBITS(n, out)                                                                              \
+	do {                                                                                       \
+		pos -= (n);                                                                        \
+		u32 v_ = 0;                                                                        \
+		for (int k_ = 0; k_ < (n); k_++) {                                                 \
+			const int bp_ = pos + k_;                                                  \
+			if (bp_ >= 0)                                                              \
+				v_ |= (u32)((bs[bp_ >> 3] >> (bp_ & 7)) & 1) << k_;                \
+		}                                                                                  \
+		(out) = v_;                                                                        \
+	} while (0)
+		u32 s1, s2, t;
+		WBITS(log, s1);
+		WBITS(log, s2);
+		if (pos < 0)
+			return -1;
+		for (;;) {
+			if (nw > 253)
+				return -1;
+			u32 c = cells[s1];
+			w[nw++] = (u8)c;
+			WBITS((int)((c >> 8) & 255), t);
+			s1 = (c >> 16) + t;
+			if (pos < 0) {
+				w[nw++] = (u8)cells[s2];
+				break;
+			}
+			if (nw > 253)
+				return -1;
+			c = cells[s2];
+			w[nw++] = (u8)c;
+			WBITS((int)((c >> 8) & 255), t);
+			s2 = (c >> 16) + t;
+			if (pos < 0) {
+				w[nw++] = (u8)cells[s1];
+				break;
+			}
+		}
+#undef WBITS
+		used = 1 + hb;
+	}
+	u32 total = 0;
+	for (int i = 0; i < nw; i++) {
+		if (w[i] > 11)
+			return -1;
+		total += w[i] ? (1u << (w[i] - 1)) : 0;
+	}
+	if (total == 0)
+		return -1;
+	const int log = hb32(total) + 1;
+	if (log > 11)
+		return -1;
+	const u32 rest = (1u << log) - total;
+	if (rest & (rest - 1))
+		return -1;
+	w[nw++] = (u8)(hb32(rest) + 1);
+	u32 c1 = 0;
+	for (int i = 0; i < nw; i++)
+		c1 += (w[i] == 1);
+	if (c1 < 2 || (c1 & 1))
+		return -1;
+	*nw_out = nw;
+	*log_out = log;
+	return used;
+}
+
+/* wave: weights -> decoding table.  Symbols are laid out by ascending weight, then symbol value;
+ * a symbol of weight r owns 2^(r-1) consecutive cells. */
+static __device__ void huf_fill(u16 *huf, const u8 *w, int nw, int log, int lane)
+{
+	/* start offset of every rank */
+	u32 start = 0;
+	for (int r = 1; r <= log; r++) {
+		u32 cnt = 0;
+		for (int g = 0; g < 256; g += 64) {
+			const int s = g + lane;
+			cnt += (u32)wv_popc(wv_ballot(s < nw && w[s] == r));
+		}
+		/* symbols of this rank, in symbol order */
+		u32 at = start;
+		for (int g = 0; g < 256 && g < nw; g += 64) {
+			const int s = g + lane;
+			const bool mine = s < nw && w[s] == r;
+			const u64 m = wv_ballot(mine);
+			const u32 n = 1u << (r - 1);
+			if (mine) {
+				const u32 base = at + wv_mbcnt(m) * n;
+				const u16 e = (u16)((u32)s | (u32)(log + 1 - r) << 8);
+				for (u32 i = 0; i < n; i++)
+					huf[base + i] = e;
+			}
+			at += (u32)wv_popc(m) * n;
+		}
+		start += cnt << (r - 1);
+	}
+}
+
+/* ------------------------------------------------------------------ copies */
+static __device__ __forceinline__ void g_copy(u8 *d, const u8 *s, u32 len)
+{
+	if (len >= 8) {
+		for (u32 i = 0; i + 8 < len; i += 8)
+			st64g(d + i, ld64u(s + i));
+		st64g(d + len - 8, ld64u(s + len - 8));
+	} else if (len >= 4) {
+		const u32 a = ld32u(s), b = ld32u(s + len - 4);
+		st32u(d, a);
+		st32u(d + len - 4, b);
+	} else {
+		for (u32 i = 0; i < len; i++)
+			d[i] = s[i];
+	}
+}
+
+/* match copy by one lane: source [d-off, ...) fully written and visible */
+static __device__ __forceinline__ void g_match(u8 *d, u32 off, u32 ml)
+{
+	const u8 *s = d - off;
+	if (off >= ml) {
+		g_copy(d, s, ml);
+	} else if (off >= 8) {
+		/* overlapping, period >= 8: forward 8-byte steps only ever read bytes already written */
+		u32 i = 0;
+		for (; i + 8 <= ml; i += 8)
+			st64g(d + i, ld64u(s + i));
+		for (; i < ml; i++)
+			d[i] = s[i];
+	} else {
+		u32 j = 0;
+		for (u32 i = 0; i < ml; i++) {
+			d[i] = s[j];
+			if (++j == off)
+				j = 0;
+		}
+	}
+}
+
+/* whole-wave copies for long runs (wave-uniform arguments) */
+static __device__ void wave_match(u8 *d, u32 off, u32 ml, int lane)
+{
+	const u8 *s = d - off;
+	if (off >= ml) {
+		wave_copy(d, s, ml, lane);
+	} else if (off >= 64) {
+		/* period >= 64: chunks of `off` bytes are independent of each other's output only one
+		 * period back; copy period by period */
+		for (u32 done = 0; done < ml; done += off) {
+			const u32 n = ml - done < off ? ml - done : off;
+			wave_copy(d + done, s + done, n, lane);
+			wave_mem_fence();
+		}
+	} else {
+		for (u32 i = (u32)lane; i < ml; i += 64)
+			d[i] = s[i % off];
+	}
+}
+
+/* ------------------------------------------------------------------ the kernel */
+extern "C" __global__ void __launch_bounds__(64)
+zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
+		    const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
+		    const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
+		    u8 *__restrict__ litbuf, u32 *__restrict__ status)
+{
+	__shared__ __attribute__((aligned(16))) ZLds L;
+	const int lane = wv_lane();
+	const u32 rec = blockIdx.x;
+	if (rec >= nrec)
+		return;
+	if (wv_readfirst(status[rec]) != ST_OK)
+		return; /* rejected by the probe kernel */
+	const u64 roff = rec_off[rec];
+	const u32 rlen = wv_readfirst(rec_len[rec]);
+	const u8 *r = stream + roff;
+	u8 *out = out_base + out_off[rec];
+	const u32 cap = wv_readfirst(out_len[rec]);
+	u8 *lit_scratch = litbuf + (u64)rec * Z_LITSLOT;
+	const u8 *mem_lo = stream, *mem_hi = stream + stream_bytes + 256; /* readable range */
+	u32 stc = ST_OK;
+
+	/* ---- record + frame header (RFC 8878 3.1.1) ---- */
+	if (rlen < 12 + 6 || uld32(r) != ZMT_SKIP_MAGIC || uld32(r + 4) != 4 || uld32(r + 8) != rlen - 12) {
+		if (lane == 0)
+			status[rec] = ST_BAD_RECORD;
+		return;
+	}
+	const u8 *f = r + 12;
+	const u32 flen = rlen - 12;
+	if (uld32(f) != ZMT_ZSTD_MAGIC) {
+		if (lane == 0)
+			status[rec] = ST_BAD_FRAME;
+		return;
+	}
+	const u32 fhd = uld8(f + 4);
+	const u32 fcs = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3, has_chk = (fhd >> 2) & 1;
+	u32 hp = 5;
+	u64 window = 0, content = ~0ull;
+	{
+		const u32 did_len = did == 3 ? 4 : did, fcs_len = fcs == 0 ? single : (1u << fcs);
+		if ((fhd & 8) || flen < 5 + (1 - single) + did_len + fcs_len) {
+			if (lane == 0)
+				status[rec] = ST_BAD_FRAME;
+			return;
+		}
+		if (did) {
+			u32 id = 0;
+			for (u32 i = 0; i < did_len; i++)
+				id |= uld8(f + hp + (1 - single) + i);
+			if (id) {
+				if (lane == 0)
+					status[rec] = ST_UNSUPPORTED;
+				return;
+			}
+		}
+		if (!single) {
+			const u32 wd = uld8(f + hp++);
+			const u64 base = 1ull << (10 + (wd >> 3));
+			window = base + (base >> 3) * (wd & 7);
+		}
+		hp += did_len;
+		if (fcs == 0 && single)
+			content = uld8(f + hp);
+		else if (fcs == 1)
+			content = uld16(f + hp) + 256;
+		else if (fcs == 2)
+			content = uld32(f + hp);
+		else if (fcs == 3)
+			content = (u64)uld32(f + hp) | (u64)uld32(f + hp + 4) << 32;
+		hp += fcs_len;
+		if (single)
+			window = content;
+	}
+	if (has_chk) {
+		/* XXH64 content checksum: valid zstd, never written by zstd-mt (ZSTD_compress, :285) */
+		if (lane == 0)
+			status[rec] = ST_UNSUPPORTED;
+		return;
+	}
+	if (content != ~0ull && content != cap) {
+		if (lane == 0)
+			status[rec] = ST_SIZE_MISMATCH;
+		return;
+	}
+	const u32 block_max = window < Z_BLOCK_MAX ? (u32)window : Z_BLOCK_MAX;
+
+	u32 rep0 = 1, rep1 = 4, rep2 = 8;
+	bool huf_ok = false;
+	int huf_log = 0;
+	bool my_tab_ok = false; /* lanes 0..2: state of the LL / OF / ML table this lane builds */
+	int my_tab_log = 0;
+	u32 opos = 0, ip = hp;
+
+	for (;;) {
+		if (flen - ip < 3) {
+			stc = ST_BAD_BLOCK;
+			break;
+		}
+		const u32 bh = uld8(f + ip) | uld8(f + ip + 1) << 8 | uld8(f + ip + 2) << 16;
+		const u32 last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
+		ip += 3;
+		const u8 *src = f + ip;
+		if (btype == 3 || bsize > block_max || (btype != 1 && flen - ip < bsize) ||
+		    (btype == 1 && flen - ip < 1)) {
+			stc = ST_BAD_BLOCK;
+			break;
+		}
+		if (btype == 0) {
+			if (cap - opos < bsize) {
+				stc = ST_SIZE_MISMATCH;
+				break;
+			}
+			wave_copy(out + opos, src, bsize, lane);
+			opos += bsize;
+			ip += bsize;
+		} else if (btype == 1) {
+			if (cap - opos < bsize) {
+				stc = ST_SIZE_MISMATCH;
+				break;
+			}
+			const u8 v = (u8)uld8(src);
+			for (u32 i = (u32)lane; i < bsize; i += 64)
+				out[opos + i] = v;
+			opos += bsize;
+			ip += 1;
+		} else {
+			/* ================= compressed block ================= */
+			const u32 bstart = opos;
+			if (bsize < 2) {
+				stc = ST_BAD_BLOCK;
+				break;
+			}
+			/* ---- literals section header + tree description, from LDS ---- */
+			wv_sync();
+			stage_load(L.stage, src, 0, 256, 0, mem_lo, mem_hi, lane);
+			wv_sync();
+			if (lane == 0) {
+				const u8 *d = L.stage;
+				const u32 ltype = d[0] & 3, sf = (d[0] >> 2) & 3;
+				u32 regen = 0, csz = 0, hl = 0, streams = 1, err = 0, tree = 0;
+				if (ltype < 2) {
+					if (sf == 0 || sf == 2) {
+						regen = d[0] >> 3;
+						hl = 1;
+					} else if (sf == 1) {
+						regen = (d[0] | d[1] << 8) >> 4;
+						hl = 2;
+					} else {
+						regen = (d[0] | d[1] << 8 | d[2] << 16) >> 4;
+						hl = 3;
+					}
+					csz = ltype == 0 ? regen : 1;
+				} else {
+					const u64 v = (u64)ld32u(d) | (u64)d[4] << 32;
+					if (sf < 2) {
+						regen = (u32)(v >> 4) & 1023;
+						csz = (u32)(v >> 14) & 1023;
+						streams = sf == 0 ? 1 : 4;
+						hl = 3;
+					} else if (sf == 2) {
+						regen = (u32)(v >> 4) & 16383;
+						csz = (u32)(v >> 18) & 16383;
+						streams = 4;
+						hl = 4;
+					} else {
+						regen = (u32)(v >> 4) & 262143;
+						csz = (u32)(v >> 22) & 262143;
+						streams = 4;
+						hl = 5;
+					}
+					if (regen == 0)
+						err = 1;
+				}
+				if (regen > block_max || hl + csz > bsize)
+					err = 1;
+				if (!err && ltype == 2) {
+					/* tree description: at most 1 + 128 bytes, inside the staged 256 */
+					u32 avail = csz < 256 - hl ? csz : 256 - hl;
+					int nw = 0, lg = 0;
+					const int used = huf_read_weights(d + hl, avail, L.w, &nw, &lg, L.sq_ll,
+									  L.norm[0], L.next[0]);
+					if (used < 0) {
+						err = 1;
+					} else {
+						tree = (u32)used;
+						L.misc[ZM_G] = (u32)nw;
+						L.misc[ZM_H] = (u32)lg;
+					}
+				}
+				L.misc[ZM_ERR] = err;
+				L.misc[ZM_A] = ltype;
+				L.misc[ZM_B] = regen;
+				L.misc[ZM_C] = csz;
+				L.misc[ZM_D] = hl;
+				L.misc[ZM_E] = streams;
+				L.misc[ZM_F] = tree;
+			}
+			wv_sync();
+			if (L.misc[ZM_ERR]) {
+				stc = ST_BAD_BLOCK;
+				break;
+			}
+			const u32 ltype = L.misc[ZM_A], regen = L.misc[ZM_B], lcsz = L.misc[ZM_C], lhl = L.misc[ZM_D];
+			const u32 nstreams = L.misc[ZM_E], tree = L.misc[ZM_F];
+			const u8 *lit = lit_scratch;
+			if (ltype == 0) {
+				lit = src + lhl;
+			} else if (ltype == 1) {
+				const u8 v = (u8)uld8(src + lhl);
+				for (u32 i = (u32)lane * 8; i < regen + 8; i += 512)
+					st64g(lit_scratch + i, 0x0101010101010101ull * v);
+			} else {
+				if (ltype == 2) {
+					const int nw = (int)L.misc[ZM_G];
+					huf_log = (int)L.misc[ZM_H];
+					for (u32 i = (u32)lane; i < 2048; i += 64)
+						L.huf[i] = 0;
+					wv_sync();
+					huf_fill(L.huf, L.w, nw, huf_log, lane);
+					huf_ok = true;
+					wv_sync();
+				} else if (!huf_ok) {
+					stc = ST_BAD_BLOCK;
+					break;
+				}
+				/* ---- Huffman streams: lane s < nstreams decodes stream s ---- */
+				const u32 body = lhl + tree; /* offset of jump table / single stream in src */
+				if (lcsz < tree + (nstreams == 4 ? 10u : 1u)) {
+					stc = ST_BAD_BLOCK;
+					break;
+				}
+				u32 s_off = body, s_len = lcsz - tree, s_n = regen, s_dst = 0;
+				bool bad = false;
+				if (nstreams == 4) {
+					const u32 j1 = uld16(src + body), j2 = uld16(src + body + 2), j3 = uld16(src + body + 4);
+					const u32 tot = lcsz - tree - 6, q = (regen + 3) / 4;
+					if (j1 + j2 + j3 >= tot || 3 * q > regen) {
+						stc = ST_BAD_BLOCK;
+						break;
+					}
+					const u32 sl = lane & 3;
+					s_off = body + 6 + (sl > 0 ? j1 : 0) + (sl > 1 ? j2 : 0) + (sl > 2 ? j3 : 0);
+					s_len = sl == 0 ? j1 : sl == 1 ? j2 : sl == 2 ? j3 : tot - j1 - j2 - j3;
+					s_n = sl < 3 ? q : regen - 3 * q;
+					s_dst = sl * q;
+				}
+				const bool dec = (u32)lane < nstreams;
+				long pos = 0; /* unread bits of my stream */
+				if (dec) {
+					const u32 lastb = s_len ? src[s_off + s_len - 1] : 0;
+					if (s_len == 0 || lastb == 0)
+						bad = true;
+					else
+						pos = 8 * (long)(s_len - 1) + hb32(lastb);
+				}
+				if (wv_any(dec && bad)) {
+					stc = ST_BAD_BLOCK;
+					break;
+				}
+				u32 done = 0;
+				while (wv_any(dec && done < s_n && !bad)) {
+					/* cooperative refill: 16 lanes per stream, 256-byte window ending at the
+					 * byte that holds the next unread bit; bytes below the stream read 0 */
+					wv_sync();
+					{
+						const int sg = lane >> 4;
+						const u32 g_off = wv_shfl(s_off, sg);
+						const u32 g_poslo = wv_shfl((u32)pos, sg);
+						const u32 g_poshi = wv_shfl((u32)((u64)pos >> 32), sg);
+						const long g_pos = (long)((u64)g_poshi << 32 | g_poslo);
+						const long whi = (g_pos + 7) >> 3;
+						if ((u32)sg < nstreams) {
+							const u32 o = 16u * ((u32)lane & 15);
+							const long rel = whi - 256 + (long)o;
+							const u8 *p = src + g_off + rel;
+							u64 a = 0, b = 0;
+							if (rel >= 0 && p + 16 <= mem_hi) {
+								a = ld64u(p);
+								b = ld64u(p + 8);
+							} else {
+								for (int k = 0; k < 8; k++) {
+									if (rel + k >= 0 && p + k < mem_hi)
+										a |= (u64)p[k] << (8 * k);
+									if (rel + 8 + k >= 0 && p + 8 + k < mem_hi)
+										b |= (u64)p[8 + k] << (8 * k);
+								}
+							}
+							u8 *w = L.stage + 256u * (u32)sg + o;
+							*(u64 *)w = a;
+							*(u64 *)(w + 8) = b;
+						}
+					}
+					wv_sync();
+					if (dec && !bad && done < s_n) {
+						const u8 *win = L.stage + 256u * (u32)lane; /* byte (whi-256+i) of my stream */
+						const long wlo = ((pos + 7) >> 3) - 256;
+						const u32 todo = s_n - done < 128 ? s_n - done : 128;
+						u8 *dst = lit_scratch + s_dst + done;
+						const int lg = huf_log;
+						u64 c = 0, acc = 0;
+						int cb = 0;
+						for (u32 i = 0; i < todo; i++) {
+							if (cb < lg) {
+								/* refill: the 8 bytes whose top byte holds bit pos-1 */
+								const long tb = (pos - 1) >> 3;
+								const u64 word = ld64u(win + (tb - 7 - wlo));
+								cb = (int)(pos - 8 * (tb - 7));
+								c = cb >= 64 ? word : word & ((1ull << cb) - 1);
+							}
+							const u32 e = L.huf[(u32)(c >> (cb - lg)) & ((1u << lg) - 1)];
+							const int nb = (int)(e >> 8);
+							cb -= nb;
+							pos -= nb;
+							acc |= (u64)(e & 255) << (8 * (i & 7));
+							if ((i & 7) == 7) {
+								st64g(dst + (i & ~7u), acc);
+								acc = 0;
+							}
+							if (nb == 0 || pos < 0) {
+								bad = true;
+								break;
+							}
+						}
+						if (!bad && (todo & 7)) {
+							const u32 b0 = todo & ~7u;
+							for (u32 k = b0; k < todo; k++)
+								dst[k] = (u8)(acc >> (8 * (k - b0)));
+						}
+						done += todo;
+						if (!bad && done == s_n && pos != 0)
+							bad = true;
+					}
+				}
+				if (wv_any(dec && bad)) {
+					stc = ST_BAD_BLOCK;
+					break;
+				}
+				wave_mem_fence(); /* literals are read back by other lanes below */
+			}
+
+			/* ---- sequences section header + table descriptions, from LDS ---- */
+			const u32 sq0 = lhl + lcsz; /* offset of the sequences section in src */
+			if (sq0 >= bsize) {
+				stc = ST_BAD_BLOCK;
+				break;
+			}
+			wv_sync();
+			stage_load(L.stage, src, (long)sq0, 512, 0, mem_lo, mem_hi, lane);
+			wv_sync();
+			if (lane == 0) {
+				const u8 *d = L.stage;
+				const u32 avail = bsize - sq0 < 512 ? bsize - sq0 : 512;
+				u32 p = 1, err = 0, nseq = d[0], modes = 0;
+				if (nseq >= 128) {
+					if (nseq == 255) {
+						nseq = (d[1] | d[2] << 8) + 0x7F00;
+						p = 3;
+					} else {
+						nseq = ((nseq - 128) << 8) + d[1];
+						p = 2;
+					}
+				}
+				if (p > avail)
+					err = 1;
+				if (!err && nseq) {
+					if (p >= avail)
+						err = 1;
+					modes = d[p++];
+					if (modes & 3)
+						err = 1;
+					for (int t = 0; t < 3 && !err; t++) {
+						const int mode = (modes >> (6 - 2 * t)) & 3;
+						const int max_sym = t == 0 ? 36 : t == 1 ? 32 : 53, max_log = t == 1 ? 8 : 9;
+						L.misc[ZM_A + t] = 0xFFFFFFFFu; /* table stays as it is */
+						if (mode == 0) {
+							const short *def = t == 0 ? Z_LL_DEF : t == 1 ? Z_OF_DEF : Z_ML_DEF;
+							const int n = t == 0 ? 36 : t == 1 ? 29 : 53;
+							for (int i = 0; i < n; i++)
+								L.norm[t][i] = def[i];
+							L.misc[ZM_A + t] = (u32)n | (u32)(t == 1 ? 5 : 6) << 8;
+						} else if (mode == 1) {
+							if (p >= avail || d[p] >= max_sym)
+								err = 1;
+							else
+								L.misc[ZM_A + t] = 0x80000000u | d[p++]; /* RLE */
+						} else if (mode == 2) {
+							int nsym = 0, lg = 0;
+							const int used = fse_read_ncount(d + p, avail - p, L.norm[t], max_sym, max_log, &nsym, &lg);
+							if (used < 0) {
+								err = 1;
+							} else {
+								p += (u32)used;
+								L.misc[ZM_A + t] = (u32)nsym | (u32)lg << 8;
+							}
+						}
+					}
+				}
+				L.misc[ZM_ERR] = err;
+				L.misc[ZM_D] = nseq;
+				L.misc[ZM_E] = p;
+			}
+			wv_sync();
+			if (L.misc[ZM_ERR]) {
+				stc = ST_BAD_BLOCK;
+				break;
+			}
+			const u32 nseq = L.misc[ZM_D];
+			const u32 sq_hdr = L.misc[ZM_E];
+			u32 lpos = 0; /* literals consumed */
+			if (nseq) {
+				/* ---- build the three tables on lanes 0..2 ---- */
+				bool terr = false;
+				if (lane < 3) {
+					const u32 spec = L.misc[ZM_A + lane];
+					u32 *cells = lane == 0 ? L.ll : lane == 1 ? L.of : L.ml;
+					if (spec == 0xFFFFFFFFu) {
+						terr = !my_tab_ok; /* repeat mode needs a previous table */
+					} else if (spec & 0x80000000u) {
+						cells[0] = spec & 255; /* RLE: one cell, no bits */
+						my_tab_log = 0;
+						my_tab_ok = true;
+					} else {
+						const int lg = (int)(spec >> 8);
+						terr = fse_build(cells, L.norm[lane], (int)(spec & 255), lg, L.next[lane]) != 0;
+						my_tab_log = lg;
+						my_tab_ok = !terr;
+					}
+				}
+				wv_sync();
+				if (wv_any(terr)) {
+					stc = ST_BAD_BLOCK;
+					break;
+				}
+				const int ll_log = (int)wv_readlane((u32)my_tab_log, 0);
+				const int of_log = (int)wv_readlane((u32)my_tab_log, 1);
+				const int ml_log = (int)wv_readlane((u32)my_tab_log, 2);
+				/* ---- FSE bitstream: src[sq0 + sq_hdr, bsize) read backwards ---- */
+				const u32 bs_off = sq0 + sq_hdr;
+				if (bs_off >= bsize) {
+					stc = ST_BAD_BLOCK;
+					break;
+				}
+				const u32 bs_len = bsize - bs_off;
+				const u32 lastb = uld8(src + bs_off + bs_len - 1);
+				if (lastb == 0) {
+					stc = ST_BAD_BLOCK;
+					break;
+				}
+				long pos = 8 * (long)(bs_len - 1) + hb32(lastb); /* lane 0's copy is the live one */
+				u32 s_ll = 0, s_of = 0, s_ml = 0;
+				bool first = true;
+				u32 r0 = rep0, r1 = rep1, r2 = rep2; /* live in lane 0 */
+				for (u32 sbase = 0; sbase < nseq && stc == ST_OK; sbase += 64) {
+					const u32 k = nseq - sbase < 64 ? nseq - sbase : 64;
+					/* window of the bitstream: 1 KiB ending at the byte of the next unread bit */
+					const long upos = (long)((u64)wv_readlane((u32)((u64)pos >> 32), 0) << 32 |
+								 wv_readlane((u32)pos, 0));
+					const long whi = (upos + 7) >> 3, wlo = whi - (long)Z_STAGE;
+					wv_sync();
+					stage_load(L.stage, src + bs_off, wlo, Z_STAGE, -(long)(bs_off + 16), mem_lo, mem_hi, lane);
+					wv_sync();
+					if (lane == 0) {
+						const u8 *win = L.stage;
+						bool err = false;
+#define SBITS(n, out)                                                                              \
+	do {                                                                                       \
+		const int n_ = (int)(n);                                                           \
+		u32 v_ = 0;                                                                        \
+		if (n_) {                                                                          \
+			pos -= n_;                                                                 \
+			const long tb_ = (pos + n_ - 1) >> 3;                                      \
+			const long at_ = tb_ - 7 - wlo;                                            \
+			if (pos < 0 || at_ < -16) {                                                \
+				err = true;                                                        \
+			} else {                                                                   \
+				const u64 w_ = ld64u(win + at_);                                   \
+				v_ = (u32)((w_ >> (pos - 8 * (tb_ - 7))) & ((1ull << n_) - 1));   \
+			}                                                                          \
+		}                                                                                  \
+		(out) = v_;                                                                        \
+	} while (0)
+						if (first) {
+							SBITS(ll_log, s_ll);
+							SBITS(of_log, s_of);
+							SBITS(ml_log, s_ml);
+							first = false;
+						}
+						for (u32 i = 0; i < k && !err; i++) {
+							const u32 cl = L.ll[s_ll], co = L.of[s_of], cm = L.ml[s_ml];
+							const u32 lc = cl & 255, oc = co & 255, mc = cm & 255;
+							u32 ofv, mlv, llv, t;
+							if (oc > 31) {
+								err = true;
+								break;
+							}
+							SBITS(oc, ofv);
+							ofv += 1u << oc;
+							SBITS(Z_ML_BITS[mc], mlv);
+							mlv += Z_ML_BASE[mc];
+							SBITS(Z_LL_BITS[lc], llv);
+							llv += Z_LL_BASE[lc];
+							if (sbase + i + 1 < nseq) {
+								SBITS((cl >> 8) & 255, t);
+								s_ll = (cl >> 16) + t;
+								SBITS((cm >> 8) & 255, t);
+								s_ml = (cm >> 16) + t;
+								SBITS((co >> 8) & 255, t);
+								s_of = (co >> 16) + t;
+							}
+							/* repeat offsets (RFC 8878 3.1.1.5) */
+							u32 off;
+							if (ofv > 3) {
+								off = ofv - 3;
+								r2 = r1;
+								r1 = r0;
+								r0 = off;
+							} else {
+								const u32 idx = ofv - 1 + (llv == 0);
+								if (idx == 0) {
+									off = r0;
+								} else {
+									off = idx == 1 ? r1 : idx == 2 ? r2 : r0 - 1;
+									if (off == 0) {
+										err = true;
+										break;
+									}
+									if (idx > 1)
+										r2 = r1;
+									r1 = r0;
+									r0 = off;
+								}
+							}
+							L.sq_ll[i] = llv;
+							L.sq_ml[i] = mlv;
+							L.sq_off[i] = off;
+						}
+#undef SBITS
+						if (!err && sbase + k == nseq && pos != 0)
+							err = true;
+						L.misc[ZM_ERR] = err;
+					}
+					wv_sync();
+					if (L.misc[ZM_ERR]) {
+						stc = ST_BAD_BLOCK;
+						break;
+					}
+					/* ---- execute the k sequences ---- */
+					const bool act0 = (u32)lane < k;
+					const u32 ll = act0 ? L.sq_ll[lane] : 0, ml = act0 ? L.sq_ml[lane] : 0;
+					const u32 off = act0 ? L.sq_off[lane] : 1;
+					const u32 len = ll + ml;
+					const u32 incl = wv_scan_incl(len), lincl = wv_scan_incl(ll);
+					const u32 tot = wv_readlane(incl, 63), ltot = wv_readlane(lincl, 63);
+					/* 64 x (2 x 131074) cannot wrap 32 bits */
+					if (ltot > regen - lpos || tot > cap - opos || opos + tot - bstart > block_max) {
+						stc = ST_BAD_BLOCK;
+						break;
+					}
+					const u32 op = opos + incl - len, mpos = op + ll, lsrc = lpos + lincl - ll;
+					if (wv_any(act0 && off > mpos)) {
+						stc = ST_BAD_BLOCK; /* reaches before the start of the frame */
+						break;
+					}
+					const u32 src_pos = mpos - off, eff = ml < off ? ml : off;
+					const u64 longm = wv_ballot(act0 && (ll > Z_CAP || ml > Z_CAP));
+					/* literals: independent of everything in this batch */
+					if (act0 && ll <= Z_CAP)
+						g_copy(out + op, lit + lsrc, ll);
+					{
+						u64 m = wv_ballot(act0 && ll > Z_CAP);
+						while (m) {
+							const int j = wv_ffs(m) - 1;
+							m &= m - 1;
+							wave_copy(out + wv_readlane(op, j), lit + wv_readlane(lsrc, j), wv_readlane(ll, j), lane);
+						}
+					}
+					wave_mem_fence();
+					/* matches: watermark rounds.  W = everything below is written and visible */
+					{
+						bool fin = !act0;
+						for (;;) {
+							const u64 unf = wv_ballot(!fin);
+							if (!unf)
+								break;
+							const int fst = wv_ffs(unf) - 1;
+							const u32 W = wv_readlane(mpos, fst);
+							if ((longm >> fst) & 1 && wv_readlane(ml, fst) > Z_CAP) {
+								/* long match at the head of the queue: whole wave */
+								wave_match(out + W, wv_readlane(off, fst), wv_readlane(ml, fst), lane);
+								if (lane == fst)
+									fin = true;
+							} else {
+								const bool ready = !fin && ml <= Z_CAP && src_pos + eff <= W;
+								if (ready) {
+									g_match(out + mpos, off, ml);
+									fin = true;
+								}
+							}
+							wave_mem_fence();
+						}
+					}
+					opos += tot;
+					lpos += ltot;
+				}
+				if (stc != ST_OK)
+					break;
+				if (lane == 0) {
+					L.misc[ZM_A] = r0;
+					L.misc[ZM_B] = r1;
+					L.misc[ZM_C] = r2;
+				}
+				wv_sync();
+				rep0 = L.misc[ZM_A];
+				rep1 = L.misc[ZM_B];
+				rep2 = L.misc[ZM_C];
+			} else if (sq_hdr != bsize - sq0) {
+				stc = ST_BAD_BLOCK;
+				break;
+			}
+			/* literals after the last sequence */
+			{
+				const u32 restl = regen - lpos;
+				if (restl > cap - opos || opos + restl - bstart > block_max) {
+					stc = ST_BAD_BLOCK;
+					break;
+				}
+				wave_copy(out + opos, lit + lpos, restl, lane);
+				opos += restl;
+			}
+			wave_mem_fence();
+			ip += bsize;
+		}
+		if (last)
+			break;
+	}
+	if (stc == ST_OK && opos != cap)
+		stc = ST_SIZE_MISMATCH;
+	if (stc == ST_OK && ip != flen)
+		stc = ST_TRAILING;
+	if (lane == 0 && stc != ST_OK)
+		status[rec] = stc;
+}
+
+/* out_len[i] = Frame_Content_Size of record i (what the host needs before it can size d_out);
+ * status[i] = ST_OK, or why the record cannot be decoded here. */
+extern "C" __global__ void __launch_bounds__(256)
+zmt_zstd_probe_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec_off,
+		      const u32 *__restrict__ rec_len, u32 nrec, u32 *__restrict__ out_len,
+		      u32 *__restrict__ status)
+{
+	const u32 i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= nrec)
+		return;
+	const u8 *r = stream + rec_off[i];
+	const u32 rlen = rec_len[i];
+	u32 st = ST_OK, n = 0;
+	if (rlen < 18 || ld32u(r) != ZMT_SKIP_MAGIC || ld32u(r + 4) != 4 || ld32u(r + 8) != rlen - 12) {
+		st = ST_BAD_RECORD;
+	} else if (ld32u(r + 12) != ZMT_ZSTD_MAGIC) {
+		st = ST_BAD_FRAME;
+	} else {
+		const u8 *f = r + 12;
+		const u32 flen = rlen - 12, fhd = f[4], fcs = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+		const u32 did_len = did == 3 ? 4 : did, fcs_len = fcs == 0 ? single : (1u << fcs);
+		const u32 hp = 5 + (1 - single) + did_len;
+		if ((fhd & 8) || flen < hp + fcs_len) {
+			st = ST_BAD_FRAME;
+		} else if (fcs_len == 0) {
+			st = ST_UNSUPPORTED; /* no content size: never written by zstd-mt (one-shot ZSTD_compress) */
+		} else {
+			u64 c = 0;
+			for (u32 k = 0; k < fcs_len; k++)
+				c |= (u64)f[hp + k] << (8 * k);
+			if (fcs == 1)
+				c += 256;
+			if (c > 0x7FFFFFFFull)
+				st = ST_UNSUPPORTED;
+			else
+				n = (u32)c;
+		}
+	}
+	out_len[i] = n;
+	status[i] = st;
+}

@@ -122,6 +122,18 @@ class Engine:
                                                    int(out_bytes), d_out_off.ptr, d_out_len.ptr,
                                                    d_status.ptr, stream), "lz4_decompress_batch")
 
+    def zstd_probe(self, d_stream, d_rec_off, d_rec_len, nrec, d_out_len, d_out_off, d_status, stream=0):
+        self._ck(self.L.gpumt_zstd_probe_sizes(self.h, d_stream.ptr, d_rec_off.ptr, d_rec_len.ptr, nrec,
+                                               d_out_len.ptr, d_out_off.ptr, d_status.ptr, stream),
+                 "zstd_probe_sizes")
+
+    def zstd_decompress(self, d_stream, stream_bytes, d_rec_off, d_rec_len, nrec, d_out, out_bytes,
+                        d_out_off, d_out_len, d_status, stream=0):
+        self._ck(self.L.gpumt_zstd_decompress_batch(self.h, d_stream.ptr, int(stream_bytes),
+                                                    d_rec_off.ptr, d_rec_len.ptr, nrec, d_out.ptr,
+                                                    int(out_bytes), d_out_off.ptr, d_out_len.ptr,
+                                                    d_status.ptr, stream), "zstd_decompress_batch")
+
     # ---- convenience round trips on host bytes (tests) ----------------------------------------
     def compress_bytes(self, data: bytes, chunk: int):
         """-> (stream bytes, rec_off[n+1] u64, rec_len[n] u32)"""
@@ -149,7 +161,7 @@ class Engine:
                 b.free()
         return stream, rec_off, rec_len
 
-    def decompress_bytes(self, stream: bytes, rec_off, rec_len):
+    def decompress_bytes(self, stream: bytes, rec_off, rec_len, codec="lz4"):
         """-> (content bytes, status[n])"""
         nrec = len(rec_len)
         d_stream = self.upload(stream)
@@ -159,13 +171,19 @@ class Engine:
         d_oo = self.alloc((nrec + 1) * 8)
         d_st = self.alloc(nrec * 4)
         try:
-            self.lz4_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo)
+            if codec == "zstd":
+                self.zstd_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo, d_st)
+            else:
+                self.lz4_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo)
             out_off = self.download(d_oo, (nrec + 1) * 8, np.uint64)
             total = int(out_off[nrec])
             d_out = self.alloc(total + 64)
             try:
                 lib().gpumt_memset(self.h, d_out.ptr, 0xCC, total + 64, 0)
-                self.lz4_decompress(d_stream, len(stream), d_ro, d_rl, nrec, d_out, total, d_oo, d_ol, d_st)
+                if codec == "zstd":
+                    self.zstd_decompress(d_stream, len(stream), d_ro, d_rl, nrec, d_out, total, d_oo, d_ol, d_st)
+                else:
+                    self.lz4_decompress(d_stream, len(stream), d_ro, d_rl, nrec, d_out, total, d_oo, d_ol, d_st)
                 status = self.download(d_st, nrec * 4, np.uint32)
                 raw = self.download(d_out, total + 64)
                 assert (raw[total:] == 0xCC).all(), "decoder wrote past the end of its output"
