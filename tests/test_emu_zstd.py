@@ -57,3 +57,15 @@ def test_emu_probe_rejects():
         bad[mut[0]] = mut[1]
         _, status = E.zstd_decompress(bytes(bad), rec=(ro, rl))
         assert status[0] == code
+
+
+@pytest.mark.skipif(not H.have_zref(), reason="reference build not present")
+def test_emu_decode_full_size_blocks():
+    """1 MiB frame of 128 KiB blocks (5-byte literal headers, long offsets, a last sequence that
+    needs no bits): too large to commit, written by the reference on the spot."""
+    level, chunk, thunk = cases.ZCASES["z_text_1m_l1"]
+    data = thunk()
+    rv, st, _, _ = H.zstdmt_compress_via(H.zref(), data, chunk, threads=2, level=level)
+    assert rv == 0
+    out, status = E.zstd_decompress(st)
+    assert (status == 0).all() and out == data

@@ -39,6 +39,8 @@ __global__ void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, con
 				    const u32 *, const u32 *, const u32 *, u32 *);
 __global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
 				    const u32 *, u8 *, u32 *);
+__global__ void zmt_zstd_dec_kernel_prof(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
+					 const u32 *, u8 *, u32 *, unsigned long long *);
 __global__ void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
 __global__ void zmt_dec_copy_kernel_prof(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
 					 const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
@@ -594,10 +596,19 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 		return GPUMT_E_HIP;
 	if (want_scratch(h, 1, nrec * (size_t)(131072 + 256)))
 		return GPUMT_E_HIP;
+	if (h->profile == 5 && !h->d_prof) {
+		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
+		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
+	}
 	PROF0(11);
-	hipLaunchKernelGGL(zmt_zstd_dec_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
-			   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
-			   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status);
+	if (h->profile == 5)
+		hipLaunchKernelGGL(zmt_zstd_dec_kernel_prof, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
+				   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
+				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status, h->d_prof);
+	else
+		hipLaunchKernelGGL(zmt_zstd_dec_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
+				   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
+				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status);
 	PROF1(11);
 	CK(hipGetLastError());
 	return GPUMT_OK;

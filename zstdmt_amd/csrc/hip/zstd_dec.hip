@@ -33,10 +33,12 @@ struct ZLds {
 	u32 ll[512], of[256], ml[512]; /* sym | nbits << 8 | base << 16 */
 	u8 below[16];   /* stage[-16..0): 8-byte reads may start below the window */
 	u8 stage[Z_STAGE + 16];
-	u32 sq_ll[64], sq_ml[64], sq_off[64];
+	u32 sq_ll[64], sq_ml[64], sq_off[64]; /* one batch of sequences: extra bits, then values */
+	u8 sc_ll[64], sc_ml[64], sc_of[64];   /* their codes */
 	u8 w[256];
 	short norm[3][64];
 	u16 next[3][64];
+	u32 llx[36], mlx[53]; /* value base | extra bits << 24 of every LL / ML code */
 	u32 misc[16];
 };
 
@@ -147,8 +149,17 @@ static __device__ int fse_read_ncount(const u8 *p, u32 len, short *norm, int max
 	return (int)((b.bit + 7) / 8);
 }
 
-/* spread + number the cells (serial, one lane per table); returns 0 or -1 */
-static __device__ int fse_build(u32 *cell, const short *norm, int nsym, int log, u16 *next)
+/* decoding cell: sym (6) | nbits (4) << 6 | extra bits of the code (5) << 10 | next-state base << 16 */
+#define ZC_SYM(c) ((c) & 63u)
+#define ZC_NB(c) (((c) >> 6) & 15u)
+#define ZC_AB(c) (((c) >> 10) & 31u)
+#define ZC_BASE(c) ((c) >> 16)
+
+/* spread + number the cells (serial, one lane per table); returns 0 or -1.
+ * xb: per-code "value base | extra bits << 24" table (LL / ML), NULL for offset codes (extra bits =
+ * the code itself) -- kind 3 = no extra bits at all (Huffman weights) */
+static __device__ int fse_build(u32 *cell, const short *norm, int nsym, int log, u16 *next, const u32 *xb,
+				int kind)
 {
 	const u32 size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
 	u32 high = size - 1, pos = 0;
@@ -175,9 +186,20 @@ static __device__ int fse_build(u32 *cell, const short *norm, int nsym, int log,
 		const u32 s = cell[u];
 		const u32 x = next[s]++;
 		const u32 nb = (u32)(log - hb32(x));
-		cell[u] = s | nb << 8 | (((x << nb) - size) & 0xFFFFu) << 16;
+		const u32 ab = kind == 3 ? 0 : xb ? xb[s] >> 24 : s;
+		cell[u] = s | nb << 6 | ab << 10 | (((x << nb) - size) & 0xFFFFu) << 16;
 	}
 	return 0;
+}
+
+/* `width` (<= 32) bits that start `topoff` bits below the top of the 128-bit window w0:w1 */
+static __device__ __forceinline__ u32 xbits(u64 w0, u64 w1, u32 topoff, u32 width)
+{
+	const u32 sh = 128u - topoff - width;
+	const u64 hi = w0 >> ((sh - 64u) & 63u);
+	const u64 lo = (w1 >> (sh & 63u)) | ((w0 << 1) << (63u - (sh & 63u)));
+	const u64 v = sh >= 64u ? hi : lo;
+	return (u32)(v & ((1ull << width) - 1));
 }
 
 /* ------------------------------------------------------------------ constants */
@@ -224,7 +246,7 @@ static __device__ int huf_read_weights(const u8 *d, u32 len, u8 *w, int *nw_out,
 			return -1;
 		int nsym, log;
 		const int u = fse_read_ncount(d + 1, (u32)hb, norm, 13, 6, &nsym, &log);
-		if (u < 0 || u >= hb || fse_build(cells, norm, nsym, log, next))
+		if (u < 0 || u >= hb || fse_build(cells, norm, nsym, log, next, nullptr, 3))
 			return -1;
 		/* backward bitstream, two interleaved states (RFC 8878 4.2.1.2) */
 		const u8 *bs = d + 1 + u;
@@ -252,21 +274,21 @@ static __device__ int huf_read_weights(const u8 *d, u32 len, u8 *w, int *nw_out,
 			if (nw > 253)
 				return -1;
 			u32 c = cells[s1];
-			w[nw++] = (u8)c;
-			WBITS((int)((c >> 8) & 255), t);
-			s1 = (c >> 16) + t;
+			w[nw++] = (u8)ZC_SYM(c);
+			WBITS((int)ZC_NB(c), t);
+			s1 = ZC_BASE(c) + t;
 			if (pos < 0) {
-				w[nw++] = (u8)cells[s2];
+				w[nw++] = (u8)ZC_SYM(cells[s2]);
 				break;
 			}
 			if (nw > 253)
 				return -1;
 			c = cells[s2];
-			w[nw++] = (u8)c;
-			WBITS((int)((c >> 8) & 255), t);
-			s2 = (c >> 16) + t;
+			w[nw++] = (u8)ZC_SYM(c);
+			WBITS((int)ZC_NB(c), t);
+			s2 = ZC_BASE(c) + t;
 			if (pos < 0) {
-				w[nw++] = (u8)cells[s1];
+				w[nw++] = (u8)ZC_SYM(cells[s1]);
 				break;
 			}
 		}
@@ -390,14 +412,46 @@ static __device__ void wave_match(u8 *d, u32 off, u32 ml, int lane)
 }
 
 /* ------------------------------------------------------------------ the kernel */
-extern "C" __global__ void __launch_bounds__(64)
-zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
-		    const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
-		    const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
-		    u8 *__restrict__ litbuf, u32 *__restrict__ status)
+#ifdef ZMT_EMU
+static inline u32 zbad_(int line)
 {
-	__shared__ __attribute__((aligned(16))) ZLds L;
+	if (getenv("ZMT_EMU_DEBUG") && wv_lane() == 0)
+		fprintf(stderr, "zstd_dec: bad block flagged at line %d\n", line);
+	return ST_BAD_BLOCK;
+}
+#define ZBAD() zbad_(__LINE__)
+#else
+#define ZBAD() ST_BAD_BLOCK
+#endif
+#ifndef ZMT_EMU
+#define ZT() (PROF ? (u64)clock64() : 0ull)
+#else
+#define ZT() 0ull
+#endif
+#define ZP(i)                                                                                      \
+	do {                                                                                       \
+		if (PROF) {                                                                        \
+			const u64 t_ = ZT();                                                       \
+			pc[PROF ? (i) : 0] += t_ - tq;                                             \
+			tq = t_;                                                                   \
+		}                                                                                  \
+	} while (0)
+
+template <bool PROF>
+static __device__ __forceinline__ void
+zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
+	      const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base, const u64 *__restrict__ out_off,
+	      const u32 *__restrict__ out_len, u8 *__restrict__ litbuf, u32 *__restrict__ status,
+	      unsigned long long *prof)
+{
 	const int lane = wv_lane();
+	u64 pc[PROF ? 8 : 1] = {0}, tq = ZT();
+	const u64 t_begin = tq;
+	(void)t_begin;
+	if (lane < 36)
+		L.llx[lane] = Z_LL_BASE[lane] | (u32)Z_LL_BITS[lane] << 24;
+	if (lane < 53)
+		L.mlx[lane] = Z_ML_BASE[lane] | (u32)Z_ML_BITS[lane] << 24;
 	const u32 rec = blockIdx.x;
 	if (rec >= nrec)
 		return;
@@ -486,7 +540,7 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 
 	for (;;) {
 		if (flen - ip < 3) {
-			stc = ST_BAD_BLOCK;
+			stc = ZBAD();
 			break;
 		}
 		const u32 bh = uld8(f + ip) | uld8(f + ip + 1) << 8 | uld8(f + ip + 2) << 16;
@@ -495,7 +549,7 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 		const u8 *src = f + ip;
 		if (btype == 3 || bsize > block_max || (btype != 1 && flen - ip < bsize) ||
 		    (btype == 1 && flen - ip < 1)) {
-			stc = ST_BAD_BLOCK;
+			stc = ZBAD();
 			break;
 		}
 		if (btype == 0) {
@@ -518,9 +572,10 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 			ip += 1;
 		} else {
 			/* ================= compressed block ================= */
+			ZP(6);
 			const u32 bstart = opos;
 			if (bsize < 2) {
-				stc = ST_BAD_BLOCK;
+				stc = ZBAD();
 				break;
 			}
 			/* ---- literals section header + tree description, from LDS ---- */
@@ -590,7 +645,7 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 			}
 			wv_sync();
 			if (L.misc[ZM_ERR]) {
-				stc = ST_BAD_BLOCK;
+				stc = ZBAD();
 				break;
 			}
 			const u32 ltype = L.misc[ZM_A], regen = L.misc[ZM_B], lcsz = L.misc[ZM_C], lhl = L.misc[ZM_D];
@@ -613,13 +668,14 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 					huf_ok = true;
 					wv_sync();
 				} else if (!huf_ok) {
-					stc = ST_BAD_BLOCK;
+					stc = ZBAD();
 					break;
 				}
+				ZP(0);
 				/* ---- Huffman streams: lane s < nstreams decodes stream s ---- */
 				const u32 body = lhl + tree; /* offset of jump table / single stream in src */
 				if (lcsz < tree + (nstreams == 4 ? 10u : 1u)) {
-					stc = ST_BAD_BLOCK;
+					stc = ZBAD();
 					break;
 				}
 				u32 s_off = body, s_len = lcsz - tree, s_n = regen, s_dst = 0;
@@ -628,7 +684,7 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 					const u32 j1 = uld16(src + body), j2 = uld16(src + body + 2), j3 = uld16(src + body + 4);
 					const u32 tot = lcsz - tree - 6, q = (regen + 3) / 4;
 					if (j1 + j2 + j3 >= tot || 3 * q > regen) {
-						stc = ST_BAD_BLOCK;
+						stc = ZBAD();
 						break;
 					}
 					const u32 sl = lane & 3;
@@ -647,7 +703,7 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 						pos = 8 * (long)(s_len - 1) + hb32(lastb);
 				}
 				if (wv_any(dec && bad)) {
-					stc = ST_BAD_BLOCK;
+					stc = ZBAD();
 					break;
 				}
 				u32 done = 0;
@@ -725,16 +781,17 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 					}
 				}
 				if (wv_any(dec && bad)) {
-					stc = ST_BAD_BLOCK;
+					stc = ZBAD();
 					break;
 				}
 				wave_mem_fence(); /* literals are read back by other lanes below */
 			}
 
+			ZP(1);
 			/* ---- sequences section header + table descriptions, from LDS ---- */
 			const u32 sq0 = lhl + lcsz; /* offset of the sequences section in src */
 			if (sq0 >= bsize) {
-				stc = ST_BAD_BLOCK;
+				stc = ZBAD();
 				break;
 			}
 			wv_sync();
@@ -794,7 +851,7 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 			}
 			wv_sync();
 			if (L.misc[ZM_ERR]) {
-				stc = ST_BAD_BLOCK;
+				stc = ZBAD();
 				break;
 			}
 			const u32 nseq = L.misc[ZM_D];
@@ -809,149 +866,178 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 					if (spec == 0xFFFFFFFFu) {
 						terr = !my_tab_ok; /* repeat mode needs a previous table */
 					} else if (spec & 0x80000000u) {
-						cells[0] = spec & 255; /* RLE: one cell, no bits */
+						const u32 sy = spec & 255; /* RLE: one cell, no state bits */
+						cells[0] = sy | (lane == 1 ? sy : (lane == 0 ? L.llx[sy] : L.mlx[sy]) >> 24) << 10;
 						my_tab_log = 0;
 						my_tab_ok = true;
 					} else {
 						const int lg = (int)(spec >> 8);
-						terr = fse_build(cells, L.norm[lane], (int)(spec & 255), lg, L.next[lane]) != 0;
+						terr = fse_build(cells, L.norm[lane], (int)(spec & 255), lg, L.next[lane],
+								 lane == 0 ? L.llx : lane == 2 ? L.mlx : (const u32 *)nullptr, lane) != 0;
 						my_tab_log = lg;
 						my_tab_ok = !terr;
 					}
 				}
 				wv_sync();
 				if (wv_any(terr)) {
-					stc = ST_BAD_BLOCK;
+					stc = ZBAD();
 					break;
 				}
 				const int ll_log = (int)wv_readlane((u32)my_tab_log, 0);
 				const int of_log = (int)wv_readlane((u32)my_tab_log, 1);
 				const int ml_log = (int)wv_readlane((u32)my_tab_log, 2);
+				ZP(2);
 				/* ---- FSE bitstream: src[sq0 + sq_hdr, bsize) read backwards ---- */
 				const u32 bs_off = sq0 + sq_hdr;
 				if (bs_off >= bsize) {
-					stc = ST_BAD_BLOCK;
+					stc = ZBAD();
 					break;
 				}
 				const u32 bs_len = bsize - bs_off;
 				const u32 lastb = uld8(src + bs_off + bs_len - 1);
 				if (lastb == 0) {
-					stc = ST_BAD_BLOCK;
+					stc = ZBAD();
 					break;
 				}
-				long pos = 8 * (long)(bs_len - 1) + hb32(lastb); /* lane 0's copy is the live one */
-				u32 s_ll = 0, s_of = 0, s_ml = 0;
-				bool first = true;
-				u32 r0 = rep0, r1 = rep1, r2 = rep2; /* live in lane 0 */
+				long pos = 8 * (long)(bs_len - 1) + hb32(lastb); /* unread bits, wave-uniform */
+				/* lanes 0 / 1 / 2 carry the LL / OF / ML state and decode their own code; the
+				 * loop below is wave-uniform (one LDS round trip per sequence): every lane reads
+				 * its state's cell and the same 128-bit window of the bitstream, the six field
+				 * widths are exchanged through SGPRs, each lane cuts its two fields out */
+				const u32 *mytab = lane == 1 ? L.of : lane == 2 ? L.ml : L.ll;
+				u32 *myval = lane == 1 ? L.sq_off : lane == 2 ? L.sq_ml : L.sq_ll;
+				u8 *mycode = lane == 1 ? L.sc_of : lane == 2 ? L.sc_ml : L.sc_ll;
+				u32 state = 0;
 				for (u32 sbase = 0; sbase < nseq && stc == ST_OK; sbase += 64) {
 					const u32 k = nseq - sbase < 64 ? nseq - sbase : 64;
 					/* window of the bitstream: 1 KiB ending at the byte of the next unread bit */
-					const long upos = (long)((u64)wv_readlane((u32)((u64)pos >> 32), 0) << 32 |
-								 wv_readlane((u32)pos, 0));
-					const long whi = (upos + 7) >> 3, wlo = whi - (long)Z_STAGE;
+					const long whi = (pos + 7) >> 3, wlo = whi - (long)Z_STAGE;
 					wv_sync();
 					stage_load(L.stage, src + bs_off, wlo, Z_STAGE, -(long)(bs_off + 16), mem_lo, mem_hi, lane);
 					wv_sync();
-					if (lane == 0) {
-						const u8 *win = L.stage;
-						bool err = false;
-#define SBITS(n, out)                                                                              \
-	do {                                                                                       \
-		const int n_ = (int)(n);                                                           \
-		u32 v_ = 0;                                                                        \
-		if (n_) {                                                                          \
-			pos -= n_;                                                                 \
-			const long tb_ = (pos + n_ - 1) >> 3;                                      \
-			const long at_ = tb_ - 7 - wlo;                                            \
-			if (pos < 0 || at_ < -16) {                                                \
-				err = true;                                                        \
-			} else {                                                                   \
-				const u64 w_ = ld64u(win + at_);                                   \
-				v_ = (u32)((w_ >> (pos - 8 * (tb_ - 7))) & ((1ull << n_) - 1));   \
-			}                                                                          \
-		}                                                                                  \
-		(out) = v_;                                                                        \
-	} while (0)
-						if (first) {
-							SBITS(ll_log, s_ll);
-							SBITS(of_log, s_of);
-							SBITS(ml_log, s_ml);
-							first = false;
+					const u8 *win = L.stage - wlo; /* win[b] = byte b of the bitstream */
+					bool err = false;
+					if (sbase == 0) {
+						/* initial states: LL, OF, ML (RFC 8878 3.1.1.3.2.1.1) */
+						if (pos < (long)(ll_log + of_log + ml_log)) {
+							stc = ZBAD();
+							break;
 						}
-						for (u32 i = 0; i < k && !err; i++) {
-							const u32 cl = L.ll[s_ll], co = L.of[s_of], cm = L.ml[s_ml];
-							const u32 lc = cl & 255, oc = co & 255, mc = cm & 255;
-							u32 ofv, mlv, llv, t;
-							if (oc > 31) {
-								err = true;
-								break;
-							}
-							SBITS(oc, ofv);
-							ofv += 1u << oc;
-							SBITS(Z_ML_BITS[mc], mlv);
-							mlv += Z_ML_BASE[mc];
-							SBITS(Z_LL_BITS[lc], llv);
-							llv += Z_LL_BASE[lc];
-							if (sbase + i + 1 < nseq) {
-								SBITS((cl >> 8) & 255, t);
-								s_ll = (cl >> 16) + t;
-								SBITS((cm >> 8) & 255, t);
-								s_ml = (cm >> 16) + t;
-								SBITS((co >> 8) & 255, t);
-								s_of = (co >> 16) + t;
-							}
-							/* repeat offsets (RFC 8878 3.1.1.5) */
-							u32 off;
-							if (ofv > 3) {
-								off = ofv - 3;
-								r2 = r1;
-								r1 = r0;
-								r0 = off;
-							} else {
-								const u32 idx = ofv - 1 + (llv == 0);
-								if (idx == 0) {
-									off = r0;
-								} else {
-									off = idx == 1 ? r1 : idx == 2 ? r2 : r0 - 1;
-									if (off == 0) {
-										err = true;
-										break;
-									}
-									if (idx > 1)
-										r2 = r1;
-									r1 = r0;
-									r0 = off;
-								}
-							}
-							L.sq_ll[i] = llv;
-							L.sq_ml[i] = mlv;
-							L.sq_off[i] = off;
-						}
-#undef SBITS
-						if (!err && sbase + k == nseq && pos != 0)
-							err = true;
-						L.misc[ZM_ERR] = err;
+						const long tb = (pos - 1) >> 3;
+						const u64 w0 = ld64u(win + tb - 7), w1 = ld64u(win + tb - 15);
+						const u32 skip = (u32)(8 * (tb + 1) - pos);
+						state = xbits(w0, w1, skip + (lane == 0 ? 0u : lane == 1 ? (u32)ll_log : (u32)(ll_log + of_log)),
+							      (u32)(lane < 3 ? my_tab_log : 0));
+						pos -= ll_log + of_log + ml_log;
 					}
-					wv_sync();
-					if (L.misc[ZM_ERR]) {
-						stc = ST_BAD_BLOCK;
+					for (u32 i = 0; i < k; i++) {
+						const u32 cell = mytab[lane < 3 ? state : 0];
+						if (pos < 0) {
+							err = true;
+							break;
+						}
+						/* pos == 0 is legal here: the last sequence may need no bits at all */
+						const long tb = (pos - 1) >> 3;
+						const u64 w0 = ld64u(win + tb - 7), w1 = ld64u(win + tb - 15);
+						const u32 skip = (u32)(8 * (tb + 1) - pos);
+						const bool lastseq = sbase + i + 1 == nseq;
+						const u32 nb = lastseq ? 0u : ZC_NB(cell), ab = ZC_AB(cell);
+						const u32 pk = ab | nb << 8;
+						const u32 p_ll = wv_readlane(pk, 0), p_of = wv_readlane(pk, 1), p_ml = wv_readlane(pk, 2);
+						const u32 a_ll = p_ll & 255, n_ll = p_ll >> 8, a_of = p_of & 255, n_of = p_of >> 8;
+						const u32 a_ml = p_ml & 255, n_ml = p_ml >> 8;
+						const u32 base3 = skip + a_of + a_ml + a_ll;
+						const u32 eo = lane == 0 ? skip + a_of + a_ml : lane == 1 ? skip : skip + a_of;
+						const u32 so = base3 + (lane == 0 ? 0u : lane == 1 ? n_ll + n_ml : n_ll);
+						const u32 extra = xbits(w0, w1, eo, ab);
+						const u32 sbits = xbits(w0, w1, so, nb);
+						if (lane < 3) {
+							myval[i] = extra;
+							mycode[i] = (u8)ZC_SYM(cell);
+						}
+						state = ZC_BASE(cell) + sbits;
+						pos -= (long)(base3 - skip + n_ll + n_ml + n_of);
+					}
+					if (err || pos < 0 || (sbase + k == nseq && pos != 0)) {
+						stc = ZBAD();
 						break;
 					}
+					wv_sync();
+					ZP(3);
 					/* ---- execute the k sequences ---- */
 					const bool act0 = (u32)lane < k;
-					const u32 ll = act0 ? L.sq_ll[lane] : 0, ml = act0 ? L.sq_ml[lane] : 0;
-					const u32 off = act0 ? L.sq_off[lane] : 1;
+					u32 ll = 0, ml = 0, ofv = 4;
+					if (act0) {
+						const u32 c_of = L.sc_of[lane];
+						ll = (L.llx[L.sc_ll[lane]] & 0xFFFFFFu) + L.sq_ll[lane];
+						ml = (L.mlx[L.sc_ml[lane]] & 0xFFFFFFu) + L.sq_ml[lane];
+						ofv = c_of > 31 ? 0u : (1u << c_of) + L.sq_off[lane];
+					}
+					if (wv_any(act0 && ofv == 0)) {
+						stc = ZBAD(); /* offset code > 31 */
+						break;
+					}
+					/* repeat offsets (RFC 8878 3.1.1.5): runs of new offsets fold into the history in
+					 * one step, only the sequences that use a repeat code are walked one by one */
+					u32 off = ofv - 3;
+					{
+						u64 repm = wv_ballot(act0 && ofv <= 3);
+						u32 prev = 0;
+						bool rerr = false;
+						for (;;) {
+							const u32 j = repm ? (u32)wv_ffs(repm) - 1 : k;
+							const u32 m = j - prev;
+							if (m >= 1) {
+								const u32 o1 = wv_readlane(off, (int)(j - 1));
+								u32 n1, n2;
+								if (m >= 3) {
+									n1 = wv_readlane(off, (int)(j - 2));
+									n2 = wv_readlane(off, (int)(j - 3));
+								} else if (m == 2) {
+									n1 = wv_readlane(off, (int)(j - 2));
+									n2 = rep0;
+								} else {
+									n1 = rep0;
+									n2 = rep1;
+								}
+								rep2 = n2;
+								rep1 = n1;
+								rep0 = o1;
+							}
+							if (j >= k)
+								break;
+							const u32 idx = wv_readlane(ofv, (int)j) - 1 + (wv_readlane(ll, (int)j) == 0);
+							u32 o = rep0;
+							if (idx) {
+								o = idx == 1 ? rep1 : idx == 2 ? rep2 : rep0 - 1;
+								if (o == 0)
+									rerr = true;
+								if (idx > 1)
+									rep2 = rep1;
+								rep1 = rep0;
+								rep0 = o;
+							}
+							if ((u32)lane == j)
+								off = o;
+							repm &= repm - 1;
+							prev = j + 1;
+						}
+						if (rerr) {
+							stc = ZBAD();
+							break;
+						}
+					}
 					const u32 len = ll + ml;
 					const u32 incl = wv_scan_incl(len), lincl = wv_scan_incl(ll);
 					const u32 tot = wv_readlane(incl, 63), ltot = wv_readlane(lincl, 63);
 					/* 64 x (2 x 131074) cannot wrap 32 bits */
 					if (ltot > regen - lpos || tot > cap - opos || opos + tot - bstart > block_max) {
-						stc = ST_BAD_BLOCK;
+						stc = ZBAD();
 						break;
 					}
 					const u32 op = opos + incl - len, mpos = op + ll, lsrc = lpos + lincl - ll;
 					if (wv_any(act0 && off > mpos)) {
-						stc = ST_BAD_BLOCK; /* reaches before the start of the frame */
+						stc = ZBAD(); /* reaches before the start of the frame */
 						break;
 					}
 					const u32 src_pos = mpos - off, eff = ml < off ? ml : off;
@@ -968,6 +1054,7 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 						}
 					}
 					wave_mem_fence();
+					ZP(4);
 					/* matches: watermark rounds.  W = everything below is written and visible */
 					{
 						bool fin = !act0;
@@ -992,29 +1079,21 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 							wave_mem_fence();
 						}
 					}
+					ZP(5);
 					opos += tot;
 					lpos += ltot;
 				}
 				if (stc != ST_OK)
 					break;
-				if (lane == 0) {
-					L.misc[ZM_A] = r0;
-					L.misc[ZM_B] = r1;
-					L.misc[ZM_C] = r2;
-				}
-				wv_sync();
-				rep0 = L.misc[ZM_A];
-				rep1 = L.misc[ZM_B];
-				rep2 = L.misc[ZM_C];
 			} else if (sq_hdr != bsize - sq0) {
-				stc = ST_BAD_BLOCK;
+				stc = ZBAD();
 				break;
 			}
 			/* literals after the last sequence */
 			{
 				const u32 restl = regen - lpos;
 				if (restl > cap - opos || opos + restl - bstart > block_max) {
-					stc = ST_BAD_BLOCK;
+					stc = ZBAD();
 					break;
 				}
 				wave_copy(out + opos, lit + lpos, restl, lane);
@@ -1026,6 +1105,15 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 		if (last)
 			break;
 	}
+	ZP(6);
+#ifndef ZMT_EMU
+	if (PROF && prof && lane == 0) {
+		for (int i = 0; i < (PROF ? 7 : 1); i++)
+			atomicAdd(prof + i, (unsigned long long)pc[i]);
+		atomicAdd(prof + 8, (unsigned long long)(ZT() - t_begin));
+		atomicAdd(prof + 9, 1ull);
+	}
+#endif
 	if (stc == ST_OK && opos != cap)
 		stc = ST_SIZE_MISMATCH;
 	if (stc == ST_OK && ip != flen)
@@ -1033,6 +1121,31 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 	if (lane == 0 && stc != ST_OK)
 		status[rec] = stc;
 }
+
+extern "C" __global__ void __launch_bounds__(64)
+zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
+		    const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
+		    const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
+		    u8 *__restrict__ litbuf, u32 *__restrict__ status)
+{
+	__shared__ __attribute__((aligned(16))) ZLds L;
+	zstd_dec_body<false>(L, stream, stream_bytes, rec_off, rec_len, nrec, out_base, out_off, out_len, litbuf,
+			     status, nullptr);
+}
+
+#ifndef ZMT_EMU
+/* same kernel with per-phase cycle counters (developer tool) */
+extern "C" __global__ void __launch_bounds__(64)
+zmt_zstd_dec_kernel_prof(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
+			 const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
+			 const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
+			 u8 *__restrict__ litbuf, u32 *__restrict__ status, unsigned long long *prof)
+{
+	__shared__ __attribute__((aligned(16))) ZLds L;
+	zstd_dec_body<true>(L, stream, stream_bytes, rec_off, rec_len, nrec, out_base, out_off, out_len, litbuf,
+			    status, prof);
+}
+#endif
 
 /* out_len[i] = Frame_Content_Size of record i (what the host needs before it can size d_out);
  * status[i] = ST_OK, or why the record cannot be decoded here. */
