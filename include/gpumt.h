@@ -143,6 +143,22 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
  * XXH64 content checksum report GPUMT_ST_UNSUPPORTED.  Same d_stream slack rule as above.
  * Internal scratch: 128 KiB + 256 B of literals per record.
  */
+/* Bytes one zstd record slot occupies: room for the record + frame header and one padded area per
+ * 128 KiB block (the blocks are compressed independently and then moved together), rounded to 256. */
+size_t gpumt_zstd_slot_stride(size_t chunk);
+
+/*
+ * Compress n bytes at d_in (the allocation must extend 64 readable bytes past n) as independent
+ * chunks of `chunk` bytes (last one shorter; n == 0 gives one empty chunk): record i (12-byte
+ * skippable header + one zstd frame that decodes to chunk i; replaces ZSTD_compress at
+ * lib/zstd-mt_compress.c:285 + header emit :296-302) is written at d_slots + i*slot_stride and its
+ * length to d_rec_len[i].  gpumt_lz4_compact then packs the records into the MT stream.
+ * The frames are valid RFC 8878 (single segment, content size, no checksum, blocks of at most
+ * 128 KiB); their bytes are not those of libzstd -- the bar for zstd is decompress-identical.
+ */
+int gpumt_zstd_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk,
+			      void *d_slots, size_t slot_stride, uint32_t *d_rec_len, int stream);
+
 int gpumt_zstd_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
 			   const uint32_t *d_rec_len, size_t nrec, uint32_t *d_out_len,
 			   uint64_t *d_out_off, uint32_t *d_status, int stream);

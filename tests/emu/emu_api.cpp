@@ -29,6 +29,8 @@ void zmt_scan_kernel(const u32 *, u32, u64 *);
 void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
 void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u8 *, u32 *);
 void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
+void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u32 *);
+void zmt_zstd_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 }
 
 using emu::dim3;
@@ -163,6 +165,29 @@ void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *re
 	emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
 		zmt_zstd_dec_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status);
 	});
+}
+
+
+size_t emu_zstd_slot_stride(size_t chunk)
+{
+	size_t nb = chunk ? (chunk + 131071) / 131072 : 1;
+	return (32 + nb * (131072 + 16) + 255) & ~(size_t)255;
+}
+
+/* zstd compress: block encoder on `grid` persistent waves (scratch starts as garbage), then assemble */
+void emu_zstd_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid)
+{
+	u32 nrec = n ? (u32)((n + chunk - 1) / chunk) : 1;
+	u32 bpr = (chunk + 131071) / 131072;
+	u32 nblk = nrec * bpr;
+	if (grid > nblk)
+		grid = nblk;
+	std::vector<u32> blk_len(nblk, 0xA5A5A5A5u), seq((size_t)grid * 3 * 32768, 0xA5A5A5A5u);
+	u32 *bl = blk_len.data(), *sq = seq.data();
+	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1},
+		    [=]() { zmt_zstd_enc_kernel(in, n, chunk, nblk, bpr, slots, stride, bl, sq); });
+	emu::launch(dim3{nrec, 1, 1}, dim3{256, 1, 1},
+		    [=]() { zmt_zstd_assemble_kernel(n, chunk, nrec, bpr, slots, stride, bl, rec_len); });
 }
 
 } /* extern "C" */

@@ -69,3 +69,33 @@ def test_emu_decode_full_size_blocks():
     assert rv == 0
     out, status = E.zstd_decompress(st)
     assert (status == 0).all() and out == data
+
+
+# ------------------------------------------------------------------------------- encoder kernels
+ENC_CASES = {
+    "empty": (131072, lambda: b""),
+    "hello": (131072, lambda: b"hello world, hello world, hello!"),
+    "text_300": (131072, lambda: cases.text(300, 2)),
+    "text_70k": (131072, lambda: cases.text(70000, 3)),
+    "text_2x128k_p5": (131072, lambda: cases.text(2 * 131072 + 5, 11)),
+    "text_300k_chunk1m": (1 << 20, lambda: cases.text(300000, 5)),
+    "random_140k": (131072, lambda: cases.rnd(140000, 3)),
+    "zeros_300k": (1 << 20, lambda: bytes(300000)),
+    "period_300": (1 << 20, lambda: cases.rep(cases.rnd(300, 9), 150000)),
+    "mixed": (262144, lambda: cases.text(50000, 4) + bytes(70000) + cases.rnd(3000, 5) + cases.text(100000, 6)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ENC_CASES))
+def test_emu_encode_decompress_identical(name):
+    chunk, thunk = ENC_CASES[name]
+    data = thunk()
+    st = E.zstd_compress(data, chunk)
+    assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
+    out, status = E.zstd_decompress(st)          # and through the emulated decoder kernels
+    assert (status == 0).all() and out == data
+    if H.have_zref():
+        rv, back, _, _ = H.zstdmt_decompress_via(H.zref(), st, threads=2)
+        assert rv == 0 and back == data
+    # independent of how many persistent waves share the blocks
+    assert E.zstd_compress(data, chunk, grid=1) == st

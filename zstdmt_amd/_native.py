@@ -43,6 +43,8 @@ GPUMT_SYMBOLS = {
     "gpumt_lz4_compact": (_i, [_vp, _vp, _sz, _u32p, _sz, _vp, _u64p, _i]),
     "gpumt_lz4_probe_sizes": (_i, [_vp, _vp, _u64p, _u32p, _sz, _u32p, _u64p, _i]),
     "gpumt_lz4_decompress_batch": (_i, [_vp, _vp, _sz, _u64p, _u32p, _sz, _vp, _sz, _u64p, _u32p, _u32p, _i]),
+    "gpumt_zstd_slot_stride": (_sz, [_sz]),
+    "gpumt_zstd_compress_batch": (_i, [_vp, _vp, _sz, _sz, _vp, _sz, _u32p, _i]),
     "gpumt_zstd_probe_sizes": (_i, [_vp, _vp, _u64p, _u32p, _sz, _u32p, _u64p, _u32p, _i]),
     "gpumt_zstd_decompress_batch": (_i, [_vp, _vp, _sz, _u64p, _u32p, _sz, _vp, _sz, _u64p, _u32p, _u32p, _i]),
     "gpumt_xxh32_batch": (_i, [_vp, _vp, _u64p, _u32p, _sz, _u32p, _i]),

@@ -41,6 +41,8 @@ __global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u
 				    const u32 *, u8 *, u32 *);
 __global__ void zmt_zstd_dec_kernel_prof(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
 					 const u32 *, u8 *, u32 *, unsigned long long *);
+__global__ void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u32 *);
+__global__ void zmt_zstd_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 __global__ void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
 __global__ void zmt_dec_copy_kernel_prof(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
 					 const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
@@ -567,6 +569,47 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 }
 
 /* ------------------------------------------------------------------ zstd */
+#define ZE_BLOCK 131072u
+#define ZE_BSTRIDE (ZE_BLOCK + 16u)
+#define ZE_HDR 32u
+#define ZE_MAXSEQ (ZE_BLOCK / 4u)
+
+size_t gpumt_zstd_slot_stride(size_t chunk)
+{
+	const size_t nb = chunk ? (chunk + ZE_BLOCK - 1) / ZE_BLOCK : 1;
+	return (ZE_HDR + nb * ZE_BSTRIDE + 255) & ~(size_t)255;
+}
+
+int gpumt_zstd_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
+			      size_t slot_stride, uint32_t *d_rec_len, int s)
+{
+	if (!h || !STREAM_OK(s) || chunk == 0 || chunk > 0x40000000u || slot_stride < gpumt_zstd_slot_stride(chunk))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	const size_t nrec = gpumt_lz4_record_count(n, chunk);
+	const u32 bpr = (u32)((chunk + ZE_BLOCK - 1) / ZE_BLOCK);
+	const size_t nblk = nrec * bpr;
+	if (nblk > 0x7FFFFFFFu)
+		return GPUMT_E_ARG;
+	/* persistent waves: 4 per CU (32 KiB LDS hash table each), blocks taken round-robin */
+	const unsigned grid = (unsigned)(nblk < 1024 ? nblk : 1024);
+	const size_t seq_bytes = (size_t)grid * 3 * ZE_MAXSEQ * 4;
+	if (want_scratch(h, 0, nblk * 4 + 64 + seq_bytes))
+		return GPUMT_E_HIP;
+	u32 *blk_len = (u32 *)h->scratch[0];
+	u32 *seqbuf = (u32 *)((u8 *)h->scratch[0] + ((nblk * 4 + 63) & ~(size_t)63));
+	PROF0(9);
+	hipLaunchKernelGGL(zmt_zstd_enc_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
+			   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);
+	hipLaunchKernelGGL(zmt_zstd_assemble_kernel, dim3((unsigned)nrec), dim3(256), 0, h->st[s], (u64)n,
+			   (u32)chunk, (u32)nrec, bpr, (u8 *)d_slots, (u64)slot_stride, (const u32 *)blk_len,
+			   d_rec_len);
+	PROF1(9);
+	CK(hipGetLastError());
+	return GPUMT_OK;
+}
+
 int gpumt_zstd_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
 			   const uint32_t *d_rec_len, size_t nrec, uint32_t *d_out_len,
 			   uint64_t *d_out_off, uint32_t *d_status, int s)

@@ -1,0 +1,502 @@
+/*
+ * zstd_enc.hip -- zstd frame encoder for gfx950.
+ *
+ * Replaces ZSTD_compress(dst, cap, chunk, n, level) as called per chunk by the reference
+ * (/root/reference/lib/zstd-mt_compress.c:285) and the record header emit (:296-302).  The bar for
+ * this codec is decompress-identical (zstd's bytes are version dependent), so the
+ * encoder is free to choose its own parse and entropy stage as long as every frame is valid
+ * RFC 8878 and decodes to the chunk; it is designed for the GPU instead of restating zstd's
+ * sequential match finder:
+ *
+ *   zmt_zstd_enc_kernel      one wave per 128 KiB block (persistent waves, blocks round-robin).
+ *     match finding          64 positions per step, one per lane: 4-byte hash, 8192-entry LDS
+ *                            table updated with atomicMax (deterministic: the newest position
+ *                            wins), candidates verified with one unaligned 8-byte compare per
+ *                            lane, long matches extended 512 bytes per step by the whole wave;
+ *     parse                  greedy, leftmost match first, resolved with ballots;
+ *     literals               raw (Huffman literals: next step), copied lane-per-run;
+ *     sequences              codes and extra bits computed lane-per-sequence, FSE-coded with the
+ *                            predefined tables (RFC 8878 3.1.1.3.2.2) by one lane from LDS.
+ *     A block that does not shrink is stored raw.
+ *   zmt_zstd_assemble_kernel one workgroup per chunk: skippable header + frame header
+ *                            (single segment, content size) + the chunk's blocks moved together.
+ *
+ * Matches stay inside their block (blocks are independent: 65536 of them per 8 GiB).
+ */
+#include "lz4_common.h"
+#include "lz4_frame.h"
+
+#define ZMT_ZSTD_MAGIC 0xFD2FB528u
+#define ZE_BLOCK 131072u
+#define ZE_BSTRIDE (ZE_BLOCK + 16u) /* area of one block inside a record slot */
+#define ZE_HDR 32u                  /* room in front of the blocks for record + frame header */
+#define ZE_HLOG 13
+#define ZE_MINMATCH 4u
+#define ZE_MAXSEQ (ZE_BLOCK / ZE_MINMATCH)
+#define ZE_CAP 64u
+
+struct ZEncLds {
+	u32 table[1u << ZE_HLOG];        /* position + 1 of the newest occurrence of a hash */
+	u16 st_ll[64], st_ml[64], st_of[32]; /* FSE state tables of the predefined distributions */
+	u32 tt_ll[36][2], tt_ml[53][2], tt_of[29][2]; /* per symbol: deltaNbBits, deltaFindState */
+	u32 llx[36], mlx[53];            /* value base | extra bits << 24 */
+	u32 sq[64][4];                   /* staged batch: codes packed, ll extra, ml extra, of extra */
+	u32 misc[8];
+};
+
+static __device__ __forceinline__ void st64g(u8 *p, u64 v) { __builtin_memcpy(p, &v, 8); }
+static __device__ __forceinline__ int hb32(u32 v) { return 31 - __builtin_clz(v); }
+
+__device__ static const short ZE_LL_DEF[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+						2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__device__ static const short ZE_OF_DEF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1,
+						1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+__device__ static const short ZE_ML_DEF[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+						1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+						1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__device__ static const u32 ZE_LL_BASE[36] = {0,  1,  2,   3,   4,   5,    6,    7,    8,    9,     10,    11,
+					       12, 13, 14,  15,  16,  18,   20,   22,   24,   28,    32,    40,
+					       48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+__device__ static const u8 ZE_LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,  0,  0,  0,  1,  1,
+					      1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__device__ static const u32 ZE_ML_BASE[53] = {3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16,
+					       17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30,
+					       31, 32, 33, 34, 35, 37, 39, 41, 43, 47, 51, 59, 67, 83,
+					       99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+__device__ static const u8 ZE_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,  0,  0,  0,
+					      0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  1,  1,  1,  1,
+					      2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+
+/* FSE compression table of a normalized distribution (one lane): state table + per-symbol
+ * transform, the encoder-side mirror of RFC 8878 4.1.1's decoding table */
+static __device__ void fse_ctable(u16 *state_tab, u32 (*tt)[2], const short *norm, int nsym, int log, u8 *scratch)
+{
+	const u32 size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+	u32 cumul[54];
+	u32 high = size - 1, pos = 0;
+	cumul[0] = 0;
+	for (int s = 0; s < nsym; s++) {
+		if (norm[s] == -1) {
+			cumul[s + 1] = cumul[s] + 1;
+			scratch[high--] = (u8)s;
+		} else {
+			cumul[s + 1] = cumul[s] + (u32)norm[s];
+		}
+	}
+	for (int s = 0; s < nsym; s++) {
+		for (int i = 0; i < norm[s]; i++) {
+			scratch[pos] = (u8)s;
+			do
+				pos = (pos + step) & mask;
+			while (pos > high);
+		}
+	}
+	for (u32 u = 0; u < size; u++) {
+		const u32 s = scratch[u];
+		state_tab[cumul[s]++] = (u16)(size + u);
+	}
+	u32 total = 0;
+	for (int s = 0; s < nsym; s++) {
+		const int c = norm[s];
+		if (c == 0) {
+			tt[s][0] = ((u32)(log + 1) << 16) - size;
+			tt[s][1] = 0;
+		} else if (c == -1 || c == 1) {
+			tt[s][0] = ((u32)log << 16) - size;
+			tt[s][1] = total - 1;
+			total++;
+		} else {
+			const u32 maxbits = (u32)(log - hb32((u32)c - 1));
+			tt[s][0] = (maxbits << 16) - ((u32)c << maxbits);
+			tt[s][1] = total - (u32)c;
+			total += (u32)c;
+		}
+	}
+}
+
+/* lane-private forward bit writer (LSB first), 4-byte flushes */
+struct BitW {
+	u8 *p, *limit;
+	u64 acc;
+	u32 nb;
+	bool ovf;
+};
+static __device__ __forceinline__ void bw_add(BitW &w, u32 v, u32 n) /* n <= 31, w.nb <= 32 */
+{
+	w.acc |= (u64)(v & ((1u << n) - 1)) << w.nb;
+	w.nb += n;
+	if (w.nb >= 32) {
+		if (w.p + 4 > w.limit)
+			w.ovf = true;
+		else
+			st32u(w.p, (u32)w.acc);
+		w.p += 4;
+		w.acc >>= 32;
+		w.nb -= 32;
+	}
+}
+
+static __device__ __forceinline__ void ze_copy(u8 *d, const u8 *s, u32 len)
+{
+	if (len >= 8) {
+		for (u32 i = 0; i + 8 < len; i += 8)
+			st64g(d + i, ld64u(s + i));
+		st64g(d + len - 8, ld64u(s + len - 8));
+	} else if (len >= 4) {
+		const u32 a = ld32u(s), b = ld32u(s + len - 4);
+		st32u(d, a);
+		st32u(d + len - 4, b);
+	} else {
+		for (u32 i = 0; i < len; i++)
+			d[i] = s[i];
+	}
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
+		    u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u32 *__restrict__ seqbuf)
+{
+	__shared__ __attribute__((aligned(16))) ZEncLds L;
+	const int lane = wv_lane();
+	u32 *const sq_ll = seqbuf + (u64)blockIdx.x * 3u * ZE_MAXSEQ;
+	u32 *const sq_ml = sq_ll + ZE_MAXSEQ, *const sq_of = sq_ml + ZE_MAXSEQ;
+
+	/* predefined FSE compression tables, once per wave: lanes 0..2 build LL / ML / OF */
+	if (lane < 36)
+		L.llx[lane] = ZE_LL_BASE[lane] | (u32)ZE_LL_BITS[lane] << 24;
+	if (lane < 53)
+		L.mlx[lane] = ZE_ML_BASE[lane] | (u32)ZE_ML_BITS[lane] << 24;
+	{
+		u8 *scr = (u8 *)L.table + 64 * lane; /* the hash table is not live yet */
+		if (lane == 0)
+			fse_ctable(L.st_ll, L.tt_ll, ZE_LL_DEF, 36, 6, scr);
+		else if (lane == 1)
+			fse_ctable(L.st_ml, L.tt_ml, ZE_ML_DEF, 53, 6, scr);
+		else if (lane == 2)
+			fse_ctable(L.st_of, L.tt_of, ZE_OF_DEF, 29, 5, scr);
+	}
+	wv_sync();
+
+	for (u32 g = blockIdx.x; g < nblk_total; g += gridDim.x) {
+		const u32 rec = g / blk_per_rec, bi = g % blk_per_rec;
+		const u64 cstart = (u64)rec * chunk;
+		const u32 clen = (u32)(n - cstart < chunk ? n - cstart : chunk);
+		const u32 bstart = bi * ZE_BLOCK;
+		if (bstart >= clen) {
+			if (lane == 0)
+				blk_len[g] = 0; /* no such block (short last chunk, or an empty input) */
+			continue;
+		}
+		const u32 bsize = clen - bstart < ZE_BLOCK ? clen - bstart : ZE_BLOCK;
+		const u32 last = bstart + bsize == clen;
+		const u8 *src = in + cstart + bstart;
+		u8 *out = slots + (u64)rec * stride + ZE_HDR + (u64)bi * ZE_BSTRIDE;
+
+		/* ------------------------------------------------ match finding + greedy parse */
+		for (u32 i = (u32)lane; i < (1u << ZE_HLOG); i += 64)
+			L.table[i] = 0;
+		wv_sync();
+		u32 ns = 0, anchor = 0, cursor = 0;
+		for (u32 p0 = 0; p0 + ZE_MINMATCH <= bsize; p0 += 64) {
+			const u32 p = p0 + (u32)lane;
+			const bool valid = p + ZE_MINMATCH <= bsize;
+			const u64 v = valid ? ld64u(src + p) : 0;
+			const u32 h = ((u32)v * 2654435761u) >> (32 - ZE_HLOG);
+			const u32 cand = valid ? L.table[h] : 0;
+			wv_sync();
+			if (valid)
+				atomicMax(&L.table[h], p + 1);
+			wv_sync();
+			if (p0 + 64 <= cursor)
+				continue; /* the whole step lies inside the previous match */
+			const bool is_c = valid && cand != 0 && p >= cursor;
+			const u32 c = cand - 1;
+			const u64 vc = is_c ? ld64u(src + c) : ~v;
+			const u64 x = v ^ vc;
+			u32 m = x ? (u32)__builtin_ctzll(x) >> 3 : 8u;
+			if (m > bsize - p && valid)
+				m = bsize - p;
+			u64 mask = wv_ballot(is_c && m >= ZE_MINMATCH);
+			while (mask) {
+				const int j = wv_ffs(mask) - 1;
+				mask &= mask - 1;
+				const u32 pj = p0 + (u32)j;
+				if (pj < cursor)
+					continue;
+				const u32 cj = wv_readlane(c, j);
+				u32 ml = wv_readlane(m, j);
+				if (ml == 8) {
+					/* extend: 64 lanes x 8 bytes per step */
+					for (u32 base = 8;; base += 512) {
+						const u32 o = base + 8u * (u32)lane;
+						u32 k = 0;
+						bool stop = true;
+						if (pj + o < bsize) {
+							const u64 y = ld64u(src + pj + o) ^ ld64u(src + cj + o);
+							k = y ? (u32)__builtin_ctzll(y) >> 3 : 8u;
+							stop = k < 8;
+						}
+						const u64 sm = wv_ballot(stop);
+						if (sm) {
+							const int f = wv_ffs(sm) - 1;
+							ml = base + 8u * (u32)f + wv_readlane(k, f);
+							break;
+						}
+					}
+					if (ml > bsize - pj)
+						ml = bsize - pj;
+				}
+				if (lane == 0) {
+					sq_ll[ns] = pj - anchor;
+					sq_ml[ns] = ml;
+					sq_of[ns] = pj - cj;
+				}
+				ns++;
+				anchor = cursor = pj + ml;
+			}
+		}
+		wave_mem_fence();
+
+		/* ------------------------------------------------ block assembly */
+		u32 csize = 0; /* compressed block content size; 0 = store raw */
+		if (ns) {
+			/* literal bytes: everything outside the matches */
+			u32 mtot = 0;
+			for (u32 b = 0; b < ns; b += 64) {
+				const u32 i = b + (u32)lane;
+				mtot += wv_readlane(wv_scan_incl(i < ns ? sq_ml[i] : 0), 63);
+			}
+			const u32 regen = bsize - mtot;
+			const u32 lh = regen < 32 ? 1u : regen < 4096 ? 2u : 3u;
+			u8 *lit = out + 3 + lh;
+			if (3 + lh + regen + 4 < bsize) {
+				if (lane == 0) {
+					if (lh == 1) {
+						lit[-1] = (u8)(regen << 3);
+					} else if (lh == 2) {
+						const u32 hv = regen << 4 | 1u << 2;
+						lit[-2] = (u8)hv;
+						lit[-1] = (u8)(hv >> 8);
+					} else {
+						const u32 hv = regen << 4 | 3u << 2;
+						lit[-3] = (u8)hv;
+						lit[-2] = (u8)(hv >> 8);
+						lit[-1] = (u8)(hv >> 16);
+					}
+				}
+				/* copy the literal runs: lane per sequence, long runs by the whole wave */
+				u32 ipos = 0, lpos = 0; /* input position / literal position before this batch */
+				for (u32 b = 0; b < ns; b += 64) {
+					const u32 i = b + (u32)lane;
+					const u32 ll = i < ns ? sq_ll[i] : 0, ml = i < ns ? sq_ml[i] : 0;
+					const u32 incl = wv_scan_incl(ll + ml), lincl = wv_scan_incl(ll);
+					const u32 s0 = ipos + incl - ll - ml, d0 = lpos + lincl - ll;
+					if (ll && ll <= ZE_CAP)
+						ze_copy(lit + d0, src + s0, ll);
+					u64 lm = wv_ballot(ll > ZE_CAP);
+					while (lm) {
+						const int j = wv_ffs(lm) - 1;
+						lm &= lm - 1;
+						wave_copy(lit + wv_readlane(d0, j), src + wv_readlane(s0, j), wv_readlane(ll, j), lane);
+					}
+					ipos += wv_readlane(incl, 63);
+					lpos += wv_readlane(lincl, 63);
+				}
+				wave_copy(lit + lpos, src + ipos, bsize - ipos, lane); /* after the last match */
+				/* sequences section */
+				u8 *sp = lit + regen;
+				u32 sh;
+				if (ns < 128) {
+					if (lane == 0)
+						sp[0] = (u8)ns;
+					sh = 1;
+				} else if (ns < 0x7F00) {
+					if (lane == 0) {
+						sp[0] = (u8)((ns >> 8) + 128);
+						sp[1] = (u8)ns;
+					}
+					sh = 2;
+				} else {
+					if (lane == 0) {
+						sp[0] = 255;
+						sp[1] = (u8)(ns - 0x7F00);
+						sp[2] = (u8)((ns - 0x7F00) >> 8);
+					}
+					sh = 3;
+				}
+				if (lane == 0)
+					sp[sh] = 0; /* Symbol_Compression_Modes: three predefined tables */
+				BitW w;
+				w.p = sp + sh + 1;
+				w.limit = out + 3 + bsize; /* anything at or beyond is not smaller than raw */
+				w.acc = 0;
+				w.nb = 0;
+				w.ovf = false;
+				u32 s_ll = 0, s_ml = 0, s_of = 0; /* FSE states, live in lane 0 */
+				/* from the last sequence to the first, 64 at a time */
+				for (u32 hi = ns; hi > 0;) {
+					const u32 k = hi < 64 ? hi : 64, lo = hi - k;
+					{
+						/* lane t stages sequence hi-1-t: codes and extra bits */
+						const u32 i = hi - 1 - (u32)lane;
+						if ((u32)lane < k) {
+							const u32 ll = sq_ll[i], mlb = sq_ml[i], ofv = sq_of[i] + 3;
+							u32 lc = 0, mc = 0;
+							for (u32 c2 = 1; c2 < 36; c2++)
+								lc += (L.llx[c2] & 0xFFFFFFu) <= ll;
+							for (u32 c2 = 1; c2 < 53; c2++)
+								mc += (L.mlx[c2] & 0xFFFFFFu) <= mlb;
+							const u32 oc = (u32)hb32(ofv);
+							L.sq[lane][0] = lc | mc << 8 | oc << 16;
+							L.sq[lane][1] = ll - (L.llx[lc] & 0xFFFFFFu);
+							L.sq[lane][2] = mlb - (L.mlx[mc] & 0xFFFFFFu);
+							L.sq[lane][3] = ofv - (1u << oc);
+						}
+					}
+					wv_sync();
+					if (lane == 0) {
+						for (u32 t = 0; t < k; t++) {
+							const u32 codes = L.sq[t][0];
+							const u32 lc = codes & 255, mc = (codes >> 8) & 255, oc = codes >> 16;
+							if (hi == ns && t == 0) {
+								/* FSE_initCState2 x3: ML, OF, LL */
+								u32 nbo = (L.tt_ml[mc][0] + (1u << 15)) >> 16;
+								s_ml = L.st_ml[(((nbo << 16) - L.tt_ml[mc][0]) >> nbo) + L.tt_ml[mc][1]];
+								nbo = (L.tt_of[oc][0] + (1u << 15)) >> 16;
+								s_of = L.st_of[(((nbo << 16) - L.tt_of[oc][0]) >> nbo) + L.tt_of[oc][1]];
+								nbo = (L.tt_ll[lc][0] + (1u << 15)) >> 16;
+								s_ll = L.st_ll[(((nbo << 16) - L.tt_ll[lc][0]) >> nbo) + L.tt_ll[lc][1]];
+							} else {
+								u32 nbo = (s_of + L.tt_of[oc][0]) >> 16;
+								bw_add(w, s_of, nbo);
+								s_of = L.st_of[(s_of >> nbo) + L.tt_of[oc][1]];
+								nbo = (s_ml + L.tt_ml[mc][0]) >> 16;
+								bw_add(w, s_ml, nbo);
+								s_ml = L.st_ml[(s_ml >> nbo) + L.tt_ml[mc][1]];
+								nbo = (s_ll + L.tt_ll[lc][0]) >> 16;
+								bw_add(w, s_ll, nbo);
+								s_ll = L.st_ll[(s_ll >> nbo) + L.tt_ll[lc][1]];
+							}
+							bw_add(w, L.sq[t][1], L.llx[lc] >> 24);
+							bw_add(w, L.sq[t][2], L.mlx[mc] >> 24);
+							bw_add(w, L.sq[t][3], oc);
+						}
+					}
+					wv_sync();
+					hi = lo;
+				}
+				if (lane == 0) {
+					bw_add(w, s_ml, 6);
+					bw_add(w, s_of, 5);
+					bw_add(w, s_ll, 6);
+					bw_add(w, 1, 1); /* end mark */
+					const u32 tail = (w.nb + 7) >> 3;
+					if (w.p + tail > w.limit) {
+						w.ovf = true;
+					} else {
+						for (u32 t = 0; t < tail; t++)
+							w.p[t] = (u8)(w.acc >> (8 * t));
+					}
+					w.p += tail;
+					L.misc[0] = w.ovf ? 0u : (u32)(w.p - (out + 3));
+				}
+				wv_sync();
+				csize = L.misc[0];
+				wv_sync();
+			}
+		}
+		if (csize && csize < bsize) {
+			if (lane == 0) {
+				const u32 bh = last | 2u << 1 | csize << 3;
+				out[0] = (u8)bh;
+				out[1] = (u8)(bh >> 8);
+				out[2] = (u8)(bh >> 16);
+				blk_len[g] = 3 + csize;
+			}
+		} else {
+			if (lane == 0) {
+				const u32 bh = last | 0u << 1 | bsize << 3;
+				out[0] = (u8)bh;
+				out[1] = (u8)(bh >> 8);
+				out[2] = (u8)(bh >> 16);
+				blk_len[g] = 3 + bsize;
+			}
+			wave_copy(out + 3, src, bsize, lane);
+		}
+		wave_mem_fence();
+	}
+}
+
+/* Record slot -> finished record: skippable header (lib/zstd-mt_compress.c:296-302), frame header
+ * (magic, single-segment descriptor, content size), the chunk's blocks moved together. */
+extern "C" __global__ void __launch_bounds__(256)
+zmt_zstd_assemble_kernel(u64 n, u32 chunk, u32 nrec, u32 blk_per_rec, u8 *__restrict__ slots, u64 stride,
+			 const u32 *__restrict__ blk_len, u32 *__restrict__ rec_len)
+{
+	const u32 rec = blockIdx.x, t = threadIdx.x;
+	if (rec >= nrec)
+		return;
+	const u64 cstart = (u64)rec * chunk;
+	const u32 clen = (u32)(n - cstart < chunk ? n - cstart : chunk);
+	u8 *slot = slots + (u64)rec * stride;
+	const u32 fcs_len = clen < 256 ? 1u : clen < 65536 + 256 ? 2u : 4u;
+	const u32 fh = 4 + 1 + fcs_len;
+	u32 at = 12 + fh;
+	const u32 nb = clen ? (clen + ZE_BLOCK - 1) / ZE_BLOCK : 0;
+	for (u32 b = 0; b < nb; b++) {
+		const u32 len = blk_len[(u64)rec * blk_per_rec + b];
+		const u8 *s = slot + ZE_HDR + (u64)b * ZE_BSTRIDE;
+		u8 *d = slot + at;
+		/* moving left, regions may overlap: forward order, one 4 KiB piece at a time */
+		for (u32 o = 0; o < len; o += 4096) {
+			const u32 m = len - o < 4096 ? len - o : 4096;
+			u64 a = 0, c = 0;
+			u8 tail[16];
+			const u32 i = 16 * t;
+			if (i + 16 <= m) {
+				a = ld64u(s + o + i);
+				c = ld64u(s + o + i + 8);
+			} else if (i < m) {
+				for (u32 k = 0; k < m - i; k++)
+					tail[k] = s[o + i + k];
+			}
+			__syncthreads();
+			if (i + 16 <= m) {
+				st64g(d + o + i, a);
+				st64g(d + o + i + 8, c);
+			} else if (i < m) {
+				for (u32 k = 0; k < m - i; k++)
+					d[o + i + k] = tail[k];
+			}
+			__syncthreads();
+		}
+		at += len;
+	}
+	if (t == 0) {
+		u8 *f = slot + 12;
+		if (nb == 0) {
+			/* empty chunk: one empty raw block marked last (the 9-byte frame libzstd writes too) */
+			slot[at] = 1;
+			slot[at + 1] = 0;
+			slot[at + 2] = 0;
+			at += 3;
+		}
+		const u32 csz = at - 12;
+		slot[0] = 0x50; slot[1] = 0x2A; slot[2] = 0x4D; slot[3] = 0x18;
+		slot[4] = 4; slot[5] = 0; slot[6] = 0; slot[7] = 0;
+		slot[8] = (u8)csz; slot[9] = (u8)(csz >> 8); slot[10] = (u8)(csz >> 16); slot[11] = (u8)(csz >> 24);
+		f[0] = 0x28; f[1] = 0xB5; f[2] = 0x2F; f[3] = 0xFD;
+		if (fcs_len == 1) {
+			f[4] = 0x20; /* single segment, 1-byte content size */
+			f[5] = (u8)clen;
+		} else if (fcs_len == 2) {
+			f[4] = 0x20 | 1u << 6;
+			f[5] = (u8)(clen - 256);
+			f[6] = (u8)((clen - 256) >> 8);
+		} else {
+			f[4] = 0x20 | 2u << 6;
+			f[5] = (u8)clen; f[6] = (u8)(clen >> 8); f[7] = (u8)(clen >> 16); f[8] = (u8)(clen >> 24);
+		}
+		rec_len[rec] = at;
+	}
+}

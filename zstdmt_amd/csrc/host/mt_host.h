@@ -1,0 +1,72 @@
+/*
+ * mt_host.h -- small helpers shared by the host engines (lz4mt_engine.c, zstdmt_engine.c):
+ * little-endian reads and a device buffer + pinned mirror pair that only ever grows.
+ * Plain C over include/gpumt.h; no HIP header.
+ */
+#ifndef ZMT_MT_HOST_H
+#define ZMT_MT_HOST_H
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gpumt.h"
+
+/*
+ * Device batches.  The kernels are latency-bound per chunk (a wave per chunk / per record), so a
+ * batch should hold thousands of chunks to fill 256 CUs; pinned host memory on the other hand costs
+ * ~0.3 s per GiB to allocate and free (measured, tools/ubench/hostalloc.hip).  Batches therefore
+ * start at 64 MiB (small inputs stay cheap) and grow to 256 MiB; the buffers live as long as the
+ * context, so repeated calls on one context do not pay for them again.
+ */
+#define BATCH_MIN ((size_t)64 << 20)
+#define BATCH_BYTES ((size_t)256 << 20)
+#define BATCH_MAXREC 8192
+
+static inline uint32_t rd32(const uint8_t *p)
+{
+	return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+static inline uint64_t rd64(const uint8_t *p)
+{
+	return (uint64_t)rd32(p) | (uint64_t)rd32(p + 4) << 32;
+}
+
+/* a device buffer + pinned mirror that only ever grows */
+typedef struct {
+	void *d;
+	void *h;
+	size_t cap;
+} dbuf;
+
+static inline int dbuf_want(gpumt_ctx *g, dbuf *b, size_t bytes, int pinned, int device)
+{
+	if (bytes <= b->cap)
+		return 0;
+	gpumt_device_sync(g);
+	if (b->d)
+		gpumt_free(g, b->d);
+	if (b->h)
+		gpumt_host_free(g, b->h);
+	b->d = b->h = NULL;
+	b->cap = 0;
+	bytes += bytes / 8 + 4096;
+	if (device && !(b->d = gpumt_malloc(g, bytes)))
+		return -1;
+	if (pinned && !(b->h = gpumt_host_alloc(g, bytes)))
+		return -1;
+	b->cap = bytes;
+	return 0;
+}
+static inline void dbuf_free(gpumt_ctx *g, dbuf *b)
+{
+	if (b->d)
+		gpumt_free(g, b->d);
+	if (b->h)
+		gpumt_host_free(g, b->h);
+	memset(b, 0, sizeof *b);
+}
+
+/* =================================================================== compression ============ */
+
+#endif

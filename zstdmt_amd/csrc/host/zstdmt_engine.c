@@ -1,0 +1,574 @@
+/*
+ * zstdmt_engine.c -- the host side of zstd-mt on MI355X: ZSTDCB_* (include/zstd-mt.h) over gpumt_*.
+ *
+ * Same pipeline as lz4mt_engine.c (batches of records through H2D / kernels / D2H on three
+ * streams, two slots), following the callback-visible behaviour of the reference
+ * (lib/zstd-mt_compress.c:208-392, lib/zstd-mt_decompress.c:209-549,693-843):
+ *   compress   one fn_read of exactly `inputsize` per chunk, one fn_write per record, in order;
+ *              counters are reset per call (:337-341); empty input still yields one frame (:264);
+ *   decompress a 16-byte sniff, then csize-4 bytes for the first record, then 12 + csize bytes per
+ *              record (:221-353); one fn_write per frame in order.
+ * Stream layouts accepted by decompress: the one the compressor writes ("pzstd style": skippable
+ * frame first, :251-284).  The legacy layouts (zstd frame first: old zstdmt 9-byte prefix, plain
+ * .zst) are SURVEY 8f-2 "next" and report frame_decompress.
+ * Plain C, no HIP header.
+ */
+#include "mt_host.h"
+#include "zstd-mt.h"
+
+size_t zstdmt_errcode;
+
+/* ------------------------------------------------------------------ errors (zstd-mt_common.c) */
+unsigned ZSTDCB_isError(size_t code)
+{
+	return code > ZSTDCB_ERROR(maxCode);
+}
+
+const char *ZSTDCB_getErrorString(size_t code)
+{
+	/* strings of lib/zstd-mt_common.c:40-61 (init_missing and canceled have none there) */
+	static const char *const codec[] = {
+		"", "device: malformed record header", "device: bad zstd frame header",
+		"device: malformed zstd block", "device: content size mismatch",
+		"device: content checksum mismatch", "device: trailing bytes after frame",
+		"device: unsupported zstd frame feature",
+	};
+	const size_t idx = (size_t)0 - code;
+	if (zstdmt_errcode >= 1 && zstdmt_errcode <= 7 && idx == ZSTDCB_error_compression_library)
+		return codec[zstdmt_errcode];
+	switch ((ZSTDCB_ErrorCode)idx) {
+	case ZSTDCB_error_no_error:
+		return "No error detected";
+	case ZSTDCB_error_memory_allocation:
+		return "Allocation error : not enough memory";
+	case ZSTDCB_error_read_fail:
+		return "Read failure";
+	case ZSTDCB_error_write_fail:
+		return "Write failure";
+	case ZSTDCB_error_data_error:
+		return "Malformed input";
+	case ZSTDCB_error_frame_compress:
+		return "Could not compress frame at once";
+	case ZSTDCB_error_frame_decompress:
+		return "Could not decompress frame at once";
+	case ZSTDCB_error_compressionParameter_unsupported:
+		return "Compression parameter is out of bound";
+	case ZSTDCB_error_compression_library:
+		return "Compression library reports failure";
+	default:
+		return "Unspecified zstmt error code"; /* sic, zstd-mt_common.c:34 */
+	}
+}
+
+/* callback return value -> library error (mt_error, zstd-mt_compress.c:160-173) */
+static size_t mt_error(int rv)
+{
+	switch (rv) {
+	case -1:
+		return ZSTDCB_ERROR(read_fail);
+	case -2:
+		return ZSTDCB_ERROR(canceled);
+	case -3:
+		return ZSTDCB_ERROR(memory_allocation);
+	}
+	return ZSTDCB_ERROR(read_fail);
+}
+
+static int is_zstd_magic(const uint8_t *p) /* IsZstd_Magic, zstd-mt_decompress.c:146-153 */
+{
+	const uint32_t m = rd32(p);
+	return m == ZSTDCB_MAGICNUMBER_V01 || (m >= ZSTDCB_MAGICNUMBER_MIN && m <= ZSTDCB_MAGICNUMBER_MAX);
+}
+
+/* Frame_Content_Size of a zstd frame header (RFC 8878 3.1.1.1), ~0 when absent / malformed */
+static uint64_t zstd_content_size(const uint8_t *f, size_t n)
+{
+	if (n < 6 || rd32(f) != ZSTDCB_MAGICNUMBER_MAX)
+		return ~(uint64_t)0;
+	{
+		const unsigned fhd = f[4], fcs = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+		const unsigned did_len = did == 3 ? 4 : did, fcs_len = fcs == 0 ? single : 1u << fcs;
+		const size_t hp = 5 + (1 - single) + did_len;
+		uint64_t c = 0;
+		if (fcs_len == 0 || n < hp + fcs_len)
+			return ~(uint64_t)0;
+		for (unsigned k = 0; k < fcs_len; k++)
+			c |= (uint64_t)f[hp + k] << (8 * k);
+		return fcs == 1 ? c + 256 : c;
+	}
+}
+
+/* =================================================================== compression */
+struct cslot {
+	dbuf in;      /* chunk data, H2D                       */
+	dbuf slots;   /* device only: per-chunk records        */
+	dbuf stream;  /* packed records, D2H                   */
+	dbuf meta;    /* rec_len[n] u32 | pad | rec_off[n+1] u64, D2H */
+	size_t n;     /* bytes in the batch                    */
+	size_t nrec;
+};
+
+struct ZSTDCB_CCtx_s {
+	int level, threads, inputsize;
+	size_t insize, outsize, curframe, frames;
+	gpumt_ctx *gpu;
+	struct cslot s[2];
+};
+
+ZSTDCB_CCtx *ZSTDCB_createCCtx(int threads, int level, int inputsize)
+{
+	/* default chunk = 1 << (windowLog[level] + 1), indexed by the level itself as in
+	 * zstd-mt_compress.c:116-127 (level 22 reads past that table there; 1 GiB here) */
+	static const int window_log[] = {19, 19, 20, 20, 20, 21, 21, 21, 21, 21, 22, 22,
+					 22, 22, 22, 23, 23, 23, 23, 25, 26, 27, 29};
+	ZSTDCB_CCtx *ctx;
+	if (threads < 1 || threads > ZSTDCB_THREAD_MAX)
+		return NULL;
+	if (level < ZSTDCB_LEVEL_MIN || level > ZSTDCB_LEVEL_MAX)
+		return NULL;
+	if (inputsize < 0)
+		return NULL;
+	ctx = (ZSTDCB_CCtx *)calloc(1, sizeof *ctx);
+	if (!ctx)
+		return NULL;
+	ctx->level = level;
+	ctx->threads = threads;
+	ctx->inputsize = inputsize ? inputsize : 1 << (window_log[level] + 1);
+	if (gpumt_open(0, &ctx->gpu) != GPUMT_OK) {
+		free(ctx); /* no device: fail loudly, there is no CPU path */
+		return NULL;
+	}
+	return ctx;
+}
+
+void ZSTDCB_freeCCtx(ZSTDCB_CCtx *ctx)
+{
+	if (!ctx)
+		return;
+	for (int i = 0; i < 2; i++) {
+		dbuf_free(ctx->gpu, &ctx->s[i].in);
+		dbuf_free(ctx->gpu, &ctx->s[i].slots);
+		dbuf_free(ctx->gpu, &ctx->s[i].stream);
+		dbuf_free(ctx->gpu, &ctx->s[i].meta);
+	}
+	gpumt_close(ctx->gpu);
+	free(ctx);
+}
+
+/* NULL context: init_missing for the compression getters (zstd-mt_compress.c:395-423) */
+size_t ZSTDCB_GetFramesCCtx(ZSTDCB_CCtx *ctx) { return ctx ? ctx->curframe : ZSTDCB_ERROR(init_missing); }
+size_t ZSTDCB_GetInsizeCCtx(ZSTDCB_CCtx *ctx) { return ctx ? ctx->insize : ZSTDCB_ERROR(init_missing); }
+size_t ZSTDCB_GetOutsizeCCtx(ZSTDCB_CCtx *ctx) { return ctx ? ctx->outsize : ZSTDCB_ERROR(init_missing); }
+
+/* one fn_read of exactly `inputsize` per chunk; EOF = zero-length read once a frame exists
+ * (pt_compress, zstd-mt_compress.c:250-277) */
+static size_t c_read_batch(ZSTDCB_CCtx *ctx, ZSTDCB_RdWr_t *io, struct cslot *s, size_t maxrec, int *eof)
+{
+	const size_t chunk = (size_t)ctx->inputsize;
+	s->n = 0;
+	s->nrec = 0;
+	while (s->nrec < maxrec) {
+		ZSTDCB_Buffer b;
+		int rv;
+		b.buf = (uint8_t *)s->in.h + s->n;
+		b.size = chunk;
+		b.allocated = chunk;
+		rv = io->fn_read(io->arg_read, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		if (b.size == 0 && ctx->frames > 0) {
+			*eof = 1;
+			break;
+		}
+		if (b.size > chunk)
+			return ZSTDCB_ERROR(read_fail);
+		ctx->insize += b.size;
+		ctx->frames++;
+		s->n += b.size;
+		s->nrec++;
+		if (b.size < chunk)
+			break; /* ragged chunk: last one of this device batch */
+	}
+	return 0;
+}
+
+static size_t c_launch(ZSTDCB_CCtx *ctx, struct cslot *s)
+{
+	gpumt_ctx *g = ctx->gpu;
+	const size_t chunk = (size_t)ctx->inputsize;
+	const size_t stride = gpumt_zstd_slot_stride(chunk);
+	uint32_t *d_len = (uint32_t *)s->meta.d;
+	uint64_t *d_off = (uint64_t *)((uint8_t *)s->meta.d + ((s->nrec * 4 + 15) & ~(size_t)15));
+	int rc = 0;
+	if (s->n)
+		rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, s->n, 1);
+	rc |= gpumt_stream_wait(g, 0, 1);
+	rc |= gpumt_zstd_compress_batch(g, s->in.d, s->n, chunk, s->slots.d, stride, d_len, 0);
+	rc |= gpumt_lz4_compact(g, s->slots.d, stride, d_len, s->nrec, s->stream.d, d_off, 0);
+	rc |= gpumt_stream_wait(g, 2, 0);
+	rc |= gpumt_memcpy_d2h(g, s->meta.h, s->meta.d, ((s->nrec * 4 + 15) & ~(size_t)15) + (s->nrec + 1) * 8, 2);
+	return rc ? ZSTDCB_ERROR(compression_library) : 0;
+}
+
+static size_t c_finish(ZSTDCB_CCtx *ctx, ZSTDCB_RdWr_t *io, struct cslot *s)
+{
+	gpumt_ctx *g = ctx->gpu;
+	const uint32_t *len = (const uint32_t *)s->meta.h;
+	const uint64_t *off = (const uint64_t *)((const uint8_t *)s->meta.h + ((s->nrec * 4 + 15) & ~(size_t)15));
+	size_t total;
+	if (gpumt_stream_sync(g, 2))
+		return ZSTDCB_ERROR(compression_library);
+	total = (size_t)off[s->nrec];
+	if (total > s->stream.cap)
+		return ZSTDCB_ERROR(frame_compress);
+	if (gpumt_memcpy_d2h(g, s->stream.h, s->stream.d, total, 2) || gpumt_stream_sync(g, 2))
+		return ZSTDCB_ERROR(compression_library);
+	for (size_t i = 0; i < s->nrec; i++) { /* pt_write: strictly in frame order */
+		ZSTDCB_Buffer b;
+		int rv;
+		b.buf = (uint8_t *)s->stream.h + off[i];
+		b.size = len[i];
+		b.allocated = len[i];
+		rv = io->fn_write(io->arg_write, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		ctx->outsize += len[i];
+		ctx->curframe++;
+	}
+	return 0;
+}
+
+size_t ZSTDCB_compressCCtx(ZSTDCB_CCtx *ctx, ZSTDCB_RdWr_t *rdwr)
+{
+	size_t chunk, stride, maxrec, err = 0;
+	int eof = 0, cur = 0, have_prev = 0;
+
+	if (!ctx)
+		return ZSTDCB_ERROR(init_missing); /* zstd-mt_compress.c:327-328 */
+	chunk = (size_t)ctx->inputsize;
+	stride = gpumt_zstd_slot_stride(chunk);
+	/* counters restart with every call (zstd-mt_compress.c:337-341) */
+	ctx->insize = ctx->outsize = ctx->frames = ctx->curframe = 0;
+	zstdmt_errcode = 0;
+	maxrec = BATCH_MIN / chunk;
+	if (maxrec < 1)
+		maxrec = 1;
+	while (!eof) {
+		struct cslot *s = &ctx->s[cur];
+		size_t lim = BATCH_BYTES / chunk;
+		if (lim < 1)
+			lim = 1;
+		if (lim > BATCH_MAXREC)
+			lim = BATCH_MAXREC;
+		if (maxrec > lim)
+			maxrec = lim;
+		if (dbuf_want(ctx->gpu, &s->in, maxrec * chunk + 512, 1, 1) ||
+		    dbuf_want(ctx->gpu, &s->slots, maxrec * stride, 0, 1) ||
+		    dbuf_want(ctx->gpu, &s->stream, maxrec * stride + 512, 1, 1) ||
+		    dbuf_want(ctx->gpu, &s->meta, maxrec * 12 + 64, 1, 1)) {
+			err = ZSTDCB_ERROR(memory_allocation);
+			break;
+		}
+		err = c_read_batch(ctx, rdwr, s, maxrec, &eof);
+		if (err)
+			break;
+		if (s->nrec) {
+			err = c_launch(ctx, s);
+			if (err)
+				break;
+		}
+		if (have_prev) {
+			err = c_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
+			have_prev = 0;
+			if (err)
+				break;
+		}
+		if (s->nrec) {
+			have_prev = 1;
+			cur ^= 1;
+		}
+		maxrec *= 4;
+	}
+	if (!err && have_prev)
+		err = c_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
+	gpumt_device_sync(ctx->gpu);
+	return err;
+}
+
+/* =================================================================== decompression */
+struct dslot {
+	dbuf in;     /* record bytes (headers included), H2D                                  */
+	dbuf meta;   /* rec_off u64[n] | out_off u64[n+1] | rec_len u32[n] | out_len u32[n], H2D */
+	dbuf status; /* u32[n], D2H                                                           */
+	dbuf out;    /* decoded chunks, D2H                                                   */
+	size_t nrec, in_bytes, out_bytes;
+};
+
+struct ZSTDCB_DCtx_s {
+	int threads, inputsize;
+	size_t budget;
+	size_t insize, outsize, curframe, frames;
+	gpumt_ctx *gpu;
+	struct dslot s[2];
+	int have_hdr; /* a record header read ahead of its batch */
+	uint32_t hdr_csize;
+	uint8_t first4[4]; /* first record: the 4 frame bytes that came with the sniff */
+	int have_first4;
+};
+
+ZSTDCB_DCtx *ZSTDCB_createDCtx(int threads, int inputsize)
+{
+	ZSTDCB_DCtx *ctx;
+	if (threads < 1 || threads > ZSTDCB_THREAD_MAX)
+		return NULL;
+	ctx = (ZSTDCB_DCtx *)calloc(1, sizeof *ctx);
+	if (!ctx)
+		return NULL;
+	ctx->threads = threads;
+	ctx->inputsize = inputsize ? inputsize : 1024 * 512; /* zstd-mt_decompress.c:125-128 */
+	if (gpumt_open(0, &ctx->gpu) != GPUMT_OK) {
+		free(ctx);
+		return NULL;
+	}
+	return ctx;
+}
+
+void ZSTDCB_freeDCtx(ZSTDCB_DCtx *ctx)
+{
+	if (!ctx)
+		return;
+	for (int i = 0; i < 2; i++) {
+		dbuf_free(ctx->gpu, &ctx->s[i].in);
+		dbuf_free(ctx->gpu, &ctx->s[i].meta);
+		dbuf_free(ctx->gpu, &ctx->s[i].status);
+		dbuf_free(ctx->gpu, &ctx->s[i].out);
+	}
+	gpumt_close(ctx->gpu);
+	free(ctx);
+}
+
+size_t ZSTDCB_GetFramesDCtx(ZSTDCB_DCtx *ctx) { return ctx ? ctx->curframe : 0; }
+size_t ZSTDCB_GetInsizeDCtx(ZSTDCB_DCtx *ctx) { return ctx ? ctx->insize : 0; }
+size_t ZSTDCB_GetOutsizeDCtx(ZSTDCB_DCtx *ctx) { return ctx ? ctx->outsize : 0; }
+
+#define D_META_BYTES(n) ((n) * 8 + ((n) + 1) * 8 + (n) * 4 + (n) * 4 + 64)
+static uint64_t *m_rec_off(struct dslot *s, int dev) { return (uint64_t *)(dev ? s->meta.d : s->meta.h); }
+static uint64_t *m_out_off(struct dslot *s, int dev) { return m_rec_off(s, dev) + BATCH_MAXREC; }
+static uint32_t *m_rec_len(struct dslot *s, int dev) { return (uint32_t *)(m_out_off(s, dev) + BATCH_MAXREC + 1); }
+static uint32_t *m_out_len(struct dslot *s, int dev) { return m_rec_len(s, dev) + BATCH_MAXREC; }
+
+/* next 12-byte record header (pt_read, zstd-mt_decompress.c:299-327) */
+static size_t d_read_header(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, uint32_t *csize, int *eof)
+{
+	uint8_t hb[12];
+	ZSTDCB_Buffer b;
+	int rv;
+	b.buf = hb;
+	b.size = 12;
+	b.allocated = 12;
+	rv = io->fn_read(io->arg_read, &b);
+	if (rv != 0)
+		return mt_error(rv);
+	if (b.size == 0) {
+		*eof = 1;
+		return 0;
+	}
+	if (b.size != 12)
+		return ZSTDCB_ERROR(read_fail);
+	if (rd32(hb) != ZSTDCB_MAGIC_SKIPPABLE)
+		return ZSTDCB_ERROR(data_error);
+	ctx->insize += 12;
+	*csize = rd32(hb + 8);
+	return 0;
+}
+
+static size_t d_read_batch(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s, int *eof)
+{
+	s->nrec = 0;
+	s->in_bytes = 0;
+	s->out_bytes = 0;
+	while (s->nrec < BATCH_MAXREC) {
+		uint32_t csize;
+		uint64_t osz;
+		uint8_t *rec;
+		ZSTDCB_Buffer b;
+		size_t err, skip = 0;
+		int rv;
+		if (ctx->have_hdr) {
+			csize = ctx->hdr_csize;
+		} else {
+			err = d_read_header(ctx, io, &csize, eof);
+			if (err)
+				return err;
+			if (*eof)
+				break;
+		}
+		if (s->nrec && (s->in_bytes + 12 + (size_t)csize > s->in.cap - 512 || s->out_bytes >= ctx->budget)) {
+			ctx->have_hdr = 1;
+			ctx->hdr_csize = csize;
+			break;
+		}
+		ctx->have_hdr = 0;
+		if (s->in_bytes + 12 + (size_t)csize + 512 > s->in.cap) {
+			dbuf old = s->in;
+			memset(&s->in, 0, sizeof s->in);
+			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + 12 + (size_t)csize + 512, 1, 1))
+				return ZSTDCB_ERROR(memory_allocation);
+			memcpy(s->in.h, old.h, s->in_bytes);
+			dbuf_free(ctx->gpu, &old);
+		}
+		rec = (uint8_t *)s->in.h + s->in_bytes;
+		rec[0] = 0x50; rec[1] = 0x2A; rec[2] = 0x4D; rec[3] = 0x18;
+		rec[4] = 4; rec[5] = rec[6] = rec[7] = 0;
+		rec[8] = (uint8_t)csize; rec[9] = (uint8_t)(csize >> 8);
+		rec[10] = (uint8_t)(csize >> 16); rec[11] = (uint8_t)(csize >> 24);
+		if (ctx->have_first4) {
+			/* first record: 4 payload bytes arrived with the 16-byte sniff (:262-270) */
+			if (csize < 4)
+				return ZSTDCB_ERROR(data_error);
+			memcpy(rec + 12, ctx->first4, 4);
+			skip = 4;
+			ctx->have_first4 = 0;
+		}
+		b.buf = rec + 12 + skip;
+		b.size = csize - skip;
+		b.allocated = b.size;
+		rv = io->fn_read(io->arg_read, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		if (b.size != csize - skip)
+			return ZSTDCB_ERROR(data_error);
+		ctx->insize += b.size;
+		ctx->frames++;
+		osz = zstd_content_size(rec + 12, csize);
+		if (osz == ~(uint64_t)0 || osz > 0x7FFFFFFFull) {
+			/* no content size: never written by zstd-mt; the reference would grow its buffer */
+			zstdmt_errcode = GPUMT_ST_UNSUPPORTED;
+			return ZSTDCB_ERROR(compression_library);
+		}
+		m_rec_off(s, 0)[s->nrec] = s->in_bytes;
+		m_rec_len(s, 0)[s->nrec] = 12 + csize;
+		m_out_off(s, 0)[s->nrec] = s->out_bytes;
+		m_out_len(s, 0)[s->nrec] = (uint32_t)osz;
+		s->in_bytes += 12 + (size_t)csize;
+		s->out_bytes += (size_t)osz;
+		s->nrec++;
+	}
+	m_out_off(s, 0)[s->nrec] = s->out_bytes;
+	return 0;
+}
+
+static size_t d_launch(ZSTDCB_DCtx *ctx, struct dslot *s)
+{
+	gpumt_ctx *g = ctx->gpu;
+	int rc = 0;
+	if (dbuf_want(g, &s->out, s->out_bytes + 64, 1, 1) || dbuf_want(g, &s->status, s->nrec * 4 + 64, 1, 1))
+		return ZSTDCB_ERROR(memory_allocation);
+	memset(s->status.h, 0, s->nrec * 4); /* GPUMT_ST_OK: the decode kernel only visits those */
+	rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, s->in_bytes, 1);
+	rc |= gpumt_memcpy_h2d(g, s->meta.d, s->meta.h, D_META_BYTES(BATCH_MAXREC), 1);
+	rc |= gpumt_memcpy_h2d(g, s->status.d, s->status.h, s->nrec * 4, 1);
+	rc |= gpumt_stream_wait(g, 0, 1);
+	rc |= gpumt_zstd_decompress_batch(g, s->in.d, s->in_bytes, m_rec_off(s, 1), m_rec_len(s, 1), s->nrec,
+					  s->out.d, s->out_bytes, m_out_off(s, 1), m_out_len(s, 1),
+					  (uint32_t *)s->status.d, 0);
+	rc |= gpumt_stream_wait(g, 2, 0);
+	rc |= gpumt_memcpy_d2h(g, s->status.h, s->status.d, s->nrec * 4, 2);
+	if (s->out_bytes)
+		rc |= gpumt_memcpy_d2h(g, s->out.h, s->out.d, s->out_bytes, 2);
+	return rc ? ZSTDCB_ERROR(compression_library) : 0;
+}
+
+static size_t d_finish(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s)
+{
+	const uint32_t *st = (const uint32_t *)s->status.h;
+	if (gpumt_stream_sync(ctx->gpu, 2))
+		return ZSTDCB_ERROR(compression_library);
+	for (size_t i = 0; i < s->nrec; i++) {
+		ZSTDCB_Buffer b;
+		int rv;
+		if (st[i] != GPUMT_ST_OK) {
+			/* pt_decompress: any ZSTD error -> compression_library, code in the global (:534-536) */
+			zstdmt_errcode = st[i];
+			return ZSTDCB_ERROR(compression_library);
+		}
+		b.buf = (uint8_t *)s->out.h + m_out_off(s, 0)[i];
+		b.size = m_out_len(s, 0)[i];
+		b.allocated = b.size;
+		rv = io->fn_write(io->arg_write, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		ctx->outsize += b.size;
+		ctx->curframe++;
+	}
+	return 0;
+}
+
+size_t ZSTDCB_decompressDCtx(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *rdwr)
+{
+	uint8_t sniff[16];
+	ZSTDCB_Buffer b;
+	size_t err = 0;
+	int rv, eof = 0, cur = 0, have_prev = 0;
+
+	if (!ctx)
+		return ZSTDCB_ERROR(compressionParameter_unsupported); /* zstd-mt_decompress.c:703-704 */
+	/* 16-byte sniff (:711-760) */
+	b.buf = sniff;
+	b.size = 16;
+	b.allocated = 16;
+	rv = rdwr->fn_read(rdwr->arg_read, &b);
+	if (rv != 0)
+		return mt_error(rv);
+	if (b.size < 16) {
+		if (b.size < 4 || !is_zstd_magic(sniff))
+			return ZSTDCB_ERROR(data_error);
+		if (b.size == 9)
+			return 0; /* the 9-byte empty zstd frame: "create empty file" (:731-736) */
+		return ZSTDCB_ERROR(frame_decompress); /* short plain .zst: single-thread path, 8f-2 */
+	}
+	if (!(rd32(sniff) == ZSTDCB_MAGIC_SKIPPABLE && is_zstd_magic(sniff + 12))) {
+		if (is_zstd_magic(sniff))
+			return ZSTDCB_ERROR(frame_decompress); /* old zstdmt prefix layout / plain .zst: 8f-2 */
+		return ZSTDCB_ERROR(data_error);
+	}
+	/* the sniff is the first record's header + 4 payload bytes (:251-284) */
+	ctx->insize += 16;
+	ctx->have_hdr = 1;
+	ctx->hdr_csize = rd32(sniff + 8);
+	memcpy(ctx->first4, sniff + 12, 4);
+	ctx->have_first4 = 1;
+	ctx->budget = BATCH_MIN;
+	while (!eof) {
+		struct dslot *s = &ctx->s[cur];
+		if (dbuf_want(ctx->gpu, &s->in, ctx->budget + (ctx->budget >> 3) + 4096, 1, 1) ||
+		    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1)) {
+			err = ZSTDCB_ERROR(memory_allocation);
+			break;
+		}
+		err = d_read_batch(ctx, rdwr, s, &eof);
+		if (err)
+			break;
+		if (s->nrec) {
+			err = d_launch(ctx, s);
+			if (err)
+				break;
+		}
+		if (have_prev) {
+			err = d_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
+			have_prev = 0;
+			if (err)
+				break;
+		}
+		if (s->nrec) {
+			have_prev = 1;
+			cur ^= 1;
+		}
+		if (ctx->budget < BATCH_BYTES)
+			ctx->budget *= 4;
+	}
+	if (!err && have_prev)
+		err = d_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
+	gpumt_device_sync(ctx->gpu);
+	return err;
+}

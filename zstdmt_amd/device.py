@@ -122,6 +122,13 @@ class Engine:
                                                    int(out_bytes), d_out_off.ptr, d_out_len.ptr,
                                                    d_status.ptr, stream), "lz4_decompress_batch")
 
+    def zstd_slot_stride(self, chunk):
+        return int(self.L.gpumt_zstd_slot_stride(chunk))
+
+    def zstd_compress(self, d_in, n, chunk, d_slots, stride, d_rec_len, stream=0):
+        self._ck(self.L.gpumt_zstd_compress_batch(self.h, d_in.ptr, int(n), int(chunk), d_slots.ptr,
+                                                  int(stride), d_rec_len.ptr, stream), "zstd_compress_batch")
+
     def zstd_probe(self, d_stream, d_rec_off, d_rec_len, nrec, d_out_len, d_out_off, d_status, stream=0):
         self._ck(self.L.gpumt_zstd_probe_sizes(self.h, d_stream.ptr, d_rec_off.ptr, d_rec_len.ptr, nrec,
                                                d_out_len.ptr, d_out_off.ptr, d_status.ptr, stream),
@@ -135,17 +142,20 @@ class Engine:
                                                     d_status.ptr, stream), "zstd_decompress_batch")
 
     # ---- convenience round trips on host bytes (tests) ----------------------------------------
-    def compress_bytes(self, data: bytes, chunk: int):
+    def compress_bytes(self, data: bytes, chunk: int, codec="lz4"):
         """-> (stream bytes, rec_off[n+1] u64, rec_len[n] u32)"""
         n = len(data)
         nrec = self.record_count(n, chunk)
-        stride = self.slot_stride(chunk)
+        stride = self.zstd_slot_stride(chunk) if codec == "zstd" else self.slot_stride(chunk)
         d_in = self.upload(data)
         d_slots = self.alloc(nrec * stride)
         d_len = self.alloc(nrec * 4)
         d_off = self.alloc((nrec + 1) * 8)
         try:
-            self.lz4_compress(d_in, n, chunk, d_slots, stride, d_len)
+            if codec == "zstd":
+                self.zstd_compress(d_in, n, chunk, d_slots, stride, d_len)
+            else:
+                self.lz4_compress(d_in, n, chunk, d_slots, stride, d_len)
             rec_len = self.download(d_len, nrec * 4, np.uint32)
             total = int(rec_len.astype(np.uint64).sum())
             d_stream = self.alloc(total + 64)
