@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gib", type=float, default=8.0, help="uncompressed GiB per GPU")
-    ap.add_argument("--chunk", type=int, default=131072)
+    ap.add_argument("--codec", choices=("lz4", "zstd"), default="lz4",
+                    help="lz4 = BASELINE configs[1] (the metric's config); zstd = configs[3], zstd-mt level 1")
+    ap.add_argument("--chunk", type=int, default=0, help="0 = 128 KiB for lz4 (configs[1]), 1 MiB for zstd (level-1 default)")
     ap.add_argument("--dec-variant", type=int, default=0)
     ap.add_argument("--enc-variant", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -61,16 +63,21 @@ def tools():
 def cpu_baseline(args):
     """oracle/_ref (reference sources + liblz4) if present, else the oracle port; bounded sample."""
     exe = os.path.join(ROOT, "oracle", "cpu_bench")
-    ref = os.path.join(ROOT, "oracle", "_ref", "liblz4mt_ref.so")
+    zstd = args.codec == "zstd"
+    ref = os.path.join(ROOT, "oracle", "_ref", "libzstdmt_ref.so" if zstd else "liblz4mt_ref.so")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "cpu_bench"],
                               stdout=subprocess.DEVNULL)
     cores = os.cpu_count() or 1
     threads = min(cores, 128)   # LZ4MT_THREAD_MAX, lib/lz4-mt.h:28
     kind = "reference" if os.path.exists(ref) else "port"
+    if zstd and kind == "port":
+        return {"value": None, "unit": "MB/s", "cores": threads, "kind": "reference",
+                "error": "oracle/_ref/libzstdmt_ref.so not present (the zstd oracle has no compressor)"}
     n = args.cpu_mib << 20
     try:
-        out = subprocess.check_output([exe, kind, ref if kind == "reference" else "-", str(n),
+        out = subprocess.check_output([exe, "reference-zstd" if zstd else kind,
+                                       ref if kind == "reference" else "-", str(n),
                                        str(args.chunk), str(threads), str(SEED)], timeout=600)
         r = json.loads(out)
     except Exception as e:  # report, never hide
@@ -79,7 +86,8 @@ def cpu_baseline(args):
             "compress_MBps": r["compress_MBps"], "decompress_MBps": r["decompress_MBps"],
             "host_cpus": cores,
             "sample": f"{args.cpu_mib} MiB of the same synthetic text, {args.chunk}-byte chunks, "
-                      f"LZ4MT_compressCCtx+LZ4MT_decompressDCtx with memcpy callbacks, T={threads}"}
+                      f"{'ZSTDCB' if zstd else 'LZ4MT'}_compressCCtx+decompressDCtx (level 1) with memcpy "
+                      f"callbacks, T={threads}"}
 
 
 def main():
@@ -105,10 +113,13 @@ def main():
     eng.set_variant("lz4_enc", args.enc_variant)
     eng.set_variant("profile", 1)
 
+    zstd = args.codec == "zstd"
+    if not args.chunk:
+        args.chunk = (1 << 20) if zstd else 131072
     n = int(args.gib * (1 << 30)) // args.chunk * args.chunk
     chunk = args.chunk
     nrec = eng.record_count(n, chunk)
-    stride = eng.slot_stride(chunk)
+    stride = eng.zstd_slot_stride(chunk) if zstd else eng.slot_stride(chunk)
 
     # ---- synthetic input, generated on the host in 256 MiB pieces, uploaded once ----
     d_in = eng.alloc(n + 64)
@@ -136,14 +147,21 @@ def main():
 
     def step():
         eng.timer_start(1)
-        eng.lz4_compress(d_in, n, chunk, d_slots, stride, d_rl)
+        if zstd:
+            eng.zstd_compress(d_in, n, chunk, d_slots, stride, d_rl)
+        else:
+            eng.lz4_compress(d_in, n, chunk, d_slots, stride, d_rl)
         eng.timer_stop(1)
         eng.timer_start(2)
         eng.lz4_compact(d_slots, stride, d_rl, nrec, d_stream, d_ro)
         eng.timer_stop(2)
         eng.timer_start(3)
-        eng.lz4_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo)
-        eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st)
+        if zstd:
+            eng.zstd_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo, d_st)
+            eng.zstd_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st)
+        else:
+            eng.lz4_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo)
+            eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st)
         eng.timer_stop(3)
 
     def barrier():
@@ -161,10 +179,12 @@ def main():
         step()
         eng.sync(0)
         # slots 1-3: API-level legs; 8..13: individual kernels (profile mode)
-        for name, slot in (("compress", 1), ("compact", 2), ("decompress", 3),
-                           ("k_xxh32_c", 8), ("k_lz4_enc", 9), ("k_scan_compact", 10),
-                           ("k_lz4_dec", 11), ("k_xxh32_d", 12), ("k_dec_frames", 13),
-                           ("k_dec_parse", 14), ("k_dec_copy", 15)):
+        slots = (("compress", 1), ("compact", 2), ("decompress", 3), ("k_lz4_enc", 9),
+                 ("k_scan_compact", 10), ("k_lz4_dec", 11))
+        if not zstd:
+            slots += (("k_xxh32_c", 8), ("k_xxh32_d", 12), ("k_dec_frames", 13), ("k_dec_parse", 14),
+                      ("k_dec_copy", 15))
+        for name, slot in slots:
             acc[name] = acc.get(name, 0.0) + eng.timer_ms(slot)
     barrier()
     wall = time.perf_counter() - t0
@@ -204,6 +224,8 @@ def main():
     alg = U + Cb                              # algorithmic bytes either direction
     t_c = (ms["compress"] + ms["compact"]) * 1e-3
     t_d = ms["decompress"] * 1e-3
+    if zstd:
+        return report_zstd(args, eng, world, wall, ms, U, Cb, nrec, chunk, bad, ok, gen_s, seg_off, gather_ms, dist)
     kern = {}
     split = args.dec_variant == 0
     ntok_bytes = 0.0   # token list written by the parse kernel and read by the copy kernel
@@ -262,6 +284,50 @@ def main():
             "what": "decode + XXH32 verify kernels together", "achieved": round(alg / t_d / 1e9, 2),
             "unit": "GB/s", "frac": round(alg / t_d / HBM_PEAK, 5)},
         "kernels": kern,
+        "decode_errors": bad, "roundtrip_verified": ok if args.verify else None,
+        "gen_s": round(gen_s, 2), "device": eng.name,
+        "segment_offset_rank0": seg_off, "gather_ms": gather_ms,
+    }
+    if not args.no_cpu:
+        res["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def report_zstd(args, eng, world, wall, ms, U, Cb, nrec, chunk, bad, ok, gen_s, seg_off, gather_ms, dist):
+    """BASELINE configs[3]: zstd-mt level 1.  Kernels: zmt_zstd_enc_kernel + zmt_zstd_assemble_kernel
+    (timer slot 9), zmt_zstd_dec_kernel (slot 11); algorithmic bytes U + C either direction."""
+    alg = U + Cb
+    t_c = (ms["compress"] + ms["compact"]) * 1e-3
+    t_d = ms["decompress"] * 1e-3
+    step_s = wall / args.steps
+
+    def roof(name, t_ms):
+        a = alg / (t_ms * 1e-3) / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s", "frac": round(a * 1e9 / HBM_PEAK, 5),
+                "frac_of_copy_ceiling": round(a * 1e9 / HBM_COPY, 5), "alg_bytes_per_launch": alg,
+                "avg_launch_ms": round(t_ms, 4), "traffic": None}
+
+    enc, dec = roof("zmt_zstd_enc_kernel(+assemble)", ms["k_lz4_enc"]), roof("zmt_zstd_dec_kernel", ms["k_lz4_dec"])
+    res = {
+        "metric": "MB/s compress+decompress, 8 GiB synthetic, zstd-mt level 1; % HBM roofline",
+        "value": round(world * U / 1e6 / step_s, 1), "unit": "MB/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(step_s * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"zstd-mt -1, {args.gib:g} GiB enwik-style synthetic per GPU, "
+                               f"{chunk // 1024} KiB chunks, device-resident compress+decompress",
+                   "chunk": chunk, "records_per_gpu": nrec, "level": 1, "ratio": round(U / Cb, 4),
+                   "parity": "decompress-identical (SURVEY 8a C4)", "parallelism": f"chunk-sharded x{world}"},
+        "compress_MBps": round(world * U / 1e6 / t_c, 1),
+        "decompress_MBps": round(world * U / 1e6 / t_d, 1),
+        "roofline": enc if ms["k_lz4_enc"] >= ms["k_lz4_dec"] else dec,
+        "roofline_compress": enc, "roofline_decompress": dec,
+        "kernels": {"k_zstd_enc": {"ms": round(ms["k_lz4_enc"], 4)}, "k_scan_compact": {"ms": round(ms["k_scan_compact"], 4)},
+                    "k_zstd_dec": {"ms": round(ms["k_lz4_dec"], 4)}},
         "decode_errors": bad, "roundtrip_verified": ok if args.verify else None,
         "gen_s": round(gen_s, 2), "device": eng.name,
         "segment_offset_rank0": seg_off, "gather_ms": gather_ms,

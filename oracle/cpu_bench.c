@@ -67,14 +67,14 @@ static double now(void)
 int main(int argc, char **argv)
 {
 	if (argc < 7) {
-		fprintf(stderr, "usage: cpu_bench reference|port ref.so bytes chunk threads seed\n");
+		fprintf(stderr, "usage: cpu_bench reference|reference-zstd|port ref.so bytes chunk threads seed\n");
 		return 2;
 	}
 	const char *kind = argv[1];
 	size_t n = strtoull(argv[3], 0, 10), chunk = strtoull(argv[4], 0, 10);
 	int T = atoi(argv[5]);
 	uint64_t seed = strtoull(argv[6], 0, 10);
-	size_t cap = zo_lz4mt_compress_bound(n, chunk);
+	size_t cap = zo_lz4mt_compress_bound(n, chunk) + n / 128 + 4096; /* also covers ZSTD_compressBound */
 	uint8_t *src = malloc(n + 64), *cmp = malloc(cap), *back = malloc(n + 64);
 	double tc, td;
 	size_t csz = 0, dsz = 0;
@@ -85,19 +85,22 @@ int main(int argc, char **argv)
 	memset(cmp, 0, cap); /* touch pages outside the timed region */
 	memset(back, 0, n);
 
-	if (!strcmp(kind, "reference")) {
+	if (!strcmp(kind, "reference") || !strcmp(kind, "reference-zstd")) {
+		/* the reference library itself: lz4-mt (LZ4MT_*) or zstd-mt (ZSTDCB_*, same shapes,
+		 * lib/zstd-mt.h:115-205), level 1 */
+		const int z = !strcmp(kind, "reference-zstd");
 		void *so = dlopen(argv[2], RTLD_NOW);
 		if (!so) {
 			fprintf(stderr, "dlopen %s: %s\n", argv[2], dlerror());
 			return 4;
 		}
-		void *(*createC)(int, int, int) = dlsym(so, "LZ4MT_createCCtx");
-		size_t (*compressC)(void *, RdWr *) = dlsym(so, "LZ4MT_compressCCtx");
-		void (*freeC)(void *) = dlsym(so, "LZ4MT_freeCCtx");
-		void *(*createD)(int, int) = dlsym(so, "LZ4MT_createDCtx");
-		size_t (*decompressD)(void *, RdWr *) = dlsym(so, "LZ4MT_decompressDCtx");
-		void (*freeD)(void *) = dlsym(so, "LZ4MT_freeDCtx");
-		unsigned (*isErr)(size_t) = dlsym(so, "LZ4MT_isError");
+		void *(*createC)(int, int, int) = dlsym(so, z ? "ZSTDCB_createCCtx" : "LZ4MT_createCCtx");
+		size_t (*compressC)(void *, RdWr *) = dlsym(so, z ? "ZSTDCB_compressCCtx" : "LZ4MT_compressCCtx");
+		void (*freeC)(void *) = dlsym(so, z ? "ZSTDCB_freeCCtx" : "LZ4MT_freeCCtx");
+		void *(*createD)(int, int) = dlsym(so, z ? "ZSTDCB_createDCtx" : "LZ4MT_createDCtx");
+		size_t (*decompressD)(void *, RdWr *) = dlsym(so, z ? "ZSTDCB_decompressDCtx" : "LZ4MT_decompressDCtx");
+		void (*freeD)(void *) = dlsym(so, z ? "ZSTDCB_freeDCtx" : "LZ4MT_freeDCtx");
+		unsigned (*isErr)(size_t) = dlsym(so, z ? "ZSTDCB_isError" : "LZ4MT_isError");
 		struct mem in = { src, n, 0 }, out = { cmp, cap, 0 };
 		RdWr io = { rd, &in, wr, &out };
 		void *c = createC(T, 1, (int)chunk);

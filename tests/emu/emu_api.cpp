@@ -29,7 +29,7 @@ void zmt_scan_kernel(const u32 *, u32, u64 *);
 void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
 void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u8 *, u32 *);
 void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
-void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u32 *);
+void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 void zmt_zstd_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 }
 
@@ -182,8 +182,10 @@ void emu_zstd_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stri
 	u32 nblk = nrec * bpr;
 	if (grid > nblk)
 		grid = nblk;
-	std::vector<u32> blk_len(nblk, 0xA5A5A5A5u), seq((size_t)grid * 3 * 32768, 0xA5A5A5A5u);
-	u32 *bl = blk_len.data(), *sq = seq.data();
+	std::vector<u32> blk_len(nblk, 0xA5A5A5A5u);
+	std::vector<u8> seq((size_t)grid * (3 * 32768 * 4 + 16 * 20544), 0xA5);
+	u32 *bl = blk_len.data();
+	u8 *sq = seq.data();
 	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1},
 		    [=]() { zmt_zstd_enc_kernel(in, n, chunk, nblk, bpr, slots, stride, bl, sq); });
 	emu::launch(dim3{nrec, 1, 1}, dim3{256, 1, 1},

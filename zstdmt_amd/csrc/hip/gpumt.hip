@@ -41,7 +41,7 @@ __global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u
 				    const u32 *, u8 *, u32 *);
 __global__ void zmt_zstd_dec_kernel_prof(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
 					 const u32 *, u8 *, u32 *, unsigned long long *);
-__global__ void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u32 *);
+__global__ void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 __global__ void zmt_zstd_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 __global__ void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
 __global__ void zmt_dec_copy_kernel_prof(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
@@ -592,13 +592,13 @@ int gpumt_zstd_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t c
 	const size_t nblk = nrec * bpr;
 	if (nblk > 0x7FFFFFFFu)
 		return GPUMT_E_ARG;
-	/* persistent waves: 4 per CU (32 KiB LDS hash table each), blocks taken round-robin */
-	const unsigned grid = (unsigned)(nblk < 1024 ? nblk : 1024);
-	const size_t seq_bytes = (size_t)grid * 3 * ZE_MAXSEQ * 4;
+	/* persistent waves: 8 per CU (16 KiB LDS hash table each), blocks taken round-robin */
+	const unsigned grid = (unsigned)(nblk < 2048 ? nblk : 2048);
+	const size_t seq_bytes = (size_t)grid * (3 * ZE_MAXSEQ * 4 + 16 * 20544);
 	if (want_scratch(h, 0, nblk * 4 + 64 + seq_bytes))
 		return GPUMT_E_HIP;
 	u32 *blk_len = (u32 *)h->scratch[0];
-	u32 *seqbuf = (u32 *)((u8 *)h->scratch[0] + ((nblk * 4 + 63) & ~(size_t)63));
+	u8 *seqbuf = (u8 *)h->scratch[0] + ((nblk * 4 + 63) & ~(size_t)63);
 	PROF0(9);
 	hipLaunchKernelGGL(zmt_zstd_enc_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
 			   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);

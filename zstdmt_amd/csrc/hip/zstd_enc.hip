@@ -36,11 +36,13 @@
 #define ZE_CAP 64u
 
 struct ZEncLds {
-	u32 table[1u << ZE_HLOG];        /* position + 1 of the newest occurrence of a hash */
+	u16 table[1u << ZE_HLOG];        /* low 16 bits of the newest position of a hash */
 	u16 st_ll[64], st_ml[64], st_of[32]; /* FSE state tables of the predefined distributions */
 	u32 tt_ll[36][2], tt_ml[53][2], tt_of[29][2]; /* per symbol: deltaNbBits, deltaFindState */
 	u32 llx[36], mlx[53];            /* value base | extra bits << 24 */
-	u32 sq[64][4];                   /* staged batch: codes packed, ll extra, ml extra, of extra */
+	u8 llcode[64], mlcode[128];      /* code of literal length v / match length v + 3 */
+	u32 stage[16][8][3];             /* 8 staged sequences (ll, ml, offset) per run */
+	u32 sb_lo[16], sb_hi[16], sb_bits[16]; /* runs: sequence range left to code, bitstream bytes */
 	u32 misc[8];
 };
 
@@ -152,21 +154,41 @@ static __device__ __forceinline__ void ze_copy(u8 *d, const u8 *s, u32 len)
 	}
 }
 
+/* FSE-code the sequences [lo, hi) of one sub-block into its own bitstream (one lane per sub-block,
+ * up to ZE_G lanes side by side; the wave stages 8 sequences per sub-block and round into LDS) */
+#define ZE_G 16u
+#define ZE_BSTMP 20544u /* bytes of temporary bitstream per sub-block: 2048 sequences x 75 bits + slack */
+#define ZE_WSCRATCH (3u * ZE_MAXSEQ * 4u + ZE_G * ZE_BSTMP) /* per persistent wave (include/gpumt.h) */
+
 extern "C" __global__ void __launch_bounds__(64)
 zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
-		    u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u32 *__restrict__ seqbuf)
+		    u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch)
 {
 	__shared__ __attribute__((aligned(16))) ZEncLds L;
 	const int lane = wv_lane();
-	u32 *const sq_ll = seqbuf + (u64)blockIdx.x * 3u * ZE_MAXSEQ;
+	u8 *const wscr = scratch + (u64)blockIdx.x * ZE_WSCRATCH;
+	u32 *const sq_ll = (u32 *)wscr;
 	u32 *const sq_ml = sq_ll + ZE_MAXSEQ, *const sq_of = sq_ml + ZE_MAXSEQ;
+	u8 *const bstmp = wscr + 3u * ZE_MAXSEQ * 4u;
 
-	/* predefined FSE compression tables, once per wave: lanes 0..2 build LL / ML / OF */
+	/* tables that do not depend on the data, once per wave: code tables (lane-parallel counts),
+	 * predefined FSE compression tables (lanes 0..2 build LL / ML / OF) */
 	if (lane < 36)
 		L.llx[lane] = ZE_LL_BASE[lane] | (u32)ZE_LL_BITS[lane] << 24;
 	if (lane < 53)
 		L.mlx[lane] = ZE_ML_BASE[lane] | (u32)ZE_ML_BITS[lane] << 24;
+	wv_sync();
 	{
+		u32 c = 0;
+		for (u32 k = 1; k < 36; k++)
+			c += (L.llx[k] & 0xFFFFFFu) <= (u32)lane;
+		L.llcode[lane] = (u8)c; /* literal lengths 0..63 */
+		for (u32 v = (u32)lane; v < 128; v += 64) {
+			c = 0;
+			for (u32 k = 1; k < 53; k++)
+				c += (L.mlx[k] & 0xFFFFFFu) <= v + 3;
+			L.mlcode[v] = (u8)c; /* match lengths 3..130 */
+		}
 		u8 *scr = (u8 *)L.table + 64 * lane; /* the hash table is not live yet */
 		if (lane == 0)
 			fse_ctable(L.st_ll, L.tt_ll, ZE_LL_DEF, 36, 6, scr);
@@ -192,105 +214,259 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 		const u8 *src = in + cstart + bstart;
 		u8 *out = slots + (u64)rec * stride + ZE_HDR + (u64)bi * ZE_BSTRIDE;
 
-		/* ------------------------------------------------ match finding + greedy parse */
+		/* ------------------------------------------------ match finding + greedy parse
+		 * 64 positions per step.  Software pipeline: the 8 input bytes of step t+2 and the
+		 * candidate bytes of step t+1 are in flight while step t is parsed, so neither global
+		 * round trip sits on the critical path.
+		 * Table entries are positions mod 64 Ki; a candidate is rebuilt as the newest position
+		 * below p with those low bits and then verified, so stale or aliased entries only cost a
+		 * missed match. */
 		for (u32 i = (u32)lane; i < (1u << ZE_HLOG); i += 64)
 			L.table[i] = 0;
 		wv_sync();
 		u32 ns = 0, anchor = 0, cursor = 0;
-		for (u32 p0 = 0; p0 + ZE_MINMATCH <= bsize; p0 += 64) {
-			const u32 p = p0 + (u32)lane;
-			const bool valid = p + ZE_MINMATCH <= bsize;
-			const u64 v = valid ? ld64u(src + p) : 0;
-			const u32 h = ((u32)v * 2654435761u) >> (32 - ZE_HLOG);
-			const u32 cand = valid ? L.table[h] : 0;
-			wv_sync();
-			if (valid)
-				atomicMax(&L.table[h], p + 1);
-			wv_sync();
-			if (p0 + 64 <= cursor)
-				continue; /* the whole step lies inside the previous match */
-			const bool is_c = valid && cand != 0 && p >= cursor;
-			const u32 c = cand - 1;
-			const u64 vc = is_c ? ld64u(src + c) : ~v;
-			const u64 x = v ^ vc;
-			u32 m = x ? (u32)__builtin_ctzll(x) >> 3 : 8u;
-			if (m > bsize - p && valid)
-				m = bsize - p;
-			u64 mask = wv_ballot(is_c && m >= ZE_MINMATCH);
-			while (mask) {
-				const int j = wv_ffs(mask) - 1;
-				mask &= mask - 1;
-				const u32 pj = p0 + (u32)j;
-				if (pj < cursor)
-					continue;
-				const u32 cj = wv_readlane(c, j);
-				u32 ml = wv_readlane(m, j);
-				if (ml == 8) {
-					/* extend: 64 lanes x 8 bytes per step */
-					for (u32 base = 8;; base += 512) {
-						const u32 o = base + 8u * (u32)lane;
-						u32 k = 0;
-						bool stop = true;
-						if (pj + o < bsize) {
-							const u64 y = ld64u(src + pj + o) ^ ld64u(src + cj + o);
-							k = y ? (u32)__builtin_ctzll(y) >> 3 : 8u;
-							stop = k < 8;
+		const u32 steps = bsize >= ZE_MINMATCH ? (bsize - ZE_MINMATCH) / 64 + 1 : 0;
+#define ZE_LOADV(t, V)                                                                             \
+	do {                                                                                       \
+		const u32 p_ = (t) * 64u + (u32)lane;                                              \
+		(V) = ((t) < steps && p_ + ZE_MINMATCH <= bsize) ? ld64u(src + p_) : 0;            \
+	} while (0)
+#define ZE_LOOKUP(t, V, Cc, VC)                                                                    \
+	do {                                                                                       \
+		const u32 p_ = (t) * 64u + (u32)lane;                                              \
+		const bool ok_ = (t) < steps && p_ + ZE_MINMATCH <= bsize;                         \
+		const u32 h_ = ((u32)(V) * 2654435761u) >> (32 - ZE_HLOG);                         \
+		const u32 e_ = ok_ ? L.table[h_] : 0;                                              \
+		wv_sync();                                                                         \
+		if (ok_)                                                                           \
+			L.table[h_] = (u16)p_;                                                     \
+		wv_sync();                                                                         \
+		/* equal hashes inside one step: the highest position must stay, whatever order the   \
+		 * LDS served the conflicting lanes in (a step never straddles a 64 Ki boundary) */    \
+		while (wv_any(ok_ && L.table[h_] < (u16)p_)) {                                     \
+			if (ok_ && L.table[h_] < (u16)p_)                                          \
+				L.table[h_] = (u16)p_;                                             \
+			wv_sync();                                                                 \
+		}                                                                                  \
+		u32 c_ = (p_ & ~0xFFFFu) | e_;                                                     \
+		if (c_ >= p_)                                                                      \
+			c_ -= 65536u;                                                              \
+		(Cc) = (ok_ && c_ < p_) ? c_ : 0xFFFFFFFFu;                                        \
+		(VC) = (Cc) != 0xFFFFFFFFu ? ld64u(src + (Cc)) : ~(V);                             \
+	} while (0)
+		u64 v0, v1, v2, vc0, vc1;
+		u32 c0, c1;
+		ZE_LOADV(0u, v0);
+		ZE_LOADV(1u, v1);
+		ZE_LOOKUP(0u, v0, c0, vc0);
+		for (u32 t = 0; t < steps; t++) {
+			ZE_LOADV(t + 2, v2);
+			ZE_LOOKUP(t + 1, v1, c1, vc1);
+			const u32 p0 = t * 64u, p = p0 + (u32)lane;
+			if (p0 + 64 > cursor) { /* else the whole step lies inside the previous match */
+				const u64 x = v0 ^ vc0;
+				u32 m = x ? (u32)__builtin_ctzll(x) >> 3 : 8u;
+				const bool cand = c0 != 0xFFFFFFFFu && p >= cursor;
+				if (cand && m > bsize - p)
+					m = bsize - p;
+				u64 mask = wv_ballot(cand && m >= ZE_MINMATCH);
+				while (mask) {
+					const int j = wv_ffs(mask) - 1;
+					mask &= mask - 1;
+					const u32 pj = p0 + (u32)j;
+					if (pj < cursor)
+						continue;
+					const u32 cj = wv_readlane(c0, j);
+					u32 ml = wv_readlane(m, j);
+					if (ml == 8) {
+						/* extend: 64 lanes x 8 bytes per step */
+						for (u32 base = 8;; base += 512) {
+							const u32 o = base + 8u * (u32)lane;
+							u32 k = 0;
+							bool stop = true;
+							if (pj + o < bsize) {
+								const u64 y = ld64u(src + pj + o) ^ ld64u(src + cj + o);
+								k = y ? (u32)__builtin_ctzll(y) >> 3 : 8u;
+								stop = k < 8;
+							}
+							const u64 sm = wv_ballot(stop);
+							if (sm) {
+								const int f = wv_ffs(sm) - 1;
+								ml = base + 8u * (u32)f + wv_readlane(k, f);
+								break;
+							}
 						}
-						const u64 sm = wv_ballot(stop);
-						if (sm) {
-							const int f = wv_ffs(sm) - 1;
-							ml = base + 8u * (u32)f + wv_readlane(k, f);
-							break;
-						}
+						if (ml > bsize - pj)
+							ml = bsize - pj;
 					}
-					if (ml > bsize - pj)
-						ml = bsize - pj;
+					if (lane == 0) {
+						sq_ll[ns] = pj - anchor;
+						sq_ml[ns] = ml;
+						sq_of[ns] = pj - cj;
+					}
+					ns++;
+					anchor = cursor = pj + ml;
 				}
-				if (lane == 0) {
-					sq_ll[ns] = pj - anchor;
-					sq_ml[ns] = ml;
-					sq_of[ns] = pj - cj;
+			}
+			v0 = v1;
+			v1 = v2;
+			c0 = c1;
+			vc0 = vc1;
+		}
+#undef ZE_LOADV
+#undef ZE_LOOKUP
+		wave_mem_fence();
+#ifdef ZMT_EMU
+		if (getenv("ZMT_EMU_DEBUG") && lane == 0) {
+			u32 hsum = 0;
+			for (u32 i = 0; i < ns; i++)
+				hsum = hsum * 31 + sq_ll[i] * 7 + sq_ml[i] * 3 + sq_of[i];
+			fprintf(stderr, "zstd_enc: block %u bsize %u ns %u seqhash %08x\n", g, bsize, ns, hsum);
+			if (getenv("ZMT_EMU_DEBUG")[0] == '2') {
+				u32 pos = 0;
+				for (u32 i = 0; i < ns && i < 40000; i++) {
+					fprintf(stderr, "S %u %u %u %u %u\n", g, pos + sq_ll[i], sq_ll[i], sq_ml[i], sq_of[i]);
+					pos += sq_ll[i] + sq_ml[i];
 				}
-				ns++;
-				anchor = cursor = pj + ml;
 			}
 		}
-		wave_mem_fence();
+#endif
 
-		/* ------------------------------------------------ block assembly */
-		u32 csize = 0; /* compressed block content size; 0 = store raw */
+		/* ------------------------------------------------ sequences -> bitstreams
+		 * The sequence list is cut into G runs of equal count; each run becomes its own zstd
+		 * block, so G lanes can FSE-code side by side (an FSE stream is a serial chain; a block
+		 * boundary costs 8 bytes).  Lane s codes run s into bstmp + s * ZE_BSTMP. */
+		u32 total = 0; /* bytes written at out; 0 = store the block raw */
 		if (ns) {
-			/* literal bytes: everything outside the matches */
-			u32 mtot = 0;
-			for (u32 b = 0; b < ns; b += 64) {
-				const u32 i = b + (u32)lane;
-				mtot += wv_readlane(wv_scan_incl(i < ns ? sq_ml[i] : 0), 63);
+			const u32 G = ns < 512 ? 1u : (ns / 512 < ZE_G ? ns / 512 : ZE_G);
+			if ((u32)lane < ZE_G) {
+				L.sb_lo[lane] = (u32)(((u64)lane * ns) / G);
+				L.sb_hi[lane] = (u32)lane < G ? (u32)(((u64)(lane + 1) * ns) / G) : L.sb_lo[lane];
 			}
-			const u32 regen = bsize - mtot;
-			const u32 lh = regen < 32 ? 1u : regen < 4096 ? 2u : 3u;
-			u8 *lit = out + 3 + lh;
-			if (3 + lh + regen + 4 < bsize) {
-				if (lane == 0) {
-					if (lh == 1) {
-						lit[-1] = (u8)(regen << 3);
-					} else if (lh == 2) {
-						const u32 hv = regen << 4 | 1u << 2;
-						lit[-2] = (u8)hv;
-						lit[-1] = (u8)(hv >> 8);
-					} else {
-						const u32 hv = regen << 4 | 3u << 2;
-						lit[-3] = (u8)hv;
-						lit[-2] = (u8)(hv >> 8);
-						lit[-1] = (u8)(hv >> 16);
+			wv_sync();
+			BitW w;
+			w.p = bstmp + (u32)lane * ZE_BSTMP;
+			w.limit = w.p + ZE_BSTMP;
+			w.acc = 0;
+			w.nb = 0;
+			w.ovf = false;
+			u32 s_ll = 0, s_ml = 0, s_of = 0;
+			bool first = true;
+			const bool coder = (u32)lane < G;
+			for (;;) {
+				/* stage: up to 8 sequences per run, taken from the end of each run backwards */
+				u32 any = 0;
+				for (u32 e = (u32)lane; e < ZE_G * 8; e += 64) {
+					const u32 sb = e >> 3, k = e & 7;
+					const u32 lo = L.sb_lo[sb], hi = L.sb_hi[sb];
+					if (sb < G && k < hi - lo) {
+						const u32 i = hi - 1 - k;
+						L.stage[sb][k][0] = sq_ll[i];
+						L.stage[sb][k][1] = sq_ml[i];
+						L.stage[sb][k][2] = sq_of[i];
+						any = 1;
 					}
 				}
-				/* copy the literal runs: lane per sequence, long runs by the whole wave */
-				u32 ipos = 0, lpos = 0; /* input position / literal position before this batch */
-				for (u32 b = 0; b < ns; b += 64) {
+				if (!wv_any(any != 0))
+					break;
+				wv_sync();
+				if (coder) {
+					const u32 lo = L.sb_lo[lane], hi = L.sb_hi[lane];
+					const u32 cnt = hi - lo < 8 ? hi - lo : 8;
+					for (u32 k = 0; k < cnt; k++) {
+						const u32 ll = L.stage[lane][k][0], mlb = L.stage[lane][k][1] - 3;
+						const u32 ofv = L.stage[lane][k][2] + 3;
+						const u32 lc = ll < 64 ? L.llcode[ll] : (u32)hb32(ll) + 19;
+						const u32 mc = mlb < 128 ? L.mlcode[mlb] : (u32)hb32(mlb) + 36;
+						const u32 oc = (u32)hb32(ofv);
+						if (first) {
+							/* FSE_initCState2 x3: ML, OF, LL */
+							u32 nbo = (L.tt_ml[mc][0] + (1u << 15)) >> 16;
+							s_ml = L.st_ml[(((nbo << 16) - L.tt_ml[mc][0]) >> nbo) + L.tt_ml[mc][1]];
+							nbo = (L.tt_of[oc][0] + (1u << 15)) >> 16;
+							s_of = L.st_of[(((nbo << 16) - L.tt_of[oc][0]) >> nbo) + L.tt_of[oc][1]];
+							nbo = (L.tt_ll[lc][0] + (1u << 15)) >> 16;
+							s_ll = L.st_ll[(((nbo << 16) - L.tt_ll[lc][0]) >> nbo) + L.tt_ll[lc][1]];
+							first = false;
+						} else {
+							u32 nbo = (s_of + L.tt_of[oc][0]) >> 16;
+							bw_add(w, s_of, nbo);
+							s_of = L.st_of[(s_of >> nbo) + L.tt_of[oc][1]];
+							nbo = (s_ml + L.tt_ml[mc][0]) >> 16;
+							bw_add(w, s_ml, nbo);
+							s_ml = L.st_ml[(s_ml >> nbo) + L.tt_ml[mc][1]];
+							nbo = (s_ll + L.tt_ll[lc][0]) >> 16;
+							bw_add(w, s_ll, nbo);
+							s_ll = L.st_ll[(s_ll >> nbo) + L.tt_ll[lc][1]];
+						}
+						bw_add(w, ll - (L.llx[lc] & 0xFFFFFFu), L.llx[lc] >> 24);
+						bw_add(w, mlb + 3 - (L.mlx[mc] & 0xFFFFFFu), L.mlx[mc] >> 24);
+						bw_add(w, ofv - (1u << oc), oc);
+					}
+					L.sb_hi[lane] = hi - cnt;
+				}
+				wv_sync();
+			}
+			if (coder) {
+				bw_add(w, s_ml, 6);
+				bw_add(w, s_of, 5);
+				bw_add(w, s_ll, 6);
+				bw_add(w, 1, 1); /* end mark */
+				const u32 tail = (w.nb + 7) >> 3;
+				if (w.p + tail > w.limit) {
+					w.ovf = true;
+				} else {
+					for (u32 t = 0; t < tail; t++)
+						w.p[t] = (u8)(w.acc >> (8 * t));
+				}
+				w.p += tail;
+				L.sb_bits[lane] = w.ovf ? 0xFFFFFFFFu : (u32)(w.p - (bstmp + (u32)lane * ZE_BSTMP));
+			}
+			wave_mem_fence();
+			wv_sync();
+
+			/* -------------------------------------------- assemble the G blocks at out */
+			u32 ipos = 0, at = 0; /* input bytes consumed, bytes written */
+			bool fits = true;
+			for (u32 sb = 0; sb < G && fits; sb++) {
+				const u32 lo = (u32)(((u64)sb * ns) / G), hi = (u32)(((u64)(sb + 1) * ns) / G);
+				const u32 nsq = hi - lo, bits = L.sb_bits[sb];
+				/* sizes of this run: literal bytes, input bytes */
+				u32 lsum = 0, isum = 0;
+				for (u32 b = lo; b < hi; b += 64) {
 					const u32 i = b + (u32)lane;
-					const u32 ll = i < ns ? sq_ll[i] : 0, ml = i < ns ? sq_ml[i] : 0;
+					const u32 ll = i < hi ? sq_ll[i] : 0, ml = i < hi ? sq_ml[i] : 0;
+					lsum += wv_readlane(wv_scan_incl(ll), 63);
+					isum += wv_readlane(wv_scan_incl(ll + ml), 63);
+				}
+				const bool fin = sb + 1 == G;
+				const u32 trail = fin ? bsize - (ipos + isum) : 0;
+				const u32 regen = lsum + trail;
+				const u32 lh = regen < 32 ? 1u : regen < 4096 ? 2u : 3u;
+				const u32 sh = nsq < 128 ? 1u : nsq < 0x7F00 ? 2u : 3u;
+				const u32 csize = lh + regen + sh + 1 + bits;
+				if (bits == 0xFFFFFFFFu || at + 3 + csize + 8 > bsize) {
+					fits = false;
+					break;
+				}
+				u8 *o = out + at;
+				if (lane == 0) {
+					const u32 bh = (fin ? last : 0u) | 2u << 1 | csize << 3;
+					o[0] = (u8)bh;
+					o[1] = (u8)(bh >> 8);
+					o[2] = (u8)(bh >> 16);
+					const u32 hv = lh == 1 ? regen << 3 : regen << 4 | (lh == 2 ? 1u : 3u) << 2;
+					for (u32 k = 0; k < lh; k++)
+						o[3 + k] = (u8)(hv >> (8 * k));
+				}
+				u8 *lit = o + 3 + lh;
+				/* literal runs: lane per sequence, long runs by the whole wave */
+				u32 ip = ipos, lpos = 0;
+				for (u32 b = lo; b < hi; b += 64) {
+					const u32 i = b + (u32)lane;
+					const u32 ll = i < hi ? sq_ll[i] : 0, ml = i < hi ? sq_ml[i] : 0;
 					const u32 incl = wv_scan_incl(ll + ml), lincl = wv_scan_incl(ll);
-					const u32 s0 = ipos + incl - ll - ml, d0 = lpos + lincl - ll;
+					const u32 s0 = ip + incl - ll - ml, d0 = lpos + lincl - ll;
 					if (ll && ll <= ZE_CAP)
 						ze_copy(lit + d0, src + s0, ll);
 					u64 lm = wv_ballot(ll > ZE_CAP);
@@ -299,120 +475,35 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 						lm &= lm - 1;
 						wave_copy(lit + wv_readlane(d0, j), src + wv_readlane(s0, j), wv_readlane(ll, j), lane);
 					}
-					ipos += wv_readlane(incl, 63);
+					ip += wv_readlane(incl, 63);
 					lpos += wv_readlane(lincl, 63);
 				}
-				wave_copy(lit + lpos, src + ipos, bsize - ipos, lane); /* after the last match */
-				/* sequences section */
+				if (trail)
+					wave_copy(lit + lpos, src + ip, trail, lane);
 				u8 *sp = lit + regen;
-				u32 sh;
-				if (ns < 128) {
-					if (lane == 0)
-						sp[0] = (u8)ns;
-					sh = 1;
-				} else if (ns < 0x7F00) {
-					if (lane == 0) {
-						sp[0] = (u8)((ns >> 8) + 128);
-						sp[1] = (u8)ns;
-					}
-					sh = 2;
-				} else {
-					if (lane == 0) {
-						sp[0] = 255;
-						sp[1] = (u8)(ns - 0x7F00);
-						sp[2] = (u8)((ns - 0x7F00) >> 8);
-					}
-					sh = 3;
-				}
-				if (lane == 0)
-					sp[sh] = 0; /* Symbol_Compression_Modes: three predefined tables */
-				BitW w;
-				w.p = sp + sh + 1;
-				w.limit = out + 3 + bsize; /* anything at or beyond is not smaller than raw */
-				w.acc = 0;
-				w.nb = 0;
-				w.ovf = false;
-				u32 s_ll = 0, s_ml = 0, s_of = 0; /* FSE states, live in lane 0 */
-				/* from the last sequence to the first, 64 at a time */
-				for (u32 hi = ns; hi > 0;) {
-					const u32 k = hi < 64 ? hi : 64, lo = hi - k;
-					{
-						/* lane t stages sequence hi-1-t: codes and extra bits */
-						const u32 i = hi - 1 - (u32)lane;
-						if ((u32)lane < k) {
-							const u32 ll = sq_ll[i], mlb = sq_ml[i], ofv = sq_of[i] + 3;
-							u32 lc = 0, mc = 0;
-							for (u32 c2 = 1; c2 < 36; c2++)
-								lc += (L.llx[c2] & 0xFFFFFFu) <= ll;
-							for (u32 c2 = 1; c2 < 53; c2++)
-								mc += (L.mlx[c2] & 0xFFFFFFu) <= mlb;
-							const u32 oc = (u32)hb32(ofv);
-							L.sq[lane][0] = lc | mc << 8 | oc << 16;
-							L.sq[lane][1] = ll - (L.llx[lc] & 0xFFFFFFu);
-							L.sq[lane][2] = mlb - (L.mlx[mc] & 0xFFFFFFu);
-							L.sq[lane][3] = ofv - (1u << oc);
-						}
-					}
-					wv_sync();
-					if (lane == 0) {
-						for (u32 t = 0; t < k; t++) {
-							const u32 codes = L.sq[t][0];
-							const u32 lc = codes & 255, mc = (codes >> 8) & 255, oc = codes >> 16;
-							if (hi == ns && t == 0) {
-								/* FSE_initCState2 x3: ML, OF, LL */
-								u32 nbo = (L.tt_ml[mc][0] + (1u << 15)) >> 16;
-								s_ml = L.st_ml[(((nbo << 16) - L.tt_ml[mc][0]) >> nbo) + L.tt_ml[mc][1]];
-								nbo = (L.tt_of[oc][0] + (1u << 15)) >> 16;
-								s_of = L.st_of[(((nbo << 16) - L.tt_of[oc][0]) >> nbo) + L.tt_of[oc][1]];
-								nbo = (L.tt_ll[lc][0] + (1u << 15)) >> 16;
-								s_ll = L.st_ll[(((nbo << 16) - L.tt_ll[lc][0]) >> nbo) + L.tt_ll[lc][1]];
-							} else {
-								u32 nbo = (s_of + L.tt_of[oc][0]) >> 16;
-								bw_add(w, s_of, nbo);
-								s_of = L.st_of[(s_of >> nbo) + L.tt_of[oc][1]];
-								nbo = (s_ml + L.tt_ml[mc][0]) >> 16;
-								bw_add(w, s_ml, nbo);
-								s_ml = L.st_ml[(s_ml >> nbo) + L.tt_ml[mc][1]];
-								nbo = (s_ll + L.tt_ll[lc][0]) >> 16;
-								bw_add(w, s_ll, nbo);
-								s_ll = L.st_ll[(s_ll >> nbo) + L.tt_ll[lc][1]];
-							}
-							bw_add(w, L.sq[t][1], L.llx[lc] >> 24);
-							bw_add(w, L.sq[t][2], L.mlx[mc] >> 24);
-							bw_add(w, L.sq[t][3], oc);
-						}
-					}
-					wv_sync();
-					hi = lo;
-				}
 				if (lane == 0) {
-					bw_add(w, s_ml, 6);
-					bw_add(w, s_of, 5);
-					bw_add(w, s_ll, 6);
-					bw_add(w, 1, 1); /* end mark */
-					const u32 tail = (w.nb + 7) >> 3;
-					if (w.p + tail > w.limit) {
-						w.ovf = true;
+					if (sh == 1) {
+						sp[0] = (u8)nsq;
+					} else if (sh == 2) {
+						sp[0] = (u8)((nsq >> 8) + 128);
+						sp[1] = (u8)nsq;
 					} else {
-						for (u32 t = 0; t < tail; t++)
-							w.p[t] = (u8)(w.acc >> (8 * t));
+						sp[0] = 255;
+						sp[1] = (u8)(nsq - 0x7F00);
+						sp[2] = (u8)((nsq - 0x7F00) >> 8);
 					}
-					w.p += tail;
-					L.misc[0] = w.ovf ? 0u : (u32)(w.p - (out + 3));
+					sp[sh] = 0; /* Symbol_Compression_Modes: three predefined tables */
 				}
-				wv_sync();
-				csize = L.misc[0];
-				wv_sync();
+				wave_copy(sp + sh + 1, bstmp + sb * ZE_BSTMP, bits, lane);
+				at += 3 + csize;
+				ipos += isum;
 			}
+			if (fits)
+				total = at;
 		}
-		if (csize && csize < bsize) {
-			if (lane == 0) {
-				const u32 bh = last | 2u << 1 | csize << 3;
-				out[0] = (u8)bh;
-				out[1] = (u8)(bh >> 8);
-				out[2] = (u8)(bh >> 16);
-				blk_len[g] = 3 + csize;
-			}
+		if (total) {
+			if (lane == 0)
+				blk_len[g] = total;
 		} else {
 			if (lane == 0) {
 				const u32 bh = last | 0u << 1 | bsize << 3;
