@@ -183,7 +183,7 @@ void emu_zstd_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stri
 	if (grid > nblk)
 		grid = nblk;
 	std::vector<u32> blk_len(nblk, 0xA5A5A5A5u);
-	std::vector<u8> seq((size_t)grid * (3 * 32768 * 4 + 16 * 20544), 0xA5);
+	std::vector<u8> seq((size_t)grid * (3 * 32768 * 4 + 16 * 20544 + 131072 + 64), 0xA5);
 	u32 *bl = blk_len.data();
 	u8 *sq = seq.data();
 	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1},

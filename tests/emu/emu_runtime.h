@@ -116,6 +116,12 @@ template <typename T> inline T atomicAdd(T *p, T v)
 	*p = o + v;
 	return o;
 }
+template <typename T> inline T atomicOr(T *p, T v)
+{
+	T o = *p;
+	*p = o | v;
+	return o;
+}
 template <typename T> inline T atomicMax(T *p, T v)
 {
 	T o = *p;

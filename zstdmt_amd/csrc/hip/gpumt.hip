@@ -594,7 +594,7 @@ int gpumt_zstd_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t c
 		return GPUMT_E_ARG;
 	/* persistent waves: 8 per CU (16 KiB LDS hash table each), blocks taken round-robin */
 	const unsigned grid = (unsigned)(nblk < 2048 ? nblk : 2048);
-	const size_t seq_bytes = (size_t)grid * (3 * ZE_MAXSEQ * 4 + 16 * 20544);
+	const size_t seq_bytes = (size_t)grid * (3 * ZE_MAXSEQ * 4 + 16 * 20544 + ZE_BLOCK + 64);
 	if (want_scratch(h, 0, nblk * 4 + 64 + seq_bytes))
 		return GPUMT_E_HIP;
 	u32 *blk_len = (u32 *)h->scratch[0];

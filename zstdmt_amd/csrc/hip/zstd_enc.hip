@@ -9,14 +9,17 @@
  * sequential match finder:
  *
  *   zmt_zstd_enc_kernel      one wave per 128 KiB block (persistent waves, blocks round-robin).
- *     match finding          64 positions per step, one per lane: 4-byte hash, 8192-entry LDS
- *                            table updated with atomicMax (deterministic: the newest position
- *                            wins), candidates verified with one unaligned 8-byte compare per
- *                            lane, long matches extended 512 bytes per step by the whole wave;
+ *     match finding          64 positions per step, one per lane: 4-byte hash, 8192-entry u16 LDS
+ *                            table (the newest position of a step wins, deterministically),
+ *                            candidates verified with one unaligned 8-byte compare per lane, loads
+ *                            software-pipelined two steps ahead, long matches extended 512 bytes
+ *                            per step by the whole wave;
  *     parse                  greedy, leftmost match first, resolved with ballots;
- *     literals               raw (Huffman literals: next step), copied lane-per-run;
- *     sequences              codes and extra bits computed lane-per-sequence, FSE-coded with the
- *                            predefined tables (RFC 8878 3.1.1.3.2.2) by one lane from LDS.
+ *     literals               gathered lane-per-run, Huffman-coded in parallel (histogram with LDS
+ *                            atomics, repaired ceil(log2) code lengths, canonical codes by ballots,
+ *                            bit packing by prefix sum + atomicOr into LDS), raw when that does not pay;
+ *     sequences              the list is cut into up to 16 zstd blocks, FSE-coded with the predefined
+ *                            tables (RFC 8878 3.1.1.3.2.2) by 16 lanes side by side.
  *     A block that does not shrink is stored raw.
  *   zmt_zstd_assemble_kernel one workgroup per chunk: skippable header + frame header
  *                            (single segment, content size) + the chunk's blocks moved together.
@@ -31,9 +34,17 @@
 #define ZE_BSTRIDE (ZE_BLOCK + 16u) /* area of one block inside a record slot */
 #define ZE_HDR 32u                  /* room in front of the blocks for record + frame header */
 #define ZE_HLOG 13
-#define ZE_MINMATCH 4u
-#define ZE_MAXSEQ (ZE_BLOCK / ZE_MINMATCH)
+#define ZE_MINMATCH 7u
+#define ZE_MAXSEQ (ZE_BLOCK / 4u) /* capacity of the per-wave sequence arrays (>= BLOCK / MINMATCH) */
 #define ZE_CAP 64u
+#ifndef ZE_HBYTES
+#define ZE_HBYTES 6
+#endif
+#if ZE_HBYTES == 4
+#define ZE_HASH(v) (((u32)(v) * 2654435761u) >> (32 - ZE_HLOG))
+#else
+#define ZE_HASH(v) ((u32)((((v) << (64 - 8 * ZE_HBYTES)) * 0x9E3779B185EBCA87ull) >> (64 - ZE_HLOG)))
+#endif
 
 struct ZEncLds {
 	u16 table[1u << ZE_HLOG];        /* low 16 bits of the newest position of a hash */
@@ -43,6 +54,9 @@ struct ZEncLds {
 	u8 llcode[64], mlcode[128];      /* code of literal length v / match length v + 3 */
 	u32 stage[16][8][3];             /* 8 staged sequences (ll, ml, offset) per run */
 	u32 sb_lo[16], sb_hi[16], sb_bits[16]; /* runs: sequence range left to code, bitstream bytes */
+	u32 hist[256];                   /* literal histogram of the block being assembled */
+	u16 hcode[256];                  /* Huffman code | length << 11 */
+	u8 hlen[256];
 	u32 misc[8];
 };
 
@@ -154,11 +168,271 @@ static __device__ __forceinline__ void ze_copy(u8 *d, const u8 *s, u32 len)
 	}
 }
 
+/* ------------------------------------------------------------------ Huffman literals
+ * RFC 8878 3.1.1.3.1 / 4.2: a literals section of type Compressed_Literals_Block with a directly
+ * described tree (4-bit weights) and four streams.  Everything but the choice of code lengths is
+ * data parallel: histogram with LDS atomics, canonical codes with ballots, the bitstreams with a
+ * prefix sum of code lengths and atomicOr into an LDS staging area.
+ * Returns the size of the section written at dst (header included), 0 = not worth it / not
+ * representable this way (caller stores the literals raw).  `stage` = 16 KiB of LDS (the hash table
+ * is idle while a block is assembled). */
+static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32 regen, u8 *dst, int lane)
+{
+	if (regen < 256)
+		return 0;
+	/* histogram */
+	for (u32 i = (u32)lane; i < 256; i += 64)
+		L.hist[i] = 0;
+	wv_sync();
+	for (u32 i = 8u * (u32)lane; i < regen; i += 512) {
+		if (i + 8 <= regen) {
+			const u64 v = ld64u(lit + i);
+			for (u32 k = 0; k < 8; k++)
+				atomicAdd(&L.hist[(u32)(v >> (8 * k)) & 255], 1u);
+		} else {
+			for (u32 k = i; k < regen; k++)
+				atomicAdd(&L.hist[lit[k]], 1u);
+		}
+	}
+	wv_sync();
+	/* lane owns symbols lane, lane+64, lane+128, lane+192 */
+	u32 cnt[4], len[4];
+	u32 present = 0, hi_sym = 0;
+	for (u32 q = 0; q < 4; q++) {
+		cnt[q] = L.hist[64 * q + (u32)lane];
+		if (cnt[q]) {
+			present++;
+			hi_sym = 64 * q + (u32)lane;
+		}
+	}
+	u32 nsym = present, maxsym = hi_sym;
+	for (int d = 32; d; d >>= 1) {
+		nsym += wv_shfl(nsym, lane ^ d);
+		const u32 o = wv_shfl(maxsym, lane ^ d);
+		maxsym = o > maxsym ? o : maxsym;
+	}
+	if (nsym < 2 || maxsym > 128)
+		return 0; /* one symbol: RLE would do, left raw here; symbols > 128 need FSE-coded weights */
+	/* code lengths: ceil(log2(N / count)) capped at 11, then repaired to a complete code
+	 * (Kraft sum exactly 2^11 in units of 2^-11) */
+	u32 K = 0;
+	for (u32 q = 0; q < 4; q++) {
+		u32 l = 0;
+		if (cnt[q]) {
+			l = 1;
+			while (l < 11 && (cnt[q] << l) < regen)
+				l++;
+			K += 1u << (11 - l);
+		}
+		len[q] = l;
+	}
+	for (int d = 32; d; d >>= 1)
+		K += wv_shfl(K, lane ^ d);
+	for (u32 guard = 0; K != 2048 && guard < 4096; guard++) {
+		/* over-subscribed: lengthen the rarest symbol that still can; under-subscribed: shorten
+		 * the most frequent symbol whose step fits the deficit */
+		const bool over = K > 2048;
+		const u32 deficit = over ? 0 : 2048 - K;
+		u32 best = over ? 0xFFFFFFFFu : 0;
+		for (u32 q = 0; q < 4; q++) {
+			if (!cnt[q])
+				continue;
+			const u32 key = cnt[q] << 8 | (64 * q + (u32)lane);
+			if (over) {
+				if (len[q] < 11 && key < best)
+					best = key;
+			} else if (len[q] > 1 && (1u << (11 - len[q])) <= deficit && key > best) {
+				best = key;
+			}
+		}
+		for (int d = 32; d; d >>= 1) {
+			const u32 o = wv_shfl(best, lane ^ d);
+			best = over ? (o < best ? o : best) : (o > best ? o : best);
+		}
+		if (best == (over ? 0xFFFFFFFFu : 0u))
+			return 0; /* cannot happen for a valid histogram; stay safe */
+		const u32 sym = best & 255, sq_ = sym >> 6;
+		if ((sym & 63) == (u32)lane) {
+			const u32 d_ = over ? 1u : 0xFFFFFFFFu; /* +1 / -1 */
+			len[0] += sq_ == 0 ? d_ : 0;
+			len[1] += sq_ == 1 ? d_ : 0;
+			len[2] += sq_ == 2 ? d_ : 0;
+			len[3] += sq_ == 3 ? d_ : 0;
+		}
+		const u32 lnew = wv_shfl(sq_ == 0 ? len[0] : sq_ == 1 ? len[1] : sq_ == 2 ? len[2] : len[3], (int)(sym & 63));
+		/* l -> l+1 removes 2^(11-lnew); l -> l-1 adds 2^(10-lnew) */
+		K = over ? K - (1u << (11 - lnew)) : K + (1u << (10 - lnew));
+	}
+	if (K != 2048)
+		return 0;
+	u32 log = 0;
+	for (u32 q = 0; q < 4; q++)
+		log = len[q] > log ? len[q] : log;
+	for (int d = 32; d; d >>= 1) {
+		const u32 o = wv_shfl(log, lane ^ d);
+		log = o > log ? o : log;
+	}
+	/* canonical codes in the decoder's table order: weight ascending, then symbol value; a symbol
+	 * of weight w owns 2^(w-1) cells starting at `start`; its code is start >> (w-1) */
+	{
+		u32 start = 0;
+		for (u32 w = 1; w <= log; w++) {
+			u32 at = start, total = 0;
+			for (u32 q = 0; q < 4; q++) {
+				const bool mine = cnt[q] && log + 1 - len[q] == w;
+				const u64 m = wv_ballot(mine);
+				if (mine) {
+					const u32 st = at + wv_mbcnt(m) * (1u << (w - 1));
+					L.hcode[64 * q + (u32)lane] = (u16)((st >> (w - 1)) | len[q] << 11);
+				}
+				at += (u32)wv_popc(m) << (w - 1);
+				total += (u32)wv_popc(m);
+			}
+			start += total << (w - 1);
+		}
+		for (u32 q = 0; q < 4; q++) {
+			L.hlen[64 * q + (u32)lane] = (u8)len[q];
+			if (!cnt[q])
+				L.hcode[64 * q + (u32)lane] = 0;
+		}
+	}
+	wv_sync();
+	/* size estimate from the histogram */
+	u32 bits = 0;
+	for (u32 q = 0; q < 4; q++)
+		bits += cnt[q] * len[q];
+	for (int d = 32; d; d >>= 1)
+		bits += wv_shfl(bits, lane ^ d);
+	const u32 tree = 1 + (maxsym + 1) / 2;
+	const u32 lh = regen < 1024 ? 3u : regen < 16384 ? 4u : 5u;
+	if (lh + tree + 6 + (bits + 7) / 8 + 4 >= regen)
+		return 0;
+	/* tree description: Number_of_Symbols = maxsym explicit weights, the last one is implied */
+	u8 *t = dst + lh;
+	if (lane == 0)
+		t[0] = (u8)(127 + maxsym);
+	for (u32 i = (u32)lane; i < (maxsym + 1) / 2; i += 64) {
+		const u32 s0 = 2 * i, s1 = 2 * i + 1;
+		const u32 w0 = L.hlen[s0] ? log + 1 - L.hlen[s0] : 0;
+		const u32 w1 = (s1 < maxsym && L.hlen[s1]) ? log + 1 - L.hlen[s1] : 0;
+		t[1 + i] = (u8)(w0 << 4 | w1);
+	}
+	/* four streams */
+	u8 *jump = t + tree, *sp = jump + 6;
+	const u32 qn = (regen + 3) / 4;
+	u32 ssz[4];
+	for (u32 k = 0; k < 4; k++) {
+		const u32 s_lo = k * qn, s_n = k < 3 ? qn : regen - 3 * qn;
+		/* symbols are laid down from the last one (lowest bits) to the first; 512 per round:
+		 * lane l takes the 8 symbols ending at hi - 8 l */
+		u32 bitpos = 0, base_bits = 0; /* stream bits placed so far / bit offset of stage[0] */
+		u32 outb = 0;                  /* bytes of this stream already at sp */
+		for (u32 i = (u32)lane; i < 4096; i += 64)
+			stage[i] = 0;
+		wv_sync();
+		for (u32 hi = s_n; hi > 0;) {
+			const u32 take = hi < 512 ? hi : 512;
+			const u32 mine_hi = hi > 8u * (u32)lane ? hi - 8u * (u32)lane : 0; /* exclusive end */
+			const u32 mine_n = mine_hi > hi - take ? (mine_hi - (hi - take) < 8 ? mine_hi - (hi - take) : 8) : 0;
+			u64 lo64 = 0;
+			u32 hi32 = 0, nb = 0;
+			if (mine_n) {
+				const u8 *p = lit + s_lo + mine_hi - mine_n;
+				for (u32 j = mine_n; j-- > 0;) { /* last symbol first */
+					const u32 e = L.hcode[p[j]];
+					const u32 l = e >> 11, c = e & 2047;
+					if (nb < 64)
+						lo64 |= (u64)c << nb;
+					if (nb + l > 64)
+						hi32 |= nb >= 64 ? c << (nb - 64) : c >> (64 - nb);
+					nb += l;
+				}
+			}
+			const u32 incl = wv_scan_incl(nb);
+			const u32 off = bitpos - base_bits + incl - nb; /* bit offset inside the stage */
+			if (nb) {
+				const u32 wi = off >> 5, sh = off & 31;
+				const u64 a = lo64 << sh;
+				atomicOr(&stage[wi], (u32)a);
+				atomicOr(&stage[wi + 1], (u32)(a >> 32));
+				const u64 b = (sh ? lo64 >> (64 - sh) : 0) | (u64)hi32 << sh;
+				if (b) {
+					atomicOr(&stage[wi + 2], (u32)b);
+					atomicOr(&stage[wi + 3], (u32)(b >> 32));
+				}
+			}
+			bitpos += wv_readlane(incl, 63);
+			hi -= take;
+			wv_sync();
+			/* flush whole words once the stage is three quarters full */
+			if (bitpos - base_bits > 3072 * 32 || hi == 0) {
+				if (hi == 0) {
+					if (lane == 0)
+						atomicOr(&stage[(bitpos - base_bits) >> 5], 1u << ((bitpos - base_bits) & 31));
+					bitpos++;
+					wv_sync();
+				}
+				const u32 nwords = hi == 0 ? (bitpos - base_bits + 31) >> 5 : (bitpos - base_bits) >> 5;
+				const u32 nbytes = hi == 0 ? (bitpos - base_bits + 7) >> 3 : nwords * 4;
+				for (u32 i = (u32)lane; i < nwords; i += 64) {
+					const u32 v = stage[i];
+					if (4 * i + 4 <= nbytes) {
+						st32u(sp + outb + 4 * i, v);
+					} else {
+						for (u32 b2 = 0; 4 * i + b2 < nbytes; b2++)
+							sp[outb + 4 * i + b2] = (u8)(v >> (8 * b2));
+					}
+				}
+				const u32 carry = hi == 0 ? 0 : stage[nwords];
+				wv_sync();
+				for (u32 i = (u32)lane; i < 4096; i += 64)
+					stage[i] = 0;
+				wv_sync();
+				if (lane == 0)
+					stage[0] = carry;
+				outb += nbytes;
+				base_bits += nwords * 32;
+				wv_sync();
+			}
+		}
+		ssz[k] = outb;
+		sp += outb;
+	}
+	const u32 csz = tree + 6 + ssz[0] + ssz[1] + ssz[2] + ssz[3];
+	if (lane == 0) {
+		jump[0] = (u8)ssz[0];
+		jump[1] = (u8)(ssz[0] >> 8);
+		jump[2] = (u8)ssz[1];
+		jump[3] = (u8)(ssz[1] >> 8);
+		jump[4] = (u8)ssz[2];
+		jump[5] = (u8)(ssz[2] >> 8);
+		/* Literals_Section_Header: type 2, size format by regen, both sizes */
+		if (lh == 3) {
+			const u32 hv = 2u | 1u << 2 | regen << 4 | csz << 14;
+			dst[0] = (u8)hv;
+			dst[1] = (u8)(hv >> 8);
+			dst[2] = (u8)(hv >> 16);
+		} else if (lh == 4) {
+			const u32 hv = 2u | 2u << 2 | regen << 4 | csz << 18;
+			dst[0] = (u8)hv;
+			dst[1] = (u8)(hv >> 8);
+			dst[2] = (u8)(hv >> 16);
+			dst[3] = (u8)(hv >> 24);
+		} else {
+			const u64 hv = 2ull | 3ull << 2 | (u64)regen << 4 | (u64)csz << 22;
+			for (u32 k = 0; k < 5; k++)
+				dst[k] = (u8)(hv >> (8 * k));
+		}
+	}
+	return lh + csz;
+}
+
 /* FSE-code the sequences [lo, hi) of one sub-block into its own bitstream (one lane per sub-block,
  * up to ZE_G lanes side by side; the wave stages 8 sequences per sub-block and round into LDS) */
 #define ZE_G 16u
 #define ZE_BSTMP 20544u /* bytes of temporary bitstream per sub-block: 2048 sequences x 75 bits + slack */
-#define ZE_WSCRATCH (3u * ZE_MAXSEQ * 4u + ZE_G * ZE_BSTMP) /* per persistent wave (include/gpumt.h) */
+#define ZE_LITBUF (ZE_BLOCK + 64u)
+#define ZE_WSCRATCH (3u * ZE_MAXSEQ * 4u + ZE_G * ZE_BSTMP + ZE_LITBUF) /* per persistent wave */
 
 extern "C" __global__ void __launch_bounds__(64)
 zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
@@ -170,6 +444,7 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 	u32 *const sq_ll = (u32 *)wscr;
 	u32 *const sq_ml = sq_ll + ZE_MAXSEQ, *const sq_of = sq_ml + ZE_MAXSEQ;
 	u8 *const bstmp = wscr + 3u * ZE_MAXSEQ * 4u;
+	u8 *const litbuf = bstmp + ZE_G * ZE_BSTMP;
 
 	/* tables that do not depend on the data, once per wave: code tables (lane-parallel counts),
 	 * predefined FSE compression tables (lanes 0..2 build LL / ML / OF) */
@@ -235,7 +510,7 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 	do {                                                                                       \
 		const u32 p_ = (t) * 64u + (u32)lane;                                              \
 		const bool ok_ = (t) < steps && p_ + ZE_MINMATCH <= bsize;                         \
-		const u32 h_ = ((u32)(V) * 2654435761u) >> (32 - ZE_HLOG);                         \
+		const u32 h_ = ZE_HASH(V);                                                         \
 		const u32 e_ = ok_ ? L.table[h_] : 0;                                              \
 		wv_sync();                                                                         \
 		if (ok_)                                                                           \
@@ -444,23 +719,13 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 				const u32 regen = lsum + trail;
 				const u32 lh = regen < 32 ? 1u : regen < 4096 ? 2u : 3u;
 				const u32 sh = nsq < 128 ? 1u : nsq < 0x7F00 ? 2u : 3u;
-				const u32 csize = lh + regen + sh + 1 + bits;
-				if (bits == 0xFFFFFFFFu || at + 3 + csize + 8 > bsize) {
+				/* room check with the literals raw (coding them only shrinks the block) */
+				if (bits == 0xFFFFFFFFu || at + 3 + lh + regen + sh + 1 + bits + 8 > bsize) {
 					fits = false;
 					break;
 				}
 				u8 *o = out + at;
-				if (lane == 0) {
-					const u32 bh = (fin ? last : 0u) | 2u << 1 | csize << 3;
-					o[0] = (u8)bh;
-					o[1] = (u8)(bh >> 8);
-					o[2] = (u8)(bh >> 16);
-					const u32 hv = lh == 1 ? regen << 3 : regen << 4 | (lh == 2 ? 1u : 3u) << 2;
-					for (u32 k = 0; k < lh; k++)
-						o[3 + k] = (u8)(hv >> (8 * k));
-				}
-				u8 *lit = o + 3 + lh;
-				/* literal runs: lane per sequence, long runs by the whole wave */
+				/* literal runs -> litbuf: lane per sequence, long runs by the whole wave */
 				u32 ip = ipos, lpos = 0;
 				for (u32 b = lo; b < hi; b += 64) {
 					const u32 i = b + (u32)lane;
@@ -468,19 +733,38 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 					const u32 incl = wv_scan_incl(ll + ml), lincl = wv_scan_incl(ll);
 					const u32 s0 = ip + incl - ll - ml, d0 = lpos + lincl - ll;
 					if (ll && ll <= ZE_CAP)
-						ze_copy(lit + d0, src + s0, ll);
+						ze_copy(litbuf + d0, src + s0, ll);
 					u64 lm = wv_ballot(ll > ZE_CAP);
 					while (lm) {
 						const int j = wv_ffs(lm) - 1;
 						lm &= lm - 1;
-						wave_copy(lit + wv_readlane(d0, j), src + wv_readlane(s0, j), wv_readlane(ll, j), lane);
+						wave_copy(litbuf + wv_readlane(d0, j), src + wv_readlane(s0, j), wv_readlane(ll, j), lane);
 					}
 					ip += wv_readlane(incl, 63);
 					lpos += wv_readlane(lincl, 63);
 				}
 				if (trail)
-					wave_copy(lit + lpos, src + ip, trail, lane);
-				u8 *sp = lit + regen;
+					wave_copy(litbuf + lpos, src + ip, trail, lane);
+				wave_mem_fence();
+				/* literals section: Huffman-coded when that pays, else raw */
+				u32 lsec = ze_huf_literals(L, (u32 *)L.table, litbuf, regen, o + 3, lane);
+				if (!lsec) {
+					if (lane == 0) {
+						const u32 hv = lh == 1 ? regen << 3 : regen << 4 | (lh == 2 ? 1u : 3u) << 2;
+						for (u32 k = 0; k < lh; k++)
+							o[3 + k] = (u8)(hv >> (8 * k));
+					}
+					wave_copy(o + 3 + lh, litbuf, regen, lane);
+					lsec = lh + regen;
+				}
+				const u32 csize = lsec + sh + 1 + bits;
+				if (lane == 0) {
+					const u32 bh = (fin ? last : 0u) | 2u << 1 | csize << 3;
+					o[0] = (u8)bh;
+					o[1] = (u8)(bh >> 8);
+					o[2] = (u8)(bh >> 16);
+				}
+				u8 *sp = o + 3 + lsec;
 				if (lane == 0) {
 					if (sh == 1) {
 						sp[0] = (u8)nsq;
