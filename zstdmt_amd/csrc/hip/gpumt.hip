@@ -42,6 +42,7 @@ __global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u
 __global__ void zmt_zstd_dec_kernel_prof(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
 					 const u32 *, u8 *, u32 *, unsigned long long *);
 __global__ void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
+__global__ void zmt_zstd_enc_kernel_prof(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *, unsigned long long *);
 __global__ void zmt_zstd_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 __global__ void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
 __global__ void zmt_dec_copy_kernel_prof(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
@@ -72,6 +73,8 @@ struct gpumt_ctx {
 	unsigned long long *d_prof; /* 16 phase counters of the profiling decoder */
 	int xflags;  /* experiment switches of the parse kernel (developer) */
 	int profile; /* record events in timer slots 8.. around individual kernels */
+	int num_cus;
+	int zenc_waves; /* resident waves of the persistent zstd encoder kernel (whole device) */
 	char err[256];
 	char name[128];
 };
@@ -156,6 +159,7 @@ int gpumt_open(int device, gpumt_ctx **out)
 		}
 		snprintf(h->name, sizeof h->name, "%s (%s, %d CUs)", p.name, p.gcnArchName,
 			 p.multiProcessorCount);
+		h->num_cus = p.multiProcessorCount;
 		if (strncmp(p.gcnArchName, "gfx950", 6) != 0) {
 			/* kernels are built for gfx950 only */
 			free(h);
@@ -592,16 +596,32 @@ int gpumt_zstd_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t c
 	const size_t nblk = nrec * bpr;
 	if (nblk > 0x7FFFFFFFu)
 		return GPUMT_E_ARG;
-	/* persistent waves: 8 per CU (16 KiB LDS hash table each), blocks taken round-robin */
-	const unsigned grid = (unsigned)(nblk < 2048 ? nblk : 2048);
+	/* persistent waves, exactly as many as stay resident (LDS-limited), blocks taken round-robin */
+	if (!h->zenc_waves) {
+		int per_cu = 0;
+		CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zmt_zstd_enc_kernel, 64, 0));
+		h->zenc_waves = (per_cu > 0 ? per_cu : 4) * (h->num_cus > 0 ? h->num_cus : 256);
+	}
+	const unsigned grid = (unsigned)(nblk < (size_t)h->zenc_waves ? nblk : (size_t)h->zenc_waves);
 	const size_t seq_bytes = (size_t)grid * (3 * ZE_MAXSEQ * 4 + 16 * 20544 + ZE_BLOCK + 64);
+	if (h->profile == 6)
+		fprintf(stderr, "gpumt: zstd encoder grid %u waves\n", grid);
 	if (want_scratch(h, 0, nblk * 4 + 64 + seq_bytes))
 		return GPUMT_E_HIP;
 	u32 *blk_len = (u32 *)h->scratch[0];
 	u8 *seqbuf = (u8 *)h->scratch[0] + ((nblk * 4 + 63) & ~(size_t)63);
+	if (h->profile == 6 && !h->d_prof) {
+		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
+		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
+	}
 	PROF0(9);
-	hipLaunchKernelGGL(zmt_zstd_enc_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
-			   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);
+	if (h->profile == 6)
+		hipLaunchKernelGGL(zmt_zstd_enc_kernel_prof, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in,
+				   (u64)n, (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len,
+				   seqbuf, h->d_prof);
+	else
+		hipLaunchKernelGGL(zmt_zstd_enc_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
+				   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);
 	hipLaunchKernelGGL(zmt_zstd_assemble_kernel, dim3((unsigned)nrec), dim3(256), 0, h->st[s], (u64)n,
 			   (u32)chunk, (u32)nrec, bpr, (u8 *)d_slots, (u64)slot_stride, (const u32 *)blk_len,
 			   d_rec_len);

@@ -37,6 +37,7 @@
 #define ZE_MINMATCH 7u
 #define ZE_MAXSEQ (ZE_BLOCK / 4u) /* capacity of the per-wave sequence arrays (>= BLOCK / MINMATCH) */
 #define ZE_CAP 64u
+#define ZE_STAGE_WORDS ((2u << ZE_HLOG) / 4u) /* the idle hash table doubles as bit-packing stage */
 #ifndef ZE_HBYTES
 #define ZE_HBYTES 6
 #endif
@@ -174,8 +175,8 @@ static __device__ __forceinline__ void ze_copy(u8 *d, const u8 *s, u32 len)
  * data parallel: histogram with LDS atomics, canonical codes with ballots, the bitstreams with a
  * prefix sum of code lengths and atomicOr into an LDS staging area.
  * Returns the size of the section written at dst (header included), 0 = not worth it / not
- * representable this way (caller stores the literals raw).  `stage` = 16 KiB of LDS (the hash table
- * is idle while a block is assembled). */
+ * representable this way (caller stores the literals raw).  `stage` = ZE_STAGE_WORDS words of LDS
+ * (the hash table is idle while a block is assembled). */
 static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32 regen, u8 *dst, int lane)
 {
 	if (regen < 256)
@@ -327,7 +328,7 @@ static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32
 		 * lane l takes the 8 symbols ending at hi - 8 l */
 		u32 bitpos = 0, base_bits = 0; /* stream bits placed so far / bit offset of stage[0] */
 		u32 outb = 0;                  /* bytes of this stream already at sp */
-		for (u32 i = (u32)lane; i < 4096; i += 64)
+		for (u32 i = (u32)lane; i < ZE_STAGE_WORDS; i += 64)
 			stage[i] = 0;
 		wv_sync();
 		for (u32 hi = s_n; hi > 0;) {
@@ -365,7 +366,7 @@ static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32
 			hi -= take;
 			wv_sync();
 			/* flush whole words once the stage is three quarters full */
-			if (bitpos - base_bits > 3072 * 32 || hi == 0) {
+			if (bitpos - base_bits > (ZE_STAGE_WORDS * 3 / 4) * 32 || hi == 0) {
 				if (hi == 0) {
 					if (lane == 0)
 						atomicOr(&stage[(bitpos - base_bits) >> 5], 1u << ((bitpos - base_bits) & 31));
@@ -385,7 +386,7 @@ static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32
 				}
 				const u32 carry = hi == 0 ? 0 : stage[nwords];
 				wv_sync();
-				for (u32 i = (u32)lane; i < 4096; i += 64)
+				for (u32 i = (u32)lane; i < ZE_STAGE_WORDS; i += 64)
 					stage[i] = 0;
 				wv_sync();
 				if (lane == 0)
@@ -434,12 +435,30 @@ static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32
 #define ZE_LITBUF (ZE_BLOCK + 64u)
 #define ZE_WSCRATCH (3u * ZE_MAXSEQ * 4u + ZE_G * ZE_BSTMP + ZE_LITBUF) /* per persistent wave */
 
-extern "C" __global__ void __launch_bounds__(64)
-zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
-		    u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch)
+#ifndef ZMT_EMU
+#define ZET() (PROF ? (u64)clock64() : 0ull)
+#else
+#define ZET() 0ull
+#endif
+#define ZEP(i)                                                                                     \
+	do {                                                                                       \
+		if (PROF) {                                                                        \
+			const u64 t_ = ZET();                                                      \
+			pc[PROF ? (i) : 0] += t_ - tq;                                             \
+			tq = t_;                                                                   \
+		}                                                                                  \
+	} while (0)
+
+template <bool PROF>
+static __device__ __forceinline__ void
+zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
+	      u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch,
+	      unsigned long long *prof)
 {
-	__shared__ __attribute__((aligned(16))) ZEncLds L;
 	const int lane = wv_lane();
+	u64 pc[PROF ? 8 : 1] = {0}, tq = ZET();
+	const u64 t_begin = tq;
+	(void)t_begin;
 	u8 *const wscr = scratch + (u64)blockIdx.x * ZE_WSCRATCH;
 	u32 *const sq_ll = (u32 *)wscr;
 	u32 *const sq_ml = sq_ll + ZE_MAXSEQ, *const sq_of = sq_ml + ZE_MAXSEQ;
@@ -489,10 +508,11 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 		const u8 *src = in + cstart + bstart;
 		u8 *out = slots + (u64)rec * stride + ZE_HDR + (u64)bi * ZE_BSTRIDE;
 
+		ZEP(5);
 		/* ------------------------------------------------ match finding + greedy parse
-		 * 64 positions per step.  Software pipeline: the 8 input bytes of step t+2 and the
-		 * candidate bytes of step t+1 are in flight while step t is parsed, so neither global
-		 * round trip sits on the critical path.
+		 * 64 positions per step.  Software pipeline: the 8 input bytes of step t+3 and the
+		 * candidate bytes of steps t+1 and t+2 are in flight while step t is parsed, so neither
+		 * global round trip sits on the critical path.
 		 * Table entries are positions mod 64 Ki; a candidate is rebuilt as the newest position
 		 * below p with those low bits and then verified, so stale or aliased entries only cost a
 		 * missed match. */
@@ -501,12 +521,15 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 		wv_sync();
 		u32 ns = 0, anchor = 0, cursor = 0;
 		const u32 steps = bsize >= ZE_MINMATCH ? (bsize - ZE_MINMATCH) / 64 + 1 : 0;
+/* All loads of the pipeline are unconditional (addresses clamped, results of invalid lanes ignored):
+ * a load under an exec mask needs its destination initialised first, and that write would have to
+ * wait for every load still in flight. */
 #define ZE_LOADV(t, V)                                                                             \
 	do {                                                                                       \
 		const u32 p_ = (t) * 64u + (u32)lane;                                              \
-		(V) = ((t) < steps && p_ + ZE_MINMATCH <= bsize) ? ld64u(src + p_) : 0;            \
+		(V) = ld64u(src + (p_ < bsize ? p_ : bsize - 1));                                  \
 	} while (0)
-#define ZE_LOOKUP(t, V, Cc, VC)                                                                    \
+#define ZE_LOOKUP(t, V, Cc, M)                                                                     \
 	do {                                                                                       \
 		const u32 p_ = (t) * 64u + (u32)lane;                                              \
 		const bool ok_ = (t) < steps && p_ + ZE_MINMATCH <= bsize;                         \
@@ -527,24 +550,55 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 		if (c_ >= p_)                                                                      \
 			c_ -= 65536u;                                                              \
 		(Cc) = (ok_ && c_ < p_) ? c_ : 0xFFFFFFFFu;                                        \
-		(VC) = (Cc) != 0xFFFFFFFFu ? ld64u(src + (Cc)) : ~(V);                             \
+		/* 24 bytes of the candidate and of the input beyond the hashed 8: most matches are   \
+		 * measured right here, without the wave-wide extension below */                      \
+		{                                                                                  \
+			const u8 *cp_ = src + ((Cc) != 0xFFFFFFFFu ? (Cc) : 0u);                   \
+			const u8 *ip_ = src + (ok_ ? p_ : 0u);                                     \
+			(M).v = (V);                                                               \
+			(M).a = ld64u(cp_);                                                        \
+			(M).b = ld64u(cp_ + 8);                                                    \
+			(M).c = ld64u(cp_ + 16);                                                   \
+			(M).d = ld64u(ip_ + 8);                                                    \
+			(M).e = ld64u(ip_ + 16);                                                   \
+		}                                                                                  \
 	} while (0)
-		u64 v0, v1, v2, vc0, vc1;
-		u32 c0, c1;
-		ZE_LOADV(0u, v0);
-		ZE_LOADV(1u, v1);
-		ZE_LOOKUP(0u, v0, c0, vc0);
-		for (u32 t = 0; t < steps; t++) {
-			ZE_LOADV(t + 2, v2);
-			ZE_LOOKUP(t + 1, v1, c1, vc1);
+		struct Cmp {
+			u64 v, a, b, c, d, e; /* input bytes 0..7, candidate bytes 0..23, input bytes 8..23 */
+		};
+		/* three register sets rotate by unrolling (copying a set would wait for its loads) */
+		Cmp M[3]; /* compare data of steps t, t+1, t+2 at index step % 3 */
+		u32 Cn[3];
+		u64 V[3]; /* hashed input word of the step that is looked up next, same indexing */
+		ZE_LOADV(0u, V[0]);
+		ZE_LOADV(1u, V[1]);
+		ZE_LOADV(2u, V[2]);
+		ZE_LOOKUP(0u, V[0], Cn[0], M[0]);
+		ZE_LOOKUP(1u, V[1], Cn[1], M[1]);
+		for (u32 t0 = 0; t0 < steps; t0 += 3) {
+		ZMT_UNROLL
+		for (int k = 0; k < 3; k++) {
+			const u32 t = t0 + (u32)k;
+			if (t >= steps)
+				break;
+			ZE_LOADV(t + 3, V[k]);
+			ZE_LOOKUP(t + 2, V[(k + 2) % 3], Cn[(k + 2) % 3], M[(k + 2) % 3]);
+			ZEP(6);
+			const Cmp &m0 = M[k];
+			const u32 c0 = Cn[k];
+			const u64 v0 = m0.v;
 			const u32 p0 = t * 64u, p = p0 + (u32)lane;
 			if (p0 + 64 > cursor) { /* else the whole step lies inside the previous match */
-				const u64 x = v0 ^ vc0;
-				u32 m = x ? (u32)__builtin_ctzll(x) >> 3 : 8u;
+				const u64 x0 = v0 ^ m0.a, x1 = m0.d ^ m0.b, x2 = m0.e ^ m0.c;
+				u32 m = x0   ? (u32)__builtin_ctzll(x0) >> 3
+					: x1 ? 8u + ((u32)__builtin_ctzll(x1) >> 3)
+					: x2 ? 16u + ((u32)__builtin_ctzll(x2) >> 3)
+					     : 24u;
 				const bool cand = c0 != 0xFFFFFFFFu && p >= cursor;
 				if (cand && m > bsize - p)
 					m = bsize - p;
 				u64 mask = wv_ballot(cand && m >= ZE_MINMATCH);
+				ZEP(7);
 				while (mask) {
 					const int j = wv_ffs(mask) - 1;
 					mask &= mask - 1;
@@ -553,9 +607,10 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 						continue;
 					const u32 cj = wv_readlane(c0, j);
 					u32 ml = wv_readlane(m, j);
-					if (ml == 8) {
+					if (ml == 24) {
+						const u64 tx_ = ZET();
 						/* extend: 64 lanes x 8 bytes per step */
-						for (u32 base = 8;; base += 512) {
+						for (u32 base = 24;; base += 512) {
 							const u32 o = base + 8u * (u32)lane;
 							u32 k = 0;
 							bool stop = true;
@@ -573,6 +628,11 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 						}
 						if (ml > bsize - pj)
 							ml = bsize - pj;
+						if (PROF) {
+							const u64 t_ = ZET();
+							pc[PROF ? 5 : 0] += t_ - tx_;
+							tq += t_ - tx_; /* not charged to the parse phase */
+						}
 					}
 					if (lane == 0) {
 						sq_ll[ns] = pj - anchor;
@@ -583,10 +643,7 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 					anchor = cursor = pj + ml;
 				}
 			}
-			v0 = v1;
-			v1 = v2;
-			c0 = c1;
-			vc0 = vc1;
+		}
 		}
 #undef ZE_LOADV
 #undef ZE_LOOKUP
@@ -607,6 +664,7 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 		}
 #endif
 
+		ZEP(0);
 		/* ------------------------------------------------ sequences -> bitstreams
 		 * The sequence list is cut into G runs of equal count; each run becomes its own zstd
 		 * block, so G lanes can FSE-code side by side (an FSE stream is a serial chain; a block
@@ -700,6 +758,7 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 			wave_mem_fence();
 			wv_sync();
 
+			ZEP(1);
 			/* -------------------------------------------- assemble the G blocks at out */
 			u32 ipos = 0, at = 0; /* input bytes consumed, bytes written */
 			bool fits = true;
@@ -725,6 +784,7 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 					break;
 				}
 				u8 *o = out + at;
+				ZEP(4);
 				/* literal runs -> litbuf: lane per sequence, long runs by the whole wave */
 				u32 ip = ipos, lpos = 0;
 				for (u32 b = lo; b < hi; b += 64) {
@@ -746,6 +806,7 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 				if (trail)
 					wave_copy(litbuf + lpos, src + ip, trail, lane);
 				wave_mem_fence();
+				ZEP(2);
 				/* literals section: Huffman-coded when that pays, else raw */
 				u32 lsec = ze_huf_literals(L, (u32 *)L.table, litbuf, regen, o + 3, lane);
 				if (!lsec) {
@@ -757,6 +818,7 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 					wave_copy(o + 3 + lh, litbuf, regen, lane);
 					lsec = lh + regen;
 				}
+				ZEP(3);
 				const u32 csize = lsec + sh + 1 + bits;
 				if (lane == 0) {
 					const u32 bh = (fin ? last : 0u) | 2u << 1 | csize << 3;
@@ -799,8 +861,37 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 			wave_copy(out + 3, src, bsize, lane);
 		}
 		wave_mem_fence();
+		ZEP(4);
 	}
+#ifndef ZMT_EMU
+	if (PROF && prof && lane == 0) {
+		for (int i = 0; i < (PROF ? 8 : 1); i++)
+			atomicAdd(prof + i, (unsigned long long)pc[i]);
+		atomicAdd(prof + 8, (unsigned long long)(ZET() - t_begin));
+		atomicAdd(prof + 9, 1ull);
+	}
+#endif
 }
+
+extern "C" __global__ void __launch_bounds__(64)
+zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
+		    u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch)
+{
+	__shared__ __attribute__((aligned(16))) ZEncLds L;
+	zstd_enc_body<false>(L, in, n, chunk, nblk_total, blk_per_rec, slots, stride, blk_len, scratch, nullptr);
+}
+
+#ifndef ZMT_EMU
+/* same kernel with per-phase cycle counters (developer tool) */
+extern "C" __global__ void __launch_bounds__(64)
+zmt_zstd_enc_kernel_prof(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
+			 u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch,
+			 unsigned long long *prof)
+{
+	__shared__ __attribute__((aligned(16))) ZEncLds L;
+	zstd_enc_body<true>(L, in, n, chunk, nblk_total, blk_per_rec, slots, stride, blk_len, scratch, prof);
+}
+#endif
 
 /* Record slot -> finished record: skippable header (lib/zstd-mt_compress.c:296-302), frame header
  * (magic, single-segment descriptor, content size), the chunk's blocks moved together. */
