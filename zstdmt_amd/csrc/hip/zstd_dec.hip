@@ -535,6 +535,7 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 	bool huf_ok = false;
 	int huf_log = 0;
 	bool my_tab_ok = false; /* lanes 0..2: state of the LL / OF / ML table this lane builds */
+	bool my_tab_pre = false; /* ... and whether it currently holds the predefined distribution */
 	int my_tab_log = 0;
 	u32 opos = 0, ip = hp;
 
@@ -827,7 +828,7 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 							const int n = t == 0 ? 36 : t == 1 ? 29 : 53;
 							for (int i = 0; i < n; i++)
 								L.norm[t][i] = def[i];
-							L.misc[ZM_A + t] = (u32)n | (u32)(t == 1 ? 5 : 6) << 8;
+							L.misc[ZM_A + t] = (u32)n | (u32)(t == 1 ? 5 : 6) << 8 | 0x40000000u; /* predefined */
 						} else if (mode == 1) {
 							if (p >= avail || d[p] >= max_sym)
 								err = 1;
@@ -870,12 +871,16 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 						cells[0] = sy | (lane == 1 ? sy : (lane == 0 ? L.llx[sy] : L.mlx[sy]) >> 24) << 10;
 						my_tab_log = 0;
 						my_tab_ok = true;
+						my_tab_pre = false;
+					} else if ((spec & 0x40000000u) && my_tab_pre && my_tab_ok) {
+						/* predefined table still in place from an earlier block: nothing to build */
 					} else {
-						const int lg = (int)(spec >> 8);
+						const int lg = (int)((spec >> 8) & 255);
 						terr = fse_build(cells, L.norm[lane], (int)(spec & 255), lg, L.next[lane],
 								 lane == 0 ? L.llx : lane == 2 ? L.mlx : (const u32 *)nullptr, lane) != 0;
 						my_tab_log = lg;
 						my_tab_ok = !terr;
+						my_tab_pre = (spec & 0x40000000u) != 0;
 					}
 				}
 				wv_sync();
@@ -931,14 +936,17 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 						pos -= ll_log + of_log + ml_log;
 					}
 					for (u32 i = 0; i < k; i++) {
+						/* pos == 0 is legal here: the last sequence may need no bits at all; pos < 0
+						 * is caught below, the reads then come from the slack below the window.
+						 * Both LDS reads of the step are issued together: one round trip. */
+						const long tb = (pos - 1) >> 3;
+						const u8 *wp = win + (pos >= 0 ? tb : 0);
+						const u64 w1 = ld64u(wp - 15), w0 = ld64u(wp - 7);
 						const u32 cell = mytab[lane < 3 ? state : 0];
 						if (pos < 0) {
 							err = true;
 							break;
 						}
-						/* pos == 0 is legal here: the last sequence may need no bits at all */
-						const long tb = (pos - 1) >> 3;
-						const u64 w0 = ld64u(win + tb - 7), w1 = ld64u(win + tb - 15);
 						const u32 skip = (u32)(8 * (tb + 1) - pos);
 						const bool lastseq = sbase + i + 1 == nseq;
 						const u32 nb = lastseq ? 0u : ZC_NB(cell), ab = ZC_AB(cell);
