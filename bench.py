@@ -303,14 +303,21 @@ def report_zstd(args, eng, world, wall, ms, U, Cb, nrec, chunk, bad, ok, gen_s, 
     t_d = ms["decompress"] * 1e-3
     step_s = wall / args.steps
 
-    def roof(name, t_ms):
+    traffic = {}
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tf) and abs(args.gib - 8.0) < 1e-9 and chunk == 1 << 20:
+        with open(tf) as f:
+            traffic = json.load(f).get("per_launch_bytes_8gib", {})
+
+    def roof(name, t_ms, pmc):
         a = alg / (t_ms * 1e-3) / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(a * 1e9 / HBM_PEAK, 5),
                 "frac_of_copy_ceiling": round(a * 1e9 / HBM_COPY, 5), "alg_bytes_per_launch": alg,
-                "avg_launch_ms": round(t_ms, 4), "traffic": None}
+                "avg_launch_ms": round(t_ms, 4), "traffic": traffic.get(pmc)}
 
-    enc, dec = roof("zmt_zstd_enc_kernel(+assemble)", ms["k_lz4_enc"]), roof("zmt_zstd_dec_kernel", ms["k_lz4_dec"])
+    enc = roof("zmt_zstd_enc_kernel(+assemble)", ms["k_lz4_enc"], "zmt_zstd_enc_kernel")
+    dec = roof("zmt_zstd_dec_kernel", ms["k_lz4_dec"], "zmt_zstd_dec_kernel")
     res = {
         "metric": "MB/s compress+decompress, 8 GiB synthetic, zstd-mt level 1; % HBM roofline",
         "value": round(world * U / 1e6 / step_s, 1), "unit": "MB/s",

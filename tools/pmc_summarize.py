@@ -38,6 +38,17 @@ stats = biggest("prof_stats/**/*_kernel_stats.csv")
 shutil.copy(stats, os.path.join(root, "profiles", f"{rnd}_kernel_stats.csv"))
 fetch = counter_avg(biggest("prof_fetch/**/*_counter_collection.csv"))
 write = counter_avg(biggest("prof_write/**/*_counter_collection.csv"))
+zstats = biggest("prof_zstd_stats/**/*_kernel_stats.csv")
+if zstats:
+    shutil.copy(zstats, os.path.join(root, "profiles", f"{rnd}_zstd_kernel_stats.csv"))
+    for part, name in ((fetch, "prof_zstd_fetch"), (write, "prof_zstd_write")):
+        f = biggest(name + "/**/*_counter_collection.csv")
+        if f:
+            for k, v in counter_avg(f).items():
+                if "zstd" in k:
+                    part[k] = v
+    zl = open(os.path.join(go, "bench_zstd.json")).read().strip().splitlines()[-1]
+    json.dump(json.loads(zl), open(os.path.join(root, "profiles", f"{rnd}_bench_zstd_8gib_1gpu.json"), "w"), indent=1)
 detail, per = [], {}
 for k in sorted(set(fetch) | set(write)):
     fb = fetch.get(k, 0.0) * 1024 * 2

@@ -13,4 +13,14 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch -
     python bench.py --steps 1 --warmup 0 --no-cpu > $O/bench_fetch.json 2> $O/prof_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -- \
     python bench.py --steps 1 --warmup 0 --no-cpu > $O/bench_write.json 2> $O/prof_write.err
+# configs[3]: zstd-mt level 1 (same workload text, 1 MiB chunks)
+rm -rf $O/prof_zstd_stats $O/prof_zstd_fetch $O/prof_zstd_write
+python bench.py --codec zstd > $O/bench_zstd.json 2> $O/bench_zstd.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_zstd_stats -- \
+    python bench.py --codec zstd --steps 2 --warmup 1 --no-cpu > $O/bench_zstd_prof.json 2> $O/prof_zstd_stats.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_zstd_fetch -- \
+    python bench.py --codec zstd --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_zstd_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_zstd_write -- \
+    python bench.py --codec zstd --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_zstd_write.err
 cat $O/bench_default.json
+cat $O/bench_zstd.json
