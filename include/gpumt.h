@@ -74,6 +74,13 @@ int   gpumt_stream_sync(gpumt_ctx *h, int stream);
 int   gpumt_device_sync(gpumt_ctx *h);
 /* make `waiter` wait (on device) for everything queued so far on `signaler` */
 int   gpumt_stream_wait(gpumt_ctx *h, int waiter, int signaler);
+/* Markers: gpumt_mark(id, stream) records marker id (0..GPUMT_NMARKS-1) behind everything queued so
+ * far on `stream`; gpumt_mark_sync(id) blocks the calling host thread until that point is reached
+ * (and nothing queued later).  Thread-safe: one thread may wait on a marker while another queues
+ * work. */
+#define GPUMT_NMARKS 8
+int   gpumt_mark(gpumt_ctx *h, int id, int stream);
+int   gpumt_mark_sync(gpumt_ctx *h, int id);
 /* raw hipStream_t of a stream index, for callers that interoperate (e.g. RCCL via torch) */
 void *gpumt_stream_handle(gpumt_ctx *h, int stream);
 

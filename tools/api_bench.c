@@ -1,21 +1,25 @@
 /*
- * api_bench.c -- end-to-end (PCIe-inclusive) throughput of the drop-in API: LZ4MT_compressCCtx /
- * LZ4MT_decompressDCtx of libzstdmt_amd.so with in-memory callbacks, i.e. the same measurement
- * oracle/cpu_bench.c makes for the reference library.  Developer tool (numbers quoted in DESIGN.md).
- *   api_bench <bytes> <chunk>
+ * api_bench.c -- end-to-end (PCIe-inclusive) throughput of the drop-in APIs of libzstdmt_amd.so:
+ * LZ4MT_* or ZSTDCB_* compressCCtx / decompressDCtx with in-memory callbacks, i.e. the same
+ * measurement oracle/cpu_bench.c makes for the reference libraries.  Developer tool (numbers quoted
+ * in DESIGN.md).  The two APIs have identical shapes, so they are bound by name at run time.
+ *   api_bench <lz4|zstd> <bytes> <chunk>
  */
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
-#include "lz4-mt.h"
-
 int zmt_gen_text(uint8_t *dst, size_t n, uint64_t seed, uint64_t offset, int threads);
 
+typedef struct { void *buf; size_t size, allocated; } Buf;
+typedef int (cb_fn)(void *, Buf *);
+typedef struct { cb_fn *fn_read; void *arg_read; cb_fn *fn_write; void *arg_write; } RdWr;
+
 struct mem { uint8_t *p; size_t n, pos; };
-static int rd(void *a, LZ4MT_Buffer *b)
+static int rd(void *a, Buf *b)
 {
 	struct mem *m = a;
 	size_t k = m->n - m->pos < b->size ? m->n - m->pos : b->size;
@@ -24,7 +28,7 @@ static int rd(void *a, LZ4MT_Buffer *b)
 	b->size = k;
 	return 0;
 }
-static int wr(void *a, LZ4MT_Buffer *b)
+static int wr(void *a, Buf *b)
 {
 	struct mem *m = a;
 	if (m->n - m->pos < b->size)
@@ -39,43 +43,69 @@ static double now(void)
 	clock_gettime(CLOCK_MONOTONIC, &ts);
 	return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
+static void *sym(void *so, const char *pfx, const char *name)
+{
+	char buf[64];
+	snprintf(buf, sizeof buf, "%s%s", pfx, name);
+	void *p = dlsym(so, buf);
+	if (!p) {
+		fprintf(stderr, "missing %s\n", buf);
+		exit(9);
+	}
+	return p;
+}
 int main(int argc, char **argv)
 {
-	size_t n = argc > 1 ? strtoull(argv[1], 0, 10) : (size_t)1 << 30;
-	int chunk = argc > 2 ? atoi(argv[2]) : 131072;
-	size_t cap = n + n / 64 + (n / chunk + 2) * 64 + 4096;
+	const char *codec = argc > 1 ? argv[1] : "lz4";
+	const char *pfx = !strcmp(codec, "zstd") ? "ZSTDCB_" : "LZ4MT_";
+	size_t n = argc > 2 ? strtoull(argv[2], 0, 10) : (size_t)1 << 30;
+	int chunk = argc > 3 ? atoi(argv[3]) : 0;
+	void *so = dlopen(argc > 4 ? argv[4] : "libzstdmt_amd.so", RTLD_NOW);
+	if (!so) {
+		fprintf(stderr, "dlopen: %s\n", dlerror());
+		return 8;
+	}
+	void *(*createC)(int, int, int) = sym(so, pfx, "createCCtx");
+	size_t (*compressC)(void *, RdWr *) = sym(so, pfx, "compressCCtx");
+	void (*freeC)(void *) = sym(so, pfx, "freeCCtx");
+	void *(*createD)(int, int) = sym(so, pfx, "createDCtx");
+	size_t (*decompressD)(void *, RdWr *) = sym(so, pfx, "decompressDCtx");
+	void (*freeD)(void *) = sym(so, pfx, "freeDCtx");
+	unsigned (*isErr)(size_t) = sym(so, pfx, "isError");
+	const char *(*errStr)(size_t) = sym(so, pfx, "getErrorString");
+	size_t cap = n + n / 64 + (n / (chunk ? chunk : 131072) + 2) * 64 + 4096;
 	uint8_t *src = malloc(n), *cmp = malloc(cap), *back = malloc(n);
 	zmt_gen_text(src, n, 20260926, 0, 32);
 	memset(cmp, 0, cap);
 	memset(back, 0, n);
 	for (int rep = 0; rep < 2; rep++) { /* rep 0 warms up (allocations, first touch) */
 		struct mem in = { src, n, 0 }, out = { cmp, cap, 0 };
-		LZ4MT_RdWr_t io = { rd, &in, wr, &out };
+		RdWr io = { rd, &in, wr, &out };
 		double t0 = now();
-		LZ4MT_CCtx *c = LZ4MT_createCCtx(4, 1, chunk);
+		void *c = createC(4, 1, chunk);
 		if (!c) { fprintf(stderr, "no device\n"); return 2; }
 		double t_create = now() - t0;
 		t0 = now();
-		size_t rv = LZ4MT_compressCCtx(c, &io);
+		size_t rv = compressC(c, &io);
 		double tc = now() - t0;
 		t0 = now();
-		LZ4MT_freeCCtx(c);
+		freeC(c);
 		double t_free = now() - t0;
 		if (rep)
 			fprintf(stderr, "compress: create %.3f s, run %.3f s, free %.3f s\n", t_create, tc, t_free);
-		if (LZ4MT_isError(rv)) { fprintf(stderr, "compress: %s\n", LZ4MT_getErrorString(rv)); return 3; }
+		if (isErr(rv)) { fprintf(stderr, "compress: %s\n", errStr(rv)); return 3; }
 		struct mem in2 = { cmp, out.pos, 0 }, out2 = { back, n, 0 };
-		LZ4MT_RdWr_t io2 = { rd, &in2, wr, &out2 };
-		LZ4MT_DCtx *d = LZ4MT_createDCtx(4, 0);
+		RdWr io2 = { rd, &in2, wr, &out2 };
+		void *d = createD(4, 0);
 		t0 = now();
-		rv = LZ4MT_decompressDCtx(d, &io2);
+		rv = decompressD(d, &io2);
 		double td = now() - t0;
-		LZ4MT_freeDCtx(d);
-		if (LZ4MT_isError(rv)) { fprintf(stderr, "decompress: %s\n", LZ4MT_getErrorString(rv)); return 4; }
+		freeD(d);
+		if (isErr(rv)) { fprintf(stderr, "decompress: %s\n", errStr(rv)); return 4; }
 		if (out2.pos != n || memcmp(src, back, n)) { fprintf(stderr, "round trip mismatch\n"); return 5; }
 		if (rep)
-			printf("{\"api\": \"LZ4MT_*\", \"bytes\": %zu, \"chunk\": %d, \"compressed\": %zu, \"compress_MBps\": %.1f, "
-			       "\"decompress_MBps\": %.1f}\n", n, chunk, out.pos, n / 1e6 / tc, n / 1e6 / td);
+			printf("{\"api\": \"%s*\", \"bytes\": %zu, \"chunk\": %d, \"compressed\": %zu, \"compress_MBps\": %.1f, "
+			       "\"decompress_MBps\": %.1f}\n", pfx, n, chunk, out.pos, n / 1e6 / tc, n / 1e6 / td);
 	}
 	return 0;
 }

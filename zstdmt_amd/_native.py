@@ -33,6 +33,8 @@ GPUMT_SYMBOLS = {
     "gpumt_stream_sync": (_i, [_vp, _i]),
     "gpumt_device_sync": (_i, [_vp]),
     "gpumt_stream_wait": (_i, [_vp, _i, _i]),
+    "gpumt_mark": (_i, [_vp, _i, _i]),
+    "gpumt_mark_sync": (_i, [_vp, _i]),
     "gpumt_stream_handle": (_vp, [_vp, _i]),
     "gpumt_timer_start": (_i, [_vp, _i, _i]),
     "gpumt_timer_stop": (_i, [_vp, _i, _i]),

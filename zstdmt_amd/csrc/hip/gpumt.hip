@@ -65,6 +65,7 @@ struct gpumt_ctx {
 	hipStream_t st[GPUMT_NSTREAMS];
 	hipEvent_t t0[NTIMERS], t1[NTIMERS];
 	hipEvent_t xev;
+	hipEvent_t mark[GPUMT_NMARKS];
 	/* scratch, grown on demand (never shrinks) */
 	void *scratch[2];        /* [0] compress side, [1] decompress side */
 	size_t scratch_bytes[2];
@@ -176,6 +177,8 @@ int gpumt_open(int device, gpumt_ctx **out)
 		(void)hipEventCreate(&h->t1[i]);
 	}
 	(void)hipEventCreateWithFlags(&h->xev, hipEventDisableTiming);
+	for (int i = 0; i < GPUMT_NMARKS; i++)
+		(void)hipEventCreateWithFlags(&h->mark[i], hipEventDisableTiming);
 	*out = h;
 	return GPUMT_OK;
 }
@@ -194,6 +197,8 @@ void gpumt_close(gpumt_ctx *h)
 		(void)hipEventDestroy(h->t1[i]);
 	}
 	(void)hipEventDestroy(h->xev);
+	for (int i = 0; i < GPUMT_NMARKS; i++)
+		(void)hipEventDestroy(h->mark[i]);
 	for (int i = 0; i < GPUMT_NSTREAMS; i++)
 		(void)hipStreamDestroy(h->st[i]);
 	free(h);
@@ -287,6 +292,24 @@ int gpumt_device_sync(gpumt_ctx *h)
 	if (use(h))
 		return GPUMT_E_HIP;
 	CK(hipDeviceSynchronize());
+	return GPUMT_OK;
+}
+int gpumt_mark(gpumt_ctx *h, int id, int s)
+{
+	if (!h || !STREAM_OK(s) || id < 0 || id >= GPUMT_NMARKS)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipEventRecord(h->mark[id], h->st[s]));
+	return GPUMT_OK;
+}
+int gpumt_mark_sync(gpumt_ctx *h, int id)
+{
+	if (!h || id < 0 || id >= GPUMT_NMARKS)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipEventSynchronize(h->mark[id]));
 	return GPUMT_OK;
 }
 int gpumt_stream_wait(gpumt_ctx *h, int waiter, int signaler)

@@ -15,6 +15,7 @@
  * This file is plain C and never includes a HIP header.
  */
 #include "mt_host.h"
+#include "mt_pipe.h"
 #include "lz4-mt.h"
 
 size_t lz4mt_errcode;
@@ -80,9 +81,11 @@ struct cslot {
 
 struct LZ4MT_CCtx_s {
 	int level, threads, inputsize;
-	size_t insize, outsize, curframe, frames;
+	size_t insize, outsize, curframe, frames; /* insize / frames: reader; outsize / curframe: writer */
 	gpumt_ctx *gpu;
-	struct cslot s[2];
+	struct cslot s[MT_NSLOT];
+	LZ4MT_RdWr_t *io; /* callbacks of the running call */
+	size_t maxrec;    /* records per device batch, grows (reader) */
 };
 
 LZ4MT_CCtx *LZ4MT_createCCtx(int threads, int level, int inputsize)
@@ -111,7 +114,7 @@ void LZ4MT_freeCCtx(LZ4MT_CCtx *ctx)
 {
 	if (!ctx)
 		return;
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < MT_NSLOT; i++) {
 		dbuf_free(ctx->gpu, &ctx->s[i].in);
 		dbuf_free(ctx->gpu, &ctx->s[i].slots);
 		dbuf_free(ctx->gpu, &ctx->s[i].stream);
@@ -180,26 +183,72 @@ static size_t c_launch(LZ4MT_CCtx *ctx, struct cslot *s)
 	return rc ? ERROR(compression_library) : 0;
 }
 
-static size_t c_finish(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *io, struct cslot *s)
+/* ---- the three roles (mt_pipe.h) ---- */
+static size_t cp_fill(void *a, int si, int *has_data, int *eof)
 {
+	LZ4MT_CCtx *ctx = (LZ4MT_CCtx *)a;
+	struct cslot *s = &ctx->s[si];
+	const size_t chunk = (size_t)ctx->inputsize, stride = gpumt_lz4_slot_stride(chunk);
+	size_t lim = BATCH_BYTES / chunk, err;
+	if (lim < 1)
+		lim = 1;
+	if (lim > BATCH_MAXREC)
+		lim = BATCH_MAXREC;
+	if (ctx->maxrec > lim)
+		ctx->maxrec = lim;
+	/* (re)size this slot for the current batch size; it is free: nothing of it is in flight */
+	if (dbuf_want(ctx->gpu, &s->in, ctx->maxrec * chunk + 512, 1, 1) ||
+	    dbuf_want(ctx->gpu, &s->slots, ctx->maxrec * stride, 0, 1) ||
+	    dbuf_want(ctx->gpu, &s->stream, ctx->maxrec * stride + 512, 1, 1) ||
+	    dbuf_want(ctx->gpu, &s->meta, ctx->maxrec * 12 + 64, 1, 1))
+		return ERROR(memory_allocation);
+	err = c_read_batch(ctx, ctx->io, s, ctx->maxrec, eof);
+	*has_data = s->nrec > 0;
+	ctx->maxrec *= 4;
+	return err;
+}
+
+static size_t cp_launch(void *a, int si)
+{
+	LZ4MT_CCtx *ctx = (LZ4MT_CCtx *)a;
+	size_t err = c_launch(ctx, &ctx->s[si]);
+	if (!err && gpumt_mark(ctx->gpu, si, 2))
+		err = ERROR(compression_library);
+	return err;
+}
+
+static size_t cp_complete(void *a, int si)
+{
+	LZ4MT_CCtx *ctx = (LZ4MT_CCtx *)a;
+	struct cslot *s = &ctx->s[si];
 	gpumt_ctx *g = ctx->gpu;
-	const uint32_t *len = (const uint32_t *)s->meta.h;
 	const uint64_t *off = (const uint64_t *)((const uint8_t *)s->meta.h + ((s->nrec * 4 + 15) & ~(size_t)15));
 	size_t total;
-	if (gpumt_stream_sync(g, 2))
+	if (gpumt_mark_sync(g, si)) /* record sizes and offsets are in host memory */
 		return ERROR(compression_library);
 	total = (size_t)off[s->nrec];
 	if (total > s->stream.cap)
 		return ERROR(frame_compress);
-	if (gpumt_memcpy_d2h(g, s->stream.h, s->stream.d, total, 2) || gpumt_stream_sync(g, 2))
+	/* the packed records: on a stream of their own, so the copy is not queued behind the next
+	 * batch's kernels */
+	if (gpumt_memcpy_d2h(g, s->stream.h, s->stream.d, total, 3) || gpumt_stream_sync(g, 3))
 		return ERROR(compression_library);
+	return 0;
+}
+
+static size_t cp_drain(void *a, int si)
+{
+	LZ4MT_CCtx *ctx = (LZ4MT_CCtx *)a;
+	struct cslot *s = &ctx->s[si];
+	const uint32_t *len = (const uint32_t *)s->meta.h;
+	const uint64_t *off = (const uint64_t *)((const uint8_t *)s->meta.h + ((s->nrec * 4 + 15) & ~(size_t)15));
 	for (size_t i = 0; i < s->nrec; i++) { /* pt_write: strictly in frame order */
 		LZ4MT_Buffer b;
 		int rv;
 		b.buf = (uint8_t *)s->stream.h + off[i];
 		b.size = len[i];
 		b.allocated = len[i];
-		rv = io->fn_write(io->arg_write, &b);
+		rv = ctx->io->fn_write(ctx->io->arg_write, &b);
 		if (rv != 0)
 			return mt_error(rv);
 		ctx->outsize += len[i];
@@ -210,59 +259,19 @@ static size_t c_finish(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *io, struct cslot *s)
 
 size_t LZ4MT_compressCCtx(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *rdwr)
 {
-	size_t chunk, stride, maxrec, err = 0;
-	int eof = 0, cur = 0, have_prev = 0;
+	static const mt_pipe_ops ops = {cp_fill, cp_launch, cp_complete, cp_drain};
+	size_t err;
 
 	if (!ctx)
 		return ERROR(compressionParameter_unsupported); /* lz4-mt_compress.c:317-318 */
 	if (ctx->level > 2)
 		return ERROR(compressionParameter_unsupported); /* LZ4HC: not on the device yet */
-	chunk = (size_t)ctx->inputsize;
-	stride = gpumt_lz4_slot_stride(chunk);
-	maxrec = BATCH_MIN / chunk;
-	if (maxrec < 1)
-		maxrec = 1;
+	ctx->io = rdwr;
+	ctx->maxrec = BATCH_MIN / (size_t)ctx->inputsize;
+	if (ctx->maxrec < 1)
+		ctx->maxrec = 1;
 	/* the reference keeps its counters across calls; so do we */
-	while (!eof) {
-		struct cslot *s = &ctx->s[cur];
-		size_t lim = BATCH_BYTES / chunk;
-		if (lim < 1)
-			lim = 1;
-		if (lim > BATCH_MAXREC)
-			lim = BATCH_MAXREC;
-		if (maxrec > lim)
-			maxrec = lim;
-		/* (re)size this slot for the current batch size; it is idle: its previous batch was
-		 * finished two iterations ago */
-		if (dbuf_want(ctx->gpu, &s->in, maxrec * chunk + 512, 1, 1) ||
-		    dbuf_want(ctx->gpu, &s->slots, maxrec * stride, 0, 1) ||
-		    dbuf_want(ctx->gpu, &s->stream, maxrec * stride + 512, 1, 1) ||
-		    dbuf_want(ctx->gpu, &s->meta, maxrec * 12 + 64, 1, 1)) {
-			err = ERROR(memory_allocation);
-			break;
-		}
-		err = c_read_batch(ctx, rdwr, s, maxrec, &eof);
-		if (err)
-			break;
-		if (s->nrec) {
-			err = c_launch(ctx, s);
-			if (err)
-				break;
-		}
-		if (have_prev) {
-			err = c_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
-			have_prev = 0;
-			if (err)
-				break;
-		}
-		if (s->nrec) {
-			have_prev = 1;
-			cur ^= 1;
-		}
-		maxrec *= 4;
-	}
-	if (!err && have_prev)
-		err = c_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
+	err = mt_pipe_run(&ops, ctx);
 	gpumt_device_sync(ctx->gpu);
 	return err;
 }
@@ -281,7 +290,8 @@ struct LZ4MT_DCtx_s {
 	size_t budget; /* output bytes per device batch, grows from BATCH_MIN to BATCH_BYTES */
 	size_t insize, outsize, curframe, frames;
 	gpumt_ctx *gpu;
-	struct dslot s[2];
+	struct dslot s[MT_NSLOT];
+	LZ4MT_RdWr_t *io;
 	/* a record header read ahead of its batch */
 	int have_hdr;
 	uint32_t hdr_csize;
@@ -308,7 +318,7 @@ void LZ4MT_freeDCtx(LZ4MT_DCtx *ctx)
 {
 	if (!ctx)
 		return;
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < MT_NSLOT; i++) {
 		dbuf_free(ctx->gpu, &ctx->s[i].in);
 		dbuf_free(ctx->gpu, &ctx->s[i].meta);
 		dbuf_free(ctx->gpu, &ctx->s[i].status);
@@ -458,11 +468,43 @@ static size_t d_launch(LZ4MT_DCtx *ctx, struct dslot *s)
 	return rc ? ERROR(compression_library) : 0;
 }
 
-static size_t d_finish(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, struct dslot *s)
+static size_t dp_fill(void *a, int si, int *has_data, int *eof)
 {
+	LZ4MT_DCtx *ctx = (LZ4MT_DCtx *)a;
+	struct dslot *s = &ctx->s[si];
+	size_t err;
+	/* input slot sized for the batch budget (compressed data is never larger than that plus
+	 * per-record overhead); the slot is free here */
+	if (dbuf_want(ctx->gpu, &s->in, ctx->budget + (ctx->budget >> 3) + 4096, 1, 1) ||
+	    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1))
+		return ERROR(memory_allocation);
+	err = d_read_batch(ctx, ctx->io, s, eof);
+	*has_data = s->nrec > 0;
+	if (ctx->budget < BATCH_BYTES)
+		ctx->budget *= 4;
+	return err;
+}
+
+static size_t dp_launch(void *a, int si)
+{
+	LZ4MT_DCtx *ctx = (LZ4MT_DCtx *)a;
+	size_t err = d_launch(ctx, &ctx->s[si]);
+	if (!err && gpumt_mark(ctx->gpu, si, 2))
+		err = ERROR(compression_library);
+	return err;
+}
+
+static size_t dp_complete(void *a, int si)
+{
+	LZ4MT_DCtx *ctx = (LZ4MT_DCtx *)a;
+	return gpumt_mark_sync(ctx->gpu, si) ? ERROR(compression_library) : 0;
+}
+
+static size_t dp_drain(void *a, int si)
+{
+	LZ4MT_DCtx *ctx = (LZ4MT_DCtx *)a;
+	struct dslot *s = &ctx->s[si];
 	const uint32_t *st = (const uint32_t *)s->status.h;
-	if (gpumt_stream_sync(ctx->gpu, 2))
-		return ERROR(compression_library);
 	for (size_t i = 0; i < s->nrec; i++) {
 		LZ4MT_Buffer b;
 		int rv;
@@ -479,7 +521,7 @@ static size_t d_finish(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, struct dslot *s)
 		b.buf = (uint8_t *)s->out.h + m_out_off(s, 0)[i];
 		b.size = m_out_len(s, 0)[i];
 		b.allocated = b.size;
-		rv = io->fn_write(io->arg_write, &b);
+		rv = ctx->io->fn_write(ctx->io->arg_write, &b);
 		if (rv != 0)
 			return mt_error(rv);
 		ctx->outsize += b.size;
@@ -490,14 +532,15 @@ static size_t d_finish(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, struct dslot *s)
 
 size_t LZ4MT_decompressDCtx(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *rdwr)
 {
+	static const mt_pipe_ops ops = {dp_fill, dp_launch, dp_complete, dp_drain};
 	uint8_t magic[4];
 	LZ4MT_Buffer b;
-	size_t err = 0;
-	int rv, eof = 0, cur = 0, have_prev = 0;
+	size_t err;
+	int rv;
 
 	if (!ctx)
 		return ERROR(compressionParameter_unsupported); /* lz4-mt_decompress.c:493-494 */
-	/* sniff: 4 bytes (lz4-mt_decompress.c:503-520) */
+	/* sniff: 4 bytes (lz4-mt_decompress.c:503-520), on the calling thread */
 	b.buf = magic;
 	b.size = 4;
 	b.allocated = 4;
@@ -513,40 +556,10 @@ size_t LZ4MT_decompressDCtx(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *rdwr)
 		 * not on the device path yet -- see INTEGRATION.md */
 		return ERROR(frame_decompress);
 	}
+	ctx->io = rdwr;
 	ctx->have_hdr = 0;
 	ctx->budget = BATCH_MIN;
-	while (!eof) {
-		struct dslot *s = &ctx->s[cur];
-		/* input slot sized for the batch budget (compressed data is never larger than that plus
-		 * per-record overhead); the slot is idle here */
-		if (dbuf_want(ctx->gpu, &s->in, ctx->budget + (ctx->budget >> 3) + 4096, 1, 1) ||
-		    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1)) {
-			err = ERROR(memory_allocation);
-			break;
-		}
-		err = d_read_batch(ctx, rdwr, s, &eof);
-		if (err)
-			break;
-		if (s->nrec) {
-			err = d_launch(ctx, s);
-			if (err)
-				break;
-		}
-		if (have_prev) {
-			err = d_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
-			have_prev = 0;
-			if (err)
-				break;
-		}
-		if (s->nrec) {
-			have_prev = 1;
-			cur ^= 1;
-		}
-		if (ctx->budget < BATCH_BYTES)
-			ctx->budget *= 4;
-	}
-	if (!err && have_prev)
-		err = d_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
+	err = mt_pipe_run(&ops, ctx);
 	gpumt_device_sync(ctx->gpu);
 	return err;
 }

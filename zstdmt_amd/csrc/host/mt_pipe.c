@@ -1,0 +1,179 @@
+/* mt_pipe.c -- see mt_pipe.h */
+#include "mt_pipe.h"
+
+#include <pthread.h>
+
+enum { S_FREE, S_FILLED, S_DONE };
+
+typedef struct {
+	const mt_pipe_ops *ops;
+	void *arg;
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+	int state[MT_NSLOT];
+	size_t err;        /* first error, sticky */
+	long n_filled;     /* batches the reader has produced */
+	long n_done;       /* batches whose results are in host memory */
+	int reader_over;   /* the reader will produce no further batch */
+	int device_over;   /* the device role will complete no further batch */
+} pipe_t;
+
+static void fail(pipe_t *p, size_t err)
+{
+	pthread_mutex_lock(&p->mu);
+	if (!p->err)
+		p->err = err;
+	pthread_cond_broadcast(&p->cv);
+	pthread_mutex_unlock(&p->mu);
+}
+
+static void *reader_main(void *a)
+{
+	pipe_t *p = (pipe_t *)a;
+	for (long b = 0;; b++) {
+		const int s = (int)(b % MT_NSLOT);
+		int has_data = 0, eof = 0;
+		size_t err;
+		pthread_mutex_lock(&p->mu);
+		while (p->state[s] != S_FREE && !p->err)
+			pthread_cond_wait(&p->cv, &p->mu);
+		err = p->err;
+		pthread_mutex_unlock(&p->mu);
+		if (err)
+			break;
+		err = p->ops->fill(p->arg, s, &has_data, &eof);
+		if (err) {
+			fail(p, err);
+			break;
+		}
+		pthread_mutex_lock(&p->mu);
+		if (has_data) {
+			p->state[s] = S_FILLED;
+			p->n_filled++;
+		}
+		if (eof || !has_data)
+			p->reader_over = 1;
+		pthread_cond_broadcast(&p->cv);
+		pthread_mutex_unlock(&p->mu);
+		if (eof || !has_data)
+			break;
+	}
+	pthread_mutex_lock(&p->mu);
+	p->reader_over = 1;
+	pthread_cond_broadcast(&p->cv);
+	pthread_mutex_unlock(&p->mu);
+	return NULL;
+}
+
+static void *writer_main(void *a)
+{
+	pipe_t *p = (pipe_t *)a;
+	for (long b = 0;; b++) {
+		const int s = (int)(b % MT_NSLOT);
+		size_t err;
+		int stop;
+		pthread_mutex_lock(&p->mu);
+		while (p->state[s] != S_DONE && !p->err && !(p->device_over && b >= p->n_done))
+			pthread_cond_wait(&p->cv, &p->mu);
+		stop = p->err || p->state[s] != S_DONE;
+		pthread_mutex_unlock(&p->mu);
+		if (stop)
+			break;
+		err = p->ops->drain(p->arg, s);
+		if (err) {
+			fail(p, err);
+			break;
+		}
+		pthread_mutex_lock(&p->mu);
+		p->state[s] = S_FREE;
+		pthread_cond_broadcast(&p->cv);
+		pthread_mutex_unlock(&p->mu);
+	}
+	return NULL;
+}
+
+/* wait until the slot is done being filled; 1 = go, 0 = no more batches / error */
+static int wait_filled(pipe_t *p, long b)
+{
+	const int s = (int)(b % MT_NSLOT);
+	int go;
+	pthread_mutex_lock(&p->mu);
+	while (!(p->state[s] == S_FILLED && b < p->n_filled) && !p->err && !(p->reader_over && b >= p->n_filled))
+		pthread_cond_wait(&p->cv, &p->mu);
+	go = !p->err && p->state[s] == S_FILLED && b < p->n_filled;
+	pthread_mutex_unlock(&p->mu);
+	return go;
+}
+
+static void mark_done(pipe_t *p, long b)
+{
+	pthread_mutex_lock(&p->mu);
+	p->state[b % MT_NSLOT] = S_DONE;
+	p->n_done = b + 1;
+	pthread_cond_broadcast(&p->cv);
+	pthread_mutex_unlock(&p->mu);
+}
+
+size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
+{
+	pipe_t p;
+	pthread_t rt, wt;
+	long b = 0, pending = -1; /* pending: launched, not yet completed */
+	size_t err;
+
+	p.ops = ops;
+	p.arg = arg;
+	p.err = 0;
+	p.n_filled = p.n_done = 0;
+	p.reader_over = p.device_over = 0;
+	for (int i = 0; i < MT_NSLOT; i++)
+		p.state[i] = S_FREE;
+	pthread_mutex_init(&p.mu, NULL);
+	pthread_cond_init(&p.cv, NULL);
+	if (pthread_create(&rt, NULL, reader_main, &p)) {
+		pthread_cond_destroy(&p.cv);
+		pthread_mutex_destroy(&p.mu);
+		return (size_t)-1; /* memory_allocation in every codec's enum */
+	}
+	if (pthread_create(&wt, NULL, writer_main, &p)) {
+		fail(&p, (size_t)-1);
+		pthread_join(rt, NULL);
+		pthread_cond_destroy(&p.cv);
+		pthread_mutex_destroy(&p.mu);
+		return (size_t)-1;
+	}
+	/* device role on the calling thread: launch b, then complete b-1, so that two batches are in
+	 * flight on the device */
+	for (;;) {
+		const int go = wait_filled(&p, b);
+		if (go) {
+			err = ops->launch(arg, (int)(b % MT_NSLOT));
+			if (err) {
+				fail(&p, err);
+				break;
+			}
+		}
+		if (pending >= 0) {
+			err = ops->complete(arg, (int)(pending % MT_NSLOT));
+			if (err) {
+				fail(&p, err);
+				break;
+			}
+			mark_done(&p, pending);
+			pending = -1;
+		}
+		if (!go)
+			break;
+		pending = b++;
+	}
+	pthread_mutex_lock(&p.mu);
+	p.device_over = 1;
+	pthread_cond_broadcast(&p.cv);
+	pthread_mutex_unlock(&p.mu);
+	pthread_join(rt, NULL);
+	pthread_join(wt, NULL);
+	err = p.err;
+	pthread_cond_destroy(&p.cv);
+	pthread_mutex_destroy(&p.mu);
+	return err;
+}

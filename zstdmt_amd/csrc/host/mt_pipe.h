@@ -1,0 +1,36 @@
+/*
+ * mt_pipe.h -- the three-role batch pipeline shared by the host engines.
+ *
+ * The reference runs T worker threads that each read a chunk, code it and write it
+ * (lib/lz4-mt_compress.c:207-310); callbacks come from library threads, never two reads or two
+ * writes at a time, but a read and a write may overlap (SURVEY.md 8b "Threading").  Here the work
+ * moves in device batches through three roles on three threads:
+ *
+ *     reader thread : fill(slot)      fn_read into the slot's pinned input
+ *     calling thread: launch(slot)    H2D + kernels + D2H, asynchronous
+ *                     complete(slot)  wait until the slot's results are in pinned memory
+ *     writer thread : drain(slot)     fn_write from the slot's pinned output, in order
+ *
+ * over MT_NSLOT slots, so reading batch b+1, the device work of batches b and b-1 and writing batch
+ * b-2 all overlap.  Order is positional (batch b lives in slot b % MT_NSLOT); the first error stops
+ * all roles and is returned.
+ */
+#ifndef ZMT_MT_PIPE_H
+#define ZMT_MT_PIPE_H
+
+#include <stddef.h>
+
+#define MT_NSLOT 4
+
+typedef struct {
+	/* fill: *has_data = 0 when the input ended before anything was read into the slot; *eof = 1
+	 * when no further batch follows this one.  All return 0 or a library error code. */
+	size_t (*fill)(void *arg, int slot, int *has_data, int *eof);
+	size_t (*launch)(void *arg, int slot);
+	size_t (*complete)(void *arg, int slot);
+	size_t (*drain)(void *arg, int slot);
+} mt_pipe_ops;
+
+size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg);
+
+#endif

@@ -14,6 +14,7 @@
  * Plain C, no HIP header.
  */
 #include "mt_host.h"
+#include "mt_pipe.h"
 #include "zstd-mt.h"
 
 size_t zstdmt_errcode;
@@ -110,9 +111,11 @@ struct cslot {
 
 struct ZSTDCB_CCtx_s {
 	int level, threads, inputsize;
-	size_t insize, outsize, curframe, frames;
+	size_t insize, outsize, curframe, frames; /* insize / frames: reader; outsize / curframe: writer */
 	gpumt_ctx *gpu;
-	struct cslot s[2];
+	struct cslot s[MT_NSLOT];
+	ZSTDCB_RdWr_t *io;
+	size_t maxrec;
 };
 
 ZSTDCB_CCtx *ZSTDCB_createCCtx(int threads, int level, int inputsize)
@@ -145,7 +148,7 @@ void ZSTDCB_freeCCtx(ZSTDCB_CCtx *ctx)
 {
 	if (!ctx)
 		return;
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < MT_NSLOT; i++) {
 		dbuf_free(ctx->gpu, &ctx->s[i].in);
 		dbuf_free(ctx->gpu, &ctx->s[i].slots);
 		dbuf_free(ctx->gpu, &ctx->s[i].stream);
@@ -210,26 +213,69 @@ static size_t c_launch(ZSTDCB_CCtx *ctx, struct cslot *s)
 	return rc ? ZSTDCB_ERROR(compression_library) : 0;
 }
 
-static size_t c_finish(ZSTDCB_CCtx *ctx, ZSTDCB_RdWr_t *io, struct cslot *s)
+/* ---- the three roles (mt_pipe.h) ---- */
+static size_t cp_fill(void *a, int si, int *has_data, int *eof)
 {
+	ZSTDCB_CCtx *ctx = (ZSTDCB_CCtx *)a;
+	struct cslot *s = &ctx->s[si];
+	const size_t chunk = (size_t)ctx->inputsize, stride = gpumt_zstd_slot_stride(chunk);
+	size_t lim = BATCH_BYTES / chunk, err;
+	if (lim < 1)
+		lim = 1;
+	if (lim > BATCH_MAXREC)
+		lim = BATCH_MAXREC;
+	if (ctx->maxrec > lim)
+		ctx->maxrec = lim;
+	if (dbuf_want(ctx->gpu, &s->in, ctx->maxrec * chunk + 512, 1, 1) ||
+	    dbuf_want(ctx->gpu, &s->slots, ctx->maxrec * stride, 0, 1) ||
+	    dbuf_want(ctx->gpu, &s->stream, ctx->maxrec * stride + 512, 1, 1) ||
+	    dbuf_want(ctx->gpu, &s->meta, ctx->maxrec * 12 + 64, 1, 1))
+		return ZSTDCB_ERROR(memory_allocation);
+	err = c_read_batch(ctx, ctx->io, s, ctx->maxrec, eof);
+	*has_data = s->nrec > 0;
+	ctx->maxrec *= 4;
+	return err;
+}
+
+static size_t cp_launch(void *a, int si)
+{
+	ZSTDCB_CCtx *ctx = (ZSTDCB_CCtx *)a;
+	size_t err = c_launch(ctx, &ctx->s[si]);
+	if (!err && gpumt_mark(ctx->gpu, si, 2))
+		err = ZSTDCB_ERROR(compression_library);
+	return err;
+}
+
+static size_t cp_complete(void *a, int si)
+{
+	ZSTDCB_CCtx *ctx = (ZSTDCB_CCtx *)a;
+	struct cslot *s = &ctx->s[si];
 	gpumt_ctx *g = ctx->gpu;
-	const uint32_t *len = (const uint32_t *)s->meta.h;
 	const uint64_t *off = (const uint64_t *)((const uint8_t *)s->meta.h + ((s->nrec * 4 + 15) & ~(size_t)15));
 	size_t total;
-	if (gpumt_stream_sync(g, 2))
+	if (gpumt_mark_sync(g, si))
 		return ZSTDCB_ERROR(compression_library);
 	total = (size_t)off[s->nrec];
 	if (total > s->stream.cap)
 		return ZSTDCB_ERROR(frame_compress);
-	if (gpumt_memcpy_d2h(g, s->stream.h, s->stream.d, total, 2) || gpumt_stream_sync(g, 2))
+	if (gpumt_memcpy_d2h(g, s->stream.h, s->stream.d, total, 3) || gpumt_stream_sync(g, 3))
 		return ZSTDCB_ERROR(compression_library);
+	return 0;
+}
+
+static size_t cp_drain(void *a, int si)
+{
+	ZSTDCB_CCtx *ctx = (ZSTDCB_CCtx *)a;
+	struct cslot *s = &ctx->s[si];
+	const uint32_t *len = (const uint32_t *)s->meta.h;
+	const uint64_t *off = (const uint64_t *)((const uint8_t *)s->meta.h + ((s->nrec * 4 + 15) & ~(size_t)15));
 	for (size_t i = 0; i < s->nrec; i++) { /* pt_write: strictly in frame order */
 		ZSTDCB_Buffer b;
 		int rv;
 		b.buf = (uint8_t *)s->stream.h + off[i];
 		b.size = len[i];
 		b.allocated = len[i];
-		rv = io->fn_write(io->arg_write, &b);
+		rv = ctx->io->fn_write(ctx->io->arg_write, &b);
 		if (rv != 0)
 			return mt_error(rv);
 		ctx->outsize += len[i];
@@ -240,57 +286,19 @@ static size_t c_finish(ZSTDCB_CCtx *ctx, ZSTDCB_RdWr_t *io, struct cslot *s)
 
 size_t ZSTDCB_compressCCtx(ZSTDCB_CCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 {
-	size_t chunk, stride, maxrec, err = 0;
-	int eof = 0, cur = 0, have_prev = 0;
+	static const mt_pipe_ops ops = {cp_fill, cp_launch, cp_complete, cp_drain};
+	size_t err;
 
 	if (!ctx)
 		return ZSTDCB_ERROR(init_missing); /* zstd-mt_compress.c:327-328 */
-	chunk = (size_t)ctx->inputsize;
-	stride = gpumt_zstd_slot_stride(chunk);
 	/* counters restart with every call (zstd-mt_compress.c:337-341) */
 	ctx->insize = ctx->outsize = ctx->frames = ctx->curframe = 0;
 	zstdmt_errcode = 0;
-	maxrec = BATCH_MIN / chunk;
-	if (maxrec < 1)
-		maxrec = 1;
-	while (!eof) {
-		struct cslot *s = &ctx->s[cur];
-		size_t lim = BATCH_BYTES / chunk;
-		if (lim < 1)
-			lim = 1;
-		if (lim > BATCH_MAXREC)
-			lim = BATCH_MAXREC;
-		if (maxrec > lim)
-			maxrec = lim;
-		if (dbuf_want(ctx->gpu, &s->in, maxrec * chunk + 512, 1, 1) ||
-		    dbuf_want(ctx->gpu, &s->slots, maxrec * stride, 0, 1) ||
-		    dbuf_want(ctx->gpu, &s->stream, maxrec * stride + 512, 1, 1) ||
-		    dbuf_want(ctx->gpu, &s->meta, maxrec * 12 + 64, 1, 1)) {
-			err = ZSTDCB_ERROR(memory_allocation);
-			break;
-		}
-		err = c_read_batch(ctx, rdwr, s, maxrec, &eof);
-		if (err)
-			break;
-		if (s->nrec) {
-			err = c_launch(ctx, s);
-			if (err)
-				break;
-		}
-		if (have_prev) {
-			err = c_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
-			have_prev = 0;
-			if (err)
-				break;
-		}
-		if (s->nrec) {
-			have_prev = 1;
-			cur ^= 1;
-		}
-		maxrec *= 4;
-	}
-	if (!err && have_prev)
-		err = c_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
+	ctx->io = rdwr;
+	ctx->maxrec = BATCH_MIN / (size_t)ctx->inputsize;
+	if (ctx->maxrec < 1)
+		ctx->maxrec = 1;
+	err = mt_pipe_run(&ops, ctx);
 	gpumt_device_sync(ctx->gpu);
 	return err;
 }
@@ -309,7 +317,8 @@ struct ZSTDCB_DCtx_s {
 	size_t budget;
 	size_t insize, outsize, curframe, frames;
 	gpumt_ctx *gpu;
-	struct dslot s[2];
+	struct dslot s[MT_NSLOT];
+	ZSTDCB_RdWr_t *io;
 	int have_hdr; /* a record header read ahead of its batch */
 	uint32_t hdr_csize;
 	uint8_t first4[4]; /* first record: the 4 frame bytes that came with the sniff */
@@ -337,7 +346,7 @@ void ZSTDCB_freeDCtx(ZSTDCB_DCtx *ctx)
 {
 	if (!ctx)
 		return;
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < MT_NSLOT; i++) {
 		dbuf_free(ctx->gpu, &ctx->s[i].in);
 		dbuf_free(ctx->gpu, &ctx->s[i].meta);
 		dbuf_free(ctx->gpu, &ctx->s[i].status);
@@ -479,11 +488,41 @@ static size_t d_launch(ZSTDCB_DCtx *ctx, struct dslot *s)
 	return rc ? ZSTDCB_ERROR(compression_library) : 0;
 }
 
-static size_t d_finish(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s)
+static size_t dp_fill(void *a, int si, int *has_data, int *eof)
 {
+	ZSTDCB_DCtx *ctx = (ZSTDCB_DCtx *)a;
+	struct dslot *s = &ctx->s[si];
+	size_t err;
+	if (dbuf_want(ctx->gpu, &s->in, ctx->budget + (ctx->budget >> 3) + 4096, 1, 1) ||
+	    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1))
+		return ZSTDCB_ERROR(memory_allocation);
+	err = d_read_batch(ctx, ctx->io, s, eof);
+	*has_data = s->nrec > 0;
+	if (ctx->budget < BATCH_BYTES)
+		ctx->budget *= 4;
+	return err;
+}
+
+static size_t dp_launch(void *a, int si)
+{
+	ZSTDCB_DCtx *ctx = (ZSTDCB_DCtx *)a;
+	size_t err = d_launch(ctx, &ctx->s[si]);
+	if (!err && gpumt_mark(ctx->gpu, si, 2))
+		err = ZSTDCB_ERROR(compression_library);
+	return err;
+}
+
+static size_t dp_complete(void *a, int si)
+{
+	ZSTDCB_DCtx *ctx = (ZSTDCB_DCtx *)a;
+	return gpumt_mark_sync(ctx->gpu, si) ? ZSTDCB_ERROR(compression_library) : 0;
+}
+
+static size_t dp_drain(void *a, int si)
+{
+	ZSTDCB_DCtx *ctx = (ZSTDCB_DCtx *)a;
+	struct dslot *s = &ctx->s[si];
 	const uint32_t *st = (const uint32_t *)s->status.h;
-	if (gpumt_stream_sync(ctx->gpu, 2))
-		return ZSTDCB_ERROR(compression_library);
 	for (size_t i = 0; i < s->nrec; i++) {
 		ZSTDCB_Buffer b;
 		int rv;
@@ -495,7 +534,7 @@ static size_t d_finish(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s)
 		b.buf = (uint8_t *)s->out.h + m_out_off(s, 0)[i];
 		b.size = m_out_len(s, 0)[i];
 		b.allocated = b.size;
-		rv = io->fn_write(io->arg_write, &b);
+		rv = ctx->io->fn_write(ctx->io->arg_write, &b);
 		if (rv != 0)
 			return mt_error(rv);
 		ctx->outsize += b.size;
@@ -508,8 +547,9 @@ size_t ZSTDCB_decompressDCtx(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 {
 	uint8_t sniff[16];
 	ZSTDCB_Buffer b;
-	size_t err = 0;
-	int rv, eof = 0, cur = 0, have_prev = 0;
+	static const mt_pipe_ops ops = {dp_fill, dp_launch, dp_complete, dp_drain};
+	size_t err;
+	int rv;
 
 	if (!ctx)
 		return ZSTDCB_ERROR(compressionParameter_unsupported); /* zstd-mt_decompress.c:703-704 */
@@ -539,36 +579,8 @@ size_t ZSTDCB_decompressDCtx(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 	memcpy(ctx->first4, sniff + 12, 4);
 	ctx->have_first4 = 1;
 	ctx->budget = BATCH_MIN;
-	while (!eof) {
-		struct dslot *s = &ctx->s[cur];
-		if (dbuf_want(ctx->gpu, &s->in, ctx->budget + (ctx->budget >> 3) + 4096, 1, 1) ||
-		    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1)) {
-			err = ZSTDCB_ERROR(memory_allocation);
-			break;
-		}
-		err = d_read_batch(ctx, rdwr, s, &eof);
-		if (err)
-			break;
-		if (s->nrec) {
-			err = d_launch(ctx, s);
-			if (err)
-				break;
-		}
-		if (have_prev) {
-			err = d_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
-			have_prev = 0;
-			if (err)
-				break;
-		}
-		if (s->nrec) {
-			have_prev = 1;
-			cur ^= 1;
-		}
-		if (ctx->budget < BATCH_BYTES)
-			ctx->budget *= 4;
-	}
-	if (!err && have_prev)
-		err = d_finish(ctx, rdwr, &ctx->s[cur ^ 1]);
+	ctx->io = rdwr;
+	err = mt_pipe_run(&ops, ctx);
 	gpumt_device_sync(ctx->gpu);
 	return err;
 }
