@@ -33,8 +33,7 @@ struct ZLds {
 	u32 ll[512], of[256], ml[512]; /* sym | nbits << 8 | base << 16 */
 	u8 below[16];   /* stage[-16..0): 8-byte reads may start below the window */
 	u8 stage[Z_STAGE + 16];
-	u32 sq_ll[64], sq_ml[64], sq_off[64]; /* one batch of sequences: extra bits, then values */
-	u8 sc_ll[64], sc_ml[64], sc_of[64];   /* their codes */
+	u64 sq[3][64]; /* one batch of sequences, per LL / OF / ML: extra bits | code << 32 */
 	u8 w[256];
 	short norm[3][64];
 	u16 next[3][64];
@@ -355,9 +354,19 @@ static __device__ void huf_fill(u16 *huf, const u8 *w, int nw, int log, int lane
 static __device__ __forceinline__ void g_copy(u8 *d, const u8 *s, u32 len)
 {
 	if (len >= 8) {
-		for (u32 i = 0; i + 8 < len; i += 8)
-			st64g(d + i, ld64u(s + i));
-		st64g(d + len - 8, ld64u(s + len - 8));
+		/* ends first: two loads cover up to 16 bytes, four up to 32 -- all issued before the
+		 * first store, so the common lengths cost one memory round trip; the middle of longer
+		 * runs (rare: Z_CAP is 64) goes piece by piece */
+		const u64 a = ld64u(s), b = ld64u(s + len - 8);
+		if (len > 16) {
+			const u64 c = ld64u(s + 8), e = ld64u(s + len - 16);
+			st64g(d + 8, c);
+			st64g(d + len - 16, e);
+			for (u32 i = 16; i + 16 < len; i += 8)
+				st64g(d + i, ld64u(s + i));
+		}
+		st64g(d, a);
+		st64g(d + len - 8, b);
 	} else if (len >= 4) {
 		const u32 a = ld32u(s), b = ld32u(s + len - 4);
 		st32u(d, a);
@@ -626,7 +635,7 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 					/* tree description: at most 1 + 128 bytes, inside the staged 256 */
 					u32 avail = csz < 256 - hl ? csz : 256 - hl;
 					int nw = 0, lg = 0;
-					const int used = huf_read_weights(d + hl, avail, L.w, &nw, &lg, L.sq_ll,
+					const int used = huf_read_weights(d + hl, avail, L.w, &nw, &lg, (u32 *)L.sq[0],
 									  L.norm[0], L.next[0]);
 					if (used < 0) {
 						err = 1;
@@ -747,35 +756,49 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 						const u32 todo = s_n - done < 128 ? s_n - done : 128;
 						u8 *dst = lit_scratch + s_dst + done;
 						const int lg = huf_log;
-						u64 c = 0, acc = 0;
-						int cb = 0;
-						for (u32 i = 0; i < todo; i++) {
-							if (cb < lg) {
-								/* refill: the 8 bytes whose top byte holds bit pos-1 */
-								const long tb = (pos - 1) >> 3;
-								const u64 word = ld64u(win + (tb - 7 - wlo));
-								cb = (int)(pos - 8 * (tb - 7));
-								c = cb >= 64 ? word : word & ((1ull << cb) - 1);
+						const u32 hm = (1u << lg) - 1;
+						int ipos = (int)pos; /* a stream holds < 2^21 bits */
+						const int iwlo = (int)wlo;
+						u32 i = 0;
+						/* eight symbols per store; the container is refilled before every four
+						 * (>= 57 fresh bits cover 4 x 11), so the symbol steps carry no branch */
+						for (; i + 8 <= todo && ipos >= 0; i += 8) {
+							u64 acc = 0;
+							ZMT_UNROLL
+							for (int hlf = 0; hlf < 2; hlf++) {
+								const int tb = (ipos - 1) >> 3;
+								const u64 word = ld64u(win + (tb - 7 - iwlo));
+								int cb = ipos - 8 * (tb - 7);
+								ZMT_UNROLL
+								for (int k = 0; k < 4; k++) {
+									const u32 e = L.huf[(u32)(word >> (cb - lg)) & hm];
+									cb -= (int)(e >> 8);
+									acc |= (u64)(e & 255) << (8 * (4 * hlf + k));
+								}
+								ipos = cb + 8 * (tb - 7);
 							}
-							const u32 e = L.huf[(u32)(c >> (cb - lg)) & ((1u << lg) - 1)];
-							const int nb = (int)(e >> 8);
-							cb -= nb;
-							pos -= nb;
-							acc |= (u64)(e & 255) << (8 * (i & 7));
-							if ((i & 7) == 7) {
-								st64g(dst + (i & ~7u), acc);
-								acc = 0;
-							}
-							if (nb == 0 || pos < 0) {
-								bad = true;
-								break;
+							st64g(dst + i, acc);
+						}
+						/* tail: fewer than eight symbols left in this round */
+						{
+							u64 c = 0;
+							int cb = 0;
+							for (; i < todo && ipos >= 0; i++) {
+								if (cb < lg) {
+									const int tb = (ipos - 1) >> 3;
+									c = ld64u(win + (tb - 7 - iwlo));
+									cb = ipos - 8 * (tb - 7);
+								}
+								const u32 e = L.huf[(u32)(c >> (cb - lg)) & hm];
+								const int nb = (int)(e >> 8);
+								cb -= nb;
+								ipos -= nb;
+								dst[i] = (u8)e;
 							}
 						}
-						if (!bad && (todo & 7)) {
-							const u32 b0 = todo & ~7u;
-							for (u32 k = b0; k < todo; k++)
-								dst[k] = (u8)(acc >> (8 * (k - b0)));
-						}
+						if (ipos < 0)
+							bad = true; /* ran past the first bit of the stream */
+						pos = ipos;
 						done += todo;
 						if (!bad && done == s_n && pos != 0)
 							bad = true;
@@ -910,8 +933,11 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 				 * its state's cell and the same 128-bit window of the bitstream, the six field
 				 * widths are exchanged through SGPRs, each lane cuts its two fields out */
 				const u32 *mytab = lane == 1 ? L.of : lane == 2 ? L.ml : L.ll;
-				u32 *myval = lane == 1 ? L.sq_off : lane == 2 ? L.sq_ml : L.sq_ll;
-				u8 *mycode = lane == 1 ? L.sc_of : lane == 2 ? L.sc_ml : L.sc_ll;
+				u64 *myval = L.sq[lane < 3 ? lane : 0];
+				/* where a lane's two fields start, as masks over the widths of the others: the
+				 * stream order is OF extra, ML extra, LL extra, LL state, ML state, OF state */
+				const u32 e_of = lane == 1 ? 0u : ~0u, e_ml = lane == 0 ? ~0u : 0u;
+				const u32 s_ll = lane == 0 ? 0u : ~0u, s_ml = lane == 1 ? ~0u : 0u;
 				u32 state = 0;
 				for (u32 sbase = 0; sbase < nseq && stc == ST_OK; sbase += 64) {
 					const u32 k = nseq - sbase < 64 ? nseq - sbase : 64;
@@ -935,37 +961,33 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 							      (u32)(lane < 3 ? my_tab_log : 0));
 						pos -= ll_log + of_log + ml_log;
 					}
+					int bp = (int)pos; /* a sequences bitstream holds < 2^21 bits */
+					const u8 *winb = win - 15;
 					for (u32 i = 0; i < k; i++) {
-						/* pos == 0 is legal here: the last sequence may need no bits at all; pos < 0
-						 * is caught below, the reads then come from the slack below the window.
-						 * Both LDS reads of the step are issued together: one round trip. */
-						const long tb = (pos - 1) >> 3;
-						const u8 *wp = win + (pos >= 0 ? tb : 0);
-						const u64 w1 = ld64u(wp - 15), w0 = ld64u(wp - 7);
-						const u32 cell = mytab[lane < 3 ? state : 0];
-						if (pos < 0) {
-							err = true;
-							break;
-						}
-						const u32 skip = (u32)(8 * (tb + 1) - pos);
-						const bool lastseq = sbase + i + 1 == nseq;
-						const u32 nb = lastseq ? 0u : ZC_NB(cell), ab = ZC_AB(cell);
+						/* bp == 0 is legal here: the last sequence may need no bits at all; a
+						 * negative bp is caught after the loop (the reads then come from the
+						 * slack below the window).  Both LDS reads of the step are issued
+						 * together: one round trip per sequence. */
+						const int tb = (bp - 1) >> 3;
+						const u64 w1 = ld64u(winb + tb), w0 = ld64u(winb + tb + 8);
+						const u32 cell = mytab[state];
+						const u32 skip = (u32)(8 * (tb + 1) - bp);
+						const u32 nb = sbase + i + 1 == nseq ? 0u : ZC_NB(cell), ab = ZC_AB(cell);
 						const u32 pk = ab | nb << 8;
 						const u32 p_ll = wv_readlane(pk, 0), p_of = wv_readlane(pk, 1), p_ml = wv_readlane(pk, 2);
 						const u32 a_ll = p_ll & 255, n_ll = p_ll >> 8, a_of = p_of & 255, n_of = p_of >> 8;
 						const u32 a_ml = p_ml & 255, n_ml = p_ml >> 8;
 						const u32 base3 = skip + a_of + a_ml + a_ll;
-						const u32 eo = lane == 0 ? skip + a_of + a_ml : lane == 1 ? skip : skip + a_of;
-						const u32 so = base3 + (lane == 0 ? 0u : lane == 1 ? n_ll + n_ml : n_ll);
+						const u32 eo = skip + (a_of & e_of) + (a_ml & e_ml);
+						const u32 so = base3 + (n_ll & s_ll) + (n_ml & s_ml);
 						const u32 extra = xbits(w0, w1, eo, ab);
 						const u32 sbits = xbits(w0, w1, so, nb);
-						if (lane < 3) {
-							myval[i] = extra;
-							mycode[i] = (u8)ZC_SYM(cell);
-						}
-						state = ZC_BASE(cell) + sbits;
-						pos -= (long)(base3 - skip + n_ll + n_ml + n_of);
+						if (lane < 3)
+							myval[i] = (u64)extra | (u64)ZC_SYM(cell) << 32;
+						state = lane < 3 ? ZC_BASE(cell) + sbits : 0;
+						bp -= (int)(base3 - skip + n_ll + n_ml + n_of);
 					}
+					pos = bp;
 					if (err || pos < 0 || (sbase + k == nseq && pos != 0)) {
 						stc = ZBAD();
 						break;
@@ -976,10 +998,11 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 					const bool act0 = (u32)lane < k;
 					u32 ll = 0, ml = 0, ofv = 4;
 					if (act0) {
-						const u32 c_of = L.sc_of[lane];
-						ll = (L.llx[L.sc_ll[lane]] & 0xFFFFFFu) + L.sq_ll[lane];
-						ml = (L.mlx[L.sc_ml[lane]] & 0xFFFFFFu) + L.sq_ml[lane];
-						ofv = c_of > 31 ? 0u : (1u << c_of) + L.sq_off[lane];
+						const u64 q_ll = L.sq[0][lane], q_of = L.sq[1][lane], q_ml = L.sq[2][lane];
+						const u32 c_of = (u32)(q_of >> 32);
+						ll = (L.llx[(u32)(q_ll >> 32)] & 0xFFFFFFu) + (u32)q_ll;
+						ml = (L.mlx[(u32)(q_ml >> 32)] & 0xFFFFFFu) + (u32)q_ml;
+						ofv = c_of > 31 ? 0u : (1u << c_of) + (u32)q_of;
 					}
 					if (wv_any(act0 && ofv == 0)) {
 						stc = ZBAD(); /* offset code > 31 */
