@@ -276,3 +276,37 @@ def lcg(n: int, seed: int) -> bytes:
 
 def sha256(b: bytes) -> str:
     return hashlib.sha256(b).hexdigest()
+
+
+def _cases():
+    from golden import cases
+    return cases
+
+
+def soup(rng, n):
+    """Borderline-compressible soup (runs, periods, noise, text, long-distance repeats, low-entropy
+    bytes incl. values above 128): raw vs Huffman literals, raw vs compressed blocks, long matches."""
+    out = bytearray()
+    while len(out) < n:
+        k = rng.choice([0, 1, 2, 3, 4, 5])
+        m = rng.randrange(1, 9000)
+        if k == 0:
+            out += _cases().rnd(m, rng.randrange(1 << 30))
+        elif k == 1:
+            out += bytes([rng.randrange(256)]) * m
+        elif k == 2:
+            out += _cases().text(m, rng.randrange(1 << 30))
+        elif k == 3:
+            unit = _cases().rnd(rng.randrange(1, 40), rng.randrange(1 << 30))
+            out += (unit * (m // len(unit) + 1))[:m]
+        elif k == 4:
+            back = rng.randrange(1, len(out) + 1) if out else 0
+            if back:
+                start = len(out) - back
+                out += out[start:start + m]
+        else:
+            lo, span = rng.randrange(256), rng.choice([2, 4, 16, 64])
+            out += bytes((lo + (b % span)) & 255 for b in _cases().rnd(m, rng.randrange(1 << 30)))
+    return bytes(out[:n])
+
+

@@ -99,3 +99,22 @@ def test_emu_encode_decompress_identical(name):
         assert rv == 0 and back == data
     # independent of how many persistent waves share the blocks
     assert E.zstd_compress(data, chunk, grid=1) == st
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_emu_fuzz_encode_and_decode(seed):
+    """Structured soup through the emulated encoder, the oracle and the emulated decoder; and, where
+    the reference build is present, reference-written streams of the same data through the decoder."""
+    import random
+    rng = random.Random(3000 + seed)
+    data = H.soup(rng, rng.choice([7, 300, 70000, 140000, rng.randrange(1, 260000)]))
+    chunk = rng.choice([65536, 131072, 1 << 20])
+    st = E.zstd_compress(data, chunk)
+    assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
+    out, status = E.zstd_decompress(st)
+    assert (status == 0).all() and out == data
+    if H.have_zref():
+        rv, rst, _, _ = H.zstdmt_compress_via(H.zref(), data, chunk, threads=2, level=rng.choice([1, 3, 9]))
+        assert rv == 0
+        out, status = E.zstd_decompress(rst)
+        assert (status == 0).all() and out == data

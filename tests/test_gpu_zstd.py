@@ -78,3 +78,35 @@ def test_corrupt_streams_status(eng):
             assert status[0] != 0
         else:
             assert status[0] == 0 and out == want
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_encode_is_decompress_identical(eng, seed):
+    import random
+    rng = random.Random(1000 + seed)
+    n = rng.choice([0, 1, 6, 7, 8, 255, 256, 257, 4095, 4096, 65535, 65536, 131071, 131072, 131073,
+                    200000, rng.randrange(1, 600000), rng.randrange(1, 3000000)])
+    chunk = rng.choice([65536, 131072, 131072, 100000, 262144, 1 << 20])
+    data = H.soup(rng, n)
+    st, ro, rl = eng.compress_bytes(data, chunk, codec="zstd")
+    assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
+    out, status = eng.decompress_bytes(st, ro, rl, codec="zstd")
+    assert (status == 0).all() and out == data
+    if H.have_zref():
+        rv, back, _, _ = H.zstdmt_decompress_via(H.zref(), st, threads=2)
+        assert rv == 0 and back == data
+
+
+@pytest.mark.skipif(not H.have_zref(), reason="reference build not on this box")
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_decode_reference_streams(eng, seed):
+    import random
+    rng = random.Random(2000 + seed)
+    data = H.soup(rng, rng.randrange(1, 2500000))
+    level = rng.choice([1, 1, 2, 3, 5, 8, 13, 19])
+    chunk = rng.choice([0, 65536, 131072, 300000, 1 << 20])
+    rv, st, _, _ = H.zstdmt_compress_via(H.zref(), data, chunk, threads=4, level=level)
+    assert rv == 0
+    ro, rl = E.walk_records(st)
+    out, status = eng.decompress_bytes(st, ro, rl, codec="zstd")
+    assert (status == 0).all() and out == data
