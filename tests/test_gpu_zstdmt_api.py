@@ -195,3 +195,16 @@ def test_roundtrip_many_batches(lib):
     assert rv == 0 and stats[0] == 300
     rv, out, _, dstats = H.zstdmt_decompress_via(lib, st, threads=8)
     assert rv == 0 and out == data and dstats == (300, len(st), len(data))
+
+
+@pytest.mark.skipif(not H.have_zref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name", ["z_hello", "z_text_3x128k", "z_mixed"])
+def test_decompress_old_zstdmt_prefix_layout(lib, name):
+    """Old "zstdmt style" streams (lib/zstd-mt_decompress.c:225-249): a 9-byte empty zstd frame in
+    front of ordinary records.  Same output, requests and counters as the reference."""
+    st = bytes([0x28, 0xB5, 0x2F, 0xFD, 0x20, 0x00, 0x01, 0x00, 0x00]) + _stream(name)
+    rv_r, d_r, io_r, st_r = H.zstdmt_decompress_via(H.zref(), st, threads=2)
+    rv_o, d_o, io_o, st_o = H.zstdmt_decompress_via(lib, st, threads=2)
+    assert rv_r == 0 and len(d_r) == MAN[name]["in_len"]
+    assert (rv_o, d_o, st_o) == (rv_r, d_r, st_r)
+    assert _strip_eof(io_o.reads) == _strip_eof(io_r.reads) and io_o.writes == io_r.writes

@@ -9,8 +9,9 @@
  *   decompress a 16-byte sniff, then csize-4 bytes for the first record, then 12 + csize bytes per
  *              record (:221-353); one fn_write per frame in order.
  * Stream layouts accepted by decompress: the one the compressor writes ("pzstd style": skippable
- * frame first, :251-284).  The legacy layouts (zstd frame first: old zstdmt 9-byte prefix, plain
- * .zst) are SURVEY 8f-2 "next" and report frame_decompress.
+ * frame first, :251-284) and the old "zstdmt style" (a 9-byte empty zstd frame in front, :225-249).
+ * Plain .zst streams (the reference's single-threaded path) are SURVEY 8f-2 "next" and report
+ * frame_decompress.
  * Plain C, no HIP header.
  */
 #include "mt_host.h"
@@ -567,17 +568,35 @@ size_t ZSTDCB_decompressDCtx(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 			return 0; /* the 9-byte empty zstd frame: "create empty file" (:731-736) */
 		return ZSTDCB_ERROR(frame_decompress); /* short plain .zst: single-thread path, 8f-2 */
 	}
-	if (!(rd32(sniff) == ZSTDCB_MAGIC_SKIPPABLE && is_zstd_magic(sniff + 12))) {
-		if (is_zstd_magic(sniff))
-			return ZSTDCB_ERROR(frame_decompress); /* old zstdmt prefix layout / plain .zst: 8f-2 */
-		return ZSTDCB_ERROR(data_error);
-	}
-	/* the sniff is the first record's header + 4 payload bytes (:251-284) */
 	ctx->insize += 16;
 	ctx->have_hdr = 1;
-	ctx->hdr_csize = rd32(sniff + 8);
-	memcpy(ctx->first4, sniff + 12, 4);
-	ctx->have_first4 = 1;
+	if (rd32(sniff) == ZSTDCB_MAGIC_SKIPPABLE && is_zstd_magic(sniff + 12)) {
+		/* "pzstd style", what the compressor writes: the sniff is the first record's header + 4
+		 * payload bytes (:251-284) */
+		ctx->hdr_csize = rd32(sniff + 8);
+		memcpy(ctx->first4, sniff + 12, 4);
+		ctx->have_first4 = 1;
+	} else if (is_zstd_magic(sniff) && rd32(sniff + 9) == ZSTDCB_MAGIC_SKIPPABLE) {
+		/* old "zstdmt style": a 9-byte empty zstd frame, then ordinary records (:225-249).  The
+		 * first header straddles the sniff: 5 more bytes complete it.  (insize: the reference
+		 * counts the sniff twice here, :221 and :239; kept.) */
+		uint8_t tail[5];
+		b.buf = tail;
+		b.size = 5;
+		b.allocated = 5;
+		rv = rdwr->fn_read(rdwr->arg_read, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		if (b.size != 5)
+			return ZSTDCB_ERROR(data_error);
+		ctx->insize += 16 + 5;
+		ctx->hdr_csize = rd32(tail + 1);
+		ctx->have_first4 = 0;
+	} else {
+		if (is_zstd_magic(sniff))
+			return ZSTDCB_ERROR(frame_decompress); /* plain .zst: single-thread path, 8f-2 */
+		return ZSTDCB_ERROR(data_error);
+	}
 	ctx->budget = BATCH_MIN;
 	ctx->io = rdwr;
 	err = mt_pipe_run(&ops, ctx);
