@@ -146,9 +146,9 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
  *
  * gpumt_zstd_decompress_batch: decode the records whose d_status is GPUMT_ST_OK (replaces
  * ZSTD_decompressStream at lib/zstd-mt_decompress.c:464): raw / RLE / compressed blocks, Huffman
- * literals, FSE sequence tables of every mode, repeat offsets; no dictionaries; frames with an
- * XXH64 content checksum report GPUMT_ST_UNSUPPORTED.  Same d_stream slack rule as above.
- * Internal scratch: 128 KiB + 256 B of literals per record.
+ * literals, FSE sequence tables of every mode, repeat offsets, XXH64 content checksum (verified, a
+ * mismatch reports GPUMT_ST_BAD_CHECKSUM); no dictionaries.  Same d_stream slack rule as above.
+ * Internal scratch: 128 KiB + 264 B per record.
  */
 /* Bytes one zstd record slot occupies: room for the record + frame header and one padded area per
  * 128 KiB block (the blocks are compressed independently and then moved together), rounded to 256. */

@@ -310,3 +310,31 @@ def soup(rng, n):
     return bytes(out[:n])
 
 
+
+
+def libzstd_frame(data: bytes, level=1, checksum=0, content_size=1):
+    """One zstd frame written by the image's libzstd with explicit frame parameters (test input
+    generator for frame flavours zstd-mt itself never writes).  None if libzstd is not present."""
+    path = "/opt/conda/lib/libzstd.so.1"
+    if not os.path.exists(path):
+        return None
+    zs = C.CDLL(path)
+    zs.ZSTD_createCCtx.restype = C.c_void_p
+    zs.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    zs.ZSTD_compress2.restype = C.c_size_t
+    zs.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    zs.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+    cctx = zs.ZSTD_createCCtx()
+    zs.ZSTD_CCtx_setParameter(cctx, 100, level)         # ZSTD_c_compressionLevel
+    zs.ZSTD_CCtx_setParameter(cctx, 201, checksum)      # ZSTD_c_checksumFlag
+    zs.ZSTD_CCtx_setParameter(cctx, 200, content_size)  # ZSTD_c_contentSizeFlag
+    dst = C.create_string_buffer(len(data) + len(data) // 64 + 1024)
+    n = zs.ZSTD_compress2(cctx, dst, len(dst), data, len(data))
+    zs.ZSTD_freeCCtx(cctx)
+    return dst.raw[:n]
+
+
+def mt_record(frame: bytes) -> bytes:
+    """12-byte skippable header + frame (lib/zstd-mt_compress.c:296-302)."""
+    import struct
+    return struct.pack("<III", 0x184D2A50, 4, len(frame)) + frame

@@ -118,3 +118,18 @@ def test_emu_fuzz_encode_and_decode(seed):
         assert rv == 0
         out, status = E.zstd_decompress(rst)
         assert (status == 0).all() and out == data
+
+
+def test_emu_checksummed_frames():
+    """Frames with an XXH64 content checksum (zstd CLI flavour): verified on the device path."""
+    data = cases.text(150000, 31)
+    fr = H.libzstd_frame(data, level=3, checksum=1)
+    if fr is None:
+        pytest.skip("libzstd not present")
+    st = H.mt_record(fr) + H.mt_record(H.libzstd_frame(data[:777], 1, 1)) + H.mt_record(H.libzstd_frame(b"", 1, 1))
+    out, status = E.zstd_decompress(st)
+    assert status.tolist() == [0, 0, 0] and out == data + data[:777]
+    bad = bytearray(st)
+    bad[12 + len(fr) - 1] ^= 0x10           # last checksum byte of the first frame
+    out, status = E.zstd_decompress(bytes(bad))
+    assert status.tolist() == [5, 0, 0]     # GPUMT_ST_BAD_CHECKSUM

@@ -110,3 +110,20 @@ def test_fuzz_decode_reference_streams(eng, seed):
     ro, rl = E.walk_records(st)
     out, status = eng.decompress_bytes(st, ro, rl, codec="zstd")
     assert (status == 0).all() and out == data
+
+
+def test_checksummed_frames(eng):
+    """Frames with an XXH64 content checksum (zstd CLI flavour): verified on the device."""
+    data = cases.text(3000000, 31)
+    parts = [data, data[:777], b"", cases.rnd(50000, 4)]
+    frames = [H.libzstd_frame(p, lvl, 1) for p, lvl in zip(parts, (3, 1, 1, 5))]
+    if frames[0] is None:
+        pytest.skip("libzstd not present")
+    st = b"".join(H.mt_record(f) for f in frames)
+    ro, rl = E.walk_records(st)
+    out, status = eng.decompress_bytes(st, ro, rl, codec="zstd")
+    assert status.tolist() == [0, 0, 0, 0] and out == b"".join(parts)
+    bad = bytearray(st)
+    bad[12 + len(frames[0]) - 2] ^= 0x01
+    out, status = eng.decompress_bytes(bytes(bad), ro, rl, codec="zstd")
+    assert status.tolist() == [5, 0, 0, 0]

@@ -38,9 +38,11 @@ __global__ void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, con
 				    const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 				    const u32 *, const u32 *, const u32 *, u32 *);
 __global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-				    const u32 *, u8 *, u32 *);
+				    const u32 *, u8 *, u32 *, u32 *, u32 *);
 __global__ void zmt_zstd_dec_kernel_prof(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-					 const u32 *, u8 *, u32 *, unsigned long long *);
+					 const u32 *, u8 *, u32 *, u32 *, u32 *, unsigned long long *);
+__global__ void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *,
+					u32 *);
 __global__ void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 __global__ void zmt_zstd_enc_kernel_prof(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *, unsigned long long *);
 __global__ void zmt_zstd_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
@@ -680,8 +682,10 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 		return GPUMT_E_ARG;
 	if (use(h))
 		return GPUMT_E_HIP;
-	if (want_scratch(h, 1, nrec * (size_t)(131072 + 256)))
+	const size_t lit_bytes = nrec * (size_t)(131072 + 256);
+	if (want_scratch(h, 1, lit_bytes + nrec * 8 + 64))
 		return GPUMT_E_HIP;
+	u32 *chk_e = (u32 *)((u8 *)h->scratch[1] + lit_bytes), *chk_v = chk_e + nrec;
 	if (h->profile == 5 && !h->d_prof) {
 		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
@@ -690,11 +694,16 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 	if (h->profile == 5)
 		hipLaunchKernelGGL(zmt_zstd_dec_kernel_prof, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
 				   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
-				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status, h->d_prof);
+				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status, chk_e, chk_v,
+				   h->d_prof);
 	else
 		hipLaunchKernelGGL(zmt_zstd_dec_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
 				   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
-				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status);
+				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status, chk_e, chk_v);
+	/* XXH64 content checksums, for the frames that carry one */
+	hipLaunchKernelGGL(zmt_xxh64_verify_kernel, dim3((unsigned)((nrec * 4 + 255) / 256)), dim3(256), 0,
+			   h->st[s], (const u8 *)d_out, d_out_off, d_out_len, (u32)nrec, (const u32 *)chk_e,
+			   (const u32 *)chk_v, d_status);
 	PROF1(11);
 	CK(hipGetLastError());
 	return GPUMT_OK;

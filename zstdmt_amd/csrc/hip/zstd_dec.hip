@@ -451,7 +451,7 @@ static __device__ __forceinline__ void
 zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
 	      const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base, const u64 *__restrict__ out_off,
 	      const u32 *__restrict__ out_len, u8 *__restrict__ litbuf, u32 *__restrict__ status,
-	      unsigned long long *prof)
+	      u32 *__restrict__ chk_expect, u32 *__restrict__ chk_valid, unsigned long long *prof)
 {
 	const int lane = wv_lane();
 	u64 pc[PROF ? 8 : 1] = {0}, tq = ZT();
@@ -464,6 +464,8 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 	const u32 rec = blockIdx.x;
 	if (rec >= nrec)
 		return;
+	if (lane == 0)
+		chk_valid[rec] = 0;
 	if (wv_readfirst(status[rec]) != ST_OK)
 		return; /* rejected by the probe kernel */
 	const u64 roff = rec_off[rec];
@@ -526,12 +528,6 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 		hp += fcs_len;
 		if (single)
 			window = content;
-	}
-	if (has_chk) {
-		/* XXH64 content checksum: valid zstd, never written by zstd-mt (ZSTD_compress, :285) */
-		if (lane == 0)
-			status[rec] = ST_UNSUPPORTED;
-		return;
 	}
 	if (content != ~0ull && content != cap) {
 		if (lane == 0)
@@ -1147,6 +1143,20 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 #endif
 	if (stc == ST_OK && opos != cap)
 		stc = ST_SIZE_MISMATCH;
+	if (stc == ST_OK && has_chk) {
+		/* Content_Checksum: low 32 bits of XXH64 of the content (RFC 8878 3.1.1); compared by
+		 * zmt_xxh64_verify_kernel once the content is complete.  zstd-mt never writes one
+		 * (one-shot ZSTD_compress, lib/zstd-mt_compress.c:285); the zstd CLI does. */
+		if (flen - ip < 4) {
+			stc = ST_BAD_FRAME;
+		} else {
+			if (lane == 0) {
+				chk_expect[rec] = uld32(f + ip);
+				chk_valid[rec] = 1;
+			}
+			ip += 4;
+		}
+	}
 	if (stc == ST_OK && ip != flen)
 		stc = ST_TRAILING;
 	if (lane == 0 && stc != ST_OK)
@@ -1157,11 +1167,12 @@ extern "C" __global__ void __launch_bounds__(64)
 zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
 		    const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
 		    const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
-		    u8 *__restrict__ litbuf, u32 *__restrict__ status)
+		    u8 *__restrict__ litbuf, u32 *__restrict__ status, u32 *__restrict__ chk_expect,
+		    u32 *__restrict__ chk_valid)
 {
 	__shared__ __attribute__((aligned(16))) ZLds L;
 	zstd_dec_body<false>(L, stream, stream_bytes, rec_off, rec_len, nrec, out_base, out_off, out_len, litbuf,
-			     status, nullptr);
+			     status, chk_expect, chk_valid, nullptr);
 }
 
 #ifndef ZMT_EMU
@@ -1170,13 +1181,83 @@ extern "C" __global__ void __launch_bounds__(64)
 zmt_zstd_dec_kernel_prof(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
 			 const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
 			 const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
-			 u8 *__restrict__ litbuf, u32 *__restrict__ status, unsigned long long *prof)
+			 u8 *__restrict__ litbuf, u32 *__restrict__ status, u32 *__restrict__ chk_expect,
+			 u32 *__restrict__ chk_valid, unsigned long long *prof)
 {
 	__shared__ __attribute__((aligned(16))) ZLds L;
 	zstd_dec_body<true>(L, stream, stream_bytes, rec_off, rec_len, nrec, out_base, out_off, out_len, litbuf,
-			    status, prof);
+			    status, chk_expect, chk_valid, prof);
 }
 #endif
+
+/* ------------------------------------------------------------------ XXH64 content checksum
+ * Four lanes per record = the four accumulators of XXH64 (one 32-byte stripe per step); only records
+ * that carry a checksum do any work. */
+#define X64_1 0x9E3779B185EBCA87ull
+#define X64_2 0xC2B2AE3D27D4EB4Full
+#define X64_3 0x165667B19E3779F9ull
+#define X64_4 0x85EBCA77C2B2AE63ull
+#define X64_5 0x27D4EB2F165667C5ull
+static __device__ __forceinline__ u64 rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+static __device__ __forceinline__ u64 x64_round(u64 acc, u64 in) { return rotl64(acc + in * X64_2, 31) * X64_1; }
+static __device__ __forceinline__ u64 x64_merge(u64 h, u64 v) { return (h ^ x64_round(0, v)) * X64_1 + X64_4; }
+static __device__ __forceinline__ u64 shfl64(u64 v, int src)
+{
+	return (u64)wv_shfl((u32)(v >> 32), src) << 32 | wv_shfl((u32)v, src);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+zmt_xxh64_verify_kernel(const u8 *__restrict__ base, const u64 *__restrict__ off,
+			const u32 *__restrict__ len, u32 n, const u32 *__restrict__ expect,
+			const u32 *__restrict__ valid, u32 *__restrict__ status)
+{
+	const u32 gtid = blockIdx.x * 256 + threadIdx.x;
+	const u32 item = gtid >> 2, a = gtid & 3;
+	const int lane = wv_lane();
+	const bool live = item < n && valid[item] && status[item] == ST_OK;
+	const u8 *p = live ? base + off[item] : base;
+	const u32 N = live ? len[item] : 0;
+	u64 v = a == 0 ? X64_1 + X64_2 : a == 1 ? X64_2 : a == 2 ? 0ull : 0ull - X64_1;
+	if (N >= 32) {
+		const u8 *q = p + 8 * a;
+		for (u32 s = 0; s < (N >> 5); s++) {
+			v = x64_round(v, ld64u(q));
+			q += 32;
+		}
+	}
+	/* all four accumulators to lane 0 of the quad (wave-uniform shuffles) */
+	const int q0 = lane & ~3;
+	const u64 v1 = shfl64(v, q0), v2 = shfl64(v, q0 + 1), v3 = shfl64(v, q0 + 2), v4 = shfl64(v, q0 + 3);
+	if (live && a == 0) {
+		u64 h;
+		if (N >= 32) {
+			h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+			h = x64_merge(h, v1);
+			h = x64_merge(h, v2);
+			h = x64_merge(h, v3);
+			h = x64_merge(h, v4);
+		} else {
+			h = X64_5;
+		}
+		h += N;
+		const u8 *t = p + (N & ~31u), *e = p + N;
+		for (; t + 8 <= e; t += 8)
+			h = rotl64(h ^ x64_round(0, ld64u(t)), 27) * X64_1 + X64_4;
+		if (t + 4 <= e) {
+			h = rotl64(h ^ (u64)ld32u(t) * X64_1, 23) * X64_2 + X64_3;
+			t += 4;
+		}
+		for (; t < e; t++)
+			h = rotl64(h ^ (u64)*t * X64_5, 11) * X64_1;
+		h ^= h >> 33;
+		h *= X64_2;
+		h ^= h >> 29;
+		h *= X64_3;
+		h ^= h >> 32;
+		if ((u32)h != expect[item])
+			status[item] = ST_BAD_CHECKSUM;
+	}
+}
 
 /* out_len[i] = Frame_Content_Size of record i (what the host needs before it can size d_out);
  * status[i] = ST_OK, or why the record cannot be decoded here. */
