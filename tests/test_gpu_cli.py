@@ -1,0 +1,99 @@
+"""The command line front ends (programs/zmt_cli.c -> zstdmt_amd/bin/{lz4-mt,zstd-mt}): option
+letters, file handling and -B report lines of the reference CLI (programs/main.c), typed the way
+BASELINE.json writes its configurations."""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+import helpers as H
+from golden import cases
+
+pytestmark = pytest.mark.gpu
+
+BIN = os.path.join(H.ROOT, "zstdmt_amd", "bin")
+LZ4 = os.path.join(BIN, "lz4-mt")
+ZSTD = os.path.join(BIN, "zstd-mt")
+with open(os.path.join(H.GOLDEN_DIR, "manifest.json")) as _f:
+    MAN = json.load(_f)["cases"]
+
+
+def run(args, data=None, check=True):
+    p = subprocess.run(args, input=data, capture_output=True, timeout=300)
+    if check:
+        assert p.returncode == 0, p.stderr.decode()
+    return p
+
+
+def test_lz4_config1_style_invocation(tmp_path):
+    """BASELINE configs[0] as typed (`lz4-mt -1 -T4` on PRNG bytes, default 4 MiB chunks; 16 MiB here
+    -> 4 frames): byte-identical stream, -B statistics lines, in-place file handling."""
+    data = cases.rnd(16 << 20, 7)
+    f = tmp_path / "blob"
+    f.write_bytes(data)
+    p = run([LZ4, "-1", "-T4", "-B", str(f)])
+    out = (tmp_path / "blob.lz4").read_bytes()
+    assert not f.exists()                                   # replaced, like gzip
+    assert out == H.oracle_compress(data, 4 << 20)          # bit-exact with the reference path
+    lines = p.stderr.decode().splitlines()
+    assert lines[0] == "Level;Threads;InSize;OutSize;Frames"
+    assert lines[1] == f"1;4;{len(data)};{len(out)};4"
+    assert lines[2] == "Real;User;Sys;MaxMem" and re.fullmatch(r"\d+\.\d+;\d+\.\d+;\d+\.\d+;\d+", lines[3])
+    run([LZ4, "-d", "-T4", str(tmp_path / "blob.lz4")])
+    assert f.read_bytes() == data and not (tmp_path / "blob.lz4").exists()
+
+
+def test_lz4_pipes_chunk_option_and_golden():
+    name = "text_3x128k_p100"
+    chunk, thunk = cases.CASES[name]
+    assert chunk == 131072
+    data = thunk()
+    # -b takes MiB; 128 KiB chunks need the library default -> use a 1 MiB case for -b, stdin/stdout here
+    p = run([LZ4, "-1", "-T2", "-b", "1", "-c"], data)
+    assert p.stdout == H.oracle_compress(data, 1 << 20)
+    back = run([LZ4, "-d", "-c"], p.stdout)
+    assert back.stdout == data
+    assert run([LZ4, "-t"], p.stdout).returncode == 0
+    bad = bytearray(p.stdout)
+    bad[len(bad) // 2] ^= 0xFF
+    r = run([LZ4, "-t"], bytes(bad), check=False)
+    assert r.returncode == 1 and b"lz4-mt" in r.stderr
+
+
+def test_lz4_levels_above_2_are_reported():
+    r = run([LZ4, "-3", "-c"], b"abc" * 1000, check=False)
+    assert r.returncode == 1 and b"Compression parameter is out of bound" in r.stderr
+
+
+def test_zstd_round_trip_keep_force_suffix(tmp_path):
+    data = cases.text(3 * (1 << 20) + 4321, 12)
+    f = tmp_path / "book.txt"
+    f.write_bytes(data)
+    p = run([ZSTD, "-1", "-T8", "-k", "-B", str(f)])
+    z = tmp_path / "book.txt.zst"
+    assert f.exists() and z.exists()
+    st = z.read_bytes()
+    assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data     # decompress-identical
+    assert p.stderr.decode().splitlines()[1] == f"1;8;{len(data)};{len(st)};4"
+    # refuses to overwrite without -f
+    r = run([ZSTD, "-1", "-k", str(f)], check=False)
+    assert r.returncode == 1 and b"already exists" in r.stderr
+    run([ZSTD, "-1", "-k", "-f", str(f)])
+    f.unlink()
+    run([ZSTD, "-d", str(z)])
+    assert f.read_bytes() == data and not z.exists()
+    # -o and -S
+    run([ZSTD, "-1", "-o", str(tmp_path / "x.bin"), str(f)])
+    assert f.exists()                                       # -o keeps the input
+    assert run([ZSTD, "-d", "-c", str(tmp_path / "x.bin")]).stdout == data
+    if H.have_zref():
+        rv, back, _, _ = H.zstdmt_decompress_via(H.zref(), (tmp_path / "x.bin").read_bytes(), threads=2)
+        assert rv == 0 and back == data
+
+
+def test_bad_arguments():
+    assert run([LZ4, "-T", "500", "-c"], b"x", check=False).returncode == 1
+    assert run([ZSTD, "-23", "-c"], b"x", check=False).returncode == 1
+    assert b"Usage" in run([ZSTD, "-h"]).stdout

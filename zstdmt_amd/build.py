@@ -67,6 +67,20 @@ def build(force=False, verbose=True):
     tsrc = os.path.join(CSRC, "tools", "gen_text.c")
     if force or _stale(tools, [tsrc]):
         _run(["gcc", "-O2", "-fPIC", "-shared", "-pthread", tsrc, "-o", tools, "-lm"])
+    # command line front ends (programs/zmt_cli.c): lz4-mt, zstd-mt + their un* / *cat personalities
+    bindir = os.path.join(HERE, "bin")
+    os.makedirs(bindir, exist_ok=True)
+    cli = os.path.join(ROOT, "programs", "zmt_cli.c")
+    for name, flags, links in (("lz4-mt", [], ("unlz4-mt", "lz4cat-mt")),
+                               ("zstd-mt", ["-DZMT_ZSTD"], ("unzstd-mt", "zstdcat-mt"))):
+        exe = os.path.join(bindir, name)
+        if force or _stale(exe, [cli, lib] + headers):
+            _run(["gcc", "-O2", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include")] + flags +
+                 [cli, "-o", exe, "-L" + LIBDIR, "-lzstdmt_amd", "-Wl,-rpath,$ORIGIN/../lib"])
+        for ln in links:
+            dst = os.path.join(bindir, ln)
+            if not os.path.lexists(dst):
+                os.symlink(name, dst)
     return lib
 
 
