@@ -641,8 +641,11 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 					}
 					ns++;
 					anchor = cursor = pj + ml;
+					/* drop every candidate the match covers in one go */
+					mask = cursor - p0 >= 64 ? 0 : mask & ~((1ull << (cursor - p0)) - 1);
 				}
 			}
+			ZEP(0);
 		}
 		}
 #undef ZE_LOADV
