@@ -15,7 +15,8 @@
  *                            software-pipelined two steps ahead, long matches extended 512 bytes
  *                            per step by the whole wave;
  *     parse                  greedy, leftmost match first, resolved with ballots;
- *     literals               gathered lane-per-run, Huffman-coded in parallel (histogram with LDS
+ *     literals               gathered lane-per-run, one Huffman code per 128 KiB unit (its first block
+ *                            carries the tree, the others are treeless), coded in parallel (histogram with LDS
  *                            atomics, repaired ceil(log2) code lengths, canonical codes by ballots,
  *                            bit packing by prefix sum + atomicOr into LDS), raw when that does not pay;
  *     sequences              the list is cut into up to 16 zstd blocks, FSE-coded with the predefined
@@ -177,10 +178,17 @@ static __device__ __forceinline__ void ze_copy(u8 *d, const u8 *s, u32 len)
  * Returns the size of the section written at dst (header included), 0 = not worth it / not
  * representable this way (caller stores the literals raw).  `stage` = ZE_STAGE_WORDS words of LDS
  * (the hash table is idle while a block is assembled). */
-static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32 regen, u8 *dst, int lane)
+struct ZHuf {
+	u32 log, maxsym; /* log == 0: no usable code (the unit's literals stay raw) */
+};
+
+/* Code for all literals of one work unit (its blocks share it: the first one carries the tree, the
+ * others are Treeless_Literals_Blocks, RFC 8878 3.1.1.3.1.1): histogram -> L.hcode / L.hlen */
+static __device__ ZHuf ze_huf_build(ZEncLds &L, const u8 *lit, u32 regen, int lane)
 {
+	ZHuf hf = {0, 0};
 	if (regen < 256)
-		return 0;
+		return hf;
 	/* histogram */
 	for (u32 i = (u32)lane; i < 256; i += 64)
 		L.hist[i] = 0;
@@ -213,7 +221,7 @@ static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32
 		maxsym = o > maxsym ? o : maxsym;
 	}
 	if (nsym < 2 || maxsym > 128)
-		return 0; /* one symbol: RLE would do, left raw here; symbols > 128 need FSE-coded weights */
+		return hf; /* one symbol: RLE would do, left raw here; symbols > 128 need FSE-coded weights */
 	/* code lengths: ceil(log2(N / count)) capped at 11, then repaired to a complete code
 	 * (Kraft sum exactly 2^11 in units of 2^-11) */
 	u32 K = 0;
@@ -251,7 +259,7 @@ static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32
 			best = over ? (o < best ? o : best) : (o > best ? o : best);
 		}
 		if (best == (over ? 0xFFFFFFFFu : 0u))
-			return 0; /* cannot happen for a valid histogram; stay safe */
+			return hf; /* cannot happen for a valid histogram; stay safe */
 		const u32 sym = best & 255, sq_ = sym >> 6;
 		if ((sym & 63) == (u32)lane) {
 			const u32 d_ = over ? 1u : 0xFFFFFFFFu; /* +1 / -1 */
@@ -265,7 +273,7 @@ static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32
 		K = over ? K - (1u << (11 - lnew)) : K + (1u << (10 - lnew));
 	}
 	if (K != 2048)
-		return 0;
+		return hf;
 	u32 log = 0;
 	for (u32 q = 0; q < 4; q++)
 		log = len[q] > log ? len[q] : log;
@@ -298,25 +306,43 @@ static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32
 		}
 	}
 	wv_sync();
-	/* size estimate from the histogram */
+	/* worth it at all?  (estimate from the histogram) */
 	u32 bits = 0;
 	for (u32 q = 0; q < 4; q++)
 		bits += cnt[q] * len[q];
 	for (int d = 32; d; d >>= 1)
 		bits += wv_shfl(bits, lane ^ d);
-	const u32 tree = 1 + (maxsym + 1) / 2;
-	const u32 lh = regen < 1024 ? 3u : regen < 16384 ? 4u : 5u;
-	if (lh + tree + 6 + (bits + 7) / 8 + 4 >= regen)
+	if (1 + (maxsym + 1) / 2 + (bits + 7) / 8 + 64 >= regen)
+		return hf;
+	hf.log = log;
+	hf.maxsym = maxsym;
+	return hf;
+}
+
+/* One literals section with the unit's code: `with_tree` = Compressed_Literals_Block (type 2, the
+ * tree described by direct 4-bit weights), else Treeless_Literals_Block (type 3).  Four streams,
+ * packed by prefix sum of code lengths + atomicOr into the LDS stage (the idle hash table).
+ * Returns the section size written at dst (header included), 0 = does not pay (caller stores raw). */
+static __device__ u32 ze_huf_encode(ZEncLds &L, u32 *stage, const ZHuf hf, const u8 *lit, u32 regen, u8 *dst,
+				    bool with_tree, int lane)
+{
+	if (hf.log == 0 || regen < 256)
 		return 0;
-	/* tree description: Number_of_Symbols = maxsym explicit weights, the last one is implied */
+	const u32 log = hf.log, maxsym = hf.maxsym;
+	const u32 tree = with_tree ? 1 + (maxsym + 1) / 2 : 0;
+	const u32 lh = regen < 1024 ? 3u : regen < 16384 ? 4u : 5u;
+	const u32 limit = regen; /* a coded section that is not smaller than the literals is dropped */
 	u8 *t = dst + lh;
-	if (lane == 0)
-		t[0] = (u8)(127 + maxsym);
-	for (u32 i = (u32)lane; i < (maxsym + 1) / 2; i += 64) {
-		const u32 s0 = 2 * i, s1 = 2 * i + 1;
-		const u32 w0 = L.hlen[s0] ? log + 1 - L.hlen[s0] : 0;
-		const u32 w1 = (s1 < maxsym && L.hlen[s1]) ? log + 1 - L.hlen[s1] : 0;
-		t[1 + i] = (u8)(w0 << 4 | w1);
+	if (with_tree) {
+		/* tree description: Number_of_Symbols = maxsym explicit weights, the last one is implied */
+		if (lane == 0)
+			t[0] = (u8)(127 + maxsym);
+		for (u32 i = (u32)lane; i < (maxsym + 1) / 2; i += 64) {
+			const u32 s0 = 2 * i, s1 = 2 * i + 1;
+			const u32 w0 = L.hlen[s0] ? log + 1 - L.hlen[s0] : 0;
+			const u32 w1 = (s1 < maxsym && L.hlen[s1]) ? log + 1 - L.hlen[s1] : 0;
+			t[1 + i] = (u8)(w0 << 4 | w1);
+		}
 	}
 	/* four streams */
 	u8 *jump = t + tree, *sp = jump + 6;
@@ -398,6 +424,8 @@ static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32
 		}
 		ssz[k] = outb;
 		sp += outb;
+		if ((u32)(sp - dst) + 8 >= limit)
+			return 0; /* incompressible slice: the room check of the caller covers raw only */
 	}
 	const u32 csz = tree + 6 + ssz[0] + ssz[1] + ssz[2] + ssz[3];
 	if (lane == 0) {
@@ -407,20 +435,21 @@ static __device__ u32 ze_huf_literals(ZEncLds &L, u32 *stage, const u8 *lit, u32
 		jump[3] = (u8)(ssz[1] >> 8);
 		jump[4] = (u8)ssz[2];
 		jump[5] = (u8)(ssz[2] >> 8);
-		/* Literals_Section_Header: type 2, size format by regen, both sizes */
+		/* Literals_Section_Header: type 2 / 3, size format by regen, both sizes */
+		const u32 ty = with_tree ? 2u : 3u;
 		if (lh == 3) {
-			const u32 hv = 2u | 1u << 2 | regen << 4 | csz << 14;
+			const u32 hv = ty | 1u << 2 | regen << 4 | csz << 14;
 			dst[0] = (u8)hv;
 			dst[1] = (u8)(hv >> 8);
 			dst[2] = (u8)(hv >> 16);
 		} else if (lh == 4) {
-			const u32 hv = 2u | 2u << 2 | regen << 4 | csz << 18;
+			const u32 hv = ty | 2u << 2 | regen << 4 | csz << 18;
 			dst[0] = (u8)hv;
 			dst[1] = (u8)(hv >> 8);
 			dst[2] = (u8)(hv >> 16);
 			dst[3] = (u8)(hv >> 24);
 		} else {
-			const u64 hv = 2ull | 3ull << 2 | (u64)regen << 4 | (u64)csz << 22;
+			const u64 hv = (u64)ty | 3ull << 2 | (u64)regen << 4 | (u64)csz << 22;
 			for (u32 k = 0; k < 5; k++)
 				dst[k] = (u8)(hv >> (8 * k));
 		}
@@ -762,8 +791,38 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			wv_sync();
 
 			ZEP(1);
+			/* -------------------------------------------- literals of the whole unit -> litbuf
+			 * (lane per sequence, long runs by the whole wave), then one Huffman code for all of
+			 * them: the first block that uses it carries the tree, the others are treeless */
+			u32 lit_total = 0;
+			{
+				u32 ip = 0, lpos = 0;
+				for (u32 b = 0; b < ns; b += 64) {
+					const u32 i = b + (u32)lane;
+					const u32 ll = i < ns ? sq_ll[i] : 0, ml = i < ns ? sq_ml[i] : 0;
+					const u32 incl = wv_scan_incl(ll + ml), lincl = wv_scan_incl(ll);
+					const u32 s0 = ip + incl - ll - ml, d0 = lpos + lincl - ll;
+					if (ll && ll <= ZE_CAP)
+						ze_copy(litbuf + d0, src + s0, ll);
+					u64 lm = wv_ballot(ll > ZE_CAP);
+					while (lm) {
+						const int j = wv_ffs(lm) - 1;
+						lm &= lm - 1;
+						wave_copy(litbuf + wv_readlane(d0, j), src + wv_readlane(s0, j), wv_readlane(ll, j), lane);
+					}
+					ip += wv_readlane(incl, 63);
+					lpos += wv_readlane(lincl, 63);
+				}
+				wave_copy(litbuf + lpos, src + ip, bsize - ip, lane); /* after the last match */
+				lit_total = lpos + (bsize - ip);
+			}
+			wave_mem_fence();
+			ZEP(2);
+			const ZHuf hf = ze_huf_build(L, litbuf, lit_total, lane);
+			bool tree_sent = false;
+			ZEP(3);
 			/* -------------------------------------------- assemble the G blocks at out */
-			u32 ipos = 0, at = 0; /* input bytes consumed, bytes written */
+			u32 ipos = 0, lbase = 0, at = 0; /* input / literal bytes consumed, bytes written */
 			bool fits = true;
 			for (u32 sb = 0; sb < G && fits; sb++) {
 				const u32 lo = (u32)(((u64)sb * ns) / G), hi = (u32)(((u64)(sb + 1) * ns) / G);
@@ -787,38 +846,18 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 					break;
 				}
 				u8 *o = out + at;
-				ZEP(4);
-				/* literal runs -> litbuf: lane per sequence, long runs by the whole wave */
-				u32 ip = ipos, lpos = 0;
-				for (u32 b = lo; b < hi; b += 64) {
-					const u32 i = b + (u32)lane;
-					const u32 ll = i < hi ? sq_ll[i] : 0, ml = i < hi ? sq_ml[i] : 0;
-					const u32 incl = wv_scan_incl(ll + ml), lincl = wv_scan_incl(ll);
-					const u32 s0 = ip + incl - ll - ml, d0 = lpos + lincl - ll;
-					if (ll && ll <= ZE_CAP)
-						ze_copy(litbuf + d0, src + s0, ll);
-					u64 lm = wv_ballot(ll > ZE_CAP);
-					while (lm) {
-						const int j = wv_ffs(lm) - 1;
-						lm &= lm - 1;
-						wave_copy(litbuf + wv_readlane(d0, j), src + wv_readlane(s0, j), wv_readlane(ll, j), lane);
-					}
-					ip += wv_readlane(incl, 63);
-					lpos += wv_readlane(lincl, 63);
-				}
-				if (trail)
-					wave_copy(litbuf + lpos, src + ip, trail, lane);
-				wave_mem_fence();
-				ZEP(2);
+				const u8 *lit = litbuf + lbase;
 				/* literals section: Huffman-coded when that pays, else raw */
-				u32 lsec = ze_huf_literals(L, (u32 *)L.table, litbuf, regen, o + 3, lane);
-				if (!lsec) {
+				u32 lsec = ze_huf_encode(L, (u32 *)L.table, hf, lit, regen, o + 3, !tree_sent, lane);
+				if (lsec) {
+					tree_sent = true;
+				} else {
 					if (lane == 0) {
 						const u32 hv = lh == 1 ? regen << 3 : regen << 4 | (lh == 2 ? 1u : 3u) << 2;
 						for (u32 k = 0; k < lh; k++)
 							o[3 + k] = (u8)(hv >> (8 * k));
 					}
-					wave_copy(o + 3 + lh, litbuf, regen, lane);
+					wave_copy(o + 3 + lh, lit, regen, lane);
 					lsec = lh + regen;
 				}
 				ZEP(3);
@@ -846,6 +885,8 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 				wave_copy(sp + sh + 1, bstmp + sb * ZE_BSTMP, bits, lane);
 				at += 3 + csize;
 				ipos += isum;
+				lbase += regen;
+				ZEP(4);
 			}
 			if (fits)
 				total = at;
