@@ -208,3 +208,14 @@ def test_decompress_old_zstdmt_prefix_layout(lib, name):
     assert rv_r == 0 and len(d_r) == MAN[name]["in_len"]
     assert (rv_o, d_o, st_o) == (rv_r, d_r, st_r)
     assert _strip_eof(io_o.reads) == _strip_eof(io_r.reads) and io_o.writes == io_r.writes
+
+
+def test_large_default_chunks(lib):
+    """Level 12 -> default chunk 1 << (windowLog[12] + 1) = 8 MiB (lib/zstd-mt_compress.c:116-127):
+    64 blocks per frame, three frames."""
+    data = cases.text(20 << 20, 44) + cases.rnd(1 << 20, 9)
+    rv, st, io, stats = H.zstdmt_compress_via(lib, data, 0, threads=4, level=12)
+    assert rv == 0 and stats[0] == 3 and all(want == 8 << 20 for want, _ in io.reads)
+    assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
+    rv, out, _, _ = H.zstdmt_decompress_via(lib, st, threads=4)
+    assert rv == 0 and out == data
