@@ -83,6 +83,10 @@ ENC_CASES = {
     "zeros_300k": (1 << 20, lambda: bytes(300000)),
     "period_300": (1 << 20, lambda: cases.rep(cases.rnd(300, 9), 150000)),
     "mixed": (262144, lambda: cases.text(50000, 4) + bytes(70000) + cases.rnd(3000, 5) + cases.text(100000, 6)),
+    # byte values above 128: the Huffman tree needs FSE-coded weights (RFC 8878 4.2.1.2)
+    "text_high_bytes": (131072, lambda: bytes(b ^ 0x80 for b in cases.text(150000, 8))),
+    "all_256_values": (1 << 20, lambda: bytes((b * 7) & 255 for b in cases.text(90000, 9))),
+    "four_high_symbols": (131072, lambda: bytes(200 + (b & 3) for b in cases.rnd(100000, 5))),
 }
 
 

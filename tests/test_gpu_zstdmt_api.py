@@ -131,6 +131,10 @@ ZC_CASES = {
     "two_symbols": (65536, lambda: bytes(65 + (b & 1) for b in cases.rnd(70000, 13))),
     "mixed": (262144, lambda: cases.text(50000, 4) + bytes(70000) + cases.rnd(3000, 5) + cases.text(200000, 6)),
     "allbytes": (0, lambda: bytes(range(256)) * 300 + cases.text(40000, 8)),
+    # byte values above 128: Huffman trees described by FSE-coded weights
+    "text_high_bytes": (0, lambda: bytes(b ^ 0x80 for b in cases.text(2500000, 8))),
+    "all_256_values": (0, lambda: bytes((b * 7) & 255 for b in cases.text(1500000, 9))),
+    "four_high_symbols": (131072, lambda: bytes(200 + (b & 3) for b in cases.rnd(300000, 5))),
 }
 
 

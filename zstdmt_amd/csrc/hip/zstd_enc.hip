@@ -59,6 +59,7 @@ struct ZEncLds {
 	u32 hist[256];                   /* literal histogram of the block being assembled */
 	u16 hcode[256];                  /* Huffman code | length << 11 */
 	u8 hlen[256];
+	u8 treebuf[136];                 /* Huffman_Tree_Description of the unit's code */
 	u32 misc[8];
 };
 
@@ -171,8 +172,8 @@ static __device__ __forceinline__ void ze_copy(u8 *d, const u8 *s, u32 len)
 }
 
 /* ------------------------------------------------------------------ Huffman literals
- * RFC 8878 3.1.1.3.1 / 4.2: a literals section of type Compressed_Literals_Block with a directly
- * described tree (4-bit weights) and four streams.  Everything but the choice of code lengths is
+ * RFC 8878 3.1.1.3.1 / 4.2: literals sections of type Compressed / Treeless_Literals_Block, the tree
+ * described by direct 4-bit weights or FSE-coded weights, four streams.  Everything but the choice of code lengths is
  * data parallel: histogram with LDS atomics, canonical codes with ballots, the bitstreams with a
  * prefix sum of code lengths and atomicOr into an LDS staging area.
  * Returns the size of the section written at dst (header included), 0 = not worth it / not
@@ -180,13 +181,173 @@ static __device__ __forceinline__ void ze_copy(u8 *d, const u8 *s, u32 len)
  * (the hash table is idle while a block is assembled). */
 struct ZHuf {
 	u32 log, maxsym; /* log == 0: no usable code (the unit's literals stay raw) */
+	u32 tree_len;    /* bytes of L.treebuf */
 };
+
+/* Huffman weights 0..maxsym-1 FSE-coded (RFC 8878 4.2.1.2), for alphabets that reach beyond byte 128
+ * where the direct 4-bit form does not exist.  One lane; `scr` = 512 bytes of idle LDS.  Writes
+ * [size byte][table description][two-state bitstream] to out, returns its length or 0 (not
+ * representable / not below 128 bytes). */
+static __device__ u32 ze_fse_weights(const u8 *hlen, u32 log, u32 n, u8 *out, u8 *scr)
+{
+	u16 *st = (u16 *)scr;                     /* 64 states */
+	u32(*tt)[2] = (u32(*)[2])(scr + 128);     /* 13 symbols */
+	u8 *spread = scr + 128 + 104;             /* 64 bytes */
+	short norm[13];
+	u32 cnt[13];
+	for (int i = 0; i < 13; i++)
+		cnt[i] = 0;
+	for (u32 i = 0; i < n; i++)
+		cnt[hlen[i] ? log + 1 - hlen[i] : 0]++;
+	u32 present = 0, maxc = 0, maxw = 0;
+	for (int i = 0; i < 13; i++) {
+		if (cnt[i]) {
+			present++;
+			maxw = (u32)i;
+			if (cnt[i] > maxc)
+				maxc = cnt[i];
+		}
+	}
+	if (n < 2 || present < 2)
+		return 0;
+	const int tl = n <= 32 ? 5 : 6;
+	const u32 size = 1u << tl;
+	/* normalise to 2^tl: proportional, every present symbol at least 1, the rounding error goes to
+	 * (or comes from) the largest entries */
+	int sum = 0;
+	for (int i = 0; i < 13; i++) {
+		int v = 0;
+		if (cnt[i]) {
+			v = (int)((cnt[i] * size + n / 2) / n);
+			if (v < 1)
+				v = 1;
+		}
+		norm[i] = (short)v;
+		sum += v;
+	}
+	while (sum != (int)size) {
+		int best = -1;
+		for (int i = 0; i < 13; i++)
+			if (norm[i] > (sum > (int)size ? 1 : 0) && (best < 0 || norm[i] > norm[best]))
+				best = i;
+		if (best < 0)
+			return 0;
+		const int d = sum > (int)size ? -1 : 1;
+		norm[best] = (short)(norm[best] + d);
+		sum += d;
+	}
+	/* table description (inverse of the reader: RFC 8878 4.1.1) */
+	u64 acc = (u64)(tl - 5);
+	u32 nb = 4, o = 1; /* out[0] = total size, filled last */
+	{
+		int remaining = (int)size + 1, threshold = (int)size, nbits = tl + 1;
+		bool prev0 = false;
+		u32 sym = 0;
+		while (remaining > 1) {
+			if (prev0) {
+				u32 start = sym;
+				while (sym <= maxw && norm[sym] == 0)
+					sym++;
+				while (sym >= start + 3) {
+					acc |= 3ull << nb;
+					nb += 2;
+					start += 3;
+				}
+				acc |= (u64)(sym - start) << nb;
+				nb += 2;
+			}
+			const int c0 = norm[sym++];
+			const int max = (2 * threshold - 1) - remaining;
+			int c = c0 + 1;
+			remaining -= c0;
+			if (c >= threshold)
+				c += max;
+			acc |= (u64)(u32)c << nb;
+			nb += (u32)nbits - (u32)(c < max);
+			prev0 = (c0 == 0);
+			while (remaining < threshold) {
+				nbits--;
+				threshold >>= 1;
+			}
+			while (nb >= 8) {
+				out[o++] = (u8)acc;
+				acc >>= 8;
+				nb -= 8;
+			}
+		}
+		if (nb)
+			out[o++] = (u8)acc;
+	}
+	/* two interleaved states over the weights, last one first (decoder: state1 yields the even
+	 * positions, state2 the odd ones) */
+	fse_ctable(st, tt, norm, (int)maxw + 1, tl, spread);
+	acc = 0;
+	nb = 0;
+#define WADD(v, k)                                                                                 \
+	do {                                                                                       \
+		acc |= (u64)((v) & ((1u << (k)) - 1)) << nb;                                       \
+		nb += (k);                                                                         \
+		while (nb >= 8) {                                                                  \
+			if (o >= 132)                                                              \
+				return 0;                                                          \
+			out[o++] = (u8)acc;                                                        \
+			acc >>= 8;                                                                 \
+			nb -= 8;                                                                   \
+		}                                                                                  \
+	} while (0)
+#define WSYM(i) ((u32)(hlen[i] ? log + 1 - hlen[i] : 0))
+#define WINIT(S, w)                                                                                \
+	do {                                                                                       \
+		const u32 nbo_ = (tt[w][0] + (1u << 15)) >> 16;                                    \
+		(S) = st[(((nbo_ << 16) - tt[w][0]) >> nbo_) + tt[w][1]];                          \
+	} while (0)
+#define WENC(S, w)                                                                                 \
+	do {                                                                                       \
+		const u32 nbo_ = ((S) + tt[w][0]) >> 16;                                           \
+		WADD((S), nbo_);                                                                   \
+		(S) = st[((S) >> nbo_) + tt[w][1]];                                                \
+	} while (0)
+	{
+		u32 s1, s2, i = n;
+		if (n & 1) {
+			WINIT(s1, WSYM(i - 1));
+			WINIT(s2, WSYM(i - 2));
+			WENC(s1, WSYM(i - 3));
+			i -= 3;
+		} else {
+			WINIT(s2, WSYM(i - 1));
+			WINIT(s1, WSYM(i - 2));
+			i -= 2;
+		}
+		while (i >= 2) {
+			WENC(s2, WSYM(i - 1));
+			WENC(s1, WSYM(i - 2));
+			i -= 2;
+		}
+		WADD(s2, (u32)tl);
+		WADD(s1, (u32)tl);
+		WADD(1u, 1u); /* end mark */
+		if (nb) {
+			if (o >= 132)
+				return 0;
+			out[o++] = (u8)acc;
+		}
+	}
+#undef WADD
+#undef WSYM
+#undef WINIT
+#undef WENC
+	if (o - 1 >= 128)
+		return 0;
+	out[0] = (u8)(o - 1);
+	return o;
+}
 
 /* Code for all literals of one work unit (its blocks share it: the first one carries the tree, the
  * others are Treeless_Literals_Blocks, RFC 8878 3.1.1.3.1.1): histogram -> L.hcode / L.hlen */
 static __device__ ZHuf ze_huf_build(ZEncLds &L, const u8 *lit, u32 regen, int lane)
 {
-	ZHuf hf = {0, 0};
+	ZHuf hf = {0, 0, 0};
 	if (regen < 256)
 		return hf;
 	/* histogram */
@@ -220,8 +381,8 @@ static __device__ ZHuf ze_huf_build(ZEncLds &L, const u8 *lit, u32 regen, int la
 		const u32 o = wv_shfl(maxsym, lane ^ d);
 		maxsym = o > maxsym ? o : maxsym;
 	}
-	if (nsym < 2 || maxsym > 128)
-		return hf; /* one symbol: RLE would do, left raw here; symbols > 128 need FSE-coded weights */
+	if (nsym < 2)
+		return hf; /* one symbol: RLE would do, left raw here */
 	/* code lengths: ceil(log2(N / count)) capped at 11, then repaired to a complete code
 	 * (Kraft sum exactly 2^11 in units of 2^-11) */
 	u32 K = 0;
@@ -314,8 +475,31 @@ static __device__ ZHuf ze_huf_build(ZEncLds &L, const u8 *lit, u32 regen, int la
 		bits += wv_shfl(bits, lane ^ d);
 	if (1 + (maxsym + 1) / 2 + (bits + 7) / 8 + 64 >= regen)
 		return hf;
+	/* tree description: maxsym explicit weights (the last symbol's is implied), as 4-bit values
+	 * while they reach no further than symbol 128, FSE-coded beyond that */
+	u32 tlen;
+	if (maxsym <= 128) {
+		tlen = 1 + (maxsym + 1) / 2;
+		if (lane == 0)
+			L.treebuf[0] = (u8)(127 + maxsym);
+		for (u32 i = (u32)lane; i < (maxsym + 1) / 2; i += 64) {
+			const u32 s0 = 2 * i, s1 = 2 * i + 1;
+			const u32 w0 = L.hlen[s0] ? log + 1 - L.hlen[s0] : 0;
+			const u32 w1 = (s1 < maxsym && L.hlen[s1]) ? log + 1 - L.hlen[s1] : 0;
+			L.treebuf[1 + i] = (u8)(w0 << 4 | w1);
+		}
+	} else {
+		if (lane == 0)
+			L.misc[0] = ze_fse_weights(L.hlen, log, maxsym, L.treebuf, (u8 *)L.stage);
+		wv_sync();
+		tlen = L.misc[0];
+		if (tlen == 0)
+			return hf; /* the weights do not fit the FSE form either: raw literals */
+	}
+	wv_sync();
 	hf.log = log;
 	hf.maxsym = maxsym;
+	hf.tree_len = tlen;
 	return hf;
 }
 
@@ -328,22 +512,12 @@ static __device__ u32 ze_huf_encode(ZEncLds &L, u32 *stage, const ZHuf hf, const
 {
 	if (hf.log == 0 || regen < 256)
 		return 0;
-	const u32 log = hf.log, maxsym = hf.maxsym;
-	const u32 tree = with_tree ? 1 + (maxsym + 1) / 2 : 0;
+	const u32 tree = with_tree ? hf.tree_len : 0;
 	const u32 lh = regen < 1024 ? 3u : regen < 16384 ? 4u : 5u;
 	const u32 limit = regen; /* a coded section that is not smaller than the literals is dropped */
 	u8 *t = dst + lh;
-	if (with_tree) {
-		/* tree description: Number_of_Symbols = maxsym explicit weights, the last one is implied */
-		if (lane == 0)
-			t[0] = (u8)(127 + maxsym);
-		for (u32 i = (u32)lane; i < (maxsym + 1) / 2; i += 64) {
-			const u32 s0 = 2 * i, s1 = 2 * i + 1;
-			const u32 w0 = L.hlen[s0] ? log + 1 - L.hlen[s0] : 0;
-			const u32 w1 = (s1 < maxsym && L.hlen[s1]) ? log + 1 - L.hlen[s1] : 0;
-			t[1 + i] = (u8)(w0 << 4 | w1);
-		}
-	}
+	for (u32 i = (u32)lane; i < tree; i += 64)
+		t[i] = L.treebuf[i];
 	/* four streams */
 	u8 *jump = t + tree, *sp = jump + 6;
 	const u32 qn = (regen + 3) / 4;
