@@ -27,7 +27,8 @@ void zmt_lz4_dec_batch(const u8 *, const u64 *, const u32 *, u32, u8 *, const u6
 void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 void zmt_scan_kernel(const u32 *, u32, u64 *);
 void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
-void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u8 *, u32 *, u32 *, u32 *);
+void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u8 *, u32 *, u32 *, u32 *, u32);
+void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u8 *, u32 *, u32 *, u32 *);
 void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *, u32 *);
 void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
 void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
@@ -165,8 +166,15 @@ void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *re
 	u8 *litp = lit.data();
 	std::vector<u32> ce(nrec, 0xA5A5A5A5u), cv(nrec, 0xA5A5A5A5u);
 	u32 *cep = ce.data(), *cvp = cv.data();
+	/* small-table variant first, then the general one for the records it handed over (status 101) */
 	emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
-		zmt_zstd_dec_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status, cep, cvp);
+		zmt_zstd_dec_small_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status, cep, cvp);
+	});
+	if (getenv("ZMT_EMU_DEBUG"))
+		for (u32 r = 0; r < nrec; r++)
+			fprintf(stderr, "zstd rec %u after small kernel: status %u\n", r, status[r]);
+	emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
+		zmt_zstd_dec_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status, cep, cvp, 101u);
 	});
 	emu::launch(dim3{(nrec * 4 + 255) / 256, 1, 1}, dim3{256, 1, 1},
 		    [=]() { zmt_xxh64_verify_kernel(out, out_off, out_len, nrec, cep, cvp, status); });

@@ -37,10 +37,12 @@ __global__ void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, 
 __global__ void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
 				    const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 				    const u32 *, const u32 *, const u32 *, u32 *);
+__global__ void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
+					  const u32 *, u8 *, u32 *, u32 *, u32 *);
 __global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-				    const u32 *, u8 *, u32 *, u32 *, u32 *);
+				    const u32 *, u8 *, u32 *, u32 *, u32 *, u32);
 __global__ void zmt_zstd_dec_kernel_prof(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-					 const u32 *, u8 *, u32 *, u32 *, u32 *, unsigned long long *);
+					 const u32 *, u8 *, u32 *, u32 *, u32 *, u32, unsigned long long *);
 __global__ void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *,
 					u32 *);
 __global__ void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
@@ -78,6 +80,7 @@ struct gpumt_ctx {
 	int profile; /* record events in timer slots 8.. around individual kernels */
 	int num_cus;
 	int zenc_waves; /* resident waves of the persistent zstd encoder kernel (whole device) */
+	int zdec_variant; /* 0 = small-table kernel, then general; 1 = general only */
 	char err[256];
 	char name[128];
 };
@@ -691,15 +694,24 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
 	}
 	PROF0(11);
-	if (h->profile == 5)
+	if (h->profile == 5) {
 		hipLaunchKernelGGL(zmt_zstd_dec_kernel_prof, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
 				   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
 				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status, chk_e, chk_v,
-				   h->d_prof);
-	else
+				   0u, h->d_prof);
+	} else {
+		/* small-table variant first (16 waves per CU); records that need the full-size tables
+		 * come back with status 101 and are decoded by the general variant (12 waves per CU) */
+		const u32 want = h->zdec_variant == 1 ? 0u : 101u;
+		if (h->zdec_variant != 1)
+			hipLaunchKernelGGL(zmt_zstd_dec_small_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
+					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
+					   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status, chk_e,
+					   chk_v);
 		hipLaunchKernelGGL(zmt_zstd_dec_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
 				   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
-				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status, chk_e, chk_v);
+				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status, chk_e, chk_v, want);
+	}
 	/* XXH64 content checksums, for the frames that carry one */
 	hipLaunchKernelGGL(zmt_xxh64_verify_kernel, dim3((unsigned)((nrec * 4 + 255) / 256)), dim3(256), 0,
 			   h->st[s], (const u8 *)d_out, d_out_off, d_out_len, (u32)nrec, (const u32 *)chk_e,
@@ -740,6 +752,9 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	} else if (!strcmp(what, "k2x")) {
 		prev = h->xflags;
 		h->xflags = variant;
+	} else if (!strcmp(what, "zstd_dec")) {
+		prev = h->zdec_variant;
+		h->zdec_variant = variant;
 	} else if (!strcmp(what, "profile")) {
 		prev = h->profile;
 		h->profile = variant;

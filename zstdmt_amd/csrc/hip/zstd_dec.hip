@@ -28,9 +28,16 @@
 #define Z_STAGE 1024u
 #define Z_CAP 64u /* longer literal runs / matches are copied by the whole wave */
 
-struct ZLds {
-	u16 huf[2048];  /* sym | nbits << 8 */
-	u32 ll[512], of[256], ml[512]; /* sym | nbits << 8 | base << 16 */
+#define ST_NEEDS_GENERAL 101u /* internal: the record needs the full-size tables (second kernel) */
+
+/* LDS of one wave.  Table capacities are template parameters: the format allows Huffman codes of up
+ * to 11 bits and FSE tables of 2^9 / 2^8 / 2^9 cells (13 KiB per wave, 12 waves per CU), but frames
+ * whose blocks stay within 10 bits and the predefined 2^6 / 2^5 / 2^6 tables -- everything the
+ * device encoder writes -- fit in 6 KiB, i.e. the 16 waves per CU the register budget allows.  The
+ * small variant runs first and hands records that exceed it to the general one. */
+template <int HCAP, int LLCAP, int OFCAP, int MLCAP> struct ZLdsT {
+	u16 huf[1 << HCAP];  /* sym | nbits << 8 */
+	u32 ll[1 << LLCAP], of[1 << OFCAP], ml[1 << MLCAP]; /* FSE cells, see ZC_* */
 	u8 below[16];   /* stage[-16..0): 8-byte reads may start below the window */
 	u8 stage[Z_STAGE + 16];
 	u64 sq[3][64]; /* one batch of sequences, per LL / OF / ML: extra bits | code << 32 */
@@ -39,7 +46,10 @@ struct ZLds {
 	u16 next[3][64];
 	u32 llx[36], mlx[53]; /* value base | extra bits << 24 of every LL / ML code */
 	u32 misc[16];
+	static constexpr int hcap = HCAP, llcap = LLCAP, ofcap = OFCAP, mlcap = MLCAP;
 };
+typedef ZLdsT<11, 9, 8, 9> ZLds;      /* everything RFC 8878 allows */
+typedef ZLdsT<10, 6, 5, 6> ZLdsSmall; /* predefined-size sequence tables, 10-bit literals */
 
 enum { ZM_ERR = 0, ZM_A, ZM_B, ZM_C, ZM_D, ZM_E, ZM_F, ZM_G, ZM_H };
 
@@ -446,9 +456,9 @@ static inline u32 zbad_(int line)
 		}                                                                                  \
 	} while (0)
 
-template <bool PROF>
+template <bool PROF, typename LDS>
 static __device__ __forceinline__ void
-zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
+zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
 	      const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base, const u64 *__restrict__ out_off,
 	      const u32 *__restrict__ out_len, u8 *__restrict__ litbuf, u32 *__restrict__ status,
 	      u32 *__restrict__ chk_expect, u32 *__restrict__ chk_valid, unsigned long long *prof)
@@ -464,10 +474,10 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 	const u32 rec = blockIdx.x;
 	if (rec >= nrec)
 		return;
+	if (wv_readfirst(status[rec]) != want_status)
+		return; /* rejected by the probe kernel, or not this variant's record */
 	if (lane == 0)
 		chk_valid[rec] = 0;
-	if (wv_readfirst(status[rec]) != ST_OK)
-		return; /* rejected by the probe kernel */
 	const u64 roff = rec_off[rec];
 	const u32 rlen = wv_readfirst(rec_len[rec]);
 	const u8 *r = stream + roff;
@@ -667,7 +677,11 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 				if (ltype == 2) {
 					const int nw = (int)L.misc[ZM_G];
 					huf_log = (int)L.misc[ZM_H];
-					for (u32 i = (u32)lane; i < 2048; i += 64)
+					if (huf_log > LDS::hcap) {
+						stc = ST_NEEDS_GENERAL;
+						break;
+					}
+					for (u32 i = (u32)lane; i < (1u << LDS::hcap); i += 64)
 						L.huf[i] = 0;
 					wv_sync();
 					huf_fill(L.huf, L.w, nw, huf_log, lane);
@@ -879,7 +893,7 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 			u32 lpos = 0; /* literals consumed */
 			if (nseq) {
 				/* ---- build the three tables on lanes 0..2 ---- */
-				bool terr = false;
+				bool terr = false, too_big = false;
 				if (lane < 3) {
 					const u32 spec = L.misc[ZM_A + lane];
 					u32 *cells = lane == 0 ? L.ll : lane == 1 ? L.of : L.ml;
@@ -895,14 +909,22 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 						/* predefined table still in place from an earlier block: nothing to build */
 					} else {
 						const int lg = (int)((spec >> 8) & 255);
+						if (lg > (lane == 0 ? LDS::llcap : lane == 1 ? LDS::ofcap : LDS::mlcap)) {
+							too_big = true;
+						} else {
 						terr = fse_build(cells, L.norm[lane], (int)(spec & 255), lg, L.next[lane],
 								 lane == 0 ? L.llx : lane == 2 ? L.mlx : (const u32 *)nullptr, lane) != 0;
 						my_tab_log = lg;
 						my_tab_ok = !terr;
 						my_tab_pre = (spec & 0x40000000u) != 0;
+						}
 					}
 				}
 				wv_sync();
+				if (wv_any(too_big)) {
+					stc = ST_NEEDS_GENERAL;
+					break;
+				}
 				if (wv_any(terr)) {
 					stc = ZBAD();
 					break;
@@ -1159,8 +1181,22 @@ zstd_dec_body(ZLds &L, const u8 *__restrict__ stream, u64 stream_bytes, const u6
 	}
 	if (stc == ST_OK && ip != flen)
 		stc = ST_TRAILING;
-	if (lane == 0 && stc != ST_OK)
+	if (lane == 0 && (stc != ST_OK || want_status != ST_OK))
 		status[rec] = stc;
+}
+
+/* records whose status is `want` (GPUMT_ST_OK after the probe, or ST_NEEDS_GENERAL after the small
+ * variant) are decoded; their status becomes OK / an error / ST_NEEDS_GENERAL (small variant only) */
+extern "C" __global__ void __launch_bounds__(64)
+zmt_zstd_dec_small_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
+			  const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
+			  const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
+			  u8 *__restrict__ litbuf, u32 *__restrict__ status, u32 *__restrict__ chk_expect,
+			  u32 *__restrict__ chk_valid)
+{
+	__shared__ __attribute__((aligned(16))) ZLdsSmall L;
+	zstd_dec_body<false>(L, (u32)ST_OK, stream, stream_bytes, rec_off, rec_len, nrec, out_base, out_off, out_len,
+			     litbuf, status, chk_expect, chk_valid, nullptr);
 }
 
 extern "C" __global__ void __launch_bounds__(64)
@@ -1168,10 +1204,10 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 		    const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
 		    const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
 		    u8 *__restrict__ litbuf, u32 *__restrict__ status, u32 *__restrict__ chk_expect,
-		    u32 *__restrict__ chk_valid)
+		    u32 *__restrict__ chk_valid, u32 want)
 {
 	__shared__ __attribute__((aligned(16))) ZLds L;
-	zstd_dec_body<false>(L, stream, stream_bytes, rec_off, rec_len, nrec, out_base, out_off, out_len, litbuf,
+	zstd_dec_body<false>(L, want, stream, stream_bytes, rec_off, rec_len, nrec, out_base, out_off, out_len, litbuf,
 			     status, chk_expect, chk_valid, nullptr);
 }
 
@@ -1182,10 +1218,10 @@ zmt_zstd_dec_kernel_prof(const u8 *__restrict__ stream, u64 stream_bytes, const 
 			 const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
 			 const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
 			 u8 *__restrict__ litbuf, u32 *__restrict__ status, u32 *__restrict__ chk_expect,
-			 u32 *__restrict__ chk_valid, unsigned long long *prof)
+			 u32 *__restrict__ chk_valid, u32 want, unsigned long long *prof)
 {
 	__shared__ __attribute__((aligned(16))) ZLds L;
-	zstd_dec_body<true>(L, stream, stream_bytes, rec_off, rec_len, nrec, out_base, out_off, out_len, litbuf,
+	zstd_dec_body<true>(L, want, stream, stream_bytes, rec_off, rec_len, nrec, out_base, out_off, out_len, litbuf,
 			    status, chk_expect, chk_valid, prof);
 }
 #endif

@@ -38,6 +38,7 @@
 #define ZE_MINMATCH 7u
 #define ZE_MAXSEQ (ZE_BLOCK / 4u) /* capacity of the per-wave sequence arrays (>= BLOCK / MINMATCH) */
 #define ZE_CAP 64u
+#define ZE_HUF_MAXLOG 10 /* longest literal code: 10 bits keep the decoder's table at 2 KiB (format max 11) */
 #define ZE_STAGE_WORDS ((2u << ZE_HLOG) / 4u) /* the idle hash table doubles as bit-packing stage */
 #ifndef ZE_HBYTES
 #define ZE_HBYTES 6
@@ -383,35 +384,36 @@ static __device__ ZHuf ze_huf_build(ZEncLds &L, const u8 *lit, u32 regen, int la
 	}
 	if (nsym < 2)
 		return hf; /* one symbol: RLE would do, left raw here */
-	/* code lengths: ceil(log2(N / count)) capped at 11, then repaired to a complete code
-	 * (Kraft sum exactly 2^11 in units of 2^-11) */
+	/* code lengths: ceil(log2(N / count)) capped at ZE_HUF_MAXLOG, then repaired to a
+	 * complete code (Kraft sum exactly KF = 2^ZE_HUF_MAXLOG in units of 1/KF) */
+	constexpr u32 HM = ZE_HUF_MAXLOG, KF = 1u << HM;
 	u32 K = 0;
 	for (u32 q = 0; q < 4; q++) {
 		u32 l = 0;
 		if (cnt[q]) {
 			l = 1;
-			while (l < 11 && (cnt[q] << l) < regen)
+			while (l < HM && (cnt[q] << l) < regen)
 				l++;
-			K += 1u << (11 - l);
+			K += 1u << (HM - l);
 		}
 		len[q] = l;
 	}
 	for (int d = 32; d; d >>= 1)
 		K += wv_shfl(K, lane ^ d);
-	for (u32 guard = 0; K != 2048 && guard < 4096; guard++) {
+	for (u32 guard = 0; K != KF && guard < 4096; guard++) {
 		/* over-subscribed: lengthen the rarest symbol that still can; under-subscribed: shorten
 		 * the most frequent symbol whose step fits the deficit */
-		const bool over = K > 2048;
-		const u32 deficit = over ? 0 : 2048 - K;
+		const bool over = K > KF;
+		const u32 deficit = over ? 0 : KF - K;
 		u32 best = over ? 0xFFFFFFFFu : 0;
 		for (u32 q = 0; q < 4; q++) {
 			if (!cnt[q])
 				continue;
 			const u32 key = cnt[q] << 8 | (64 * q + (u32)lane);
 			if (over) {
-				if (len[q] < 11 && key < best)
+				if (len[q] < HM && key < best)
 					best = key;
-			} else if (len[q] > 1 && (1u << (11 - len[q])) <= deficit && key > best) {
+			} else if (len[q] > 1 && (1u << (HM - len[q])) <= deficit && key > best) {
 				best = key;
 			}
 		}
@@ -430,10 +432,10 @@ static __device__ ZHuf ze_huf_build(ZEncLds &L, const u8 *lit, u32 regen, int la
 			len[3] += sq_ == 3 ? d_ : 0;
 		}
 		const u32 lnew = wv_shfl(sq_ == 0 ? len[0] : sq_ == 1 ? len[1] : sq_ == 2 ? len[2] : len[3], (int)(sym & 63));
-		/* l -> l+1 removes 2^(11-lnew); l -> l-1 adds 2^(10-lnew) */
-		K = over ? K - (1u << (11 - lnew)) : K + (1u << (10 - lnew));
+		/* l -> l+1 removes 2^(HM-lnew); l -> l-1 adds 2^(HM-1-lnew) */
+		K = over ? K - (1u << (HM - lnew)) : K + (1u << (HM - 1 - lnew));
 	}
-	if (K != 2048)
+	if (K != KF)
 		return hf;
 	u32 log = 0;
 	for (u32 q = 0; q < 4; q++)
