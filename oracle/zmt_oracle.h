@@ -111,6 +111,14 @@ size_t zo_zstd_decompress_frame(const uint8_t *src, size_t slen, uint8_t *dst, s
 /* Whole zstd-mt stream ("pzstd style" records, what lib/zstd-mt_compress.c:296-302 writes). */
 size_t zo_zstdmt_decompress(const uint8_t *src, size_t slen, uint8_t *dst, size_t cap);
 
+/* ---- brotli-mt decompress (brotli_oracle.c).  `blob` = zstdmt_amd/csrc/data/brotli_static.bin ---- */
+/* one raw brotli stream (RFC 7932); returns decoded size, -1 malformed / truncated, -2 does not fit */
+long zo_brotli_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, const uint8_t *blob);
+/* dictionary word transform t (RFC 7932 Appendix B); returns bytes written to dst (<= len + 13) */
+size_t zo_brotli_transform(const uint8_t *blob, uint8_t *dst, const uint8_t *word, uint32_t len, uint32_t t);
+/* whole brotli-mt stream of 16-byte-header records (lib/brotli-mt_decompress.c:187-377) */
+size_t zo_brotlimt_decompress(const uint8_t *src, size_t slen, uint8_t *dst, size_t cap, const uint8_t *blob);
+
 #ifdef __cplusplus
 }
 #endif

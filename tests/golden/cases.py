@@ -115,3 +115,66 @@ ZCASES = {
     "z_mixed_l9":     (9, 0, lambda: text(50000, 4) + bytes(70000) + rnd(3000, 5) + text(200000, 6)),
     "z_allbytes":     (1, 0, lambda: bytes(range(256)) * 300 + text(40000, 8)),
 }
+
+
+# ---- brotli-mt decoder inputs: name -> (level, chunk size (0 = the level's default), input thunk) ----
+# Streams are written by the reference build (gen_golden_brotli.py: lib/brotli-mt_compress.c + the
+# image's libbrotlienc 1.0.9, lgwin 24).  Levels 0/1 give one-pass codes and uncompressed
+# meta-blocks, 2..4 simple context-free codes, 5..9 context modelling, block splitting and static
+# dictionary words with transforms, 10/11 the full optimiser.  Chunk sizes are multiples of 64 KiB:
+# the hint field counts 64 KiB units (lib/brotli-mt_compress.c:294-304).
+def english(n, seed=1):
+    """Prose out of common English / HTML tokens, so that static-dictionary words and their
+    transforms (capitalised, with affixes) are used by the encoder."""
+    import random
+    r = random.Random(seed)
+    words = ("the of and to in is that for it as was with be by on not he this are or his from at which but have an "
+             "had they you were their one all we can her has there been if more when will would who so no said what up "
+             "information international government university development different important following "
+             "available including national president american political education community however another "
+             "company system program number people world state history general public research service "
+             "business social language century national country between because through against").split()
+    html = ['<div class="', '</div>', '<a href="http://www.', '.com/">', '<span style="', '</span>', "<p>", "</p>\n",
+            '<td width="', "<br />"]
+    out = []
+    size = 0
+    while size < n:
+        k = r.random()
+        if k < 0.06:
+            w = r.choice(html)
+        else:
+            w = r.choice(words)
+            if k < 0.16:
+                w = w.capitalize()
+            elif k < 0.18:
+                w = w.upper()
+            w += r.choice([" ", " ", " ", " ", ", ", ". ", "\n", "'s ", "ing ", "ed "])
+        out.append(w)
+        size += len(w)
+    return "".join(out).encode()[:n]
+
+
+BCASES = {
+    "b_empty":          (3, 0, lambda: b""),
+    "b_one":            (3, 0, lambda: b"x"),
+    "b_hello":          (0, 0, lambda: b"hello world, hello world, hello!"),
+    "b_text_3000_l1":   (1, 0, lambda: text(3000, 5)),
+    "b_text_64k_l0":    (0, 0, lambda: text(64 * K)),
+    "b_text_64k_l2":    (2, 0, lambda: text(64 * K)),
+    "b_text_200k_l3":   (3, 0, lambda: text(200 * K, 7)),
+    "b_text_200k_l5":   (5, 0, lambda: text(200 * K, 7)),
+    "b_text_200k_l9":   (9, 0, lambda: text(200 * K, 7)),
+    "b_text_100k_l11":  (11, 0, lambda: text(100 * K, 7)),
+    "b_text_3x128k":    (4, CH, lambda: text(3 * CH + 100, 11)),
+    "b_english_l5":     (5, 0, lambda: english(120000, 2)),
+    "b_english_l9":     (9, 0, lambda: english(120000, 3)),
+    "b_english_l11":    (11, 0, lambda: english(60000, 4)),
+    "b_english_chunks": (6, 65536, lambda: english(3 * 65536 + 777, 5)),
+    "b_random_100k":    (3, 0, lambda: rnd(100000, 3)),
+    "b_zeros_300k":     (3, 0, lambda: bytes(300000)),
+    "b_period_300":     (1, 0, lambda: rep(rnd(300, 9), 200000)),
+    "b_lowentropy":     (5, 0, lambda: bytes(b & 3 for b in rnd(150000, 12))),
+    "b_mixed_l1":       (1, 0, lambda: text(50000, 4) + bytes(70000) + rnd(3000, 5) + english(100000, 6)),
+    "b_mixed_l7":       (7, 0, lambda: text(50000, 4) + bytes(70000) + rnd(3000, 5) + english(100000, 6)),
+    "b_allbytes":       (4, 0, lambda: bytes(range(256)) * 300 + text(40000, 8)),
+}
