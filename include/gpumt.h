@@ -174,6 +174,23 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 				void *d_out, size_t out_bytes, const uint64_t *d_out_off,
 				const uint32_t *d_out_len, uint32_t *d_status, int stream);
 
+/* ---- brotli-mt records (16-byte header + one raw brotli stream, lib/brotli-mt_compress.c:285-304) ----
+ *
+ * gpumt_brotli_decompress_batch: decode nrec brotli streams (replaces BrotliDecoderDecompress at
+ * lib/brotli-mt_decompress.c:344-346).  Stream i is d_stream + d_rec_off[i], d_rec_len[i] bytes (the
+ * payload behind the 16-byte header, which the host parses while reading, :187-284); its output goes
+ * to d_out + d_out_off[i] and may take d_out_cap[i] bytes (hint << 16, :236-239).  d_out_len[i]
+ * receives the decoded size, d_status[i] GPUMT_ST_OK, GPUMT_ST_BAD_BLOCK (malformed / truncated
+ * stream) or GPUMT_ST_SIZE_MISMATCH (output exceeds the capacity) -- the reference reports
+ * frame_decompress for both.  Complete RFC 7932 decoder incl. the static dictionary.  Same
+ * d_stream slack rule as above.  Internal scratch: GPUMT_BROTLI_SCRATCH bytes per resident wave.
+ */
+#define GPUMT_BROTLI_SCRATCH 825856u
+int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
+				  const uint32_t *d_rec_len, size_t nrec, void *d_out,
+				  const uint64_t *d_out_off, const uint32_t *d_out_cap,
+				  uint32_t *d_out_len, uint32_t *d_status, int stream);
+
 /* XXH32 (seed 0) of n items: item i = d_base + d_off[i], d_len[i] bytes -> d_hash[i]. */
 int gpumt_xxh32_batch(gpumt_ctx *h, const void *d_base, const uint64_t *d_off,
 		      const uint32_t *d_len, size_t n, uint32_t *d_hash, int stream);

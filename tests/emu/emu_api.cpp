@@ -28,6 +28,7 @@ void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 void zmt_scan_kernel(const u32 *, u32, u64 *);
 void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
 void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u8 *, u32 *, u32 *, u32 *, u32);
+void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u8 *, const u8 *);
 void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u8 *, u32 *, u32 *, u32 *);
 void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *, u32 *);
 void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
@@ -180,6 +181,20 @@ void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *re
 		    [=]() { zmt_xxh64_verify_kernel(out, out_off, out_len, nrec, cep, cvp, status); });
 }
 
+
+/* brotli: `grid` persistent waves, each with its own (garbage-initialised) scratch */
+void emu_brotli_decompress_batch(const u8 *stream, const u64 *rec_off, const u32 *rec_len, u32 nrec, u8 *out,
+				 const u64 *out_off, const u32 *out_cap, u32 *out_len, u32 *status,
+				 const u8 *blob, u32 grid)
+{
+	if (grid > nrec)
+		grid = nrec;
+	std::vector<u8> scr((size_t)grid * 825856u, 0xA5);
+	u8 *sp = scr.data();
+	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1}, [=]() {
+		zmt_brotli_dec_kernel(stream, rec_off, rec_len, nrec, out, out_off, out_cap, out_len, status, sp, blob);
+	});
+}
 
 size_t emu_zstd_slot_stride(size_t chunk)
 {

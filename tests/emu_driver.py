@@ -2,6 +2,7 @@
 gpumt_* device API, on numpy host buffers.  TEST HARNESS ONLY."""
 import ctypes as C
 import os
+import struct
 import subprocess
 
 import numpy as np
@@ -107,6 +108,50 @@ def zstd_decompress(stream: bytes, rec=None):
                                 _p(out), _p(out_off), _p(out_len), _p(status))
     assert (out[total:] == 0xCC).all(), "decoder wrote past the end of its output"
     return out[:total].tobytes(), status
+
+
+def walk_brotli_records(stream: bytes):
+    """16-byte brotli-mt headers -> (payload offsets u64[n], payload sizes u32[n], capacities u32[n]);
+    what the host engine does while reading (lib/brotli-mt_decompress.c:187-284)"""
+    ro, rl, cap = [], [], []
+    ip = 0
+    while ip < len(stream):
+        assert len(stream) - ip >= 16
+        magic, eight, csize, br, hint = struct.unpack_from("<IIIHH", stream, ip)
+        assert magic == 0x184D2A50 and eight == 8 and br == 0x5242
+        ro.append(ip + 16)
+        rl.append(csize)
+        cap.append(hint << 16)
+        ip += 16 + csize
+    assert ip == len(stream)
+    return np.array(ro, np.uint64), np.array(rl, np.uint32), np.array(cap, np.uint32)
+
+
+def brotli_decompress(stream: bytes, grid: int = 2, rec=None):
+    """brotli-mt stream -> (list of decoded records, status[n]) through the emulated decoder"""
+    L = lib()
+    ro, rl, cap = rec if rec is not None else walk_brotli_records(stream)
+    nrec = len(ro)
+    with open(H.BROTLI_BLOB, "rb") as f:
+        blob = np.frombuffer(f.read(), np.uint8).copy()
+    sbuf = np.frombuffer(stream + b"\xEE" * 300, np.uint8).copy()
+    out_off = np.zeros(nrec + 1, np.uint64)
+    out_off[1:] = np.cumsum(cap.astype(np.uint64))
+    total = int(out_off[nrec])
+    out = np.full(total + 64, 0xCC, np.uint8)
+    out_len = np.full(nrec, 0xFFFFFFFF, np.uint32)
+    status = np.full(nrec, 99, np.uint32)
+    L.emu_brotli_decompress_batch(_p(sbuf), _p(ro), _p(rl), C.c_uint32(nrec), _p(out), _p(out_off), _p(cap),
+                                  _p(out_len), _p(status), _p(blob), C.c_uint32(grid))
+    assert (out[total:] == 0xCC).all(), "decoder wrote past the end of its output"
+    recs = []
+    for i in range(nrec):
+        o = int(out_off[i])
+        n = int(out_len[i]) if status[i] == 0 else 0
+        assert n <= int(cap[i])
+        assert (out[o + n:o + int(cap[i])] == 0xCC).all() or status[i] != 0, "wrote past the decoded size"
+        recs.append(out[o:o + n].tobytes())
+    return recs, status
 
 
 def zstd_compress(data: bytes, chunk: int, grid: int = 3):

@@ -1,0 +1,92 @@
+"""brotli decoder kernel (zstdmt_amd/csrc/hip/brotli_dec.hip) compiled for the host fiber emulator,
+against the golden streams of the reference build and the oracle.  CPU only; the same checks run on
+the device in test_gpu_brotli.py at full sizes."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import emu_driver as E
+import helpers as H
+from golden import cases
+
+GDIR = os.path.join(H.GOLDEN_DIR, "brotli")
+with open(os.path.join(GDIR, "manifest.json")) as f:
+    MAN = json.load(f)["cases"]
+
+SMALL = ["b_empty", "b_one", "b_hello", "b_text_3000_l1", "b_text_64k_l0", "b_text_64k_l2", "b_english_l11",
+         "b_period_300", "b_zeros_300k", "b_allbytes"]
+needs_lib = pytest.mark.skipif(not H.have_libbrotli(), reason="libbrotli 1.0.9 not in this image")
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_golden_streams(name):
+    ent = MAN[name]
+    with open(os.path.join(GDIR, ent["out_file"]), "rb") as f:
+        st = f.read()
+    recs, status = E.brotli_decompress(st)
+    assert (status == 0).all()
+    out = b"".join(recs)
+    assert len(out) == ent["in_len"] and H.sha256(out) == ent["in_sha256"]
+
+
+def test_multi_record_persistent_waves():
+    """five records on two persistent waves: scratch and register state carry nothing over"""
+    names = ["b_hello", "b_english_l11", "b_one", "b_text_3000_l1", "b_empty"]
+    st = b""
+    want = []
+    for n in names:
+        with open(os.path.join(GDIR, MAN[n]["out_file"]), "rb") as f:
+            st += f.read()
+        want.append(H.sha256(cases.BCASES[n][2]()))
+    recs, status = E.brotli_decompress(st, grid=2)
+    assert (status == 0).all()
+    assert [H.sha256(r) for r in recs] == want
+
+
+@needs_lib
+@pytest.mark.parametrize("quality", [0, 2, 5, 9, 11])
+def test_live_streams_match_oracle(quality):
+    d = cases.english(14000, 40 + quality) + cases.text(6000, 41) + bytes(300) + cases.rnd(500, 42)
+    for lgwin in (22, 10):
+        st = H.libbrotli_compress(d, quality, lgwin)
+        assert H.oracle_brotli_decompress(st, len(d)) == d
+        recs, status = E.brotli_decompress(H.brotli_record(st, 1))
+        assert status[0] == 0 and recs[0] == d
+
+
+@needs_lib
+def test_corrupt_streams_same_verdict():
+    d = cases.english(5000, 51) + cases.text(3000, 52)
+    st = H.libbrotli_compress(d, 6, 22)
+    rng = random.Random(5)
+    recs = []
+    for _ in range(24):
+        s = bytearray(st)
+        for _ in range(rng.choice([1, 2])):
+            s[rng.randrange(len(s))] ^= 1 << rng.randrange(8)
+        recs.append(bytes(s))
+    stream = b"".join(H.brotli_record(s, 1) for s in recs)
+    outs, status = E.brotli_decompress(stream, grid=3)
+    for s, o, stc in zip(recs, outs, status):
+        want = H.oracle_brotli_decompress(s, 65536)
+        if isinstance(want, int):
+            assert stc != 0
+        else:
+            assert stc == 0 and o == want
+
+
+def test_capacity_and_truncation():
+    ent = MAN["b_text_3000_l1"]
+    with open(os.path.join(GDIR, ent["out_file"]), "rb") as f:
+        st = f.read()
+    ro, rl, cap = E.walk_brotli_records(st)
+    cap2 = np.array([2048], np.uint32)  # capacity below the decoded size
+    recs, status = E.brotli_decompress(st, rec=(ro, rl, cap2))
+    assert status[0] == 4
+    rl2 = rl.copy()
+    rl2[0] -= 7  # payload cut short
+    recs, status = E.brotli_decompress(st, rec=(ro, rl2, cap))
+    assert status[0] == 3

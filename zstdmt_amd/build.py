@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 
-HIP_SRCS = ["xxh32.hip", "lz4_enc.hip", "lz4_enc3.hip", "lz4_dec.hip", "lz4_dec_batch.hip", "lz4_dec_split.hip", "zstd_dec.hip", "zstd_enc.hip", "pack.hip", "gpumt.hip"]
+HIP_SRCS = ["xxh32.hip", "lz4_enc.hip", "lz4_enc3.hip", "lz4_dec.hip", "lz4_dec_batch.hip", "lz4_dec_split.hip", "zstd_dec.hip", "zstd_enc.hip", "brotli_dec.hip", "pack.hip", "gpumt.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 HIPFLAGS += os.environ.get("ZMT_HIPFLAGS", "").split()   # developer: -D overrides for A/B builds
@@ -57,8 +57,10 @@ def build(force=False, verbose=True):
             s = os.path.join(hostdir, src)
             o = os.path.join(OBJDIR, src + ".o")
             hh = [os.path.join(hostdir, h) for h in os.listdir(hostdir) if h.endswith(".h")]
+            datadir = os.path.join(CSRC, "data")
+            hh += [os.path.join(datadir, d) for d in os.listdir(datadir)]
             if force or _stale(o, [s] + headers + hh):
-                _run(["gcc"] + CFLAGS + ["-c", s, "-o", o])
+                _run(["gcc"] + CFLAGS + ["-Wa,-I" + datadir, "-c", s, "-o", o])
             objs.append(o)
     lib = os.path.join(LIBDIR, "libzstdmt_amd.so")
     if force or _stale(lib, objs):

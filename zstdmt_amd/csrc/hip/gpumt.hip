@@ -37,6 +37,8 @@ __global__ void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, 
 __global__ void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
 				    const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 				    const u32 *, const u32 *, const u32 *, u32 *);
+__global__ void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *,
+				      u32 *, u32 *, u8 *, const u8 *);
 __global__ void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
 					  const u32 *, u8 *, u32 *, u32 *, u32 *);
 __global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
@@ -81,6 +83,8 @@ struct gpumt_ctx {
 	int num_cus;
 	int zenc_waves; /* resident waves of the persistent zstd encoder kernel (whole device) */
 	int zdec_variant; /* 0 = small-table kernel, then general; 1 = general only */
+	int bdec_waves;   /* resident waves of the persistent brotli decoder kernel (whole device) */
+	void *d_brotli_static; /* device copy of the RFC 7932 constant data */
 	char err[256];
 	char name[128];
 };
@@ -717,6 +721,41 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 			   h->st[s], (const u8 *)d_out, d_out_off, d_out_len, (u32)nrec, (const u32 *)chk_e,
 			   (const u32 *)chk_v, d_status);
 	PROF1(11);
+	CK(hipGetLastError());
+	return GPUMT_OK;
+}
+
+extern "C" const unsigned char zmt_brotli_static[], zmt_brotli_static_end[];
+
+int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
+				  const uint32_t *d_rec_len, size_t nrec, void *d_out,
+				  const uint64_t *d_out_off, const uint32_t *d_out_cap,
+				  uint32_t *d_out_len, uint32_t *d_status, int s)
+{
+	if (!h || !STREAM_OK(s) || nrec == 0 || nrec > 0x3FFFFFFFu)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	if (!h->d_brotli_static) {
+		const size_t n = (size_t)(zmt_brotli_static_end - zmt_brotli_static);
+		CK(hipMalloc(&h->d_brotli_static, n + 64));
+		CK(hipMemcpy(h->d_brotli_static, zmt_brotli_static, n, hipMemcpyHostToDevice));
+	}
+	if (!h->bdec_waves) {
+		int per_cu = 0;
+		CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zmt_brotli_dec_kernel, 64, 0));
+		h->bdec_waves = (per_cu > 0 ? per_cu : 4) * (h->num_cus > 0 ? h->num_cus : 256);
+		if (getenv("GPUMT_VERBOSE"))
+			fprintf(stderr, "gpumt: brotli decoder grid %d waves\n", h->bdec_waves);
+	}
+	const unsigned grid = (unsigned)(nrec < (size_t)h->bdec_waves ? nrec : (size_t)h->bdec_waves);
+	if (want_scratch(h, 1, (size_t)grid * GPUMT_BROTLI_SCRATCH))
+		return GPUMT_E_HIP;
+	PROF0(12);
+	hipLaunchKernelGGL(zmt_brotli_dec_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_stream, d_rec_off,
+			   d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap, d_out_len, d_status,
+			   (u8 *)h->scratch[1], (const u8 *)h->d_brotli_static);
+	PROF1(12);
 	CK(hipGetLastError());
 	return GPUMT_OK;
 }

@@ -141,6 +141,42 @@ class Engine:
                                                     int(out_bytes), d_out_off.ptr, d_out_len.ptr,
                                                     d_status.ptr, stream), "zstd_decompress_batch")
 
+    def brotli_decompress(self, d_stream, d_rec_off, d_rec_len, nrec, d_out, d_out_off, d_out_cap, d_out_len,
+                          d_status, stream=0):
+        self._ck(self.L.gpumt_brotli_decompress_batch(self.h, d_stream.ptr, d_rec_off.ptr, d_rec_len.ptr, nrec,
+                                                      d_out.ptr, d_out_off.ptr, d_out_cap.ptr, d_out_len.ptr,
+                                                      d_status.ptr, stream), "brotli_decompress_batch")
+
+    def brotli_decompress_bytes(self, stream: bytes, rec_off, rec_len, cap):
+        """Records of a brotli-mt stream (payload offsets / sizes / capacities as the host engine
+        parses them) -> (list of decoded records, status[n])"""
+        nrec = len(rec_off)
+        out_off = np.zeros(nrec + 1, np.uint64)
+        out_off[1:] = np.cumsum(np.asarray(cap, np.uint64))
+        total = int(out_off[nrec])
+        d_stream = self.upload(stream + b"\0" * 256)
+        d_ro, d_rl = self.upload(np.asarray(rec_off, np.uint64).copy()), self.upload(np.asarray(rec_len, np.uint32).copy())
+        d_oo, d_oc = self.upload(out_off), self.upload(np.asarray(cap, np.uint32).copy())
+        d_ol, d_st = self.alloc(nrec * 4), self.alloc(nrec * 4)
+        d_out = self.upload(np.full(total + 64, 0xCC, np.uint8))
+        try:
+            self.brotli_decompress(d_stream, d_ro, d_rl, nrec, d_out, d_oo, d_oc, d_ol, d_st)
+            status = self.download(d_st, nrec * 4, np.uint32)
+            out_len = self.download(d_ol, nrec * 4, np.uint32)
+            raw = self.download(d_out, total + 64)
+        finally:
+            for b in (d_stream, d_ro, d_rl, d_oo, d_oc, d_ol, d_st, d_out):
+                b.free()
+        assert (raw[total:] == 0xCC).all(), "decoder wrote past the end of its output"
+        recs = []
+        for i in range(nrec):
+            o, n = int(out_off[i]), int(out_len[i])
+            assert n <= int(cap[i])
+            if status[i] == 0:
+                assert (raw[o + n:o + int(cap[i])] == 0xCC).all(), "wrote past the decoded size"
+            recs.append(raw[o:o + n].tobytes())
+        return recs, status
+
     # ---- convenience round trips on host bytes (tests) ----------------------------------------
     def compress_bytes(self, data: bytes, chunk: int, codec="lz4"):
         """-> (stream bytes, rec_off[n+1] u64, rec_len[n] u32)"""
