@@ -1,0 +1,158 @@
+"""The drop-in boundary for brotli-mt decompression: BROTLIMT_* of libzstdmt_amd.so
+(include/brotli-mt.h) driven through the reference's callback protocol (lib/brotli-mt.h), against
+streams the reference wrote and -- where oracle/_ref travelled -- the reference library itself,
+call for call."""
+import ctypes as C
+import json
+import os
+
+import pytest
+
+import helpers as H
+from golden import cases
+
+pytestmark = pytest.mark.gpu
+
+BDIR = os.path.join(H.GOLDEN_DIR, "brotli")
+MAN = json.load(open(os.path.join(BDIR, "manifest.json")))["cases"]
+ERR = lambda e: C.c_size_t(-e).value  # noqa: E731  (size_t)-enum
+E_MEM, E_READ, E_WRITE, E_DATA, E_FC, E_FD, E_PARAM, E_LIB, E_CANCEL = range(1, 10)
+needs_ref = pytest.mark.skipif(not H.have_bref(), reason="reference build not on this box")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from zstdmt_amd._native import lib_path
+    return H.bind_lz4mt(C.CDLL(lib_path()), "BROTLIMT_")
+
+
+def _stream(name):
+    ent = MAN[name]
+    if "out_file" in ent:
+        return open(os.path.join(BDIR, ent["out_file"]), "rb").read()
+    if not H.have_bref():
+        pytest.skip("stream not committed (size) and no reference build on this box")
+    level, chunk, thunk = cases.BCASES[name]
+    rv, st, _, _ = H.brotlimt_compress_via(H.bref(), thunk(), chunk, threads=2, level=level)
+    assert rv == 0
+    return st
+
+
+def _strip_eof(reads):
+    r = list(reads)
+    while r and r[-1][1] == 0:
+        r.pop()
+    return r
+
+
+@pytest.mark.parametrize("name", sorted(MAN))
+def test_decompress_reference_streams(lib, name):
+    ent = MAN[name]
+    st = _stream(name)
+    rv, out, io, stats = H.brotlimt_decompress_via(lib, st, threads=4)
+    assert rv == 0
+    assert len(out) == ent["in_len"] and H.sha256(out) == ent["in_sha256"]
+    # frames written, bytes read (headers included), bytes written -- as the reference counts them
+    assert stats == (ent["frames"], ent["d_insize"], ent["d_outsize"])
+    # one fn_write per frame, in order
+    assert len(io.writes) == ent["frames"] and sum(io.writes) == ent["in_len"]
+    # reads: 4-byte sniff, 12 header bytes, payload; then 16 + payload per record (pt_read)
+    assert io.reads[0] == (4, 4) and io.reads[1] == (12, 12)
+
+
+@needs_ref
+@pytest.mark.parametrize("name", ["b_empty", "b_hello", "b_text_3x128k", "b_english_chunks", "b_mixed_l7"])
+def test_same_callback_trace_as_reference(lib, name):
+    """T=1 on the reference is fully sequential: identical request sizes, identical writes"""
+    st = _stream(name)
+    rv_r, out_r, io_r, stats_r = H.brotlimt_decompress_via(H.bref(), st, threads=1)
+    rv_o, out_o, io_o, stats_o = H.brotlimt_decompress_via(lib, st, threads=1)
+    assert rv_r == 0 and rv_o == 0 and out_r == out_o and stats_r == stats_o
+    assert _strip_eof(io_r.reads) == _strip_eof(io_o.reads)
+    assert io_r.writes == io_o.writes
+
+
+@needs_ref
+@pytest.mark.parametrize("level,chunk,mib", [(1, 0, 9), (0, 65536, 3), (4, 1 << 20, 6), (6, 0, 7), (9, 1 << 19, 3)])
+def test_many_records(lib, level, chunk, mib):
+    data = cases.text((mib << 20) + 4321, 70 + level) + cases.english(400000, level)
+    rv, st, _, cstats = H.brotlimt_compress_via(H.bref(), data, chunk, threads=16, level=level)
+    assert rv == 0
+    rv, out, io, stats = H.brotlimt_decompress_via(lib, st, threads=8)
+    assert rv == 0 and out == data
+    assert stats == (cstats[0], len(st), len(data))
+
+
+def test_errors(lib):
+    st = _stream("b_text_3x128k")
+    # not a skippable frame at all
+    rv, _, _, _ = H.brotlimt_decompress_via(lib, b"\x00" * 64)
+    assert rv == ERR(E_DATA)
+    # shorter than the sniff
+    rv, _, _, _ = H.brotlimt_decompress_via(lib, st[:3])
+    assert rv == ERR(E_DATA)
+    # header cut: read_fail; payload cut: data_error (pt_read)
+    rv, _, _, _ = H.brotlimt_decompress_via(lib, st[:10])
+    assert rv == ERR(E_READ)
+    rv, _, _, _ = H.brotlimt_decompress_via(lib, st[:16 + 100])
+    assert rv == ERR(E_DATA)
+    # bad length field / bad "BR"
+    bad = bytearray(st)
+    bad[4] = 4
+    rv, _, _, _ = H.brotlimt_decompress_via(lib, bytes(bad))
+    assert rv == ERR(E_DATA)
+    bad = bytearray(st)
+    bad[12] = 0x41
+    rv, _, _, _ = H.brotlimt_decompress_via(lib, bytes(bad))
+    assert rv == ERR(E_DATA)
+    # second record's magic
+    ro = 16 + int.from_bytes(st[8:12], "little")
+    bad = bytearray(st)
+    bad[ro] ^= 0xFF
+    rv, _, _, _ = H.brotlimt_decompress_via(lib, bytes(bad))
+    assert rv == ERR(E_DATA)
+    # a damaged brotli stream / a hint that is too small: frame_decompress
+    bad = bytearray(st)
+    bad[16 + 50] ^= 0x55
+    bad[16 + 51] ^= 0xAA
+    rv, _, _, _ = H.brotlimt_decompress_via(lib, bytes(bad))
+    assert rv == ERR(E_FD)
+    bad = bytearray(st)
+    bad[14] = 1  # first record decodes to 128 KiB
+    rv, _, _, _ = H.brotlimt_decompress_via(lib, bytes(bad))
+    assert rv == ERR(E_FD)
+    assert lib.BROTLIMT_isError(rv) == 1
+    assert lib.BROTLIMT_getErrorString(rv) == b"Could not decompress frame at once"
+
+
+def test_callback_errors_and_arguments(lib):
+    st = _stream("b_text_3x128k")
+    for fail_at, code, want in ((0, -1, E_READ), (1, -2, E_CANCEL), (2, -3, E_MEM)):
+        io = H.MemIO(st, fail_read_at=fail_at, read_rv=code)
+        ctx = lib.BROTLIMT_createDCtx(2, 0)
+        assert lib.BROTLIMT_decompressDCtx(ctx, C.byref(io.rdwr)) == ERR(want)
+        lib.BROTLIMT_freeDCtx(ctx)
+    io = H.MemIO(st, fail_write_at=1, write_rv=-1)
+    ctx = lib.BROTLIMT_createDCtx(2, 0)
+    assert lib.BROTLIMT_decompressDCtx(ctx, C.byref(io.rdwr)) == ERR(E_READ)  # mt_error maps -1 to read_fail
+    lib.BROTLIMT_freeDCtx(ctx)
+    assert not lib.BROTLIMT_createDCtx(0, 0) and not lib.BROTLIMT_createDCtx(129, 0)
+    assert lib.BROTLIMT_decompressDCtx(None, None) == ERR(E_PARAM)
+    # compression side: argument validation as the reference, no device encoder yet
+    assert not lib.BROTLIMT_createCCtx(0, 3, 0) and not lib.BROTLIMT_createCCtx(1, 12, 0)
+    c = lib.BROTLIMT_createCCtx(4, 11, 0)
+    assert c
+    io = H.MemIO(b"abc")
+    assert lib.BROTLIMT_compressCCtx(c, C.byref(io.rdwr)) == ERR(E_PARAM)
+    assert io.reads == []
+    lib.BROTLIMT_freeCCtx(c)
+
+
+def test_context_reuse(lib):
+    a, b = _stream("b_text_3x128k"), _stream("b_english_chunks")
+    ctx = lib.BROTLIMT_createDCtx(2, 0)
+    for st, name in ((a, "b_text_3x128k"), (b, "b_english_chunks"), (a, "b_text_3x128k")):
+        io = H.MemIO(st)
+        assert lib.BROTLIMT_decompressDCtx(ctx, C.byref(io.rdwr)) == 0
+        assert H.sha256(io.result()) == MAN[name]["in_sha256"]
+    lib.BROTLIMT_freeDCtx(ctx)

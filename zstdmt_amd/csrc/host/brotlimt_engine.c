@@ -1,0 +1,349 @@
+/*
+ * brotlimt_engine.c -- the host side of brotli-mt on MI355X: BROTLIMT_* (include/brotli-mt.h) over
+ * gpumt_*.
+ *
+ * Decompression follows the callback-visible behaviour of the reference
+ * (lib/brotli-mt_decompress.c:187-454): a 4-byte sniff that must be the skippable magic (:397-407),
+ * 12 more header bytes for the first record and 16 for every later one (:197-224), the payload in
+ * one read (:255-262), one fn_write per record in order; the output capacity of a record is
+ * hint << 16 and nothing else (:236-239), a stream that does not decode into it fails with
+ * frame_decompress (:348-351).  Records move through the same three-role batch pipeline as the other
+ * codecs (mt_pipe.h): H2D / decode kernel / D2H on three streams.
+ * Compression: not on the device yet (see include/brotli-mt.h).
+ * Plain C, no HIP header.
+ */
+#include "mt_host.h"
+#include "mt_pipe.h"
+#include "brotli-mt.h"
+
+/* ------------------------------------------------------------------ errors (brotli-mt_common.c) */
+unsigned BROTLIMT_isError(size_t code)
+{
+	return code > BROTLIMT_ERROR(maxCode);
+}
+
+const char *BROTLIMT_getErrorString(size_t code)
+{
+	/* strings of lib/brotli-mt_common.c:37-57 */
+	switch ((BROTLIMT_ErrorCode)((size_t)0 - code)) {
+	case BROTLIMT_error_no_error:
+		return "No error detected";
+	case BROTLIMT_error_memory_allocation:
+		return "Allocation error : not enough memory";
+	case BROTLIMT_error_read_fail:
+		return "Read failure";
+	case BROTLIMT_error_write_fail:
+		return "Write failure";
+	case BROTLIMT_error_data_error:
+		return "Malformed input";
+	case BROTLIMT_error_frame_compress:
+		return "Could not compress frame at once";
+	case BROTLIMT_error_frame_decompress:
+		return "Could not decompress frame at once";
+	case BROTLIMT_error_compressionParameter_unsupported:
+		return "Compression parameter is out of bound";
+	default:
+		return "Unspecified brotli error code";
+	}
+}
+
+/* callback return value -> library error (mt_error, brotli-mt_decompress.c:142-155) */
+static size_t mt_error(int rv)
+{
+	switch (rv) {
+	case -1:
+		return BROTLIMT_ERROR(read_fail);
+	case -2:
+		return BROTLIMT_ERROR(canceled);
+	case -3:
+		return BROTLIMT_ERROR(memory_allocation);
+	}
+	return BROTLIMT_ERROR(read_fail);
+}
+
+/* =================================================================== compression (not yet) */
+struct BROTLIMT_CCtx_s {
+	int threads, level, inputsize;
+};
+
+BROTLIMT_CCtx *BROTLIMT_createCCtx(int threads, int level, int inputsize)
+{
+	BROTLIMT_CCtx *ctx;
+	if (threads < 1 || threads > BROTLIMT_THREAD_MAX)
+		return NULL;
+	if (level < BROTLIMT_LEVEL_MIN || level > BROTLIMT_LEVEL_MAX)
+		return NULL;
+	ctx = (BROTLIMT_CCtx *)calloc(1, sizeof *ctx);
+	if (!ctx)
+		return NULL;
+	ctx->threads = threads;
+	ctx->level = level;
+	ctx->inputsize = inputsize ? inputsize : 1024 * 1024 * (level ? level : 1); /* :105-109 */
+	return ctx;
+}
+
+size_t BROTLIMT_compressCCtx(BROTLIMT_CCtx *ctx, BROTLIMT_RdWr_t *rdwr)
+{
+	(void)ctx;
+	(void)rdwr;
+	return BROTLIMT_ERROR(compressionParameter_unsupported);
+}
+
+size_t BROTLIMT_GetFramesCCtx(BROTLIMT_CCtx *ctx) { (void)ctx; return 0; }
+size_t BROTLIMT_GetInsizeCCtx(BROTLIMT_CCtx *ctx) { (void)ctx; return 0; }
+size_t BROTLIMT_GetOutsizeCCtx(BROTLIMT_CCtx *ctx) { (void)ctx; return 0; }
+void BROTLIMT_freeCCtx(BROTLIMT_CCtx *ctx) { free(ctx); }
+
+/* =================================================================== decompression */
+struct dslot {
+	dbuf in;   /* record payloads back to back, H2D                                              */
+	dbuf meta; /* rec_off u64[n] | out_off u64[n+1] | rec_len u32[n] | out_cap u32[n], H2D       */
+	dbuf res;  /* out_len u32[n] | status u32[n], D2H                                            */
+	dbuf out;  /* one slot of hint << 16 bytes per record, D2H                                   */
+	size_t nrec, in_bytes, out_bytes;
+};
+
+struct BROTLIMT_DCtx_s {
+	int threads, inputsize;
+	size_t budget;
+	size_t insize, outsize, curframe, frames;
+	gpumt_ctx *gpu;
+	struct dslot s[MT_NSLOT];
+	BROTLIMT_RdWr_t *io;
+	int have_hdr; /* a record header read ahead of its batch */
+	uint32_t hdr_csize, hdr_hint;
+	int first; /* the next header is the first one: its magic came with the sniff */
+};
+
+BROTLIMT_DCtx *BROTLIMT_createDCtx(int threads, int inputsize)
+{
+	BROTLIMT_DCtx *ctx;
+	if (threads < 1 || threads > BROTLIMT_THREAD_MAX)
+		return NULL;
+	ctx = (BROTLIMT_DCtx *)calloc(1, sizeof *ctx);
+	if (!ctx)
+		return NULL;
+	ctx->threads = threads;
+	ctx->inputsize = inputsize ? inputsize : 1024 * 64; /* brotli-mt_decompress.c:110-113 */
+	if (gpumt_open(0, &ctx->gpu) != GPUMT_OK) {
+		free(ctx);
+		return NULL;
+	}
+	return ctx;
+}
+
+void BROTLIMT_freeDCtx(BROTLIMT_DCtx *ctx)
+{
+	if (!ctx)
+		return;
+	for (int i = 0; i < MT_NSLOT; i++) {
+		dbuf_free(ctx->gpu, &ctx->s[i].in);
+		dbuf_free(ctx->gpu, &ctx->s[i].meta);
+		dbuf_free(ctx->gpu, &ctx->s[i].res);
+		dbuf_free(ctx->gpu, &ctx->s[i].out);
+	}
+	gpumt_close(ctx->gpu);
+	free(ctx);
+}
+
+size_t BROTLIMT_GetFramesDCtx(BROTLIMT_DCtx *ctx) { return ctx ? ctx->curframe : 0; }
+size_t BROTLIMT_GetInsizeDCtx(BROTLIMT_DCtx *ctx) { return ctx ? ctx->insize : 0; }
+size_t BROTLIMT_GetOutsizeDCtx(BROTLIMT_DCtx *ctx) { return ctx ? ctx->outsize : 0; }
+
+#define D_META_BYTES(n) ((n) * 8 + ((n) + 1) * 8 + (n) * 4 + (n) * 4 + 64)
+static uint64_t *m_rec_off(struct dslot *s, int dev) { return (uint64_t *)(dev ? s->meta.d : s->meta.h); }
+static uint64_t *m_out_off(struct dslot *s, int dev) { return m_rec_off(s, dev) + BATCH_MAXREC; }
+static uint32_t *m_rec_len(struct dslot *s, int dev) { return (uint32_t *)(m_out_off(s, dev) + BATCH_MAXREC + 1); }
+static uint32_t *m_out_cap(struct dslot *s, int dev) { return m_rec_len(s, dev) + BATCH_MAXREC; }
+static uint32_t *r_out_len(struct dslot *s, int dev) { return (uint32_t *)(dev ? s->res.d : s->res.h); }
+static uint32_t *r_status(struct dslot *s, int dev) { return r_out_len(s, dev) + BATCH_MAXREC; }
+
+/* next record header (pt_read, brotli-mt_decompress.c:193-240): 12 bytes after the sniff, else 16 */
+static size_t d_read_header(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *io, uint32_t *csize, uint32_t *hint, int *eof)
+{
+	uint8_t hb[16];
+	BROTLIMT_Buffer b;
+	int rv;
+	const size_t want = ctx->first ? 12 : 16;
+	b.buf = ctx->first ? hb + 4 : hb;
+	b.size = want;
+	b.allocated = want;
+	rv = io->fn_read(io->arg_read, &b);
+	if (rv != 0)
+		return mt_error(rv);
+	if (!ctx->first && b.size == 0) {
+		*eof = 1;
+		return 0;
+	}
+	if (b.size != want)
+		return BROTLIMT_ERROR(read_fail);
+	if (!ctx->first && rd32(hb) != BROTLIMT_MAGIC_SKIPPABLE)
+		return BROTLIMT_ERROR(data_error);
+	ctx->first = 0;
+	if (rd32(hb + 4) != 8)
+		return BROTLIMT_ERROR(data_error);
+	if (((uint32_t)hb[12] | (uint32_t)hb[13] << 8) != BROTLIMT_MAGICNUMBER)
+		return BROTLIMT_ERROR(data_error);
+	ctx->insize += 16;
+	*csize = rd32(hb + 8);
+	*hint = (uint32_t)hb[14] | (uint32_t)hb[15] << 8;
+	return 0;
+}
+
+static size_t d_read_batch(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *io, struct dslot *s, int *eof)
+{
+	s->nrec = 0;
+	s->in_bytes = 0;
+	s->out_bytes = 0;
+	while (s->nrec < BATCH_MAXREC) {
+		uint32_t csize, hint;
+		BROTLIMT_Buffer b;
+		size_t err, cap;
+		int rv;
+		if (ctx->have_hdr) {
+			csize = ctx->hdr_csize;
+			hint = ctx->hdr_hint;
+		} else {
+			err = d_read_header(ctx, io, &csize, &hint, eof);
+			if (err)
+				return err;
+			if (*eof)
+				break;
+		}
+		cap = (size_t)hint << 16;
+		if (s->nrec && (s->in_bytes + (size_t)csize > s->in.cap - 512 || s->out_bytes + cap > ctx->budget)) {
+			ctx->have_hdr = 1;
+			ctx->hdr_csize = csize;
+			ctx->hdr_hint = hint;
+			break;
+		}
+		ctx->have_hdr = 0;
+		if (s->in_bytes + (size_t)csize + 512 > s->in.cap) {
+			dbuf old = s->in;
+			memset(&s->in, 0, sizeof s->in);
+			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + (size_t)csize + 512, 1, 1))
+				return BROTLIMT_ERROR(memory_allocation);
+			memcpy(s->in.h, old.h, s->in_bytes);
+			dbuf_free(ctx->gpu, &old);
+		}
+		b.buf = (uint8_t *)s->in.h + s->in_bytes;
+		b.size = csize;
+		b.allocated = csize;
+		rv = io->fn_read(io->arg_read, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		if (b.size != csize)
+			return BROTLIMT_ERROR(data_error); /* "needed more bytes!" (:259-260) */
+		ctx->insize += csize;
+		ctx->frames++;
+		m_rec_off(s, 0)[s->nrec] = s->in_bytes;
+		m_rec_len(s, 0)[s->nrec] = csize;
+		m_out_off(s, 0)[s->nrec] = s->out_bytes;
+		m_out_cap(s, 0)[s->nrec] = (uint32_t)cap;
+		s->in_bytes += csize;
+		s->out_bytes += cap;
+		s->nrec++;
+	}
+	m_out_off(s, 0)[s->nrec] = s->out_bytes;
+	return 0;
+}
+
+static size_t d_launch(BROTLIMT_DCtx *ctx, struct dslot *s)
+{
+	gpumt_ctx *g = ctx->gpu;
+	int rc = 0;
+	if (dbuf_want(g, &s->out, s->out_bytes + 64, 1, 1) || dbuf_want(g, &s->res, BATCH_MAXREC * 8 + 64, 1, 1))
+		return BROTLIMT_ERROR(memory_allocation);
+	rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, s->in_bytes + 256, 1);
+	rc |= gpumt_memcpy_h2d(g, s->meta.d, s->meta.h, D_META_BYTES(BATCH_MAXREC), 1);
+	rc |= gpumt_stream_wait(g, 0, 1);
+	rc |= gpumt_brotli_decompress_batch(g, s->in.d, m_rec_off(s, 1), m_rec_len(s, 1), s->nrec, s->out.d,
+					    m_out_off(s, 1), m_out_cap(s, 1), r_out_len(s, 1), r_status(s, 1), 0);
+	rc |= gpumt_stream_wait(g, 2, 0);
+	rc |= gpumt_memcpy_d2h(g, s->res.h, s->res.d, BATCH_MAXREC * 8, 2);
+	if (s->out_bytes)
+		rc |= gpumt_memcpy_d2h(g, s->out.h, s->out.d, s->out_bytes, 2);
+	return rc ? BROTLIMT_ERROR(frame_decompress) : 0;
+}
+
+static size_t dp_fill(void *a, int si, int *has_data, int *eof)
+{
+	BROTLIMT_DCtx *ctx = (BROTLIMT_DCtx *)a;
+	struct dslot *s = &ctx->s[si];
+	size_t err;
+	if (dbuf_want(ctx->gpu, &s->in, ctx->budget + (ctx->budget >> 3) + 4096, 1, 1) ||
+	    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1))
+		return BROTLIMT_ERROR(memory_allocation);
+	err = d_read_batch(ctx, ctx->io, s, eof);
+	*has_data = s->nrec > 0;
+	if (ctx->budget < BATCH_BYTES)
+		ctx->budget *= 4;
+	return err;
+}
+
+static size_t dp_launch(void *a, int si)
+{
+	BROTLIMT_DCtx *ctx = (BROTLIMT_DCtx *)a;
+	size_t err = d_launch(ctx, &ctx->s[si]);
+	if (!err && gpumt_mark(ctx->gpu, si, 2))
+		err = BROTLIMT_ERROR(frame_decompress);
+	return err;
+}
+
+static size_t dp_complete(void *a, int si)
+{
+	BROTLIMT_DCtx *ctx = (BROTLIMT_DCtx *)a;
+	return gpumt_mark_sync(ctx->gpu, si) ? BROTLIMT_ERROR(frame_decompress) : 0;
+}
+
+static size_t dp_drain(void *a, int si)
+{
+	BROTLIMT_DCtx *ctx = (BROTLIMT_DCtx *)a;
+	struct dslot *s = &ctx->s[si];
+	const uint32_t *st = r_status(s, 0), *ol = r_out_len(s, 0);
+	for (size_t i = 0; i < s->nrec; i++) {
+		BROTLIMT_Buffer b;
+		int rv;
+		if (st[i] != GPUMT_ST_OK)
+			return BROTLIMT_ERROR(frame_decompress); /* pt_decompress :348-351 */
+		b.buf = (uint8_t *)s->out.h + m_out_off(s, 0)[i];
+		b.size = ol[i];
+		b.allocated = m_out_cap(s, 0)[i];
+		rv = ctx->io->fn_write(ctx->io->arg_write, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		ctx->outsize += b.size;
+		ctx->curframe++;
+	}
+	return 0;
+}
+
+size_t BROTLIMT_decompressDCtx(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *rdwr)
+{
+	uint8_t sniff[4];
+	BROTLIMT_Buffer b;
+	static const mt_pipe_ops ops = {dp_fill, dp_launch, dp_complete, dp_drain};
+	size_t err;
+	int rv;
+
+	if (!ctx)
+		return BROTLIMT_ERROR(compressionParameter_unsupported); /* brotli-mt_decompress.c:387-388 */
+	/* 4-byte sniff: only the skippable-frame layout exists for brotli (:397-407) */
+	b.buf = sniff;
+	b.size = 4;
+	b.allocated = 4;
+	rv = rdwr->fn_read(rdwr->arg_read, &b);
+	if (rv != 0)
+		return mt_error(rv);
+	if (b.size != 4)
+		return BROTLIMT_ERROR(data_error);
+	if (rd32(sniff) != BROTLIMT_MAGIC_SKIPPABLE)
+		return BROTLIMT_ERROR(data_error);
+	ctx->first = 1;
+	ctx->have_hdr = 0;
+	ctx->budget = BATCH_MIN;
+	ctx->io = rdwr;
+	err = mt_pipe_run(&ops, ctx);
+	gpumt_device_sync(ctx->gpu);
+	return err;
+}
