@@ -5,6 +5,7 @@
  * API the reference CLI uses (programs/main.c:228-245 / :276-293): LZ4MT_createCCtx ->
  * LZ4MT_compressCCtx with fn_read/fn_write callbacks (here memcpy, so disk is excluded) and the
  * DCtx mirror.  Two kinds:
+ *   reference-zstd / reference-brotli : the same for oracle/_ref/lib{zstd,brotli}mt_ref.so
  *   reference : oracle/_ref/liblz4mt_ref.so = the reference's own lib/lz4-mt_*.c + liblz4 (dlopen)
  *   port      : the oracle restatement (zo_lz4mt_*_mt), T threads
  * Prints one JSON object.
@@ -67,7 +68,7 @@ static double now(void)
 int main(int argc, char **argv)
 {
 	if (argc < 7) {
-		fprintf(stderr, "usage: cpu_bench reference|reference-zstd|port ref.so bytes chunk threads seed\n");
+		fprintf(stderr, "usage: cpu_bench reference|reference-zstd|reference-brotli|port ref.so bytes chunk threads seed\n");
 		return 2;
 	}
 	const char *kind = argv[1];
@@ -85,22 +86,22 @@ int main(int argc, char **argv)
 	memset(cmp, 0, cap); /* touch pages outside the timed region */
 	memset(back, 0, n);
 
-	if (!strcmp(kind, "reference") || !strcmp(kind, "reference-zstd")) {
+	if (!strcmp(kind, "reference") || !strcmp(kind, "reference-zstd") || !strcmp(kind, "reference-brotli")) {
 		/* the reference library itself: lz4-mt (LZ4MT_*) or zstd-mt (ZSTDCB_*, same shapes,
 		 * lib/zstd-mt.h:115-205), level 1 */
-		const int z = !strcmp(kind, "reference-zstd");
+		const int z = !strcmp(kind, "reference-zstd") ? 1 : !strcmp(kind, "reference-brotli") ? 2 : 0;
 		void *so = dlopen(argv[2], RTLD_NOW);
 		if (!so) {
 			fprintf(stderr, "dlopen %s: %s\n", argv[2], dlerror());
 			return 4;
 		}
-		void *(*createC)(int, int, int) = dlsym(so, z ? "ZSTDCB_createCCtx" : "LZ4MT_createCCtx");
-		size_t (*compressC)(void *, RdWr *) = dlsym(so, z ? "ZSTDCB_compressCCtx" : "LZ4MT_compressCCtx");
-		void (*freeC)(void *) = dlsym(so, z ? "ZSTDCB_freeCCtx" : "LZ4MT_freeCCtx");
-		void *(*createD)(int, int) = dlsym(so, z ? "ZSTDCB_createDCtx" : "LZ4MT_createDCtx");
-		size_t (*decompressD)(void *, RdWr *) = dlsym(so, z ? "ZSTDCB_decompressDCtx" : "LZ4MT_decompressDCtx");
-		void (*freeD)(void *) = dlsym(so, z ? "ZSTDCB_freeDCtx" : "LZ4MT_freeDCtx");
-		unsigned (*isErr)(size_t) = dlsym(so, z ? "ZSTDCB_isError" : "LZ4MT_isError");
+		void *(*createC)(int, int, int) = dlsym(so, z == 2 ? "BROTLIMT_createCCtx" : z ? "ZSTDCB_createCCtx" : "LZ4MT_createCCtx");
+		size_t (*compressC)(void *, RdWr *) = dlsym(so, z == 2 ? "BROTLIMT_compressCCtx" : z ? "ZSTDCB_compressCCtx" : "LZ4MT_compressCCtx");
+		void (*freeC)(void *) = dlsym(so, z == 2 ? "BROTLIMT_freeCCtx" : z ? "ZSTDCB_freeCCtx" : "LZ4MT_freeCCtx");
+		void *(*createD)(int, int) = dlsym(so, z == 2 ? "BROTLIMT_createDCtx" : z ? "ZSTDCB_createDCtx" : "LZ4MT_createDCtx");
+		size_t (*decompressD)(void *, RdWr *) = dlsym(so, z == 2 ? "BROTLIMT_decompressDCtx" : z ? "ZSTDCB_decompressDCtx" : "LZ4MT_decompressDCtx");
+		void (*freeD)(void *) = dlsym(so, z == 2 ? "BROTLIMT_freeDCtx" : z ? "ZSTDCB_freeDCtx" : "LZ4MT_freeDCtx");
+		unsigned (*isErr)(size_t) = dlsym(so, z == 2 ? "BROTLIMT_isError" : z ? "ZSTDCB_isError" : "LZ4MT_isError");
 		struct mem in = { src, n, 0 }, out = { cmp, cap, 0 };
 		RdWr io = { rd, &in, wr, &out };
 		void *c = createC(T, 1, (int)chunk);

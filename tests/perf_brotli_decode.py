@@ -53,6 +53,20 @@ def main():
         e.sync()
         dt = time.time() - t
         print(f"decode {dt*1e3:.2f} ms  {n/dt/1e9:.1f} GB/s out, {(n+len(st))/dt/1e9:.1f} GB/s alg", flush=True)
+    if os.environ.get("BPROF"):
+        import ctypes as C
+        e.set_variant("profile", 7)
+        cnt = (C.c_ulonglong * 16)()
+        e.L.gpumt_debug_counters(e.h, cnt, 16)
+        e.brotli_decompress(d_stream, d_ro, d_rl, nrec, d_out, d_oo, d_oc, d_ol, d_st)
+        e.sync()
+        e.L.gpumt_debug_counters(e.h, cnt, 16)
+        c = list(cnt)
+        w = max(c[9], 1)
+        nm = ["headers", "cmd", "literals", "distance", "copy-batches", "dict/raw", "rest"]
+        print("  Mcycles per wave: " + ", ".join(f"{nm[i]}={c[i]/w/1e6:.2f}" for i in range(7)) +
+              f" total={c[8]/w/1e6:.2f} waves={c[9]}")
+        e.set_variant("profile", 0)
     status = e.download(d_st, nrec * 4, np.uint32)
     olen = e.download(d_ol, nrec * 4, np.uint32)
     ok = bool((status == 0).all())

@@ -11,8 +11,7 @@
  * A brotli stream is ONE serial bitstream per record: every symbol's position depends on the
  * length of the symbol before it, so the wave decodes in wave-uniform control flow and uses its
  * lanes where the format has width:
- *   - the input is held in a register window (lane i = dword i of 256 stream bytes, the next
- *     window already in flight); the bit accumulator is refilled with v_readlane, no memory
+ *   - the input is held in a register window (lane i = dword i of 256 stream bytes); the bit accumulator is refilled with v_readlane, no memory
  *     access sits on the decode chain;
  *   - prefix codes are kept in canonical form: lane l of a tree's vector holds the left-aligned
  *     end of the code range of length l, so ONE compare + ballot finds a symbol's length; the
@@ -30,19 +29,14 @@
 #include "lz4_frame.h"
 #include "match_copy.h"
 
-#define BR_NLIT_LDS 16u
+#define BR_NLIT_LDS 8u
 #define BR_LIT_STRIDE 384u   /* 16 x u64 vector + 256 x u8 sorted symbols */
 #define BR_CMD_STRIDE 1536u  /* vector + 704 x u16 */
 #define BR_DIST_STRIDE 1216u /* vector + 544 x u16 */
 #define BR_BT_STRIDE 704u    /* block type (258) / block count (26) / context map (272) codes */
 #define BR_NCMD_LDS 1u
-#define BR_NDIST_LDS 2u
+#define BR_NDIST_LDS 1u
 #define BR_CAP 64u /* longer copies are moved by the whole wave */
-#ifdef ZMT_EMU
-#define ZMT_NOINLINE
-#else
-#define ZMT_NOINLINE __noinline__
-#endif
 
 /* scratch of one wave in HBM (include/gpumt.h GPUMT_BROTLI_SCRATCH) */
 #define BR_G_LIT 0u
@@ -54,6 +48,18 @@
 #define BR_G_END (BR_G_DCMAP + 4u * 256u)
 #define BR_WSCRATCH ((BR_G_END + 255u) & ~255u)
 static_assert(BR_WSCRATCH == 825856u, "keep GPUMT_BROTLI_SCRATCH (include/gpumt.h) in step");
+
+#ifdef ZMT_EMU
+#define ZMT_NOUNROLL
+#define ZMT_NOINLINE inline
+#define BR_SETTLE(v) ((void)(v))
+#else
+#define ZMT_NOINLINE __forceinline__
+#define ZMT_NOUNROLL _Pragma("nounroll")
+/* make a value loaded from HBM arrive inside the (rare) branch that loaded it: left pending, every
+ * later use on the common path would wait for ALL memory operations in flight, stores included */
+#define BR_SETTLE(v) asm volatile("" ::"v"(v))
+#endif
 
 struct BrLds {
 	u8 lut[2048];
@@ -93,12 +99,10 @@ static __device__ __forceinline__ u32 br_rev15(u32 v) { return __brev(v) >> 17; 
 struct BrBits {
 	const u8 *p;
 	u32 n;
-	u32 win;   /* lane i: stream bytes [wbyte + 4 i, +4) */
-	u32 wnext; /* the window after it, already requested */
+	u32 win; /* lane i: stream bytes [wbyte + 4 i, +4) */
 	u32 wbyte, widx;
 	u64 acc;
 	u32 navail;
-	u64 used; /* bits consumed since the start of the stream */
 };
 
 static __device__ __forceinline__ u32 br_load_win(const u8 *p, u32 n, u32 wbyte, int lane)
@@ -119,20 +123,22 @@ static __device__ __forceinline__ void br_seek(BrBits &b, u32 byte, int lane)
 {
 	b.wbyte = byte;
 	b.win = br_load_win(b.p, b.n, byte, lane);
-	b.wnext = br_load_win(b.p, b.n, byte + 256u, lane);
+	BR_SETTLE(b.win);
 	b.widx = 0;
 	b.acc = 0;
 	b.navail = 0;
-	b.used = 8ull * byte;
 }
 
 static __device__ __forceinline__ void br_refill(BrBits &b, int lane)
 {
 	if (b.navail <= 32) {
 		if (b.widx == 64) {
+			/* no prefetch of the next window: a register with a load in flight cannot be
+			 * carried through the branches of the decode loop (every copy of it would wait
+			 * for all memory operations, stores included); one wait per 256 stream bytes */
 			b.wbyte += 256u;
-			b.win = b.wnext;
-			b.wnext = br_load_win(b.p, b.n, b.wbyte + 256u, lane);
+			b.win = br_load_win(b.p, b.n, b.wbyte, lane);
+			BR_SETTLE(b.win);
 			b.widx = 0;
 		}
 		const u32 d = wv_readlane(b.win, (int)b.widx);
@@ -142,21 +148,31 @@ static __device__ __forceinline__ void br_refill(BrBits &b, int lane)
 	}
 }
 
-/* Out-of-line helpers take and return the reader by value (a reader handed over by reference would
- * live in memory, and with it every value derived from it would count as lane-varying); the
- * wave-uniform fields are pinned back to SGPRs after such a call. */
+/* bits consumed since the start of the stream: everything fetched into the accumulator minus what
+ * is still in it */
+static __device__ __forceinline__ u64 br_used(const BrBits &b)
+{
+	return 8ull * b.wbyte + 32ull * b.widx - b.navail;
+}
+/* the stream ended before the bits consumed so far (windows past the end read as zeros) */
+static __device__ __forceinline__ bool br_over(const BrBits &b)
+{
+	return br_used(b) > 8ull * b.n;
+}
+
+/* The header parsers take and return the reader by value and pin its wave-uniform fields to SGPRs
+ * afterwards: should the compiler ever keep one of them out of line, the reader must not end up
+ * living in memory (every value derived from it would count as lane-varying). */
 static __device__ __forceinline__ BrBits br_pin(const BrBits &r)
 {
 	BrBits b;
 	b.p = r.p;
 	b.n = wv_readfirst(r.n);
 	b.win = r.win;
-	b.wnext = r.wnext;
 	b.wbyte = wv_readfirst(r.wbyte);
 	b.widx = wv_readfirst(r.widx);
 	b.acc = (u64)wv_readfirst((u32)r.acc) | (u64)wv_readfirst((u32)(r.acc >> 32)) << 32;
 	b.navail = wv_readfirst(r.navail);
-	b.used = (u64)wv_readfirst((u32)r.used) | (u64)wv_readfirst((u32)(r.used >> 32)) << 32;
 	return b;
 }
 
@@ -167,7 +183,6 @@ static __device__ __forceinline__ u32 br_get(BrBits &b, u32 n, int lane)
 	const u32 v = (u32)b.acc & ((1u << n) - 1u);
 	b.acc >>= n;
 	b.navail -= n;
-	b.used += n;
 	return v;
 }
 
@@ -231,7 +246,6 @@ static __device__ __forceinline__ u32 br_sym_index(BrBits &b, u32 va, u32 vi, u3
 	const u32 a = wv_readlane(va, sel), i0 = wv_readlane(vi, sel);
 	b.acc >>= l;
 	b.navail -= (u32)l;
-	b.used += (u32)l;
 	return i0 + ((c - (a >> 16)) >> (15 - l));
 }
 
@@ -248,12 +262,14 @@ static __device__ __forceinline__ u32 br_sym16(BrBits &b, const BrTree &t, bool 
 
 /* lens[0, A) (LDS) -> tree record at rec.  The caller has checked that the code is complete or
  * has exactly one symbol. */
-static __device__ void br_build(u8 *rec, const u8 *lens, u32 A, bool sym16, int lane)
+static __device__ ZMT_NOINLINE void br_build(u8 *rec, const u8 *lens, u32 A, bool sym16, int lane)
 {
 	u32 cnt = 0, one = 0;
+	ZMT_NOUNROLL
 	for (u32 s0 = 0; s0 < A; s0 += 64) {
 		const u32 s = s0 + (u32)lane;
 		const u32 ln = s < A ? lens[s] : 0;
+		ZMT_NOUNROLL
 		for (u32 l = 1; l <= 15; l++) {
 			const u64 m = wv_ballot(ln == l);
 			if ((u32)lane == l)
@@ -278,6 +294,7 @@ static __device__ void br_build(u8 *rec, const u8 *lens, u32 A, bool sym16, int 
 		}
 	} else {
 		u32 code = 0, index = 0;
+		ZMT_NOUNROLL
 		for (u32 l = 1; l <= 15; l++) {
 			const u32 c = wv_readlane(cnt, (int)l);
 			const u32 lo = code << (15 - l), hi = (code + c) << (15 - l);
@@ -287,6 +304,7 @@ static __device__ void br_build(u8 *rec, const u8 *lens, u32 A, bool sym16, int 
 			}
 			if (c) {
 				u32 run = index;
+				ZMT_NOUNROLL
 				for (u32 s0 = 0; s0 < A; s0 += 64) {
 					const u32 s = s0 + (u32)lane;
 					const bool mine = s < A && lens[s] == l;
@@ -364,6 +382,7 @@ static __device__ ZMT_NOINLINE BrBits br_read_code_core(BrBits b, BrLds &L, u8 *
 		u32 cl_len = 0; /* lane i: length of code-length symbol i */
 		int space = 32;
 		u32 ncodes = 0;
+		ZMT_NOUNROLL
 		for (u32 i = hskip; i < 18; i++) {
 			br_refill(b, lane);
 			const u32 pk = (u32)b.acc & 15u;
@@ -386,7 +405,6 @@ static __device__ ZMT_NOINLINE BrBits br_read_code_core(BrBits b, BrLds &L, u8 *
 			}
 			b.acc >>= nb;
 			b.navail -= nb;
-			b.used += nb;
 			const u32 sym = ut8(BR_CL_ORDER, i);
 			if ((u32)lane == sym)
 				cl_len = v;
@@ -520,7 +538,7 @@ static __device__ ZMT_NOINLINE BrBits br_context_map_core(BrBits b, BrLds &L, u8
 	u32 i = 0;
 	while (i < size) {
 		const u32 s = br_sym16(b, t, bad, lane);
-		if (bad || b.used > 8ull * b.n)
+		if (bad || br_over(b))
 			return b;
 		u32 v = 0, reps = 1;
 		if (s && s <= rlemax) {
@@ -602,7 +620,7 @@ static __device__ __forceinline__ bool br_context_map(BrBits &b, BrLds &L, u8 *m
 /* RFC 7932 section 8 + Appendix B: transform `tidx` of the `copy`-byte word `widx`, written at d;
  * returns the number of bytes, 0xFFFFFFFF when they do not fit `room`.  Lane 0 assembles the
  * (at most 24 + 2 x 8 byte) string in LDS, the wave stores it. */
-static __device__ u32 br_dict_word(BrLds &L, const u8 *blob, u32 copy, u32 widx, u32 tidx, u8 *d, u32 room, int lane)
+static __device__ __forceinline__ u32 br_dict_word(BrLds &L, const u8 *blob, u32 copy, u32 widx, u32 tidx, u8 *d, u32 room, int lane)
 {
 	const u8 *dict = blob + uld32(blob + 8), *tr = blob + uld32(blob + 16) + 3 * tidx;
 	const u8 *psmap = blob + uld32(blob + 20), *ps = blob + uld32(blob + 24);
@@ -660,18 +678,54 @@ static __device__ u32 br_dict_word(BrLds &L, const u8 *blob, u32 copy, u32 widx,
 	return total;
 }
 
+/* whole-wave copy of a match (plain or overlapping); same as wave_match of match_copy.h, inlined: the
+ * kernel makes no calls, so no value has to sit in the sparse callee-saved register ranges */
+static __device__ __forceinline__ void br_wave_match(u8 *d, u32 off, u32 ml, int lane)
+{
+	const u8 *s = d - off;
+	if (off >= ml) {
+		wave_copy(d, s, ml, lane);
+	} else if (off >= 64) {
+		for (u32 done = 0; done < ml; done += off) {
+			const u32 n = ml - done < off ? ml - done : off;
+			wave_copy(d + done, s + done, n, lane);
+			wave_mem_fence();
+		}
+	} else {
+		for (u32 i = (u32)lane; i < ml; i += 64)
+			d[i] = s[i % off];
+	}
+}
+
 /* ------------------------------------------------------------------ the kernel
  * grid = min(nrec, resident waves); wave w decodes records w, w + grid, ...  out_len[r] receives the
  * decoded size, status[r] GPUMT_ST_OK / BAD_BLOCK (malformed or truncated) / SIZE_MISMATCH (does
  * not fit the record's capacity). */
-extern "C" __global__ void __launch_bounds__(64)
-zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec_off, const u32 *__restrict__ rec_len,
-		      u32 nrec, u8 *out_base, const u64 *__restrict__ out_off, const u32 *__restrict__ out_cap,
-		      u32 *__restrict__ out_len, u32 *__restrict__ status, u8 *__restrict__ scratch,
-		      const u8 *__restrict__ blob)
+#ifndef ZMT_EMU
+#define BRT() (PROF ? (u64)clock64() : 0ull)
+#else
+#define BRT() 0ull
+#endif
+#define BRP(i)                                                                                     \
+	do {                                                                                       \
+		if (PROF) {                                                                        \
+			const u64 t_ = BRT();                                                      \
+			pc[PROF ? (i) : 0] += t_ - tq;                                             \
+			tq = t_;                                                                   \
+		}                                                                                  \
+	} while (0)
+
+template <bool PROF>
+static __device__ __forceinline__ void
+brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__ rec_off, const u32 *__restrict__ rec_len,
+		u32 nrec, u8 *out_base, const u64 *__restrict__ out_off, const u32 *__restrict__ out_cap,
+		u32 *__restrict__ out_len, u32 *__restrict__ status, u8 *__restrict__ scratch,
+		const u8 *__restrict__ blob, unsigned long long *prof)
 {
-	__shared__ __attribute__((aligned(16))) BrLds L;
 	const int lane = wv_lane();
+	u64 pc[PROF ? 8 : 1] = {0}, tq = BRT();
+	const u64 t_begin = tq;
+	(void)t_begin;
 	u8 *const G = scratch + (u64)blockIdx.x * BR_WSCRATCH;
 	{
 		const u8 *ctx = blob + uld32(blob + 12);
@@ -744,7 +798,7 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 				const u32 W_ = wv_readlane(bm_pos, fst_);                          \
 				const u32 hl_ = wv_readlane(ml_, fst_);                            \
 				if (hl_ > BR_CAP) {                                                \
-					wave_match(out + W_, wv_readlane(bm_dist, fst_), hl_, lane); \
+					br_wave_match(out + W_, wv_readlane(bm_dist, fst_), hl_, lane); \
 					if (lane == fst_)                                          \
 						fin_ = true;                                       \
 				} else {                                                           \
@@ -761,7 +815,7 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 	} while (0)
 
 		while (stc == ST_OK) {
-			if (b.used > 8ull * b.n) {
+			if (br_over(b)) {
 				stc = BRBAD();
 				break;
 			}
@@ -785,10 +839,10 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 				}
 				if (nb)
 					skip++;
-				if ((b.used & 7) && br_get(b, 8 - (u32)(b.used & 7), lane))
+				if ((br_used(b) & 7) && br_get(b, 8 - (u32)(br_used(b) & 7), lane))
 					e = true;
-				const u64 at = b.used >> 3;
-				if (e || b.used > 8ull * b.n || at + skip > b.n) {
+				const u64 at = br_used(b) >> 3;
+				if (e || br_over(b) || at + skip > b.n) {
 					stc = BRBAD();
 					break;
 				}
@@ -814,12 +868,12 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 			mlen++;
 			if (!is_last && br_get(b, 1, lane)) {
 				/* uncompressed meta-block */
-				if ((b.used & 7) && br_get(b, 8 - (u32)(b.used & 7), lane)) {
+				if ((br_used(b) & 7) && br_get(b, 8 - (u32)(br_used(b) & 7), lane)) {
 					stc = BRBAD();
 					break;
 				}
-				const u64 at = b.used >> 3;
-				if (b.used > 8ull * b.n || at + mlen > b.n) {
+				const u64 at = br_used(b) >> 3;
+				if (br_over(b) || at + mlen > b.n) {
 					stc = BRBAD();
 					break;
 				}
@@ -856,7 +910,7 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 			BR_CAT_HDR(c0, 0);
 			BR_CAT_HDR(c1, 1);
 			BR_CAT_HDR(c2, 2);
-			if (bad || b.used > 8ull * b.n) {
+			if (bad || br_over(b)) {
 				stc = BRBAD();
 				break;
 			}
@@ -890,11 +944,11 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 #define BR_CMD_REC(t) ((t) < BR_NCMD_LDS ? L.cmd + (t) * BR_CMD_STRIDE : G + BR_G_CMD + (t) * BR_CMD_STRIDE)
 #define BR_DIST_REC(t) ((t) < BR_NDIST_LDS ? L.dist + (t) * BR_DIST_STRIDE : G + BR_G_DIST + (t) * BR_DIST_STRIDE)
 			for (u32 i = 0; i < ntl && !bad; i++)
-				bad = !br_read_code(b, L, BR_LIT_REC(i), 256, false, lane) || b.used > 8ull * b.n;
+				bad = !br_read_code(b, L, BR_LIT_REC(i), 256, false, lane) || br_over(b);
 			for (u32 i = 0; i < c1.ntypes && !bad; i++)
-				bad = !br_read_code(b, L, BR_CMD_REC(i), 704, true, lane) || b.used > 8ull * b.n;
+				bad = !br_read_code(b, L, BR_CMD_REC(i), 704, true, lane) || br_over(b);
 			for (u32 i = 0; i < ntd && !bad; i++)
-				bad = !br_read_code(b, L, BR_DIST_REC(i), dist_alphabet, true, lane) || b.used > 8ull * b.n;
+				bad = !br_read_code(b, L, BR_DIST_REC(i), dist_alphabet, true, lane) || br_over(b);
 			if (bad) {
 				stc = BRBAD();
 				break;
@@ -915,8 +969,10 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 		if (lane < 16) {                                                                   \
 			if ((t) < (nlds))                                                          \
 				e_ = *(const u64 *)((ldsarr) + (t) * (stride) + 8 * lane);         \
-			else                                                                       \
+			else {                                                                     \
 				e_ = *(const u64 *)(G + (goff) + (t) * (stride) + 8 * lane);       \
+				BR_SETTLE(e_);                                                     \
+			}                                                                          \
 		}                                                                                  \
 		va_ = (u32)e_;                                                                     \
 		vi_ = (u32)(e_ >> 32);                                                             \
@@ -936,6 +992,7 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 			e_ = *(const u64 *)(L.dist + t_ * BR_DIST_STRIDE + 8 * ((u32)lane & 15)); \
 		else                                                                               \
 			e_ = *(const u64 *)(G + BR_G_DIST + t_ * BR_DIST_STRIDE + 8 * ((u32)lane & 15)); \
+		BR_SETTLE(e_);                                                                     \
 		dva = (u32)e_;                                                                     \
 		dvi = (u32)(e_ >> 32);                                                             \
 		dtree_k = t_;                                                                      \
@@ -956,11 +1013,8 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 				p2 = pos > 1 ? uld8(out + pos - 2) : 0;
 			}
 			u32 left = mlen;
+			BRP(0);
 			while (left) {
-				if (b.used > 8ull * b.n) {
-					hbad = true;
-					break;
-				}
 				if (c1.left == 0) {
 					br_switch(b, c1, gbt, 1, hbad, lane);
 					BR_VEC(cva, cvi, L.cmd, BR_NCMD_LDS, BR_CMD_STRIDE, BR_G_CMD, c1.type);
@@ -970,13 +1024,13 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 				{
 					const u32 k = br_sym_index(b, cva, cvi, 0, hbad, lane);
 					if (c1.type < BR_NCMD_LDS)
-						cs = *(const u16 *)(L.cmd + c1.type * BR_CMD_STRIDE + 128 + 2 * k);
+						cs = wv_readfirst(*(const u16 *)(L.cmd + c1.type * BR_CMD_STRIDE + 128 + 2 * k));
 					else
-						cs = *(const u16 *)(G + BR_G_CMD + c1.type * BR_CMD_STRIDE + 128 + 2 * k);
-					cs = wv_readfirst(cs);
+						cs = wv_readfirst(*(const u16 *)(G + BR_G_CMD + c1.type * BR_CMD_STRIDE + 128 + 2 * k));
 				}
 				if (hbad)
 					break;
+				BRP(1);
 				/* insert / copy code of the symbol: the 11 cells of RFC 7932 section 5, code bases
 				 * in units of 8 packed two bits per cell */
 				const u32 cell = cs >> 6;
@@ -1038,10 +1092,9 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 						BR_VEC(va, vi, L.lit, BR_NLIT_LDS, BR_LIT_STRIDE, BR_G_LIT, tr);
 						const u32 k = br_sym_index(b, va, vi, 0, hbad, lane);
 						if (tr < BR_NLIT_LDS)
-							sy = L.lit[tr * BR_LIT_STRIDE + 128 + k];
+							sy = wv_readfirst(L.lit[tr * BR_LIT_STRIDE + 128 + k]);
 						else
-							sy = G[BR_G_LIT + tr * BR_LIT_STRIDE + 128 + k];
-						sy = wv_readfirst(sy);
+							sy = wv_readfirst(G[BR_G_LIT + tr * BR_LIT_STRIDE + 128 + k]);
 						p2 = p1;
 						p1 = sy;
 						litv = (u32)lane == (pos & 63) ? sy : litv;
@@ -1050,10 +1103,10 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 							BR_FLUSH();
 					}
 				}
-				if (hbad || b.used > 8ull * b.n) {
-					hbad = true;
-					break;
-				}
+				if (hbad)
+					break; /* a truncated stream shows at the end of the meta-block: windows past
+						* the end read as zeros, the loop is bounded by MLEN */
+				BRP(2);
 				if (!left)
 					break;
 				/* ---- distance (section 4) ---- */
@@ -1077,10 +1130,9 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 					const u32 tr = wv_readlane(dtree_k, (int)(16 * dctx));
 					u32 dc;
 					if (tr < BR_NDIST_LDS)
-						dc = *(const u16 *)(L.dist + tr * BR_DIST_STRIDE + 128 + 2 * k);
+						dc = wv_readfirst(*(const u16 *)(L.dist + tr * BR_DIST_STRIDE + 128 + 2 * k));
 					else
-						dc = *(const u16 *)(G + BR_G_DIST + tr * BR_DIST_STRIDE + 128 + 2 * k);
-					dc = wv_readfirst(dc);
+						dc = wv_readfirst(*(const u16 *)(G + BR_G_DIST + tr * BR_DIST_STRIDE + 128 + 2 * k));
 					if (dc < 16) {
 						const u32 which = dc < 4 ? dc : dc < 10 ? 0 : 1;
 						const u32 r = which == 0 ? rb3 : which == 1 ? rb2 : which == 2 ? rb1 : rb0;
@@ -1113,12 +1165,9 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 						dist = (u32)dd;
 					}
 				}
-				if (b.used > 8ull * b.n) {
-					hbad = true;
-					break;
-				}
 				const u32 max_dist = pos < max_backward ? pos : max_backward;
 				BR_FLUSH();
+				BRP(3);
 				if (dist > max_dist) {
 					if (copy < 4 || copy > 24) {
 						hbad = true;
@@ -1154,6 +1203,7 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 					pos += wn;
 					lit_lo = pos;
 					left -= wn;
+					BRP(5);
 				} else {
 					if (copy > left) {
 						hbad = true;
@@ -1179,14 +1229,16 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 						pos += copy;
 						lit_lo = pos;
 						left -= copy;
-						if (nbatch == 64)
+						if (nbatch == 64) {
 							BR_EXEC();
+							BRP(4);
+						}
 					} else {
 						wave_mem_fence();
 						const u8 *s = out + pos - dist;
 						p1 = uld8(s + (copy - 1) % dist);
 						p2 = uld8(s + (copy - 2) % dist);
-						wave_match(out + pos, dist, copy, lane);
+						br_wave_match(out + pos, dist, copy, lane);
 						wave_mem_fence();
 						pos += copy;
 						lit_lo = pos;
@@ -1194,7 +1246,7 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 					}
 				}
 			}
-			bad = hbad;
+			bad = hbad || br_over(b);
 			if (bad && stc == ST_OK)
 				stc = BRBAD();
 			if (stc != ST_OK || is_last)
@@ -1202,9 +1254,9 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 		}
 		if (stc == ST_OK) {
 			/* zero padding up to the byte boundary; bytes after it are ignored */
-			if ((b.used & 7) && br_get(b, 8 - (u32)(b.used & 7), lane))
+			if ((br_used(b) & 7) && br_get(b, 8 - (u32)(br_used(b) & 7), lane))
 				stc = BRBAD();
-			if (b.used > 8ull * b.n)
+			if (br_over(b))
 				stc = BRBAD();
 		}
 		BR_FLUSH();
@@ -1214,5 +1266,43 @@ zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 			status[rec] = stc;
 			out_len[rec] = stc == ST_OK ? pos : 0;
 		}
+		BRP(6);
 	}
+#ifndef ZMT_EMU
+	if (PROF && prof && lane == 0) {
+		for (int i = 0; i < (PROF ? 7 : 1); i++)
+			atomicAdd(prof + i, (unsigned long long)pc[i]);
+		atomicAdd(prof + 8, (unsigned long long)(BRT() - t_begin));
+		atomicAdd(prof + 9, 1ull);
+	}
+#endif
 }
+
+/* 4 waves per SIMD (128 VGPRs) and < 10 KiB of LDS: 16 records per CU.  One record keeps a wave busy
+ * with a chain of dependent scalar and cross-lane operations, so the number of records in flight is
+ * what sets the throughput. */
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+zmt_brotli_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec_off, const u32 *__restrict__ rec_len,
+		      u32 nrec, u8 *out_base, const u64 *__restrict__ out_off, const u32 *__restrict__ out_cap,
+		      u32 *__restrict__ out_len, u32 *__restrict__ status, u8 *__restrict__ scratch,
+		      const u8 *__restrict__ blob)
+{
+	__shared__ __attribute__((aligned(16))) BrLds L;
+	brotli_dec_body<false>(L, stream, rec_off, rec_len, nrec, out_base, out_off, out_cap, out_len, status, scratch,
+			       blob, nullptr);
+}
+
+#ifndef ZMT_EMU
+/* same kernel with per-phase cycle counters (developer tool): 0 headers + tables, 1 insert&copy
+ * symbols, 2 literals, 3 distances, 4 copy batches, 5 dictionary words / uncompressed, 6 rest */
+extern "C" __global__ void __launch_bounds__(64)
+zmt_brotli_dec_kernel_prof(const u8 *__restrict__ stream, const u64 *__restrict__ rec_off,
+			   const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base, const u64 *__restrict__ out_off,
+			   const u32 *__restrict__ out_cap, u32 *__restrict__ out_len, u32 *__restrict__ status,
+			   u8 *__restrict__ scratch, const u8 *__restrict__ blob, unsigned long long *prof)
+{
+	__shared__ __attribute__((aligned(16))) BrLds L;
+	brotli_dec_body<true>(L, stream, rec_off, rec_len, nrec, out_base, out_off, out_cap, out_len, status, scratch,
+			      blob, prof);
+}
+#endif

@@ -39,6 +39,8 @@ __global__ void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, con
 				    const u32 *, const u32 *, const u32 *, u32 *);
 __global__ void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *,
 				      u32 *, u32 *, u8 *, const u8 *);
+__global__ void zmt_brotli_dec_kernel_prof(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
+					   const u32 *, u32 *, u32 *, u8 *, const u8 *, unsigned long long *);
 __global__ void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
 					  const u32 *, u8 *, u32 *, u32 *, u32 *);
 __global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
@@ -751,10 +753,19 @@ int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint
 	const unsigned grid = (unsigned)(nrec < (size_t)h->bdec_waves ? nrec : (size_t)h->bdec_waves);
 	if (want_scratch(h, 1, (size_t)grid * GPUMT_BROTLI_SCRATCH))
 		return GPUMT_E_HIP;
+	if (h->profile == 7 && !h->d_prof) {
+		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
+		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
+	}
 	PROF0(12);
-	hipLaunchKernelGGL(zmt_brotli_dec_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_stream, d_rec_off,
-			   d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap, d_out_len, d_status,
-			   (u8 *)h->scratch[1], (const u8 *)h->d_brotli_static);
+	if (h->profile == 7)
+		hipLaunchKernelGGL(zmt_brotli_dec_kernel_prof, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_stream,
+				   d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap, d_out_len,
+				   d_status, (u8 *)h->scratch[1], (const u8 *)h->d_brotli_static, h->d_prof);
+	else
+		hipLaunchKernelGGL(zmt_brotli_dec_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_stream,
+				   d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap, d_out_len,
+				   d_status, (u8 *)h->scratch[1], (const u8 *)h->d_brotli_static);
 	PROF1(12);
 	CK(hipGetLastError());
 	return GPUMT_OK;
