@@ -42,8 +42,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gib", type=float, default=8.0, help="uncompressed GiB per GPU")
-    ap.add_argument("--codec", choices=("lz4", "zstd"), default="lz4",
-                    help="lz4 = BASELINE configs[1] (the metric's config); zstd = configs[3], zstd-mt level 1")
+    ap.add_argument("--codec", choices=("lz4", "zstd", "brotli"), default="lz4",
+                    help="lz4 = BASELINE configs[1] (the metric's config); zstd = configs[3], zstd-mt level 1; "
+                         "brotli = configs[4], brotli-mt decompress of level-1 streams at 1 MiB chunks")
     ap.add_argument("--chunk", type=int, default=0, help="0 = 128 KiB for lz4 (configs[1]), 1 MiB for zstd (level-1 default)")
     ap.add_argument("--dec-variant", type=int, default=0)
     ap.add_argument("--enc-variant", type=int, default=0)
@@ -64,24 +65,32 @@ def cpu_baseline(args):
     """oracle/_ref (reference sources + liblz4) if present, else the oracle port; bounded sample."""
     exe = os.path.join(ROOT, "oracle", "cpu_bench")
     zstd = args.codec == "zstd"
-    ref = os.path.join(ROOT, "oracle", "_ref", "libzstdmt_ref.so" if zstd else "liblz4mt_ref.so")
+    brotli = args.codec == "brotli"
+    ref = os.path.join(ROOT, "oracle", "_ref", "libbrotlimt_ref.so" if brotli else
+                       "libzstdmt_ref.so" if zstd else "liblz4mt_ref.so")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "cpu_bench"],
                               stdout=subprocess.DEVNULL)
     cores = os.cpu_count() or 1
     threads = min(cores, 128)   # LZ4MT_THREAD_MAX, lib/lz4-mt.h:28
     kind = "reference" if os.path.exists(ref) else "port"
-    if zstd and kind == "port":
+    if (zstd or brotli) and kind == "port":
         return {"value": None, "unit": "MB/s", "cores": threads, "kind": "reference",
-                "error": "oracle/_ref/libzstdmt_ref.so not present (the zstd oracle has no compressor)"}
+                "error": f"{os.path.basename(ref)} not present (the {args.codec} oracle has no compressor)"}
     n = args.cpu_mib << 20
     try:
-        out = subprocess.check_output([exe, "reference-zstd" if zstd else kind,
+        out = subprocess.check_output([exe, "reference-brotli" if brotli else "reference-zstd" if zstd else kind,
                                        ref if kind == "reference" else "-", str(n),
                                        str(args.chunk), str(threads), str(SEED)], timeout=600)
         r = json.loads(out)
     except Exception as e:  # report, never hide
         return {"value": None, "unit": "MB/s", "cores": threads, "kind": kind, "error": repr(e)}
+    if brotli:
+        return {"value": r["decompress_MBps"], "unit": "MB/s", "cores": threads, "kind": kind,
+                "compress_MBps": r["compress_MBps"], "decompress_MBps": r["decompress_MBps"], "host_cpus": cores,
+                "sample": f"{args.cpu_mib} MiB of the same synthetic text, {args.chunk}-byte chunks, level 1: "
+                          f"BROTLIMT_decompressDCtx of the stream BROTLIMT_compressCCtx wrote, memcpy "
+                          f"callbacks, T={threads}"}
     return {"value": r["roundtrip_MBps"], "unit": "MB/s", "cores": threads, "kind": kind,
             "compress_MBps": r["compress_MBps"], "decompress_MBps": r["decompress_MBps"],
             "host_cpus": cores,
@@ -114,6 +123,8 @@ def main():
     eng.set_variant("profile", 1)
 
     zstd = args.codec == "zstd"
+    if args.codec == "brotli":
+        return bench_brotli(args, eng, rank, world, dist)
     if not args.chunk:
         args.chunk = (1 << 20) if zstd else 131072
     n = int(args.gib * (1 << 30)) // args.chunk * args.chunk
@@ -338,6 +349,184 @@ def report_zstd(args, eng, world, wall, ms, U, Cb, nrec, chunk, bad, ok, gen_s, 
         "decode_errors": bad, "roundtrip_verified": ok if args.verify else None,
         "gen_s": round(gen_s, 2), "device": eng.name,
         "segment_offset_rank0": seg_off, "gather_ms": gather_ms,
+    }
+    if not args.no_cpu:
+        res["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def reference_brotli_stream(data, chunk, level, threads):
+    """The workload's input: `data` compressed by the REFERENCE's brotli-mt (oracle/_ref, SURVEY 8d
+    "cfg5: the same text compressed by own/oracle brotli at 1 MiB chunks").  The device has no brotli
+    encoder yet, so the compressed input can only come from the reference build; this is input
+    preparation on the host, outside the timed region."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libbrotlimt_ref.so")
+    lib = C.CDLL(so)
+
+    class Buf(C.Structure):
+        _fields_ = [("buf", C.c_void_p), ("size", C.c_size_t), ("allocated", C.c_size_t)]
+    FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Buf))
+
+    class RdWr(C.Structure):
+        _fields_ = [("fn_read", FN), ("arg_read", C.c_void_p), ("fn_write", FN), ("arg_write", C.c_void_p)]
+    lib.BROTLIMT_createCCtx.restype = C.c_void_p
+    lib.BROTLIMT_createCCtx.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.BROTLIMT_compressCCtx.restype = C.c_size_t
+    lib.BROTLIMT_compressCCtx.argtypes = [C.c_void_p, C.POINTER(RdWr)]
+    lib.BROTLIMT_freeCCtx.argtypes = [C.c_void_p]
+    lib.BROTLIMT_isError.argtypes = [C.c_size_t]
+    src = data.ctypes.data
+    n = data.nbytes
+    state = {"pos": 0}
+    out = []
+
+    def rd(_a, bp):
+        b = bp.contents
+        m = min(b.size, n - state["pos"])
+        if m:
+            C.memmove(b.buf, src + state["pos"], m)
+        state["pos"] += m
+        b.size = m
+        return 0
+
+    def wr(_a, bp):
+        b = bp.contents
+        out.append(C.string_at(b.buf, b.size))
+        return 0
+    frd, fwr = FN(rd), FN(wr)
+    io = RdWr(frd, None, fwr, None)
+    ctx = lib.BROTLIMT_createCCtx(threads, level, chunk)
+    rv = lib.BROTLIMT_compressCCtx(ctx, C.byref(io))
+    lib.BROTLIMT_freeCCtx(ctx)
+    if lib.BROTLIMT_isError(rv):
+        raise RuntimeError("reference brotli-mt compress failed")
+    return b"".join(out)
+
+
+def bench_brotli(args, eng, rank, world, dist):
+    """BASELINE configs[4]: brotli-mt decompress.  Input: level-1 streams of the synthetic text at
+    1 MiB chunks (the reference's default chunk for level 1, lib/brotli-mt_compress.c:105-109), written
+    by the reference build; one step = gpumt_brotli_decompress_batch over all records of the rank,
+    input and output resident in HBM.  value = uncompressed MB/s (decompress only: there is no
+    compression on this path)."""
+    import struct
+    L, h = eng.L, eng.h
+    chunk = args.chunk or (1 << 20)
+    args.chunk = chunk
+    n = int(args.gib * (1 << 30)) // chunk * chunk
+    base_n = min(n, 1 << 30) // chunk * chunk          # compressed once on the host, replicated in HBM
+    reps = (n + base_n - 1) // base_n
+    n = base_n * reps
+    T = tools()
+    threads = min(os.cpu_count() or 1, 128) // max(1, world) or 1
+    t0 = time.time()
+    text = np.empty(base_n, np.uint8)
+    T.zmt_gen_text(text.ctypes.data, base_n, SEED, rank * base_n, threads)
+    stream = reference_brotli_stream(text, chunk, 1, threads)
+    # record table (what the host engine parses while reading, lib/brotli-mt_decompress.c:187-284)
+    ro, rl, cap = [], [], []
+    ip = 0
+    while ip < len(stream):
+        magic, eight, csize, br, hint = struct.unpack_from("<IIIHH", stream, ip)
+        assert magic == 0x184D2A50 and eight == 8 and br == 0x5242
+        ro.append(ip + 16)
+        rl.append(csize)
+        cap.append(hint << 16)
+        ip += 16 + csize
+    gen_s = time.time() - t0
+    nb = len(ro)
+    nrec = nb * reps
+    seg = (len(stream) + 511) & ~255                     # replica stride in HBM
+    rec_off = np.concatenate([np.asarray(ro, np.uint64) + np.uint64(r * seg) for r in range(reps)])
+    rec_len = np.tile(np.asarray(rl, np.uint32), reps)
+    out_cap = np.tile(np.asarray(cap, np.uint32), reps)
+    out_off = np.zeros(nrec + 1, np.uint64)
+    out_off[1:] = np.cumsum(out_cap.astype(np.uint64))
+    total_cap = int(out_off[nrec])
+    d_stream = eng.alloc(seg * reps + 512)
+    hs = np.frombuffer(stream, np.uint8)
+    for r in range(reps):
+        eng._ck(L.gpumt_memcpy_h2d(h, d_stream.ptr + r * seg, hs.ctypes.data, hs.nbytes, 0), "h2d")
+    eng.sync(0)
+    d_ro, d_rl, d_oo, d_oc = eng.upload(rec_off), eng.upload(rec_len), eng.upload(out_off), eng.upload(out_cap)
+    d_ol, d_st = eng.alloc(nrec * 4), eng.alloc(nrec * 4)
+    d_out = eng.alloc(total_cap + 64)
+
+    def step():
+        eng.timer_start(3)
+        eng.brotli_decompress(d_stream, d_ro, d_rl, nrec, d_out, d_oo, d_oc, d_ol, d_st)
+        eng.timer_stop(3)
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            dist.barrier()
+        eng.sync()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    acc = {"decompress": 0.0, "k_brotli_dec": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        eng.sync(0)
+        acc["decompress"] += eng.timer_ms(3)
+        acc["k_brotli_dec"] += eng.timer_ms(12)
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tw = torch.tensor([wall], device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    ms = {k: v / args.steps for k, v in acc.items()}
+    status = eng.download(d_st, nrec * 4, np.uint32)
+    olen = eng.download(d_ol, nrec * 4, np.uint32)
+    bad = int((status != 0).sum())
+    U = float(olen.astype(np.uint64).sum())
+    # content check of the first replica (always: it is 1 GiB at most)
+    ok = bad == 0 and int(U) == n
+    if ok:
+        got = eng.download(d_out, base_n)              # capacities == chunk sizes for full chunks
+        ok = bool((got == text).all()) if int(out_off[nb]) == base_n else None
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    Cb = float(sum(rl) + 16 * nb) * reps
+    alg = U + Cb
+    step_s = wall / args.steps
+    t_k = ms["k_brotli_dec"] * 1e-3
+    a = alg / t_k / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tf) and abs(args.gib - 8.0) < 1e-9 and chunk == 1 << 20:
+        with open(tf) as f:
+            traffic = json.load(f).get("per_launch_bytes_8gib", {}).get("zmt_brotli_dec_kernel")
+    res = {
+        "metric": "MB/s decompress, 8 GiB synthetic, brotli-mt (level-1 streams); % HBM roofline",
+        "value": round(world * U / 1e6 / step_s, 1), "unit": "MB/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(step_s * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"brotli-mt decompress, {n / (1 << 30):g} GiB enwik-style synthetic per GPU, "
+                               f"{chunk // 1024} KiB chunks compressed at level 1 by the reference build "
+                               f"({base_n >> 20} MiB compressed on the host, replicated x{reps} in HBM), "
+                               f"device-resident decode",
+                   "chunk": chunk, "records_per_gpu": nrec, "level": 1, "ratio": round(U / Cb, 4),
+                   "parallelism": f"record-sharded x{world}"},
+        "decompress_MBps": round(world * U / 1e6 / (ms["decompress"] * 1e-3), 1),
+        "roofline": {"kernel": "zmt_brotli_dec_kernel", "bound": "hbm", "achieved": round(a, 2),
+                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(a * 1e9 / HBM_PEAK, 5),
+                     "frac_of_copy_ceiling": round(a * 1e9 / HBM_COPY, 5), "alg_bytes_per_launch": alg,
+                     "avg_launch_ms": round(ms["k_brotli_dec"], 4), "traffic": traffic},
+        "kernels": {"k_brotli_dec": {"ms": round(ms["k_brotli_dec"], 4)}},
+        "decode_errors": bad, "roundtrip_verified": ok,
+        "gen_s": round(gen_s, 2), "device": eng.name,
     }
     if not args.no_cpu:
         res["cpu_baseline"] = cpu_baseline(args)
