@@ -4,7 +4,7 @@
  * A small gzip-like front end with the option letters, file handling and -B report lines of the
  * reference CLI (/root/reference/programs/main.c:124-165 usage text, :166-170 + :238-243 "-B"
  * statistics line, :970-977 timing line), so that BASELINE.json's configurations can be typed as
- * written ("lz4-mt -1 -T4 FILE").  One source, the codec is chosen at build time (-DZMT_ZSTD) like
+ * written ("lz4-mt -1 -T4 FILE").  One source, the codec is chosen at build time (-DZMT_ZSTD, -DZMT_BROTLI) like
  * the reference does with programs/lz4-mt.c / programs/zstd-mt.c; the personality (compress /
  * decompress / cat) follows argv[0].  Not implemented: -l (listing), -L, -C.
  */
@@ -17,7 +17,20 @@
 #include <sys/time.h>
 #include <unistd.h>
 
-#ifdef ZMT_ZSTD
+#if defined(ZMT_BROTLI)
+#include "brotli-mt.h"
+#define PROGNAME "brotli-mt"
+#define UNZIP "unbrotli-mt"
+#define ZCAT "brotlicat-mt"
+#define SUFFIX ".brot"
+#define LEVEL_DEF 3
+#define LEVEL_MIN BROTLIMT_LEVEL_MIN
+#define LEVEL_MAX BROTLIMT_LEVEL_MAX
+#define THREAD_MAX BROTLIMT_THREAD_MAX
+#define MT(x) BROTLIMT_##x
+typedef BROTLIMT_Buffer MT_Buffer;
+typedef BROTLIMT_RdWr_t MT_RdWr_t;
+#elif defined(ZMT_ZSTD)
 #include "zstd-mt.h"
 #define PROGNAME "zstd-mt"
 #define UNZIP "unzstd-mt"

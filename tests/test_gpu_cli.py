@@ -97,3 +97,27 @@ def test_bad_arguments():
     assert run([LZ4, "-T", "500", "-c"], b"x", check=False).returncode == 1
     assert run([ZSTD, "-23", "-c"], b"x", check=False).returncode == 1
     assert b"Usage" in run([ZSTD, "-h"]).stdout
+
+
+def test_brotli_decompress_personalities(tmp_path):
+    """brotli-mt: decompression of a stream the reference wrote (committed fixture), through -d, the
+    un*/cat personalities and -t; compression reports the library's answer."""
+    bdir = os.path.join(H.GOLDEN_DIR, "brotli")
+    with open(os.path.join(bdir, "manifest.json")) as f:
+        ent = json.load(f)["cases"]["b_english_chunks"]
+    st = open(os.path.join(bdir, ent["out_file"]), "rb").read()
+    brotli = os.path.join(BIN, "brotli-mt")
+    f = tmp_path / "page.html.brot"
+    f.write_bytes(st)
+    run([brotli, "-d", "-k", "-T4", str(f)])
+    out = (tmp_path / "page.html").read_bytes()
+    assert len(out) == ent["in_len"] and H.sha256(out) == ent["in_sha256"]
+    assert run([os.path.join(BIN, "brotlicat-mt")], st).stdout == out
+    assert run([brotli, "-t"], st).returncode == 0
+    bad = bytearray(st)
+    bad[100] ^= 0xFF
+    bad[101] ^= 0xFF
+    r = run([brotli, "-t"], bytes(bad), check=False)
+    assert r.returncode == 1 and b"Could not decompress frame at once" in r.stderr
+    r = run([brotli, "-1", "-c"], b"abc" * 1000, check=False)
+    assert r.returncode == 1 and b"Compression parameter is out of bound" in r.stderr

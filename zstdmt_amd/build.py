@@ -69,12 +69,13 @@ def build(force=False, verbose=True):
     tsrc = os.path.join(CSRC, "tools", "gen_text.c")
     if force or _stale(tools, [tsrc]):
         _run(["gcc", "-O2", "-fPIC", "-shared", "-pthread", tsrc, "-o", tools, "-lm"])
-    # command line front ends (programs/zmt_cli.c): lz4-mt, zstd-mt + their un* / *cat personalities
+    # command line front ends (programs/zmt_cli.c): lz4-mt, zstd-mt, brotli-mt (decompression) + their un* / *cat personalities
     bindir = os.path.join(HERE, "bin")
     os.makedirs(bindir, exist_ok=True)
     cli = os.path.join(ROOT, "programs", "zmt_cli.c")
     for name, flags, links in (("lz4-mt", [], ("unlz4-mt", "lz4cat-mt")),
-                               ("zstd-mt", ["-DZMT_ZSTD"], ("unzstd-mt", "zstdcat-mt"))):
+                               ("zstd-mt", ["-DZMT_ZSTD"], ("unzstd-mt", "zstdcat-mt")),
+                               ("brotli-mt", ["-DZMT_BROTLI"], ("unbrotli-mt", "brotlicat-mt"))):
         exe = os.path.join(bindir, name)
         if force or _stale(exe, [cli, lib] + headers):
             _run(["gcc", "-O2", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include")] + flags +
