@@ -49,6 +49,17 @@ if zstats:
                     part[k] = v
     zl = open(os.path.join(go, "bench_zstd.json")).read().strip().splitlines()[-1]
     json.dump(json.loads(zl), open(os.path.join(root, "profiles", f"{rnd}_bench_zstd_8gib_1gpu.json"), "w"), indent=1)
+bstats = biggest("prof_brotli_stats/**/*_kernel_stats.csv")
+if bstats:
+    shutil.copy(bstats, os.path.join(root, "profiles", f"{rnd}_brotli_kernel_stats.csv"))
+    for part, name in ((fetch, "prof_brotli_fetch"), (write, "prof_brotli_write")):
+        f = biggest(name + "/**/*_counter_collection.csv")
+        if f:
+            for k, v in counter_avg(f).items():
+                if "brotli" in k:
+                    part[k] = v
+    bl = open(os.path.join(go, "bench_brotli.json")).read().strip().splitlines()[-1]
+    json.dump(json.loads(bl), open(os.path.join(root, "profiles", f"{rnd}_bench_brotli_8gib_1gpu.json"), "w"), indent=1)
 detail, per = [], {}
 for k in sorted(set(fetch) | set(write)):
     fb = fetch.get(k, 0.0) * 1024 * 2

@@ -22,5 +22,15 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_zstd_fe
     python bench.py --codec zstd --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_zstd_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_zstd_write -- \
     python bench.py --codec zstd --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_zstd_write.err
+# configs[4]: brotli-mt decompress (level-1 streams written by the reference build, 1 MiB chunks)
+rm -rf $O/prof_brotli_stats $O/prof_brotli_fetch $O/prof_brotli_write
+python bench.py --codec brotli > $O/bench_brotli.json 2> $O/bench_brotli.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_brotli_stats -- \
+    python bench.py --codec brotli --steps 2 --warmup 1 --no-cpu > $O/bench_brotli_prof.json 2> $O/prof_brotli_stats.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_brotli_fetch -- \
+    python bench.py --codec brotli --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_brotli_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_brotli_write -- \
+    python bench.py --codec brotli --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_brotli_write.err
 cat $O/bench_default.json
 cat $O/bench_zstd.json
+cat $O/bench_brotli.json

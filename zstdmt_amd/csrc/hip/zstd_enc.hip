@@ -34,7 +34,9 @@
 #define ZE_BLOCK 131072u
 #define ZE_BSTRIDE (ZE_BLOCK + 16u) /* area of one block inside a record slot */
 #define ZE_HDR 32u                  /* room in front of the blocks for record + frame header */
+#ifndef ZE_HLOG
 #define ZE_HLOG 13
+#endif
 #define ZE_MINMATCH 7u
 #define ZE_MAXSEQ (ZE_BLOCK / 4u) /* capacity of the per-wave sequence arrays (>= BLOCK / MINMATCH) */
 #define ZE_CAP 64u
