@@ -322,13 +322,15 @@ def report_zstd(args, eng, world, wall, ms, U, Cb, nrec, chunk, bad, ok, gen_s, 
 
     def roof(name, t_ms, pmc):
         a = alg / (t_ms * 1e-3) / 1e9
+        tr = [traffic.get(k) for k in pmc if traffic.get(k) is not None]
         return {"kernel": name, "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(a * 1e9 / HBM_PEAK, 5),
                 "frac_of_copy_ceiling": round(a * 1e9 / HBM_COPY, 5), "alg_bytes_per_launch": alg,
-                "avg_launch_ms": round(t_ms, 4), "traffic": traffic.get(pmc)}
+                "avg_launch_ms": round(t_ms, 4), "traffic": sum(tr) if tr else None}
 
-    enc = roof("zmt_zstd_enc_kernel(+assemble)", ms["k_lz4_enc"], "zmt_zstd_enc_kernel")
-    dec = roof("zmt_zstd_dec_kernel", ms["k_lz4_dec"], "zmt_zstd_dec_kernel")
+    enc = roof("zmt_zstd_enc_kernel(+assemble)", ms["k_lz4_enc"], ("zmt_zstd_enc_kernel", "zmt_zstd_assemble_kernel"))
+    dec = roof("zmt_zstd_dec_small_kernel(+zmt_zstd_dec_kernel for frames with full-size tables)", ms["k_lz4_dec"],
+               ("zmt_zstd_dec_small_kernel", "zmt_zstd_dec_kernel"))
     res = {
         "metric": "MB/s compress+decompress, 8 GiB synthetic, zstd-mt level 1; % HBM roofline",
         "value": round(world * U / 1e6 / step_s, 1), "unit": "MB/s",
