@@ -945,8 +945,25 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 #define BR_DIST_REC(t) ((t) < BR_NDIST_LDS ? L.dist + (t) * BR_DIST_STRIDE : G + BR_G_DIST + (t) * BR_DIST_STRIDE)
 			for (u32 i = 0; i < ntl && !bad; i++)
 				bad = !br_read_code(b, L, BR_LIT_REC(i), 256, false, lane) || br_over(b);
-			for (u32 i = 0; i < c1.ntypes && !bad; i++)
+			for (u32 i = 0; i < c1.ntypes && !bad; i++) {
 				bad = !br_read_code(b, L, BR_CMD_REC(i), 704, true, lane) || br_over(b);
+				/* the decode loop wants the insert / copy length codes of an insert&copy symbol,
+				 * not its number: rewrite the tree's symbol array once as
+				 * insert code | copy code << 5 | "distance is the last one" << 10 (RFC 7932 section 5:
+				 * 11 cells of 8 x 8 codes, code bases in units of 8 packed two bits per cell) */
+				u16 *sy = (u16 *)(BR_CMD_REC(i) + 128);
+				for (u32 k = (u32)lane; k < 704; k += 64) {
+					const u32 v = sy[k];
+					if (v < 704) {
+						const u32 cell = v >> 6;
+						const u32 icode = (((0x298500u >> (2 * cell)) & 3u) << 3) + ((v >> 3) & 7);
+						const u32 ccode = (((0x262444u >> (2 * cell)) & 3u) << 3) + (v & 7);
+						sy[k] = (u16)(icode | ccode << 5 | (v < 128 ? 1u << 10 : 0u));
+					}
+				}
+				wv_sync();
+				wave_mem_fence();
+			}
 			for (u32 i = 0; i < ntd && !bad; i++)
 				bad = !br_read_code(b, L, BR_DIST_REC(i), dist_alphabet, true, lane) || br_over(b);
 			if (bad) {
@@ -1012,6 +1029,11 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 				p1 = pos > 0 ? uld8(out + pos - 1) : 0;
 				p2 = pos > 1 ? uld8(out + pos - 2) : 0;
 			}
+			/* MLEN bytes must fit the record's capacity; the loop then only checks against MLEN */
+			if (mlen > cap - pos) {
+				stc = ST_SIZE_MISMATCH;
+				break;
+			}
 			u32 left = mlen;
 			BRP(0);
 			while (left) {
@@ -1031,25 +1053,53 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 				if (hbad)
 					break;
 				BRP(1);
-				/* insert / copy code of the symbol: the 11 cells of RFC 7932 section 5, code bases
-				 * in units of 8 packed two bits per cell */
-				const u32 cell = cs >> 6;
-				const u32 icode = (((0x298500u >> (2 * cell)) & 3u) << 3) + ((cs >> 3) & 7);
-				const u32 ccode = (((0x262444u >> (2 * cell)) & 3u) << 3) + (cs & 7);
+				const u32 icode = cs & 31, ccode = (cs >> 5) & 31; /* packed when the tree was read */
+				const bool last_dist = (cs >> 10) & 1;
 				const u32 ki = wv_readfirst(L.kins[icode]), kc = wv_readfirst(L.kcopy[ccode]);
-				u32 ins = (ki & 0xFFFFFFu) + br_get(b, ki >> 24, lane);
+				u32 ins = ki & 0xFFFFFFu, copy = kc & 0xFFFFFFu;
+				{
+					/* extra bits of both lengths, in one read when they fit (nearly always) */
+					const u32 ib = ki >> 24, cb = kc >> 24;
+					if (ib + cb <= 24) {
+						const u32 x = br_get(b, ib + cb, lane);
+						ins += x & ((1u << ib) - 1u);
+						copy += x >> ib;
+					} else {
+						ins += br_get(b, ib, lane);
+						copy += br_get(b, cb, lane);
+					}
+				}
 				const u32 ins0 = ins;
-				const u32 copy = (kc & 0xFFFFFFu) + br_get(b, kc >> 24, lane);
 				if (ins > left) {
 					hbad = true;
 					break;
 				}
-				if (ins > cap - pos) {
-					stc = ST_SIZE_MISMATCH;
-					break;
-				}
 				left -= ins;
-				if (ctx_free) {
+				if (ctx_free && c0.ntypes == 1) {
+					/* one literal tree, one block type (what levels 0..4 write): no block switch
+					 * can fall inside the run, and the run is cut where the pending-literal
+					 * register fills up, so the inner loop carries no checks.  The symbol of
+					 * literal i is fetched from LDS while literal i + 1 is being located. */
+					u32 todo = ins;
+					while (todo) {
+						const u32 room = 64u - (pos & 63u);
+						const u32 seg = todo < room ? todo : room;
+						todo -= seg;
+						u32 kprev = br_sym_index(b, lva, lvi, 0, hbad, lane);
+						for (u32 i = 1; i < seg; i++) {
+							const u32 syp = L.lit[128 + kprev];
+							const u32 k = br_sym_index(b, lva, lvi, 0, hbad, lane);
+							litv = (u32)lane == (pos & 63) ? syp : litv;
+							pos++;
+							kprev = k;
+						}
+						const u32 syl = L.lit[128 + kprev];
+						litv = (u32)lane == (pos & 63) ? syl : litv;
+						pos++;
+						if ((pos & 63) == 0)
+							BR_FLUSH();
+					}
+				} else if (ctx_free) {
 					/* the symbol of literal i is fetched from LDS while literal i + 1 is being
 					 * located in the bitstream */
 					u32 kprev = 0xFFFFFFFFu;
@@ -1112,7 +1162,7 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 				/* ---- distance (section 4) ---- */
 				u32 dist;
 				bool push = true;
-				if (cs < 128) {
+				if (last_dist) {
 					dist = rb3;
 					push = false;
 				} else {
@@ -1181,13 +1231,9 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 						break;
 					}
 					BR_EXEC();
-					const u32 room = left < cap - pos ? left : cap - pos;
-					const u32 wn = wv_readfirst(br_dict_word(L, blob, copy, widx, tidx, out + pos, room, lane));
+					const u32 wn = wv_readfirst(br_dict_word(L, blob, copy, widx, tidx, out + pos, left, lane));
 					if (wn == 0xFFFFFFFFu) {
-						if (left <= cap - pos)
-							hbad = true;
-						else
-							stc = ST_SIZE_MISMATCH;
+						hbad = true;
 						break;
 					}
 					if (wn == 0 && ins0 == 0) {
@@ -1207,10 +1253,6 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 				} else {
 					if (copy > left) {
 						hbad = true;
-						break;
-					}
-					if (copy > cap - pos) {
-						stc = ST_SIZE_MISMATCH;
 						break;
 					}
 					if (push) {
