@@ -206,10 +206,12 @@ zmt_dec_frames_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 #else
 #define KT() 0ull
 #endif
+#ifndef P_RING
 #define P_RING 384u  /* three 128-byte units per lane */
+#endif
 #define P_UNIT 128u  /* refill granule: one aligned line of the stream */
 typedef u32 v4u __attribute__((vector_size(16)));
-#define P_RSTRIDE 400u /* row stride of the input rings: 384 + 16-byte mirror */
+#define P_RSTRIDE (P_RING + 16u) /* row stride of the input rings: ring + 16-byte mirror */
 #define P_TSTRIDE 136u /* row stride of the token tile (64 x u16 + pad) */
 
 /* ring offset of g-coordinate g for a lane whose ring lap starts at rb (0 <= g - rb < 2 * P_RING) */
