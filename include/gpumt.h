@@ -148,6 +148,9 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
  * ZSTD_decompressStream at lib/zstd-mt_decompress.c:464): raw / RLE / compressed blocks, Huffman
  * literals, FSE sequence tables of every mode, repeat offsets, XXH64 content checksum (verified, a
  * mismatch reports GPUMT_ST_BAD_CHECKSUM); no dictionaries.  Same d_stream slack rule as above.
+ * d_out_len[i] is the exact content size for frames that state one (what the probe returns); for a
+ * frame without a content size (streaming writers, plain .zst files) the caller passes a capacity
+ * there and the decoder replaces it by the decoded size.
  * Internal scratch: 128 KiB + 264 B per record.
  */
 /* Bytes one zstd record slot occupies: room for the record + frame header and one padded area per
@@ -172,7 +175,7 @@ int gpumt_zstd_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d
 int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream_bytes,
 				const uint64_t *d_rec_off, const uint32_t *d_rec_len, size_t nrec,
 				void *d_out, size_t out_bytes, const uint64_t *d_out_off,
-				const uint32_t *d_out_len, uint32_t *d_status, int stream);
+				uint32_t *d_out_len, uint32_t *d_status, int stream);
 
 /* ---- brotli-mt records (16-byte header + one raw brotli stream, lib/brotli-mt_compress.c:285-304) ----
  *

@@ -27,9 +27,9 @@ void zmt_lz4_dec_batch(const u8 *, const u64 *, const u32 *, u32, u8 *, const u6
 void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 void zmt_scan_kernel(const u32 *, u32, u64 *);
 void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
-void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u8 *, u32 *, u32 *, u32 *, u32);
+void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *, u32);
 void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u8 *, const u8 *);
-void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u8 *, u32 *, u32 *, u32 *);
+void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *);
 void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *, u32 *);
 void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
 void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
@@ -161,7 +161,7 @@ void emu_zstd_probe(const u8 *stream, const u64 *rec_off, const u32 *rec_len, u3
 }
 
 void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *rec_off, const u32 *rec_len,
-			       u32 nrec, u8 *out, const u64 *out_off, const u32 *out_len, u32 *status)
+			       u32 nrec, u8 *out, const u64 *out_off, u32 *out_len, u32 *status)
 {
 	std::vector<u8> lit((size_t)nrec * (131072 + 256), 0xA5);
 	u8 *litp = lit.data();

@@ -223,3 +223,54 @@ def test_large_default_chunks(lib):
     assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
     rv, out, _, _ = H.zstdmt_decompress_via(lib, st, threads=4)
     assert rv == 0 and out == data
+
+
+# ---- plain .zst streams (the reference's single-threaded path, lib/zstd-mt_decompress.c:552-687) ----
+def _plain_cases():
+    a = cases.text(300000, 81)
+    b = cases.rnd(50000, 82) + bytes(200000) + cases.text(700000, 83)
+    big = cases.text(5 << 20, 84)
+    return {
+        # frames of the library flavours zstd-mt never writes: no content size, checksums, high levels
+        "one_frame": [H.libzstd_frame(a, 3)],
+        "no_content_size": [H.libzstd_frame(a, 1, content_size=0)],
+        "checksum_no_size": [H.libzstd_frame(b, 5, checksum=1, content_size=0)],
+        "three_frames": [H.libzstd_frame(a, 1), H.libzstd_frame(b, 9, content_size=0), H.libzstd_frame(a[:1000], 19)],
+        "skippable_between": [H.libzstd_frame(a, 2), b"\x5A\x2A\x4D\x18" + (7).to_bytes(4, "little") + b"comment",
+                              H.libzstd_frame(b, 2)],
+        "large_window_many_blocks": [H.libzstd_frame(big, 6, content_size=0)],
+        "tiny": [H.libzstd_frame(b"abc", 1)],            # shorter than the 16-byte sniff
+        "empty_with_size": [H.libzstd_frame(b"", 1), H.libzstd_frame(a, 1)],
+    }, {"one_frame": a, "no_content_size": a, "checksum_no_size": b, "three_frames": a + b + a[:1000],
+        "skippable_between": a + b, "large_window_many_blocks": big, "tiny": b"abc", "empty_with_size": a}
+
+
+@pytest.mark.skipif(H.libzstd_frame(b"x") is None, reason="libzstd not on this box")
+@pytest.mark.parametrize("name", ["one_frame", "no_content_size", "checksum_no_size", "three_frames",
+                                  "skippable_between", "large_window_many_blocks", "tiny", "empty_with_size"])
+def test_decompress_plain_zst_streams(lib, name):
+    streams, plain = _plain_cases()
+    st = b"".join(streams[name])
+    rv, out, io, stats = H.zstdmt_decompress_via(lib, st, threads=4)
+    assert rv == 0 and out == plain[name]
+    assert stats == (0, len(st), len(plain[name]))      # st_decompress counts no frames
+    assert max(io.writes, default=0) <= 131072           # pieces of ZSTD_DStreamOutSize() at most
+    if H.have_zref():
+        rv_r, out_r, io_r, stats_r = H.zstdmt_decompress_via(H.zref(), st, threads=4)
+        assert rv_r == 0 and out_r == out and stats_r == stats
+        assert _strip_eof(io_r.reads)[:2] == _strip_eof(io.reads)[:2]   # sniff, then the rest of the first buffer
+
+
+@pytest.mark.skipif(H.libzstd_frame(b"x") is None, reason="libzstd not on this box")
+def test_plain_zst_errors(lib):
+    a = cases.text(200000, 91)
+    f = H.libzstd_frame(a, 3, checksum=1)
+    for bad in (f[:len(f) // 2], f[:-1]):                # truncated inside a block / inside the checksum
+        rv, _, _, _ = H.zstdmt_decompress_via(lib, bad)
+        assert rv == ERR(E_LIB)
+    dmg = bytearray(f)
+    dmg[len(f) // 2] ^= 0x40
+    rv, _, _, _ = H.zstdmt_decompress_via(lib, bytes(dmg))
+    assert rv == ERR(E_LIB)
+    rv, _, _, _ = H.zstdmt_decompress_via(lib, f + b"garbage after the frame....")
+    assert rv == ERR(E_LIB)

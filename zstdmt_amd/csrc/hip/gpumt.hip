@@ -42,11 +42,11 @@ __global__ void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32,
 __global__ void zmt_brotli_dec_kernel_prof(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
 					   const u32 *, u32 *, u32 *, u8 *, const u8 *, unsigned long long *);
 __global__ void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-					  const u32 *, u8 *, u32 *, u32 *, u32 *);
+					  u32 *, u8 *, u32 *, u32 *, u32 *);
 __global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-				    const u32 *, u8 *, u32 *, u32 *, u32 *, u32);
+				    u32 *, u8 *, u32 *, u32 *, u32 *, u32);
 __global__ void zmt_zstd_dec_kernel_prof(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-					 const u32 *, u8 *, u32 *, u32 *, u32 *, u32, unsigned long long *);
+					 u32 *, u8 *, u32 *, u32 *, u32 *, u32, unsigned long long *);
 __global__ void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *,
 					u32 *);
 __global__ void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
@@ -684,7 +684,7 @@ int gpumt_zstd_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d
 int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream_bytes,
 				const uint64_t *d_rec_off, const uint32_t *d_rec_len, size_t nrec,
 				void *d_out, size_t out_bytes, const uint64_t *d_out_off,
-				const uint32_t *d_out_len, uint32_t *d_status, int s)
+				uint32_t *d_out_len, uint32_t *d_status, int s)
 {
 	(void)out_bytes;
 	if (!h || !STREAM_OK(s) || nrec == 0 || nrec > 0x3FFFFFFFu)
@@ -720,7 +720,7 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 	}
 	/* XXH64 content checksums, for the frames that carry one */
 	hipLaunchKernelGGL(zmt_xxh64_verify_kernel, dim3((unsigned)((nrec * 4 + 255) / 256)), dim3(256), 0,
-			   h->st[s], (const u8 *)d_out, d_out_off, d_out_len, (u32)nrec, (const u32 *)chk_e,
+			   h->st[s], (const u8 *)d_out, d_out_off, (const u32 *)d_out_len, (u32)nrec, (const u32 *)chk_e,
 			   (const u32 *)chk_v, d_status);
 	PROF1(11);
 	CK(hipGetLastError());

@@ -390,7 +390,7 @@ template <bool PROF, typename LDS>
 static __device__ __forceinline__ void
 zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
 	      const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base, const u64 *__restrict__ out_off,
-	      const u32 *__restrict__ out_len, u8 *__restrict__ litbuf, u32 *__restrict__ status,
+	      u32 *__restrict__ out_len, u8 *__restrict__ litbuf, u32 *__restrict__ status,
 	      u32 *__restrict__ chk_expect, u32 *__restrict__ chk_valid, unsigned long long *prof)
 {
 	const int lane = wv_lane();
@@ -1093,8 +1093,12 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 		atomicAdd(prof + 9, 1ull);
 	}
 #endif
-	if (stc == ST_OK && opos != cap)
+	/* a frame that states its content size must produce exactly that (= the caller's out_len); one
+	 * that does not (streaming writers; never zstd-mt) was given a capacity and reports its size */
+	if (stc == ST_OK && content != ~0ull && opos != cap)
 		stc = ST_SIZE_MISMATCH;
+	if (stc == ST_OK && content == ~0ull && lane == 0)
+		out_len[rec] = opos;
 	if (stc == ST_OK && has_chk) {
 		/* Content_Checksum: low 32 bits of XXH64 of the content (RFC 8878 3.1.1); compared by
 		 * zmt_xxh64_verify_kernel once the content is complete.  zstd-mt never writes one
@@ -1120,7 +1124,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 extern "C" __global__ void __launch_bounds__(64)
 zmt_zstd_dec_small_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
 			  const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
-			  const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
+			  const u64 *__restrict__ out_off, u32 *__restrict__ out_len,
 			  u8 *__restrict__ litbuf, u32 *__restrict__ status, u32 *__restrict__ chk_expect,
 			  u32 *__restrict__ chk_valid)
 {
@@ -1132,7 +1136,7 @@ zmt_zstd_dec_small_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const
 extern "C" __global__ void __launch_bounds__(64)
 zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
 		    const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
-		    const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
+		    const u64 *__restrict__ out_off, u32 *__restrict__ out_len,
 		    u8 *__restrict__ litbuf, u32 *__restrict__ status, u32 *__restrict__ chk_expect,
 		    u32 *__restrict__ chk_valid, u32 want)
 {
@@ -1146,7 +1150,7 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 extern "C" __global__ void __launch_bounds__(64)
 zmt_zstd_dec_kernel_prof(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
 			 const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
-			 const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
+			 const u64 *__restrict__ out_off, u32 *__restrict__ out_len,
 			 u8 *__restrict__ litbuf, u32 *__restrict__ status, u32 *__restrict__ chk_expect,
 			 u32 *__restrict__ chk_valid, u32 want, unsigned long long *prof)
 {

@@ -10,8 +10,8 @@
  *              record (:221-353); one fn_write per frame in order.
  * Stream layouts accepted by decompress: the one the compressor writes ("pzstd style": skippable
  * frame first, :251-284) and the old "zstdmt style" (a 9-byte empty zstd frame in front, :225-249).
- * Plain .zst streams (the reference's single-threaded path) are SURVEY 8f-2 "next" and report
- * frame_decompress.
+ * Plain .zst streams (the reference's single-threaded path) are split into frames on the
+ * host and decoded by the same kernels (plain_decompress below).
  * Plain C, no HIP header.
  */
 #include "mt_host.h"
@@ -544,6 +544,239 @@ static size_t dp_drain(void *a, int si)
 	return 0;
 }
 
+/* =================================================================== plain .zst streams
+ * The reference hands anything that starts with a zstd frame (and is not the old zstdmt layout) to
+ * its single-threaded ZSTD_decompressStream loop (st_decompress, zstd-mt_decompress.c:552-687):
+ * frames of the zstd CLI / library, any number of them, possibly without a content size and with
+ * skippable frames in between.  Here the input is read to its end (same request sizes as the
+ * reference: ZSTD_DStreamInSize() = 128 KiB + 3), split into frames on the host by walking the
+ * block headers (RFC 8878 3.1.1.2), and decoded by the same device kernels, one wave per frame;
+ * frames that do not state their content size get the sum of their block bounds as capacity and the
+ * decoder reports the size.  Output leaves in pieces of at most ZSTD_DStreamOutSize() = 128 KiB like
+ * the reference's; GetFrames stays 0 as in the reference (st_decompress counts no frames). */
+#define ZSTD_IN_CHUNK 131075u
+#define ZSTD_OUT_CHUNK 131072u
+
+/* one frame at p[0..n): total length and output bound; 0 = malformed / truncated */
+static size_t zstd_frame_extent(const uint8_t *p, size_t n, uint64_t *bound, int *sized)
+{
+	if (n < 6)
+		return 0;
+	const unsigned fhd = p[4], fcs = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3, chk = (fhd >> 2) & 1;
+	const unsigned did_len = did == 3 ? 4 : did, fcs_len = fcs == 0 ? single : 1u << fcs;
+	size_t hp = 5;
+	uint64_t window = 0, content = 0, sum = 0;
+	if ((fhd & 8) || n < 5 + (1 - single) + did_len + fcs_len)
+		return 0;
+	if (!single) {
+		const unsigned wd = p[hp++];
+		const uint64_t base = 1ull << (10 + (wd >> 3));
+		window = base + (base >> 3) * (wd & 7);
+	}
+	hp += did_len;
+	for (unsigned k = 0; k < fcs_len; k++)
+		content |= (uint64_t)p[hp + k] << (8 * k);
+	if (fcs == 1)
+		content += 256;
+	hp += fcs_len;
+	if (single)
+		window = content;
+	const uint64_t block_max = window < 131072 ? window : 131072;
+	for (;;) {
+		if (n - hp < 3)
+			return 0;
+		const uint32_t bh = (uint32_t)p[hp] | (uint32_t)p[hp + 1] << 8 | (uint32_t)p[hp + 2] << 16;
+		const uint32_t last = bh & 1, type = (bh >> 1) & 3, bsize = bh >> 3;
+		hp += 3;
+		if (type == 3)
+			return 0;
+		if (type == 1) { /* RLE: one byte regenerates bsize */
+			if (n - hp < 1)
+				return 0;
+			hp += 1;
+			sum += bsize;
+		} else {
+			if (n - hp < bsize)
+				return 0;
+			hp += bsize;
+			sum += type == 0 ? bsize : block_max;
+		}
+		if (last)
+			break;
+	}
+	if (chk) {
+		if (n - hp < 4)
+			return 0;
+		hp += 4;
+	}
+	*sized = fcs_len != 0;
+	*bound = fcs_len ? content : sum;
+	return hp;
+}
+
+static size_t plain_write(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, const uint8_t *p, size_t n)
+{
+	while (n) {
+		ZSTDCB_Buffer b;
+		const size_t k = n < ZSTD_OUT_CHUNK ? n : ZSTD_OUT_CHUNK;
+		int rv;
+		b.buf = (void *)p;
+		b.size = k;
+		b.allocated = k;
+		rv = io->fn_write(io->arg_write, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		ctx->outsize += k;
+		p += k;
+		n -= k;
+	}
+	return 0;
+}
+
+static size_t plain_decompress(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, const uint8_t *first, size_t nfirst, int at_eof)
+{
+	uint8_t *raw = (uint8_t *)malloc(ZSTD_IN_CHUNK);
+	size_t cap = ZSTD_IN_CHUNK, n = nfirst, err = 0, ip = 0;
+	struct dslot *s = &ctx->s[0];
+	gpumt_ctx *g = ctx->gpu;
+	if (!raw)
+		return ZSTDCB_ERROR(memory_allocation);
+	memcpy(raw, first, nfirst);
+	/* ---- read to the end: first request fills the first buffer behind the sniffed bytes (:590-609) ---- */
+	while (!at_eof) {
+		ZSTDCB_Buffer b;
+		int rv;
+		const size_t want = n == nfirst ? ZSTD_IN_CHUNK - nfirst : ZSTD_IN_CHUNK;
+		if (n + want > cap) {
+			uint8_t *nr;
+			cap = cap * 2 + want;
+			nr = (uint8_t *)realloc(raw, cap);
+			if (!nr) {
+				free(raw);
+				return ZSTDCB_ERROR(memory_allocation);
+			}
+			raw = nr;
+		}
+		b.buf = raw + n;
+		b.size = want;
+		b.allocated = want;
+		rv = io->fn_read(io->arg_read, &b);
+		if (rv != 0) {
+			free(raw);
+			return mt_error(rv);
+		}
+		if (b.size == 0)
+			break;
+		n += b.size;
+	}
+	ctx->insize += n;
+	/* ---- frames, in batches the device buffers can hold ---- */
+	while (ip < n && !err) {
+		size_t in_bytes = 0, out_bytes = 0, nrec = 0;
+		if (dbuf_want(g, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1)) {
+			err = ZSTDCB_ERROR(memory_allocation);
+			break;
+		}
+		/* pass 1: extents of the frames of this batch */
+		size_t jp = ip;
+		while (jp < n && nrec < BATCH_MAXREC) {
+			uint64_t bound;
+			int sized;
+			size_t flen;
+			if (n - jp >= 8 && (rd32(raw + jp) & 0xFFFFFFF0u) == ZSTDCB_MAGIC_SKIPPABLE) {
+				const size_t sk = 8 + (size_t)rd32(raw + jp + 4);
+				if (sk > n - jp) {
+					err = ZSTDCB_ERROR(compression_library);
+					break;
+				}
+				jp += sk;
+				continue;
+			}
+			if (n - jp < 4 || rd32(raw + jp) != ZSTDCB_MAGICNUMBER_MAX ||
+			    !(flen = zstd_frame_extent(raw + jp, n - jp, &bound, &sized)) || flen > 0xFFFFFFF0u ||
+			    bound > 0x7FFFFFFFull) {
+				zstdmt_errcode = GPUMT_ST_BAD_FRAME;
+				err = ZSTDCB_ERROR(compression_library);
+				break;
+			}
+			if (nrec && (in_bytes + 12 + flen > BATCH_BYTES || out_bytes + bound > 4 * BATCH_BYTES))
+				break;
+			m_rec_off(s, 0)[nrec] = in_bytes;
+			m_rec_len(s, 0)[nrec] = (uint32_t)(12 + flen);
+			m_out_off(s, 0)[nrec] = out_bytes;
+			m_out_len(s, 0)[nrec] = (uint32_t)bound;
+			in_bytes += 12 + flen;
+			out_bytes += (size_t)bound;
+			nrec++;
+			jp += flen;
+		}
+		if (err)
+			break;
+		if (!nrec) { /* only skippable frames were left */
+			ip = jp;
+			continue;
+		}
+		m_out_off(s, 0)[nrec] = out_bytes;
+		if (dbuf_want(g, &s->in, in_bytes + 512, 1, 1) || dbuf_want(g, &s->out, out_bytes + 64, 1, 1) ||
+		    dbuf_want(g, &s->status, nrec * 4 + 64, 1, 1)) {
+			err = ZSTDCB_ERROR(memory_allocation);
+			break;
+		}
+		/* pass 2: records = 12-byte skippable header + frame, the layout the kernels take */
+		{
+			size_t k = 0, q = ip;
+			while (k < nrec) {
+				if ((rd32(raw + q) & 0xFFFFFFF0u) == ZSTDCB_MAGIC_SKIPPABLE) {
+					q += 8 + (size_t)rd32(raw + q + 4);
+					continue;
+				}
+				const uint32_t flen = m_rec_len(s, 0)[k] - 12;
+				uint8_t *rec = (uint8_t *)s->in.h + m_rec_off(s, 0)[k];
+				rec[0] = 0x50; rec[1] = 0x2A; rec[2] = 0x4D; rec[3] = 0x18;
+				rec[4] = 4; rec[5] = rec[6] = rec[7] = 0;
+				rec[8] = (uint8_t)flen; rec[9] = (uint8_t)(flen >> 8);
+				rec[10] = (uint8_t)(flen >> 16); rec[11] = (uint8_t)(flen >> 24);
+				memcpy(rec + 12, raw + q, flen);
+				q += flen;
+				k++;
+			}
+		}
+		s->nrec = nrec;
+		s->in_bytes = in_bytes;
+		s->out_bytes = out_bytes;
+		{
+			int rc = 0;
+			memset(s->status.h, 0, nrec * 4);
+			rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, in_bytes, 0);
+			rc |= gpumt_memcpy_h2d(g, s->meta.d, s->meta.h, D_META_BYTES(BATCH_MAXREC), 0);
+			rc |= gpumt_memcpy_h2d(g, s->status.d, s->status.h, nrec * 4, 0);
+			rc |= gpumt_zstd_decompress_batch(g, s->in.d, in_bytes, m_rec_off(s, 1), m_rec_len(s, 1), nrec, s->out.d,
+							  out_bytes, m_out_off(s, 1), m_out_len(s, 1), (uint32_t *)s->status.d, 0);
+			rc |= gpumt_memcpy_d2h(g, s->status.h, s->status.d, nrec * 4, 0);
+			rc |= gpumt_memcpy_d2h(g, m_out_len(s, 0), m_out_len(s, 1), nrec * 4, 0); /* sizes of unsized frames */
+			if (out_bytes)
+				rc |= gpumt_memcpy_d2h(g, s->out.h, s->out.d, out_bytes, 0);
+			rc |= gpumt_stream_sync(g, 0);
+			if (rc) {
+				err = ZSTDCB_ERROR(compression_library);
+				break;
+			}
+		}
+		for (size_t i = 0; i < nrec && !err; i++) {
+			const uint32_t st = ((const uint32_t *)s->status.h)[i];
+			if (st != GPUMT_ST_OK) {
+				zstdmt_errcode = st;
+				err = ZSTDCB_ERROR(compression_library);
+				break;
+			}
+			err = plain_write(ctx, io, (const uint8_t *)s->out.h + m_out_off(s, 0)[i], m_out_len(s, 0)[i]);
+		}
+		ip = jp;
+	}
+	free(raw);
+	return err;
+}
+
 size_t ZSTDCB_decompressDCtx(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 {
 	uint8_t sniff[16];
@@ -566,7 +799,7 @@ size_t ZSTDCB_decompressDCtx(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 			return ZSTDCB_ERROR(data_error);
 		if (b.size == 9)
 			return 0; /* the 9-byte empty zstd frame: "create empty file" (:731-736) */
-		return ZSTDCB_ERROR(frame_decompress); /* short plain .zst: single-thread path, 8f-2 */
+		return plain_decompress(ctx, rdwr, sniff, b.size, 1); /* a plain .zst shorter than the sniff */
 	}
 	ctx->insize += 16;
 	ctx->have_hdr = 1;
@@ -593,8 +826,10 @@ size_t ZSTDCB_decompressDCtx(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 		ctx->hdr_csize = rd32(tail + 1);
 		ctx->have_first4 = 0;
 	} else {
-		if (is_zstd_magic(sniff))
-			return ZSTDCB_ERROR(frame_decompress); /* plain .zst: single-thread path, 8f-2 */
+		if (is_zstd_magic(sniff)) {
+			ctx->insize -= 16; /* counted with the rest of the input below */
+			return plain_decompress(ctx, rdwr, sniff, 16, 0); /* "some std zstd stream" (:755-759) */
+		}
 		return ZSTDCB_ERROR(data_error);
 	}
 	ctx->budget = BATCH_MIN;
