@@ -135,7 +135,7 @@ int gpumt_lz4_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d_
 int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream_bytes,
 			       const uint64_t *d_rec_off, const uint32_t *d_rec_len, size_t nrec,
 			       void *d_out, size_t out_bytes, const uint64_t *d_out_off,
-			       const uint32_t *d_out_len, uint32_t *d_status, int stream);
+			       uint32_t *d_out_len, uint32_t *d_status, int stream);
 
 /* ---- zstd-mt records (12-byte skippable header + one zstd frame, lib/zstd-mt_compress.c:296-302) ----
  *

@@ -18,7 +18,7 @@ void zmt_lz4_enc_v1_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u3
 void zmt_lz4_enc3_u16_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
 void zmt_lz4_enc3_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
 void zmt_lz4_enc3_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
-void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u32 *, u32);
+void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u32 *, u32 *, u32 *, u32);
 void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
 void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *, u32 *, unsigned long long *, u32);
@@ -105,7 +105,7 @@ void emu_lz4_probe_sizes(const u8 *stream, const u64 *rec_off, const u32 *rec_le
 
 void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, const u64 *rec_off,
 			      const u32 *rec_len, u32 nrec, u8 *out, u64 out_bytes, const u64 *out_off,
-			      const u32 *out_len, u32 *status)
+			      u32 *out_len, u32 *status)
 {
 	std::vector<u32> ce(nrec), cv(nrec);
 	u32 *cep = ce.data(), *cvp = cv.data();

@@ -434,3 +434,39 @@ def mt_record(frame: bytes) -> bytes:
     """12-byte skippable header + frame (lib/zstd-mt_compress.c:296-302)."""
     import struct
     return struct.pack("<III", 0x184D2A50, 4, len(frame)) + frame
+
+
+def liblz4_frame(data: bytes, block_id=7, linked=1, content_size=0, checksum=1, level=1, block_checksum=0):
+    """One LZ4 frame written by the image's liblz4 with explicit frame parameters (test input for the
+    plain .lz4 flavours lz4-mt itself never writes: the lz4 tool's defaults are 4 MiB linked blocks, a
+    content checksum and no content size).  None if liblz4 is not present."""
+    path = next((p for p in ("/opt/conda/lib/liblz4.so.1", "/usr/lib/x86_64-linux-gnu/liblz4.so.1")
+                 if os.path.exists(p)), None)
+    if path is None:
+        return None
+    lz = C.CDLL(path)
+
+    class FrameInfo(C.Structure):
+        _fields_ = [("blockSizeID", C.c_int), ("blockMode", C.c_int), ("contentChecksumFlag", C.c_int),
+                    ("frameType", C.c_int), ("contentSize", C.c_ulonglong), ("dictID", C.c_uint),
+                    ("blockChecksumFlag", C.c_int)]
+
+    class Prefs(C.Structure):
+        _fields_ = [("frameInfo", FrameInfo), ("compressionLevel", C.c_int), ("autoFlush", C.c_uint),
+                    ("favorDecSpeed", C.c_uint), ("reserved", C.c_uint * 3)]
+    pr = Prefs()
+    pr.frameInfo.blockSizeID = block_id
+    pr.frameInfo.blockMode = 0 if linked else 1          # LZ4F_blockLinked = 0
+    pr.frameInfo.contentChecksumFlag = checksum
+    pr.frameInfo.contentSize = len(data) if content_size else 0
+    pr.frameInfo.blockChecksumFlag = block_checksum
+    pr.compressionLevel = level
+    lz.LZ4F_compressFrameBound.restype = C.c_size_t
+    lz.LZ4F_compressFrameBound.argtypes = [C.c_size_t, C.POINTER(Prefs)]
+    lz.LZ4F_compressFrame.restype = C.c_size_t
+    lz.LZ4F_compressFrame.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(Prefs)]
+    cap = lz.LZ4F_compressFrameBound(len(data), C.byref(pr))
+    dst = C.create_string_buffer(cap)
+    n = lz.LZ4F_compressFrame(dst, cap, data, len(data), C.byref(pr))
+    assert n <= cap
+    return dst.raw[:n]

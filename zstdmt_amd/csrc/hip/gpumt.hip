@@ -28,7 +28,7 @@ __global__ void zmt_lz4_enc3_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u6
 __global__ void zmt_lz4_enc3_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
 					unsigned long long *);
 __global__ void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
-				   const u32 *, u32 *, u32 *, u32 *, u32);
+				   u32 *, u32 *, u32 *, u32 *, u32);
 __global__ void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 __global__ void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *,
 				      const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
@@ -506,7 +506,7 @@ int gpumt_lz4_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d_
 int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream_bytes,
 			       const uint64_t *d_rec_off, const uint32_t *d_rec_len, size_t nrec,
 			       void *d_out, size_t out_bytes, const uint64_t *d_out_off,
-			       const uint32_t *d_out_len, uint32_t *d_status, int s)
+			       uint32_t *d_out_len, uint32_t *d_status, int s)
 {
 	if (!h || !STREAM_OK(s) || nrec == 0 || nrec > 0x3FFFFFFFu)
 		return GPUMT_E_ARG;

@@ -85,7 +85,7 @@ static __device__ u32 decode_block_serial(const u8 *src, u32 slen, u8 *out, u32 
 extern "C" __global__ void __launch_bounds__(64)
 zmt_lz4_dec_serial(const u8 *__restrict__ stream, const u64 *__restrict__ rec_off,
 		   const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
-		   const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
+		   const u64 *__restrict__ out_off, u32 *__restrict__ out_len,
 		   u32 *__restrict__ status, u32 *__restrict__ chk_expect,
 		   u32 *__restrict__ chk_valid, u32 only_status)
 {
@@ -152,10 +152,14 @@ zmt_lz4_dec_serial(const u8 *__restrict__ stream, const u64 *__restrict__ rec_of
 		}
 		ip += bsz;
 	}
-	if ((fi.has_csize && fi.csize != (u64)opos) || opos != cap) {
+	/* a frame that states its content size must produce exactly that (= out_len); one that does not
+	 * (plain .lz4 files of the lz4 tool; never lz4-mt) was given a capacity and reports its size */
+	if (fi.has_csize ? (fi.csize != (u64)opos || opos != cap) : opos > cap) {
 		st = ST_SIZE_MISMATCH;
 		goto done;
 	}
+	if (!fi.has_csize && lane == 0)
+		out_len[rec] = opos;
 	if (fi.has_ccheck) {
 		if (flen - ip < 4) {
 			st = ST_BAD_BLOCK;

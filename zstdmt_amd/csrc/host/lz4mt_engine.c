@@ -530,6 +530,203 @@ static size_t dp_drain(void *a, int si)
 	return 0;
 }
 
+/* =================================================================== plain .lz4 streams
+ * A stream that starts with an LZ4 frame instead of a skippable record is decoded by the reference
+ * on one thread with streaming LZ4F_decompress (st_decompress, lz4-mt_decompress.c:391-483): files of
+ * the lz4 tool, any number of frames, typically 4 MiB linked blocks and no content size.  Here the
+ * input is read to its end, split into frames on the host by walking the block headers (LZ4 frame
+ * format: FLG / BD, optional content size and dictionary id, 4-byte block sizes, end mark, optional
+ * content checksum) and decoded by the frame-serial kernel, one wave per frame; a frame that does not
+ * state its content size gets blocks x block-maximum as capacity and the decoder reports the size.
+ * GetFrames stays 0 as in the reference (st_decompress counts no frames). */
+static size_t lz4_frame_extent(const uint8_t *p, size_t n, uint64_t *bound, int *supported)
+{
+	if (n < 7)
+		return 0;
+	const unsigned flg = p[4], bd = p[5];
+	const unsigned bsid = (bd >> 4) & 7;
+	const int has_csize = (flg >> 3) & 1, has_dict = flg & 1, bchk = (flg >> 4) & 1, cchk = (flg >> 2) & 1;
+	size_t hp = 6 + (has_csize ? 8 : 0) + (has_dict ? 4 : 0) + 1;
+	uint64_t sum = 0, blkmax;
+	if ((flg >> 6) != 1 || bsid < 4 || n < hp)
+		return 0;
+	blkmax = 1ull << (8 + 2 * bsid); /* 4 -> 64 KiB ... 7 -> 4 MiB */
+	*supported = !(bchk || has_dict); /* block checksums / dictionaries: not on the device */
+	for (;;) {
+		uint32_t bh, bsz;
+		if (n - hp < 4)
+			return 0;
+		bh = rd32(p + hp);
+		hp += 4;
+		if (bh == 0)
+			break;
+		bsz = bh & 0x7FFFFFFFu;
+		if (bsz > blkmax || n - hp < bsz + (bchk ? 4u : 0u))
+			return 0;
+		hp += bsz + (bchk ? 4u : 0u);
+		sum += (bh & 0x80000000u) ? bsz : blkmax;
+	}
+	if (cchk) {
+		if (n - hp < 4)
+			return 0;
+		hp += 4;
+	}
+	*bound = has_csize ? rd64(p + 6) : sum;
+	return hp;
+}
+
+static size_t plain_decompress(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, const uint8_t *first)
+{
+	const size_t chunk = (size_t)ctx->inputsize;
+	const size_t piece = chunk < 65536 ? 65536 : chunk;
+	uint8_t *raw = (uint8_t *)malloc(chunk + 4);
+	size_t cap = chunk + 4, n = 4, err = 0, ip = 0;
+	struct dslot *s = &ctx->s[0];
+	gpumt_ctx *g = ctx->gpu;
+	if (!raw)
+		return ERROR(memory_allocation);
+	memcpy(raw, first, 4);
+	for (;;) { /* read to the end in inputsize requests (:462-476) */
+		LZ4MT_Buffer b;
+		int rv;
+		if (n + chunk > cap) {
+			uint8_t *nr;
+			cap = cap * 2 + chunk;
+			nr = (uint8_t *)realloc(raw, cap);
+			if (!nr) {
+				free(raw);
+				return ERROR(memory_allocation);
+			}
+			raw = nr;
+		}
+		b.buf = raw + n;
+		b.size = chunk;
+		b.allocated = chunk;
+		rv = io->fn_read(io->arg_read, &b);
+		if (rv != 0) {
+			free(raw);
+			return mt_error(rv);
+		}
+		if (b.size == 0)
+			break;
+		n += b.size;
+	}
+	ctx->insize = n;
+	ctx->outsize = 0;
+	while (ip < n && !err) {
+		size_t in_bytes = 0, out_bytes = 0, nrec = 0, jp = ip;
+		if (dbuf_want(g, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1)) {
+			err = ERROR(memory_allocation);
+			break;
+		}
+		while (jp < n && nrec < BATCH_MAXREC) {
+			uint64_t bound = 0;
+			int supported = 0;
+			size_t flen;
+			if (n - jp >= 8 && (rd32(raw + jp) & 0xFFFFFFF0u) == LZ4FMT_MAGIC_SKIPPABLE) {
+				const size_t sk = 8 + (size_t)rd32(raw + jp + 4);
+				if (sk > n - jp) {
+					err = ERROR(compression_library);
+					break;
+				}
+				jp += sk;
+				continue;
+			}
+			if (n - jp < 4 || rd32(raw + jp) != LZ4FMT_MAGICNUMBER ||
+			    !(flen = lz4_frame_extent(raw + jp, n - jp, &bound, &supported)) || !supported ||
+			    flen > 0xFFFFFFF0u || bound > 0x7FFFFFFFull) {
+				err = ERROR(compression_library);
+				break;
+			}
+			if (nrec && (in_bytes + 12 + flen > BATCH_BYTES || out_bytes + bound > 4 * BATCH_BYTES))
+				break;
+			m_rec_off(s, 0)[nrec] = in_bytes;
+			m_rec_len(s, 0)[nrec] = (uint32_t)(12 + flen);
+			m_out_off(s, 0)[nrec] = out_bytes;
+			m_out_len(s, 0)[nrec] = (uint32_t)bound;
+			in_bytes += 12 + flen;
+			out_bytes += (size_t)bound;
+			nrec++;
+			jp += flen;
+		}
+		if (err)
+			break;
+		if (!nrec) {
+			ip = jp;
+			continue;
+		}
+		m_out_off(s, 0)[nrec] = out_bytes;
+		if (dbuf_want(g, &s->in, in_bytes + 512, 1, 1) || dbuf_want(g, &s->out, out_bytes + 64, 1, 1) ||
+		    dbuf_want(g, &s->status, nrec * 4 + 64, 1, 1)) {
+			err = ERROR(memory_allocation);
+			break;
+		}
+		{
+			size_t k = 0, q = ip;
+			while (k < nrec) {
+				if ((rd32(raw + q) & 0xFFFFFFF0u) == LZ4FMT_MAGIC_SKIPPABLE) {
+					q += 8 + (size_t)rd32(raw + q + 4);
+					continue;
+				}
+				const uint32_t flen = m_rec_len(s, 0)[k] - 12;
+				uint8_t *rec = (uint8_t *)s->in.h + m_rec_off(s, 0)[k];
+				rec[0] = 0x50; rec[1] = 0x2A; rec[2] = 0x4D; rec[3] = 0x18;
+				rec[4] = 4; rec[5] = rec[6] = rec[7] = 0;
+				rec[8] = (uint8_t)flen; rec[9] = (uint8_t)(flen >> 8);
+				rec[10] = (uint8_t)(flen >> 16); rec[11] = (uint8_t)(flen >> 24);
+				memcpy(rec + 12, raw + q, flen);
+				q += flen;
+				k++;
+			}
+		}
+		{
+			/* frame-serial kernel for every record: block sizes and counts are arbitrary here */
+			const int prev = gpumt_set_variant(g, "lz4_dec", 1);
+			int rc = 0;
+			rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, in_bytes, 0);
+			rc |= gpumt_memcpy_h2d(g, s->meta.d, s->meta.h, D_META_BYTES(BATCH_MAXREC), 0);
+			rc |= gpumt_lz4_decompress_batch(g, s->in.d, in_bytes, m_rec_off(s, 1), m_rec_len(s, 1), nrec, s->out.d,
+							 out_bytes, m_out_off(s, 1), m_out_len(s, 1), (uint32_t *)s->status.d, 0);
+			rc |= gpumt_memcpy_d2h(g, s->status.h, s->status.d, nrec * 4, 0);
+			rc |= gpumt_memcpy_d2h(g, m_out_len(s, 0), m_out_len(s, 1), nrec * 4, 0);
+			if (out_bytes)
+				rc |= gpumt_memcpy_d2h(g, s->out.h, s->out.d, out_bytes, 0);
+			rc |= gpumt_stream_sync(g, 0);
+			gpumt_set_variant(g, "lz4_dec", prev);
+			if (rc) {
+				err = ERROR(compression_library);
+				break;
+			}
+		}
+		for (size_t i = 0; i < nrec && !err; i++) {
+			const uint8_t *o = (const uint8_t *)s->out.h + m_out_off(s, 0)[i];
+			size_t left = m_out_len(s, 0)[i];
+			if (((const uint32_t *)s->status.h)[i] != GPUMT_ST_OK) {
+				lz4mt_errcode = ((const uint32_t *)s->status.h)[i];
+				err = ERROR(compression_library);
+				break;
+			}
+			while (left && !err) {
+				LZ4MT_Buffer b;
+				const size_t k = left < piece ? left : piece;
+				int rv;
+				b.buf = (void *)o;
+				b.size = k;
+				b.allocated = k;
+				rv = io->fn_write(io->arg_write, &b);
+				if (rv != 0)
+					err = mt_error(rv);
+				ctx->outsize += k;
+				o += k;
+				left -= k;
+			}
+		}
+		ip = jp;
+	}
+	free(raw);
+	return err;
+}
+
 size_t LZ4MT_decompressDCtx(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *rdwr)
 {
 	static const mt_pipe_ops ops = {dp_fill, dp_launch, dp_complete, dp_drain};
@@ -552,9 +749,8 @@ size_t LZ4MT_decompressDCtx(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *rdwr)
 	if (rd32(magic) != LZ4FMT_MAGIC_SKIPPABLE) {
 		if (rd32(magic) != LZ4FMT_MAGICNUMBER)
 			return ERROR(data_error);
-		/* plain .lz4 stream: the reference decodes it single-threaded (st_decompress, :391-483);
-		 * not on the device path yet -- see INTEGRATION.md */
-		return ERROR(frame_decompress);
+		/* plain .lz4 stream: the reference decodes it single-threaded (st_decompress, :391-483) */
+		return plain_decompress(ctx, rdwr, magic);
 	}
 	ctx->io = rdwr;
 	ctx->have_hdr = 0;
