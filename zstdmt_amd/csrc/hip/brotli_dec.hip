@@ -37,6 +37,9 @@
 #define BR_NCMD_LDS 1u
 #define BR_NDIST_LDS 1u
 #define BR_CAP 64u /* longer copies are moved by the whole wave */
+/* uniform branches are what a single wave pays most for: keep the common path falling through */
+#define BR_RARE(c) __builtin_expect(!!(c), 0)
+#define BR_OFTEN(c) __builtin_expect(!!(c), 1)
 
 /* scratch of one wave in HBM (include/gpumt.h GPUMT_BROTLI_SCRATCH) */
 #define BR_G_LIT 0u
@@ -132,7 +135,7 @@ static __device__ __forceinline__ void br_seek(BrBits &b, u32 byte, int lane)
 static __device__ __forceinline__ void br_refill(BrBits &b, int lane)
 {
 	if (b.navail <= 32) {
-		if (b.widx == 64) {
+		if (BR_RARE(b.widx == 64)) {
 			/* no prefetch of the next window: a register with a load in flight cannot be
 			 * carried through the branches of the decode loop (every copy of it would wait
 			 * for all memory operations, stores included); one wait per 256 stream bytes */
@@ -237,7 +240,7 @@ static __device__ __forceinline__ u32 br_sym_index(BrBits &b, u32 va, u32 vi, u3
 	const u32 c = br_rev15((u32)b.acc);
 	u64 m = wv_ballot(c < (va & 0xFFFFu));
 	m = (m >> (16 * grp)) & 0xFFFFull;
-	if (!m) {
+	if (BR_RARE(!m)) {
 		bad = true;
 		return 0;
 	}
@@ -1037,7 +1040,7 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 			u32 left = mlen;
 			BRP(0);
 			while (left) {
-				if (c1.left == 0) {
+				if (BR_RARE(c1.left == 0)) {
 					br_switch(b, c1, gbt, 1, hbad, lane);
 					BR_VEC(cva, cvi, L.cmd, BR_NCMD_LDS, BR_CMD_STRIDE, BR_G_CMD, c1.type);
 				}
@@ -1050,7 +1053,7 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 					else
 						cs = wv_readfirst(*(const u16 *)(G + BR_G_CMD + c1.type * BR_CMD_STRIDE + 128 + 2 * k));
 				}
-				if (hbad)
+				if (BR_RARE(hbad))
 					break;
 				BRP(1);
 				const u32 icode = cs & 31, ccode = (cs >> 5) & 31; /* packed when the tree was read */
@@ -1060,7 +1063,7 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 				{
 					/* extra bits of both lengths, in one read when they fit (nearly always) */
 					const u32 ib = ki >> 24, cb = kc >> 24;
-					if (ib + cb <= 24) {
+					if (BR_OFTEN(ib + cb <= 24)) {
 						const u32 x = br_get(b, ib + cb, lane);
 						ins += x & ((1u << ib) - 1u);
 						copy += x >> ib;
@@ -1070,7 +1073,7 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 					}
 				}
 				const u32 ins0 = ins;
-				if (ins > left) {
+				if (BR_RARE(ins > left)) {
 					hbad = true;
 					break;
 				}
@@ -1096,7 +1099,7 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 						const u32 syl = L.lit[128 + kprev];
 						litv = (u32)lane == (pos & 63) ? syl : litv;
 						pos++;
-						if ((pos & 63) == 0)
+						if (BR_RARE((pos & 63) == 0))
 							BR_FLUSH();
 					}
 				} else if (ctx_free) {
@@ -1166,7 +1169,7 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 					dist = rb3;
 					push = false;
 				} else {
-					if (c2.left == 0) {
+					if (BR_RARE(c2.left == 0)) {
 						br_switch(b, c2, gbt, 2, hbad, lane);
 						if (hbad)
 							break;
@@ -1218,7 +1221,7 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 				const u32 max_dist = pos < max_backward ? pos : max_backward;
 				BR_FLUSH();
 				BRP(3);
-				if (dist > max_dist) {
+				if (BR_RARE(dist > max_dist)) {
 					if (copy < 4 || copy > 24) {
 						hbad = true;
 						break;
@@ -1251,7 +1254,7 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 					left -= wn;
 					BRP(5);
 				} else {
-					if (copy > left) {
+					if (BR_RARE(copy > left)) {
 						hbad = true;
 						break;
 					}
@@ -1271,7 +1274,7 @@ brotli_dec_body(BrLds &L, const u8 *__restrict__ stream, const u64 *__restrict__
 						pos += copy;
 						lit_lo = pos;
 						left -= copy;
-						if (nbatch == 64) {
+						if (BR_RARE(nbatch == 64)) {
 							BR_EXEC();
 							BRP(4);
 						}
