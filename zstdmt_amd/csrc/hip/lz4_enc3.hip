@@ -29,6 +29,8 @@
 #endif
 #define IPIECE 512u /* refill granule: 8 bytes per lane */
 #define IMIRROR 16u
+/* uniform branches are what a single wave pays most for: keep the common path falling through */
+#define E_RARE(c) __builtin_expect(!!(c), 0)
 
 enum { T_U16 = 0, T_P17 = 1, T_U32 = 2 };
 
@@ -248,7 +250,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				const bool valid = (u32)lane < bsz && cur + gap <= mflimit_p1;
 				const u32 cur0 = wv_readlane(cur, 0); /* first probe of the batch */
 				const u64 vm = wv_ballot(valid);
-				if (vm == 0)
+				if (E_RARE(vm == 0))
 					goto last_literals;
 				EPC(R, 7);
 				ring_want(R, cur0, lane);
@@ -265,7 +267,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					wv_sync();
 					if (valid)
 						bitmap[h >> 5] = 0;
-					if (any_dup) {
+					if (E_RARE(any_dup)) {
 						for (u32 i = 0; i < bsz; i++) {
 							const u32 hi_ = wv_readlane(h, (int)i);
 							const bool vi = (vm >> i) & 1;
@@ -304,7 +306,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						found = true;
 						break;
 					}
-					if (nvalid < bsz)
+					if (E_RARE(nvalid < bsz))
 						goto last_literals;
 				}
 				kbase += bsz;
@@ -338,7 +340,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			if (back > nb)
 				back = nb;
 			fwd = smf ? (u32)wv_ffs(smf) - 1 : 64;
-			if (back == 64) { /* rare: catch-up continues beyond 64 bytes */
+			if (E_RARE(back == 64)) { /* rare: catch-up continues beyond 64 bytes */
 				u32 ip2 = ip - 64, m2 = match - 64;
 				for (;;) {
 					u32 r2 = ip2 - anchor;
@@ -361,7 +363,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						break;
 				}
 			}
-			if (!smf) { /* rare: the match runs on beyond 64 bytes */
+			if (E_RARE(!smf)) { /* rare: the match runs on beyond 64 bytes */
 				u32 base = 64;
 				for (;;) {
 					ring_want(R, ip + MINMATCH + base, lane);
@@ -386,10 +388,10 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		{
 			u32 lit = ip - anchor;
 			token = op++;
-			if (op + lit + (2 + 1 + LASTLITERALS) + lit / 255 > cap)
+			if (E_RARE(op + lit + (2 + 1 + LASTLITERALS) + lit / 255 > cap))
 				return 0;
 			tokhi = (lit >= 15 ? 15u : lit) << 4;
-			if (lit >= 15)
+			if (E_RARE(lit >= 15))
 				op += put_len_ext3(dst + op, lit - 15, lane);
 			copy_literals(R, dst + op, anchor, lit, lane);
 			op += lit;
@@ -401,15 +403,15 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				st16u(dst + op, ip - match);
 			op += 2;
 			ip += mc + MINMATCH;
-			if (op + (1 + LASTLITERALS) + (mc + 240) / 255 > cap)
+			if (E_RARE(op + (1 + LASTLITERALS) + (mc + 240) / 255 > cap))
 				return 0;
 			if (lane == 0)
 				dst[token] = (u8)(tokhi | (mc >= 15 ? 15u : mc));
-			if (mc >= 15)
+			if (E_RARE(mc >= 15))
 				op += put_len_ext3(dst + op, mc - 15, lane);
 			anchor = ip;
 			EPC(R, 4);
-			if (ip >= mflimit_p1)
+			if (E_RARE(ip >= mflimit_p1))
 				goto block_done;
 			ring_want(R, ip, lane);
 			{
@@ -445,7 +447,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					const u64 sm = wv_ballot(stp);
 					u32 eqn = sm ? (u32)wv_ffs(sm) - 1 : 64;
 					rm = eqn >= MINMATCH;
-					if (rm && !sm) { /* rare: more than 64 equal bytes */
+					if (E_RARE(rm && !sm)) { /* rare: more than 64 equal bytes */
 						u32 base = 64;
 						for (;;) {
 							ring_want(R, ip + base, lane);

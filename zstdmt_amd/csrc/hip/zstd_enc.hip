@@ -823,11 +823,11 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 					const int j = wv_ffs(mask) - 1;
 					mask &= mask - 1;
 					const u32 pj = p0 + (u32)j;
-					if (pj < cursor)
+					if (__builtin_expect(pj < cursor, 0))
 						continue;
 					const u32 cj = wv_readlane(c0, j);
 					u32 ml = wv_readlane(m, j);
-					if (ml == 24) {
+					if (__builtin_expect(ml == 24, 0)) {
 						const u64 tx_ = ZET();
 						/* extend: 64 lanes x 8 bytes per step */
 						for (u32 base = 24;; base += 512) {
