@@ -135,3 +135,28 @@ def test_more_records_than_resident_waves(eng):
     recs, status = eng.brotli_decompress_bytes(st, ro, rl, cap)
     assert (status == 0).all()
     assert all(recs[i] == want[i % 4] for i in range(6000))
+
+
+def test_garbage_streams_same_verdict_as_oracle(eng):
+    """Records of random bytes (and of random bytes behind a plausible header): nothing hangs, nothing
+    is written outside the record's slot, and the verdict -- in the rare accepted case also the
+    content -- is the oracle's."""
+    rng = random.Random(99)
+    variants = []
+    for i in range(3000):
+        n = rng.choice([1, 2, 3, 5, 8, 17, 40, 100, 300, 1000])
+        body = bytes(rng.randrange(256) for _ in range(n))
+        if i % 3 == 0:      # WBITS + a compressed meta-block header of a few hundred bytes
+            body = bytes([0x1B, 0x0A + (rng.randrange(4) << 4), rng.randrange(4)]) + body
+        elif i % 3 == 1:    # all-zero or all-one tails
+            body = body[:n // 2] + bytes([rng.choice([0, 0xFF])]) * (n - n // 2)
+        variants.append(body)
+    stream = b"".join(H.brotli_record(s, 1) for s in variants)
+    ro, rl, cap = E.walk_brotli_records(stream)
+    recs, status = eng.brotli_decompress_bytes(stream, ro, rl, cap)
+    for s, o, stc in zip(variants, recs, status):
+        want = H.oracle_brotli_decompress(s, 65536)
+        if isinstance(want, int):
+            assert stc != 0, s.hex()
+        else:
+            assert stc == 0 and o == want, s.hex()
