@@ -1,5 +1,5 @@
 /*
- * brotli-mt.h -- drop-in C API of the brotli-mt library, decompression served by the MI355X engine.
+ * brotli-mt.h -- drop-in C API of the brotli-mt library, served by the MI355X engine.
  *
  * ABI-compatible with mcmilk/zstdmt's lib/brotli-mt.h (reference: /root/reference/lib/brotli-mt.h:
  * 27-157): same symbols (BROTLIMT_*), struct layouts, enum values, callback protocol and wire format
@@ -9,9 +9,10 @@
  *
  *   - BROTLIMT_decompressDCtx decodes what the reference writes, at any level 0..11, on the device
  *     (complete RFC 7932 decoder, zstdmt_amd/csrc/hip/brotli_dec.hip);
- *   - the compression side is not on the device yet (SURVEY.md 8f-4 "next"): BROTLIMT_createCCtx
- *     validates its arguments like the reference, BROTLIMT_compressCCtx reports
- *     compressionParameter_unsupported without touching the callbacks.
+ *   - BROTLIMT_compressCCtx writes valid brotli streams that the reference (and any brotli decoder)
+ *     decodes to the input: the bar for this codec is decompress-identical (brotli's bytes are version
+ *     dependent); `level` is validated (0..11) and sets the default chunk size, the device encoder has
+ *     a single setting (zstdmt_amd/csrc/hip/brotli_enc.hip).
  */
 #ifndef BROTLIMT_H
 #define BROTLIMT_H
@@ -74,7 +75,7 @@ typedef struct {
 typedef struct BROTLIMT_CCtx_s BROTLIMT_CCtx;
 
 /* threads 1..BROTLIMT_THREAD_MAX, level 0..11, inputsize = chunk bytes (0 -> 1 MiB x max(level, 1),
- * lib/brotli-mt_compress.c:105-109); NULL on invalid arguments */
+ * lib/brotli-mt_compress.c:105-109); NULL on invalid arguments or when no MI355X device can be opened */
 BROTLIMT_CCtx *BROTLIMT_createCCtx(int threads, int level, int inputsize);
 size_t BROTLIMT_compressCCtx(BROTLIMT_CCtx *ctx, BROTLIMT_RdWr_t *rdwr);
 size_t BROTLIMT_GetFramesCCtx(BROTLIMT_CCtx *ctx);

@@ -188,6 +188,16 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
  * frame_decompress for both.  Complete RFC 7932 decoder incl. the static dictionary.  Same
  * d_stream slack rule as above.  Internal scratch: GPUMT_BROTLI_SCRATCH bytes per resident wave.
  */
+/* gpumt_brotli_compress_batch: chunk i = d_in[i*chunk, ...) -> one record (16-byte brotli-mt header with
+ * the output hint, lib/brotli-mt_compress.c:285-304, + one raw brotli stream that decodes to the
+ * chunk; replaces BrotliEncoderCompress at :269-272) at d_slots + i*slot_stride, its length to
+ * d_rec_len[i]; slot_stride >= gpumt_zstd_slot_stride(chunk).  gpumt_lz4_compact packs the records.
+ * The streams are valid RFC 7932 (window 2^18, one meta-block per 128 KiB with its own three prefix
+ * codes, byte-aligned by empty metadata meta-blocks); their bytes are not libbrotli's -- the bar for
+ * brotli is decompress-identical. */
+int gpumt_brotli_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
+				size_t slot_stride, uint32_t *d_rec_len, int stream);
+
 #define GPUMT_BROTLI_SCRATCH 825856u
 int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
 				  const uint32_t *d_rec_len, size_t nrec, void *d_out,

@@ -28,6 +28,8 @@ void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 void zmt_scan_kernel(const u32 *, u32, u64 *);
 void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
 void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *, u32);
+void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
+void zmt_brotli_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u8 *, const u8 *);
 void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *);
 void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *, u32 *);
@@ -181,6 +183,25 @@ void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *re
 		    [=]() { zmt_xxh64_verify_kernel(out, out_off, out_len, nrec, cep, cvp, status); });
 }
 
+
+/* brotli compress: block encoder on `grid` persistent waves (scratch starts as garbage), then assemble;
+ * slot geometry is the zstd one */
+void emu_brotli_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid)
+{
+	u32 nrec = n ? (u32)((n + chunk - 1) / chunk) : 1;
+	u32 bpr = (chunk + 131071) / 131072;
+	u32 nblk = nrec * bpr;
+	if (grid > nblk)
+		grid = nblk;
+	std::vector<u32> blk_len(nblk, 0xA5A5A5A5u);
+	std::vector<u8> seq((size_t)grid * (3 * 32768 * 4), 0xA5);
+	u32 *bl = blk_len.data();
+	u8 *sq = seq.data();
+	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1},
+		    [=]() { zmt_brotli_enc_kernel(in, n, chunk, nblk, bpr, slots, stride, bl, sq); });
+	emu::launch(dim3{nrec, 1, 1}, dim3{256, 1, 1},
+		    [=]() { zmt_brotli_assemble_kernel(n, chunk, nrec, bpr, slots, stride, bl, rec_len); });
+}
 
 /* brotli: `grid` persistent waves, each with its own (garbage-initialised) scratch */
 void emu_brotli_decompress_batch(const u8 *stream, const u64 *rec_off, const u32 *rec_len, u32 nrec, u8 *out,

@@ -138,14 +138,91 @@ def test_callback_errors_and_arguments(lib):
     lib.BROTLIMT_freeDCtx(ctx)
     assert not lib.BROTLIMT_createDCtx(0, 0) and not lib.BROTLIMT_createDCtx(129, 0)
     assert lib.BROTLIMT_decompressDCtx(None, None) == ERR(E_PARAM)
-    # compression side: argument validation as the reference, no device encoder yet
+    # compression side: argument validation as the reference
     assert not lib.BROTLIMT_createCCtx(0, 3, 0) and not lib.BROTLIMT_createCCtx(1, 12, 0)
-    c = lib.BROTLIMT_createCCtx(4, 11, 0)
-    assert c
-    io = H.MemIO(b"abc")
-    assert lib.BROTLIMT_compressCCtx(c, C.byref(io.rdwr)) == ERR(E_PARAM)
-    assert io.reads == []
-    lib.BROTLIMT_freeCCtx(c)
+    assert lib.BROTLIMT_compressCCtx(None, None) == ERR(E_PARAM)
+
+
+# ---- compression: decompress-identical (brotli's bytes are version dependent) ----
+ZC_CASES = {
+    "empty": (b"", 0, 3), "one": (b"x", 0, 1), "hello": (b"hello world, hello world, hello!", 65536, 0),
+    "text_3x128k": (cases.text(3 * 131072 + 100, 11), 131072, 4),
+    "text_default_chunk": (cases.text(2500000, 12), 0, 1),        # 1 MiB chunks at level 1
+    "english_64k_chunks": (cases.english(300000, 13), 65536, 6),
+    "random": (cases.rnd(200000, 14), 131072, 2),
+    "zeros": (bytes(700000), 0, 1),
+    "mixed": (cases.text(50000, 4) + bytes(70000) + cases.rnd(3000, 5) + cases.english(100000, 6), 1 << 20, 5),
+    "allbytes": (bytes(range(256)) * 300 + cases.text(40000, 8), 131072, 9),
+    "two_symbols": (bytes(65 + (b & 1) for b in cases.rnd(70000, 13)), 65536, 3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ZC_CASES))
+def test_compress_decompress_identical(lib, name):
+    data, chunk, level = ZC_CASES[name]
+    rv, st, io, stats = H.brotlimt_compress_via(lib, data, chunk, threads=4, level=level)
+    assert rv == 0
+    eff = chunk or (1 << 20) * max(level, 1)
+    nrec = max(1, -(-len(data) // eff))
+    assert stats == (nrec, len(data), len(st)) and len(io.writes) == nrec
+    assert all(want == eff for want, _ in io.reads)
+    # record headers: magic, 8, csize, "BR", hint (lib/brotli-mt_compress.c:285-304)
+    ip = 0
+    for i in range(nrec):
+        import struct
+        magic, eight, csize, br, hint = struct.unpack_from("<IIIHH", st, ip)
+        clen = min(eff, len(data) - i * eff)
+        assert (magic, eight, br) == (0x184D2A50, 8, 0x5242)
+        assert hint == ((clen >> 16) + 1 if clen < eff else eff >> 16)
+        ip += 16 + csize
+    assert ip == len(st)
+    # the oracle, the device decoder and -- where it travelled -- the reference library decode it
+    assert H.oracle_brotlimt_decompress(st, len(data) + 65536) == data
+    rv, out, _, dstats = H.brotlimt_decompress_via(lib, st, threads=4)
+    assert rv == 0 and out == data and dstats == (nrec, len(st), len(data))
+    if H.have_bref():
+        rv, out, _, _ = H.brotlimt_decompress_via(H.bref(), st, threads=4)
+        assert rv == 0 and out == data
+    if len(data) > 100000 and name not in ("random",):
+        assert len(st) < len(data)
+
+
+@needs_ref
+def test_compress_same_callback_trace_as_reference(lib):
+    """request sizes, write count and counters of the reference; the payload bytes differ by design"""
+    data = cases.text(5 * 65536 + 777, 21)
+    rv_r, st_r, io_r, stats_r = H.brotlimt_compress_via(H.bref(), data, 65536, threads=1, level=3)
+    rv_o, st_o, io_o, stats_o = H.brotlimt_compress_via(lib, data, 65536, threads=1, level=3)
+    assert rv_r == 0 and rv_o == 0
+    assert _strip_eof(io_r.reads) == _strip_eof(io_o.reads)
+    assert len(io_r.writes) == len(io_o.writes) and stats_r[:2] == stats_o[:2]
+    # same hints in the same places
+    for st in (st_r, st_o):
+        assert st[12:14] == b"BR"
+    assert st_r[14:16] == st_o[14:16]
+
+
+def test_compress_many_batches_and_determinism(lib):
+    data = cases.text(40 << 20, 31)
+    rv, st1, _, stats = H.brotlimt_compress_via(lib, data, 1 << 20, threads=8, level=1)
+    assert rv == 0 and stats[0] == 40
+    rv, st2, _, _ = H.brotlimt_compress_via(lib, data, 1 << 20, threads=2, level=1)
+    assert rv == 0 and st1 == st2
+    rv, out, _, _ = H.brotlimt_decompress_via(lib, st1, threads=8)
+    assert rv == 0 and out == data
+
+
+def test_compress_callback_errors(lib):
+    data = cases.text(400000, 41)
+    for fail_at, code, want in ((0, -1, E_READ), (1, -2, E_CANCEL), (2, -3, E_MEM)):
+        io = H.MemIO(data, fail_read_at=fail_at, read_rv=code)
+        ctx = lib.BROTLIMT_createCCtx(2, 1, 65536)
+        assert lib.BROTLIMT_compressCCtx(ctx, C.byref(io.rdwr)) == ERR(want)
+        lib.BROTLIMT_freeCCtx(ctx)
+    io = H.MemIO(data, fail_write_at=1, write_rv=-1)
+    ctx = lib.BROTLIMT_createCCtx(2, 1, 65536)
+    assert lib.BROTLIMT_compressCCtx(ctx, C.byref(io.rdwr)) == ERR(E_READ)
+    lib.BROTLIMT_freeCCtx(ctx)
 
 
 def test_context_reuse(lib):

@@ -37,6 +37,8 @@ __global__ void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, 
 __global__ void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
 				    const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 				    const u32 *, const u32 *, const u32 *, u32 *);
+__global__ void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
+__global__ void zmt_brotli_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 __global__ void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *,
 				      u32 *, u32 *, u8 *, const u8 *);
 __global__ void zmt_brotli_dec_kernel_prof(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
@@ -86,6 +88,7 @@ struct gpumt_ctx {
 	int zenc_waves; /* resident waves of the persistent zstd encoder kernel (whole device) */
 	int zdec_variant; /* 0 = small-table kernel, then general; 1 = general only */
 	int bdec_waves;   /* resident waves of the persistent brotli decoder kernel (whole device) */
+	int benc_waves;   /* ... of the brotli encoder kernel */
 	void *d_brotli_static; /* device copy of the RFC 7932 constant data */
 	char err[256];
 	char name[128];
@@ -723,6 +726,43 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 			   h->st[s], (const u8 *)d_out, d_out_off, (const u32 *)d_out_len, (u32)nrec, (const u32 *)chk_e,
 			   (const u32 *)chk_v, d_status);
 	PROF1(11);
+	CK(hipGetLastError());
+	return GPUMT_OK;
+}
+
+/* brotli-mt compress: same slot geometry as zstd (gpumt_zstd_slot_stride), 16-byte record headers */
+int gpumt_brotli_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
+				size_t slot_stride, uint32_t *d_rec_len, int s)
+{
+	if (!h || !STREAM_OK(s) || chunk == 0 || chunk > 0x40000000u || slot_stride < gpumt_zstd_slot_stride(chunk))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	const size_t nrec = gpumt_lz4_record_count(n, chunk);
+	const u32 bpr = (u32)((chunk + ZE_BLOCK - 1) / ZE_BLOCK);
+	const size_t nblk = nrec * bpr;
+	if (nblk > 0x7FFFFFFFu)
+		return GPUMT_E_ARG;
+	if (!h->benc_waves) {
+		int per_cu = 0;
+		CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zmt_brotli_enc_kernel, 64, 0));
+		h->benc_waves = (per_cu > 0 ? per_cu : 4) * (h->num_cus > 0 ? h->num_cus : 256);
+		if (getenv("GPUMT_VERBOSE"))
+			fprintf(stderr, "gpumt: brotli encoder grid %d waves\n", h->benc_waves);
+	}
+	const unsigned grid = (unsigned)(nblk < (size_t)h->benc_waves ? nblk : (size_t)h->benc_waves);
+	const size_t seq_bytes = (size_t)grid * (3 * ZE_MAXSEQ * 4);
+	if (want_scratch(h, 0, nblk * 4 + 64 + seq_bytes))
+		return GPUMT_E_HIP;
+	u32 *blk_len = (u32 *)h->scratch[0];
+	u8 *seqbuf = (u8 *)h->scratch[0] + ((nblk * 4 + 63) & ~(size_t)63);
+	PROF0(9);
+	hipLaunchKernelGGL(zmt_brotli_enc_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
+			   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);
+	hipLaunchKernelGGL(zmt_brotli_assemble_kernel, dim3((unsigned)nrec), dim3(256), 0, h->st[s], (u64)n,
+			   (u32)chunk, (u32)nrec, bpr, (u8 *)d_slots, (u64)slot_stride, (const u32 *)blk_len,
+			   d_rec_len);
+	PROF1(9);
 	CK(hipGetLastError());
 	return GPUMT_OK;
 }

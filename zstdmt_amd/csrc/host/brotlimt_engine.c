@@ -9,7 +9,7 @@
  * hint << 16 and nothing else (:236-239), a stream that does not decode into it fails with
  * frame_decompress (:348-351).  Records move through the same three-role batch pipeline as the other
  * codecs (mt_pipe.h): H2D / decode kernel / D2H on three streams.
- * Compression: not on the device yet (see include/brotli-mt.h).
+ * Compression: pt_compress behaviour over the device encoder, see below.
  * Plain C, no HIP header.
  */
 #include "mt_host.h"
@@ -61,9 +61,29 @@ static size_t mt_error(int rv)
 	return BROTLIMT_ERROR(read_fail);
 }
 
-/* =================================================================== compression (not yet) */
+/* =================================================================== compression
+ * pt_compress of the reference (lib/brotli-mt_compress.c:194-318): one fn_read of exactly
+ * `inputsize` per chunk, EOF = a zero-length read once a frame exists (an empty input still yields
+ * one record), a short read becomes a short record and the loop goes on; one fn_write per record
+ * in order: 16-byte header (hint = 64 KiB units the decoder must provide, :294-304) + one brotli
+ * stream.  The streams come from the device encoder (gpumt_brotli_compress_batch) and are
+ * decompress-identical to the input; `level` is validated and sets the default chunk size. */
+struct cslot {
+	dbuf in;      /* chunk data, H2D                       */
+	dbuf slots;   /* device only: per-chunk records        */
+	dbuf stream;  /* packed records, D2H                   */
+	dbuf meta;    /* rec_len[n] u32 | pad | rec_off[n+1] u64, D2H */
+	size_t n;     /* bytes in the batch                    */
+	size_t nrec;
+};
+
 struct BROTLIMT_CCtx_s {
-	int threads, level, inputsize;
+	int level, threads, inputsize;
+	size_t insize, outsize, curframe, frames; /* insize / frames: reader; outsize / curframe: writer */
+	gpumt_ctx *gpu;
+	struct cslot s[MT_NSLOT];
+	BROTLIMT_RdWr_t *io;
+	size_t maxrec;
 };
 
 BROTLIMT_CCtx *BROTLIMT_createCCtx(int threads, int level, int inputsize)
@@ -73,26 +93,172 @@ BROTLIMT_CCtx *BROTLIMT_createCCtx(int threads, int level, int inputsize)
 		return NULL;
 	if (level < BROTLIMT_LEVEL_MIN || level > BROTLIMT_LEVEL_MAX)
 		return NULL;
+	if (inputsize < 0)
+		return NULL;
 	ctx = (BROTLIMT_CCtx *)calloc(1, sizeof *ctx);
 	if (!ctx)
 		return NULL;
 	ctx->threads = threads;
 	ctx->level = level;
 	ctx->inputsize = inputsize ? inputsize : 1024 * 1024 * (level ? level : 1); /* :105-109 */
+	if (gpumt_open(0, &ctx->gpu) != GPUMT_OK) {
+		free(ctx); /* no device: fail loudly, there is no CPU path */
+		return NULL;
+	}
 	return ctx;
+}
+
+void BROTLIMT_freeCCtx(BROTLIMT_CCtx *ctx)
+{
+	if (!ctx)
+		return;
+	for (int i = 0; i < MT_NSLOT; i++) {
+		dbuf_free(ctx->gpu, &ctx->s[i].in);
+		dbuf_free(ctx->gpu, &ctx->s[i].slots);
+		dbuf_free(ctx->gpu, &ctx->s[i].stream);
+		dbuf_free(ctx->gpu, &ctx->s[i].meta);
+	}
+	gpumt_close(ctx->gpu);
+	free(ctx);
+}
+
+size_t BROTLIMT_GetFramesCCtx(BROTLIMT_CCtx *ctx) { return ctx ? ctx->curframe : 0; }
+size_t BROTLIMT_GetInsizeCCtx(BROTLIMT_CCtx *ctx) { return ctx ? ctx->insize : 0; }
+size_t BROTLIMT_GetOutsizeCCtx(BROTLIMT_CCtx *ctx) { return ctx ? ctx->outsize : 0; }
+
+static size_t c_read_batch(BROTLIMT_CCtx *ctx, BROTLIMT_RdWr_t *io, struct cslot *s, size_t maxrec, int *eof)
+{
+	const size_t chunk = (size_t)ctx->inputsize;
+	s->n = 0;
+	s->nrec = 0;
+	while (s->nrec < maxrec) {
+		BROTLIMT_Buffer b;
+		int rv;
+		b.buf = (uint8_t *)s->in.h + s->n;
+		b.size = chunk;
+		b.allocated = chunk;
+		rv = io->fn_read(io->arg_read, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		if (b.size == 0 && ctx->frames > 0) {
+			*eof = 1;
+			break;
+		}
+		if (b.size > chunk)
+			return BROTLIMT_ERROR(read_fail);
+		ctx->insize += b.size;
+		ctx->frames++;
+		s->n += b.size;
+		s->nrec++;
+		if (b.size < chunk)
+			break; /* ragged chunk: last one of this device batch */
+	}
+	return 0;
+}
+
+static size_t c_launch(BROTLIMT_CCtx *ctx, struct cslot *s)
+{
+	gpumt_ctx *g = ctx->gpu;
+	const size_t chunk = (size_t)ctx->inputsize;
+	const size_t stride = gpumt_zstd_slot_stride(chunk);
+	uint32_t *d_len = (uint32_t *)s->meta.d;
+	uint64_t *d_off = (uint64_t *)((uint8_t *)s->meta.d + ((s->nrec * 4 + 15) & ~(size_t)15));
+	int rc = 0;
+	if (s->n)
+		rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, s->n, 1);
+	rc |= gpumt_stream_wait(g, 0, 1);
+	rc |= gpumt_brotli_compress_batch(g, s->in.d, s->n, chunk, s->slots.d, stride, d_len, 0);
+	rc |= gpumt_lz4_compact(g, s->slots.d, stride, d_len, s->nrec, s->stream.d, d_off, 0);
+	rc |= gpumt_stream_wait(g, 2, 0);
+	rc |= gpumt_memcpy_d2h(g, s->meta.h, s->meta.d, ((s->nrec * 4 + 15) & ~(size_t)15) + (s->nrec + 1) * 8, 2);
+	return rc ? BROTLIMT_ERROR(frame_compress) : 0;
+}
+
+static size_t cp_fill(void *a, int si, int *has_data, int *eof)
+{
+	BROTLIMT_CCtx *ctx = (BROTLIMT_CCtx *)a;
+	struct cslot *s = &ctx->s[si];
+	const size_t chunk = (size_t)ctx->inputsize, stride = gpumt_zstd_slot_stride(chunk);
+	size_t lim = BATCH_BYTES / chunk, err;
+	if (lim < 1)
+		lim = 1;
+	if (lim > BATCH_MAXREC)
+		lim = BATCH_MAXREC;
+	if (ctx->maxrec > lim)
+		ctx->maxrec = lim;
+	if (dbuf_want(ctx->gpu, &s->in, ctx->maxrec * chunk + 512, 1, 1) ||
+	    dbuf_want(ctx->gpu, &s->slots, ctx->maxrec * stride, 0, 1) ||
+	    dbuf_want(ctx->gpu, &s->stream, ctx->maxrec * stride + 512, 1, 1) ||
+	    dbuf_want(ctx->gpu, &s->meta, ctx->maxrec * 12 + 64, 1, 1))
+		return BROTLIMT_ERROR(memory_allocation);
+	err = c_read_batch(ctx, ctx->io, s, ctx->maxrec, eof);
+	*has_data = s->nrec > 0;
+	ctx->maxrec *= 4;
+	return err;
+}
+
+static size_t cp_launch(void *a, int si)
+{
+	BROTLIMT_CCtx *ctx = (BROTLIMT_CCtx *)a;
+	size_t err = c_launch(ctx, &ctx->s[si]);
+	if (!err && gpumt_mark(ctx->gpu, si, 2))
+		err = BROTLIMT_ERROR(frame_compress);
+	return err;
+}
+
+static size_t cp_complete(void *a, int si)
+{
+	BROTLIMT_CCtx *ctx = (BROTLIMT_CCtx *)a;
+	struct cslot *s = &ctx->s[si];
+	gpumt_ctx *g = ctx->gpu;
+	const uint64_t *off = (const uint64_t *)((const uint8_t *)s->meta.h + ((s->nrec * 4 + 15) & ~(size_t)15));
+	size_t total;
+	if (gpumt_mark_sync(g, si))
+		return BROTLIMT_ERROR(frame_compress);
+	total = (size_t)off[s->nrec];
+	if (total > s->stream.cap)
+		return BROTLIMT_ERROR(frame_compress);
+	if (gpumt_memcpy_d2h(g, s->stream.h, s->stream.d, total, 3) || gpumt_stream_sync(g, 3))
+		return BROTLIMT_ERROR(frame_compress);
+	return 0;
+}
+
+static size_t cp_drain(void *a, int si)
+{
+	BROTLIMT_CCtx *ctx = (BROTLIMT_CCtx *)a;
+	struct cslot *s = &ctx->s[si];
+	const uint32_t *len = (const uint32_t *)s->meta.h;
+	const uint64_t *off = (const uint64_t *)((const uint8_t *)s->meta.h + ((s->nrec * 4 + 15) & ~(size_t)15));
+	for (size_t i = 0; i < s->nrec; i++) { /* pt_write: strictly in frame order */
+		BROTLIMT_Buffer b;
+		int rv;
+		b.buf = (uint8_t *)s->stream.h + off[i];
+		b.size = len[i];
+		b.allocated = len[i];
+		rv = ctx->io->fn_write(ctx->io->arg_write, &b);
+		if (rv != 0)
+			return mt_error(rv);
+		ctx->outsize += len[i];
+		ctx->curframe++;
+	}
+	return 0;
 }
 
 size_t BROTLIMT_compressCCtx(BROTLIMT_CCtx *ctx, BROTLIMT_RdWr_t *rdwr)
 {
-	(void)ctx;
-	(void)rdwr;
-	return BROTLIMT_ERROR(compressionParameter_unsupported);
-}
+	static const mt_pipe_ops ops = {cp_fill, cp_launch, cp_complete, cp_drain};
+	size_t err;
 
-size_t BROTLIMT_GetFramesCCtx(BROTLIMT_CCtx *ctx) { (void)ctx; return 0; }
-size_t BROTLIMT_GetInsizeCCtx(BROTLIMT_CCtx *ctx) { (void)ctx; return 0; }
-size_t BROTLIMT_GetOutsizeCCtx(BROTLIMT_CCtx *ctx) { (void)ctx; return 0; }
-void BROTLIMT_freeCCtx(BROTLIMT_CCtx *ctx) { free(ctx); }
+	if (!ctx)
+		return BROTLIMT_ERROR(compressionParameter_unsupported); /* brotli-mt_compress.c:325-326 */
+	ctx->io = rdwr;
+	ctx->maxrec = BATCH_MIN / (size_t)ctx->inputsize;
+	if (ctx->maxrec < 1)
+		ctx->maxrec = 1;
+	err = mt_pipe_run(&ops, ctx);
+	gpumt_device_sync(ctx->gpu);
+	return err;
+}
 
 /* =================================================================== decompression */
 struct dslot {

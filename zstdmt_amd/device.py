@@ -141,6 +141,10 @@ class Engine:
                                                     int(out_bytes), d_out_off.ptr, d_out_len.ptr,
                                                     d_status.ptr, stream), "zstd_decompress_batch")
 
+    def brotli_compress(self, d_in, n, chunk, d_slots, stride, d_rec_len, stream=0):
+        self._ck(self.L.gpumt_brotli_compress_batch(self.h, d_in.ptr, int(n), int(chunk), d_slots.ptr,
+                                                    int(stride), d_rec_len.ptr, stream), "brotli_compress_batch")
+
     def brotli_decompress(self, d_stream, d_rec_off, d_rec_len, nrec, d_out, d_out_off, d_out_cap, d_out_len,
                           d_status, stream=0):
         self._ck(self.L.gpumt_brotli_decompress_batch(self.h, d_stream.ptr, d_rec_off.ptr, d_rec_len.ptr, nrec,
@@ -182,7 +186,7 @@ class Engine:
         """-> (stream bytes, rec_off[n+1] u64, rec_len[n] u32)"""
         n = len(data)
         nrec = self.record_count(n, chunk)
-        stride = self.zstd_slot_stride(chunk) if codec == "zstd" else self.slot_stride(chunk)
+        stride = self.zstd_slot_stride(chunk) if codec in ("zstd", "brotli") else self.slot_stride(chunk)
         d_in = self.upload(data)
         d_slots = self.alloc(nrec * stride)
         d_len = self.alloc(nrec * 4)
@@ -190,6 +194,8 @@ class Engine:
         try:
             if codec == "zstd":
                 self.zstd_compress(d_in, n, chunk, d_slots, stride, d_len)
+            elif codec == "brotli":
+                self.brotli_compress(d_in, n, chunk, d_slots, stride, d_len)
             else:
                 self.lz4_compress(d_in, n, chunk, d_slots, stride, d_len)
             rec_len = self.download(d_len, nrec * 4, np.uint32)
