@@ -494,6 +494,47 @@ def bench_brotli(args, eng, rank, world, dist):
     if ok:
         got = eng.download(d_out, base_n)              # capacities == chunk sizes for full chunks
         ok = bool((got == text).all()) if int(out_off[nb]) == base_n else None
+    # ---- the device encoder on the same text (not part of `value`: configs[4] is decompress) ----
+    own = None
+    try:
+        d_text = eng.alloc(n + 64)
+        for r in range(reps):
+            eng._ck(L.gpumt_memcpy_h2d(h, d_text.ptr + r * base_n, text.ctypes.data, base_n, 0), "h2d")
+        eng.sync(0)
+        stride = eng.zstd_slot_stride(chunk)
+        nrec_c = n // chunk
+        d_slots = eng.alloc(nrec_c * stride)
+        d_cl, d_co = eng.alloc(nrec_c * 4), eng.alloc((nrec_c + 1) * 8)
+        d_cs = eng.alloc(nrec_c * stride)
+        for it in range(2):
+            eng.timer_start(1)
+            eng.brotli_compress(d_text, n, chunk, d_slots, stride, d_cl)
+            eng.lz4_compact(d_slots, stride, d_cl, nrec_c, d_cs, d_co)
+            eng.timer_stop(1)
+            eng.sync(0)
+        t_enc = eng.timer_ms(1)
+        c_own = int(eng.download(d_co, 8, np.uint64, offset=nrec_c * 8)[0])
+        # decode the device encoder's streams
+        crl = eng.download(d_cl, nrec_c * 4, np.uint32)
+        cro = eng.download(d_co, nrec_c * 8, np.uint64) + np.uint64(16)
+        d_ro2, d_rl2 = eng.upload(cro), eng.upload((crl - 16).astype(np.uint32))
+        cap2 = np.full(nrec_c, chunk, np.uint32)
+        oo2 = np.arange(nrec_c + 1, dtype=np.uint64) * np.uint64(chunk)
+        d_oo2, d_oc2 = eng.upload(oo2), eng.upload(cap2)
+        for it in range(2):
+            eng.timer_start(2)
+            eng.brotli_decompress(d_cs, d_ro2, d_rl2, nrec_c, d_out, d_oo2, d_oc2, d_ol, d_st)
+            eng.timer_stop(2)
+            eng.sync(0)
+        t_dec = eng.timer_ms(2)
+        st2 = eng.download(d_st, nrec_c * 4, np.uint32)
+        ok2 = bool((st2 == 0).all()) and bool((eng.download(d_out, base_n) == text).all())
+        own = {"what": "zmt_brotli_enc_kernel(+assemble+compact) on the same text, and the decode of its streams",
+               "compress_ms": round(t_enc, 3), "compress_MBps": round(world * n / 1e6 / (t_enc * 1e-3), 1),
+               "ratio": round(n / c_own, 4), "decompress_ms": round(t_dec, 3),
+               "decompress_MBps": round(world * n / 1e6 / (t_dec * 1e-3), 1), "roundtrip_verified": ok2}
+    except Exception as e:  # report, never hide
+        own = {"error": repr(e)}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -527,6 +568,7 @@ def bench_brotli(args, eng, rank, world, dist):
                      "frac_of_copy_ceiling": round(a * 1e9 / HBM_COPY, 5), "alg_bytes_per_launch": alg,
                      "avg_launch_ms": round(ms["k_brotli_dec"], 4), "traffic": traffic},
         "kernels": {"k_brotli_dec": {"ms": round(ms["k_brotli_dec"], 4)}},
+        "device_encoder": own,
         "decode_errors": bad, "roundtrip_verified": ok,
         "gen_s": round(gen_s, 2), "device": eng.name,
     }
