@@ -101,7 +101,7 @@ def test_bad_arguments():
 
 def test_brotli_decompress_personalities(tmp_path):
     """brotli-mt: decompression of a stream the reference wrote (committed fixture), through -d, the
-    un*/cat personalities and -t; compression reports the library's answer."""
+    un*/cat personalities and -t; compression through -1 -c (decompress-identical)."""
     bdir = os.path.join(H.GOLDEN_DIR, "brotli")
     with open(os.path.join(bdir, "manifest.json")) as f:
         ent = json.load(f)["cases"]["b_english_chunks"]
@@ -119,5 +119,8 @@ def test_brotli_decompress_personalities(tmp_path):
     bad[101] ^= 0xFF
     r = run([brotli, "-t"], bytes(bad), check=False)
     assert r.returncode == 1 and b"Could not decompress frame at once" in r.stderr
-    r = run([brotli, "-1", "-c"], b"abc" * 1000, check=False)
-    assert r.returncode == 1 and b"Compression parameter is out of bound" in r.stderr
+    # compression round trip through the command line
+    data = cases.english(200000, 3)
+    z = run([brotli, "-1", "-c"], data).stdout
+    assert len(z) < len(data) and H.oracle_brotlimt_decompress(z, len(data) + 65536) == data
+    assert run([brotli, "-d", "-c"], z).stdout == data

@@ -69,7 +69,7 @@ def build(force=False, verbose=True):
     tsrc = os.path.join(CSRC, "tools", "gen_text.c")
     if force or _stale(tools, [tsrc]):
         _run(["gcc", "-O2", "-fPIC", "-shared", "-pthread", tsrc, "-o", tools, "-lm"])
-    # command line front ends (programs/zmt_cli.c): lz4-mt, zstd-mt, brotli-mt (decompression) + their un* / *cat personalities
+    # command line front ends (programs/zmt_cli.c): lz4-mt, zstd-mt, brotli-mt + their un* / *cat personalities
     bindir = os.path.join(HERE, "bin")
     os.makedirs(bindir, exist_ok=True)
     cli = os.path.join(ROOT, "programs", "zmt_cli.c")
