@@ -16,8 +16,7 @@ GDIR = os.path.join(H.GOLDEN_DIR, "brotli")
 with open(os.path.join(GDIR, "manifest.json")) as f:
     MAN = json.load(f)["cases"]
 
-SMALL = ["b_empty", "b_one", "b_hello", "b_text_3000_l1", "b_text_64k_l0", "b_text_64k_l2", "b_english_l11",
-         "b_period_300", "b_zeros_300k", "b_allbytes"]
+SMALL = ["b_empty", "b_one", "b_hello", "b_text_3000_l1", "b_text_64k_l0", "b_english_l11", "b_period_300"]
 needs_lib = pytest.mark.skipif(not H.have_libbrotli(), reason="libbrotli 1.0.9 not in this image")
 
 
@@ -96,11 +95,11 @@ def test_capacity_and_truncation():
 ENC = {
     "empty": (b"", 65536), "one": (b"a", 65536), "hello": (b"hello world hello world hello world", 65536),
     "text_3000": (cases.text(3000, 5), 65536),
-    "text_70k": (cases.text(70000, 6), 131072),            # 4-nibble MLEN in the second... single block, 5 nibbles
+    "text_66k": (cases.text(66000, 6), 131072),            # MLEN - 1 >= 65536: 5 nibbles
     "english_40k": (cases.english(40000, 2), 65536),       # MLEN - 1 < 65536: 4 nibbles
-    "zeros": (bytes(100000), 131072),
-    "random": (cases.rnd(20000, 3), 65536),                # does not shrink: uncompressed meta-block
-    "two_blocks_two_chunks": (cases.text(200000, 7), 131072),
+    "zeros": (bytes(30000), 131072),
+    "random": (cases.rnd(8000, 3), 65536),                 # does not shrink: uncompressed meta-block
+    "two_blocks_two_chunks": (cases.text(140000, 7), 131072),
     "one_symbol_then_text": (b"z" * 5000 + cases.text(5000, 9), 65536),
 }
 
@@ -120,5 +119,5 @@ def test_encoder_round_trip(name):
 
 
 def test_encoder_is_deterministic_across_grids():
-    data = cases.text(300000, 17)
-    assert E.brotli_compress(data, 131072, grid=1) == E.brotli_compress(data, 131072, grid=3)
+    data = cases.text(140000, 17)
+    assert E.brotli_compress(data, 65536, grid=1) == E.brotli_compress(data, 65536, grid=3)
