@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--cpu-mib", type=int, default=2048, help="cpu_baseline sample size")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of segments")
     ap.add_argument("--verify", action="store_true", help="download and compare the round trip")
+    ap.add_argument("--no-encoder", action="store_true",
+                    help="--codec brotli: skip the device-encoder leg (profiling runs of the decoder alone)")
     return ap.parse_args()
 
 
@@ -497,6 +499,8 @@ def bench_brotli(args, eng, rank, world, dist):
     # ---- the device encoder on the same text (not part of `value`: configs[4] is decompress) ----
     own = None
     try:
+        if args.no_encoder:
+            raise RuntimeError("skipped (--no-encoder)")
         d_text = eng.alloc(n + 64)
         for r in range(reps):
             eng._ck(L.gpumt_memcpy_h2d(h, d_text.ptr + r * base_n, text.ctypes.data, base_n, 0), "h2d")

@@ -58,6 +58,9 @@ if bstats:
             for k, v in counter_avg(f).items():
                 if "brotli" in k:
                     part[k] = v
+    best = biggest("prof_brotli_enc_stats/**/*_kernel_stats.csv")
+    if best:
+        shutil.copy(best, os.path.join(root, "profiles", f"{rnd}_brotli_enc_kernel_stats.csv"))
     bl = open(os.path.join(go, "bench_brotli.json")).read().strip().splitlines()[-1]
     json.dump(json.loads(bl), open(os.path.join(root, "profiles", f"{rnd}_bench_brotli_8gib_1gpu.json"), "w"), indent=1)
 detail, per = [], {}

@@ -25,12 +25,17 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_zstd_wr
 # configs[4]: brotli-mt decompress (level-1 streams written by the reference build, 1 MiB chunks)
 rm -rf $O/prof_brotli_stats $O/prof_brotli_fetch $O/prof_brotli_write
 python bench.py --codec brotli > $O/bench_brotli.json 2> $O/bench_brotli.err
+# (the decoder alone: the device-encoder leg of the bench would mix a second workload into its averages)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_brotli_stats -- \
-    python bench.py --codec brotli --steps 2 --warmup 1 --no-cpu > $O/bench_brotli_prof.json 2> $O/prof_brotli_stats.err
+    python bench.py --codec brotli --steps 2 --warmup 1 --no-cpu --no-encoder > $O/bench_brotli_prof.json 2> $O/prof_brotli_stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_brotli_fetch -- \
-    python bench.py --codec brotli --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_brotli_fetch.err
+    python bench.py --codec brotli --steps 1 --warmup 0 --no-cpu --no-encoder > /dev/null 2> $O/prof_brotli_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_brotli_write -- \
-    python bench.py --codec brotli --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_brotli_write.err
+    python bench.py --codec brotli --steps 1 --warmup 0 --no-cpu --no-encoder > /dev/null 2> $O/prof_brotli_write.err
+# the device encoder + the decode of its own streams (zmt_brotli_enc_kernel lines)
+rm -rf $O/prof_brotli_enc_stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_brotli_enc_stats -- \
+    python bench.py --codec brotli --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_brotli_enc_stats.err
 cat $O/bench_default.json
 cat $O/bench_zstd.json
 cat $O/bench_brotli.json
