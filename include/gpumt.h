@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-#define GPUMT_NSTREAMS 4
+/* streams 0..3: kernels / H2D / small D2H / bulk D2H of the host engines' pipeline; 4..7: one extra
+ * kernel stream per batch slot, so that the batches of a pipeline overlap on the device (every
+ * launching stream has its own internal scratch) */
+#define GPUMT_NSTREAMS 8
 
 enum {
 	GPUMT_OK = 0,

@@ -77,8 +77,9 @@ struct gpumt_ctx {
 	hipEvent_t xev;
 	hipEvent_t mark[GPUMT_NMARKS];
 	/* scratch, grown on demand (never shrinks) */
-	void *scratch[2];        /* [0] compress side, [1] decompress side */
-	size_t scratch_bytes[2];
+	void *scratch[2][GPUMT_NSTREAMS]; /* [0] compress side, [1] decompress side; one per launching stream, so
+					   * batches launched on different streams can overlap */
+	size_t scratch_bytes[2][GPUMT_NSTREAMS];
 	int dec_variant;
 	int enc_variant; /* 0 = v3 (LDS input ring, small batches, 17-bit table), 1 = v1, 2 = v2 */
 	unsigned long long *d_prof; /* 16 phase counters of the profiling decoder */
@@ -124,19 +125,19 @@ static int use(gpumt_ctx *h)
 	return GPUMT_OK;
 }
 
-static int want_scratch(gpumt_ctx *h, int k, size_t bytes)
+static int want_scratch(gpumt_ctx *h, int k, int s, size_t bytes)
 {
-	if (bytes <= h->scratch_bytes[k])
+	if (bytes <= h->scratch_bytes[k][s])
 		return GPUMT_OK;
-	if (h->scratch[k]) {
+	if (h->scratch[k][s]) {
 		CK(hipDeviceSynchronize());
-		CK(hipFree(h->scratch[k]));
-		h->scratch[k] = NULL;
-		h->scratch_bytes[k] = 0;
+		CK(hipFree(h->scratch[k][s]));
+		h->scratch[k][s] = NULL;
+		h->scratch_bytes[k][s] = 0;
 	}
 	bytes = (bytes + 0xFFFFF) & ~(size_t)0xFFFFF;
-	CK(hipMalloc(&h->scratch[k], bytes));
-	h->scratch_bytes[k] = bytes;
+	CK(hipMalloc(&h->scratch[k][s], bytes));
+	h->scratch_bytes[k][s] = bytes;
 	return GPUMT_OK;
 }
 
@@ -204,8 +205,9 @@ void gpumt_close(gpumt_ctx *h)
 	(void)hipSetDevice(h->device);
 	(void)hipDeviceSynchronize();
 	for (int k = 0; k < 2; k++)
-		if (h->scratch[k])
-			(void)hipFree(h->scratch[k]);
+		for (int i = 0; i < GPUMT_NSTREAMS; i++)
+			if (h->scratch[k][i])
+				(void)hipFree(h->scratch[k][i]);
 	for (int i = 0; i < NTIMERS; i++) {
 		(void)hipEventDestroy(h->t0[i]);
 		(void)hipEventDestroy(h->t1[i]);
@@ -415,9 +417,9 @@ int gpumt_lz4_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t ch
 	if (use(h))
 		return GPUMT_E_HIP;
 	/* scratch: off[nrec] u64 | len[nrec] u32 | chk[nrec] u32 */
-	if (want_scratch(h, 0, nrec * 16))
+	if (want_scratch(h, 0, s, nrec * 16))
 		return GPUMT_E_HIP;
-	u64 *off = (u64 *)h->scratch[0];
+	u64 *off = (u64 *)h->scratch[0][s];
 	u32 *len = (u32 *)(off + nrec);
 	u32 *chk = len + nrec;
 	hipLaunchKernelGGL(zmt_iota_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0,
@@ -542,9 +544,9 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
 	}
-	if (want_scratch(h, 1, split ? off : nrec * 8 + 32))
+	if (want_scratch(h, 1, s, split ? off : nrec * 8 + 32))
 		return GPUMT_E_HIP;
-	u8 *sc = (u8 *)h->scratch[1];
+	u8 *sc = (u8 *)h->scratch[1][s];
 	u32 *ce = (u32 *)(sc + ce_o), *cv = (u32 *)(sc + cv_o);
 	PROF0(11);
 	if (split) {
@@ -643,10 +645,10 @@ int gpumt_zstd_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t c
 	const size_t seq_bytes = (size_t)grid * (3 * ZE_MAXSEQ * 4 + 16 * 20544 + ZE_BLOCK + 64);
 	if (h->profile == 6)
 		fprintf(stderr, "gpumt: zstd encoder grid %u waves\n", grid);
-	if (want_scratch(h, 0, nblk * 4 + 64 + seq_bytes))
+	if (want_scratch(h, 0, s, nblk * 4 + 64 + seq_bytes))
 		return GPUMT_E_HIP;
-	u32 *blk_len = (u32 *)h->scratch[0];
-	u8 *seqbuf = (u8 *)h->scratch[0] + ((nblk * 4 + 63) & ~(size_t)63);
+	u32 *blk_len = (u32 *)h->scratch[0][s];
+	u8 *seqbuf = (u8 *)h->scratch[0][s] + ((nblk * 4 + 63) & ~(size_t)63);
 	if (h->profile == 6 && !h->d_prof) {
 		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
@@ -695,9 +697,9 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 	if (use(h))
 		return GPUMT_E_HIP;
 	const size_t lit_bytes = nrec * (size_t)(131072 + 256);
-	if (want_scratch(h, 1, lit_bytes + nrec * 8 + 64))
+	if (want_scratch(h, 1, s, lit_bytes + nrec * 8 + 64))
 		return GPUMT_E_HIP;
-	u32 *chk_e = (u32 *)((u8 *)h->scratch[1] + lit_bytes), *chk_v = chk_e + nrec;
+	u32 *chk_e = (u32 *)((u8 *)h->scratch[1][s] + lit_bytes), *chk_v = chk_e + nrec;
 	if (h->profile == 5 && !h->d_prof) {
 		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
@@ -706,7 +708,7 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 	if (h->profile == 5) {
 		hipLaunchKernelGGL(zmt_zstd_dec_kernel_prof, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
 				   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
-				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status, chk_e, chk_v,
+				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1][s], d_status, chk_e, chk_v,
 				   0u, h->d_prof);
 	} else {
 		/* small-table variant first (16 waves per CU); records that need the full-size tables
@@ -715,11 +717,11 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 		if (h->zdec_variant != 1)
 			hipLaunchKernelGGL(zmt_zstd_dec_small_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
 					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
-					   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status, chk_e,
+					   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1][s], d_status, chk_e,
 					   chk_v);
 		hipLaunchKernelGGL(zmt_zstd_dec_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
 				   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
-				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1], d_status, chk_e, chk_v, want);
+				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1][s], d_status, chk_e, chk_v, want);
 	}
 	/* XXH64 content checksums, for the frames that carry one */
 	hipLaunchKernelGGL(zmt_xxh64_verify_kernel, dim3((unsigned)((nrec * 4 + 255) / 256)), dim3(256), 0,
@@ -752,10 +754,10 @@ int gpumt_brotli_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t
 	}
 	const unsigned grid = (unsigned)(nblk < (size_t)h->benc_waves ? nblk : (size_t)h->benc_waves);
 	const size_t seq_bytes = (size_t)grid * (3 * ZE_MAXSEQ * 4);
-	if (want_scratch(h, 0, nblk * 4 + 64 + seq_bytes))
+	if (want_scratch(h, 0, s, nblk * 4 + 64 + seq_bytes))
 		return GPUMT_E_HIP;
-	u32 *blk_len = (u32 *)h->scratch[0];
-	u8 *seqbuf = (u8 *)h->scratch[0] + ((nblk * 4 + 63) & ~(size_t)63);
+	u32 *blk_len = (u32 *)h->scratch[0][s];
+	u8 *seqbuf = (u8 *)h->scratch[0][s] + ((nblk * 4 + 63) & ~(size_t)63);
 	PROF0(9);
 	hipLaunchKernelGGL(zmt_brotli_enc_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
 			   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);
@@ -791,7 +793,7 @@ int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint
 			fprintf(stderr, "gpumt: brotli decoder grid %d waves\n", h->bdec_waves);
 	}
 	const unsigned grid = (unsigned)(nrec < (size_t)h->bdec_waves ? nrec : (size_t)h->bdec_waves);
-	if (want_scratch(h, 1, (size_t)grid * GPUMT_BROTLI_SCRATCH))
+	if (want_scratch(h, 1, s, (size_t)grid * GPUMT_BROTLI_SCRATCH))
 		return GPUMT_E_HIP;
 	if (h->profile == 7 && !h->d_prof) {
 		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
@@ -801,11 +803,11 @@ int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint
 	if (h->profile == 7)
 		hipLaunchKernelGGL(zmt_brotli_dec_kernel_prof, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_stream,
 				   d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap, d_out_len,
-				   d_status, (u8 *)h->scratch[1], (const u8 *)h->d_brotli_static, h->d_prof);
+				   d_status, (u8 *)h->scratch[1][s], (const u8 *)h->d_brotli_static, h->d_prof);
 	else
 		hipLaunchKernelGGL(zmt_brotli_dec_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_stream,
 				   d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap, d_out_len,
-				   d_status, (u8 *)h->scratch[1], (const u8 *)h->d_brotli_static);
+				   d_status, (u8 *)h->scratch[1][s], (const u8 *)h->d_brotli_static);
 	PROF1(12);
 	CK(hipGetLastError());
 	return GPUMT_OK;

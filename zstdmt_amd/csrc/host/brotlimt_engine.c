@@ -417,15 +417,18 @@ static size_t d_read_batch(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *io, struct dslot
 static size_t d_launch(BROTLIMT_DCtx *ctx, struct dslot *s)
 {
 	gpumt_ctx *g = ctx->gpu;
+	/* each batch slot launches on its own kernel stream (4 + slot): the decoders are bound by the
+	 * latency of a record, so the batches of the pipeline must overlap on the device */
+	const int ks = 4 + (int)(s - ctx->s);
 	int rc = 0;
 	if (dbuf_want(g, &s->out, s->out_bytes + 64, 1, 1) || dbuf_want(g, &s->res, BATCH_MAXREC * 8 + 64, 1, 1))
 		return BROTLIMT_ERROR(memory_allocation);
 	rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, s->in_bytes + 256, 1);
 	rc |= gpumt_memcpy_h2d(g, s->meta.d, s->meta.h, D_META_BYTES(BATCH_MAXREC), 1);
-	rc |= gpumt_stream_wait(g, 0, 1);
+	rc |= gpumt_stream_wait(g, ks, 1);
 	rc |= gpumt_brotli_decompress_batch(g, s->in.d, m_rec_off(s, 1), m_rec_len(s, 1), s->nrec, s->out.d,
-					    m_out_off(s, 1), m_out_cap(s, 1), r_out_len(s, 1), r_status(s, 1), 0);
-	rc |= gpumt_stream_wait(g, 2, 0);
+					    m_out_off(s, 1), m_out_cap(s, 1), r_out_len(s, 1), r_status(s, 1), ks);
+	rc |= gpumt_stream_wait(g, 2, ks);
 	rc |= gpumt_memcpy_d2h(g, s->res.h, s->res.d, BATCH_MAXREC * 8, 2);
 	if (s->out_bytes)
 		rc |= gpumt_memcpy_d2h(g, s->out.h, s->out.d, s->out_bytes, 2);

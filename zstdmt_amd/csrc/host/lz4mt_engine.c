@@ -452,16 +452,19 @@ static size_t d_read_batch(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, struct dslot *s, i
 static size_t d_launch(LZ4MT_DCtx *ctx, struct dslot *s)
 {
 	gpumt_ctx *g = ctx->gpu;
+	/* each batch slot launches on its own kernel stream (4 + slot): the decoders are bound by the
+	 * latency of a record, so the batches of the pipeline must overlap on the device */
+	const int ks = 4 + (int)(s - ctx->s);
 	int rc = 0;
 	if (dbuf_want(g, &s->out, s->out_bytes + 64, 1, 1) || dbuf_want(g, &s->status, s->nrec * 4 + 64, 1, 1))
 		return ERROR(memory_allocation);
 	rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, s->in_bytes, 1);
 	rc |= gpumt_memcpy_h2d(g, s->meta.d, s->meta.h, D_META_BYTES(BATCH_MAXREC), 1);
-	rc |= gpumt_stream_wait(g, 0, 1);
+	rc |= gpumt_stream_wait(g, ks, 1);
 	rc |= gpumt_lz4_decompress_batch(g, s->in.d, s->in_bytes, m_rec_off(s, 1), m_rec_len(s, 1), s->nrec,
 					 s->out.d, s->out_bytes, m_out_off(s, 1), m_out_len(s, 1),
-					 (uint32_t *)s->status.d, 0);
-	rc |= gpumt_stream_wait(g, 2, 0);
+					 (uint32_t *)s->status.d, ks);
+	rc |= gpumt_stream_wait(g, 2, ks);
 	rc |= gpumt_memcpy_d2h(g, s->status.h, s->status.d, s->nrec * 4, 2);
 	if (s->out_bytes)
 		rc |= gpumt_memcpy_d2h(g, s->out.h, s->out.d, s->out_bytes, 2);

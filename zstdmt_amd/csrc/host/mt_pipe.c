@@ -118,7 +118,7 @@ size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
 {
 	pipe_t p;
 	pthread_t rt, wt;
-	long b = 0, pending = -1; /* pending: launched, not yet completed */
+	long b = 0;
 	size_t err;
 
 	p.ops = ops;
@@ -142,29 +142,36 @@ size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
 		pthread_mutex_destroy(&p.mu);
 		return (size_t)-1;
 	}
-	/* device role on the calling thread: launch b, then complete b-1, so that two batches are in
-	 * flight on the device */
-	for (;;) {
-		const int go = wait_filled(&p, b);
-		if (go) {
-			err = ops->launch(arg, (int)(b % MT_NSLOT));
+	/* device role on the calling thread: launch every batch as soon as it is filled and complete the
+	 * oldest one once MT_NSLOT - 1 are in flight (the remaining slot is the one being filled or
+	 * drained), so that the device always has several batches to overlap */
+	{
+		long done = 0; /* batches [done, b) are launched and not completed */
+		for (;;) {
+			const int go = wait_filled(&p, b);
+			if (go) {
+				err = ops->launch(arg, (int)(b % MT_NSLOT));
+				if (err) {
+					fail(&p, err);
+					break;
+				}
+				b++;
+			}
+			err = 0;
+			while (done < b && (!go || b - done >= MT_NSLOT - 1)) {
+				err = ops->complete(arg, (int)(done % MT_NSLOT));
+				if (err)
+					break;
+				mark_done(&p, done);
+				done++;
+			}
 			if (err) {
 				fail(&p, err);
 				break;
 			}
-		}
-		if (pending >= 0) {
-			err = ops->complete(arg, (int)(pending % MT_NSLOT));
-			if (err) {
-				fail(&p, err);
+			if (!go)
 				break;
-			}
-			mark_done(&p, pending);
-			pending = -1;
 		}
-		if (!go)
-			break;
-		pending = b++;
 	}
 	pthread_mutex_lock(&p.mu);
 	p.device_over = 1;
