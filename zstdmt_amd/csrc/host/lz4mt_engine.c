@@ -8,8 +8,8 @@
  *        fn_read -> pinned in[s]  --H2D (stream 1)-->  kernels (stream 0)  --D2H (stream 2)-->
  *        pinned out[s] -> fn_write
  *
- * with two slots s, so that reading batch i+1 and writing batch i-1 overlap the kernels of
- * batch i.  Callback-visible behaviour follows the reference: compress issues one fn_read of
+ * over the four slots of mt_pipe.h (up to three batches on the device, decompress on per-slot
+ * kernel streams, while another is read into or written out).  Callback-visible behaviour follows the reference: compress issues one fn_read of
  * exactly `inputsize` bytes per chunk and one fn_write per record, in input order; decompress
  * reads 4, then 8|12 header bytes and the payload per record, and writes one chunk per call.
  * This file is plain C and never includes a HIP header.

@@ -2,7 +2,7 @@
  * zstdmt_engine.c -- the host side of zstd-mt on MI355X: ZSTDCB_* (include/zstd-mt.h) over gpumt_*.
  *
  * Same pipeline as lz4mt_engine.c (batches of records through H2D / kernels / D2H on three
- * streams, two slots), following the callback-visible behaviour of the reference
+ * streams, four slots: mt_pipe.h), following the callback-visible behaviour of the reference
  * (lib/zstd-mt_compress.c:208-392, lib/zstd-mt_decompress.c:209-549,693-843):
  *   compress   one fn_read of exactly `inputsize` per chunk, one fn_write per record, in order;
  *              counters are reset per call (:337-341); empty input still yields one frame (:264);
