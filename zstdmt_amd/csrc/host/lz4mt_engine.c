@@ -168,6 +168,7 @@ static size_t c_read_batch(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *io, struct cslot *s, s
 static size_t c_launch(LZ4MT_CCtx *ctx, struct cslot *s)
 {
 	gpumt_ctx *g = ctx->gpu;
+	const int ks = 4 + (int)(s - ctx->s); /* the slot's own kernel stream: batches overlap on the device */
 	const size_t chunk = (size_t)ctx->inputsize;
 	const size_t stride = gpumt_lz4_slot_stride(chunk);
 	uint32_t *d_len = (uint32_t *)s->meta.d;
@@ -175,10 +176,10 @@ static size_t c_launch(LZ4MT_CCtx *ctx, struct cslot *s)
 	int rc = 0;
 	if (s->n)
 		rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, s->n, 1);
-	rc |= gpumt_stream_wait(g, 0, 1);
-	rc |= gpumt_lz4_compress_batch(g, s->in.d, s->n, chunk, s->slots.d, stride, d_len, 0);
-	rc |= gpumt_lz4_compact(g, s->slots.d, stride, d_len, s->nrec, s->stream.d, d_off, 0);
-	rc |= gpumt_stream_wait(g, 2, 0);
+	rc |= gpumt_stream_wait(g, ks, 1);
+	rc |= gpumt_lz4_compress_batch(g, s->in.d, s->n, chunk, s->slots.d, stride, d_len, ks);
+	rc |= gpumt_lz4_compact(g, s->slots.d, stride, d_len, s->nrec, s->stream.d, d_off, ks);
+	rc |= gpumt_stream_wait(g, 2, ks);
 	rc |= gpumt_memcpy_d2h(g, s->meta.h, s->meta.d, ((s->nrec * 4 + 15) & ~(size_t)15) + (s->nrec + 1) * 8, 2);
 	return rc ? ERROR(compression_library) : 0;
 }
