@@ -14,9 +14,10 @@
  *                               canonical codes by ballots, the lengths written as a complex prefix
  *                               code whose code-length code is the flat 4-bit one.  A match with the
  *                               distance of the one before it uses the implicit / zero distance code.
- *                               The command stream is laid down by the wave in stream order (64-bit
- *                               scalar bit accumulator; literal codes looked up lane-parallel per
- *                               64-byte window of the input).  An empty metadata meta-block pads
+ *                               The command stream is laid down 64 commands at a time: bit offsets by
+ *                               prefix sums, every lane ORs its command and the lanes together the
+ *                               batch's literal codes into an LDS stage that leaves as dword stores
+ *                               (a bit-serial writer covers headers and oversize batches).  An empty metadata meta-block pads
  *                               every meta-block to a byte boundary, so the blocks of a chunk are
  *                               coded independently and concatenated; a block that does not shrink
  *                               becomes an uncompressed meta-block.
@@ -254,6 +255,22 @@ static __device__ void be_write_code(BeBits &w, BEncLds &L, u32 base, u32 A, u32
 		}
 	}
 }
+
+/* OR the n <= 63 low bits of v into the LDS bit stage at bit offset `at` (lanes in parallel) */
+static __device__ __forceinline__ void be_or_bits(u32 *stage, u32 at, u64 v, u32 n)
+{
+	if (!n)
+		return;
+	const u32 wi = at >> 5, sh = at & 31;
+	const u32 w0 = (u32)(v << sh), w1 = (u32)(sh ? v >> (32 - sh) : v >> 32), w2 = sh ? (u32)(v >> (64 - sh)) : 0u;
+	if (w0)
+		atomicOr(&stage[wi], w0);
+	if (w1)
+		atomicOr(&stage[wi + 1], w1);
+	if (w2)
+		atomicOr(&stage[wi + 2], w2);
+}
+#define BE_STAGE_WORDS 640u /* 20 480 bits: a batch of 64 commands is ~5 Kbit on text */
 
 /* ------------------------------------------------------------------ commands
  * One sequence (insert literals, copy length, distance) -> insert&copy symbol, distance symbol and
@@ -545,6 +562,9 @@ zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_tota
 		 * 64-byte window of the input (lane t = byte wbase + t), the loop then only reads lanes. */
 		const u32 room = bsize > 64 ? bsize - 64 : 0; /* stop when the block would not shrink */
 		bool fits = codes_ok && bsize > 64;
+#ifdef BE_SKIP_EMIT /* developer: time everything but the command emission */
+		fits = false;
+#endif
 		{
 			u32 prev_of = 0, pos = 0, wbase = 0x80000000u, wcode = 0, wlen = 0;
 			for (u32 s0 = 0; s0 < ns + 1 && fits; s0 += 64) {
@@ -563,6 +583,96 @@ zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_tota
 							  ? (u32)L.code[BE_DIST + c.dsym] | (u32)L.len[BE_DIST + c.dsym] << 16
 							  : 0u;
 				const u32 k = ns + (tail_lits ? 1u : 0u) - s0 < 64 ? ns + (tail_lits ? 1u : 0u) - s0 : 64;
+				/* ---- the batch side by side: every lane places its own command, the literals of the
+				 * batch are spread over the lanes, all into an LDS stage (the histograms are dead by
+				 * now); a batch whose bits do not fit the stage goes through the serial loop below ---- */
+				u32 *const stage = L.hist;
+				u32 *const a_pre = L.hist + BE_STAGE_WORDS, *const a_lp = a_pre + 64, *const a_lbits = a_lp + 64;
+				u32 *const a_lbase = a_lbits + 64, *const a_sh = a_lbase + 64;
+				const u32 seqlen = ll + ml;
+				const u32 incl_pos = wv_scan_incl(seqlen);
+				const u32 lp = pos + incl_pos - seqlen; /* block position of this lane's first literal */
+				const u32 incl_ll = wv_scan_incl(ll);
+				const u32 T = wv_readlane(incl_ll, 63);
+				const u32 cl = ccode >> 16, dl = dcode >> 16;
+				const u32 hdrbits = (u32)lane < k ? cl + c.ib + c.cb : 0;
+				const u32 dbits = (u32)lane < k && c.dsym != 0xFFFFFFFFu ? dl + c.db : 0;
+				wv_sync();
+				a_pre[lane] = incl_ll - ll;
+				a_lp[lane] = lp;
+				a_lbits[lane] = 0;
+				a_lbase[lane] = 0;
+				wv_sync();
+				/* pass 1: literal bits per command; owner of literal t = last lane whose first literal
+				 * index is <= t */
+				u32 cum_carry = 0;
+				for (u32 t0 = 0; t0 < T; t0 += 64) {
+					const u32 t = t0 + (u32)lane;
+					const bool v = t < T;
+					u32 j = 0;
+					for (u32 st = 32; st; st >>= 1)
+						if (j + st < 64 && a_pre[j + st] <= t)
+							j += st;
+					const u32 byte = v ? src[a_lp[j] + (t - a_pre[j])] : 0;
+					const u32 ln = v ? L.len[BE_LIT + byte] : 0;
+					const u32 inc = wv_scan_incl(ln);
+					if (v) {
+						atomicAdd(&a_lbits[j], ln);
+						if (t == a_pre[j])
+							a_lbase[j] = cum_carry + inc - ln;
+					}
+					cum_carry += wv_readlane(inc, 63);
+				}
+				wv_sync();
+				const u32 lbits = a_lbits[lane];
+				const u32 tot = hdrbits + lbits + dbits;
+				const u32 incl_s = wv_scan_incl(tot);
+				const u32 S = w.n + incl_s - tot;
+				const u32 B = wv_readlane(incl_s, 63);
+				if (w.n + B + 96 <= BE_STAGE_WORDS * 32) {
+					const u32 nw = (w.n + B + 31) / 32 + 3;
+					for (u32 q = (u32)lane; q < nw; q += 64)
+						stage[q] = 0;
+					a_sh[lane] = S + hdrbits - a_lbase[lane];
+					wv_sync();
+					if (lane == 0)
+						stage[0] = (u32)w.acc; /* the bits not yet stored */
+					wv_sync();
+					if ((u32)lane < k) {
+						be_or_bits(stage, S, (u64)(ccode & 0xFFFFu) | (u64)c.ix << cl | (u64)c.cx << (cl + c.ib), hdrbits);
+						be_or_bits(stage, S + hdrbits + lbits, (u64)(dcode & 0xFFFFu) | (u64)c.dx << dl, dbits);
+					}
+					u32 cc2 = 0;
+					for (u32 t0 = 0; t0 < T; t0 += 64) {
+						const u32 t = t0 + (u32)lane;
+						const bool v = t < T;
+						u32 j = 0;
+						for (u32 st = 32; st; st >>= 1)
+							if (j + st < 64 && a_pre[j + st] <= t)
+								j += st;
+						const u32 byte = v ? src[a_lp[j] + (t - a_pre[j])] : 0;
+						const u32 ln = v ? L.len[BE_LIT + byte] : 0;
+						const u32 inc = wv_scan_incl(ln);
+						if (v)
+							be_or_bits(stage, a_sh[j] + cc2 + inc - ln, L.code[BE_LIT + byte], ln);
+						cc2 += wv_readlane(inc, 63);
+					}
+					wv_sync();
+					{
+						const u32 nbits = w.n + B, nwords = nbits >> 5;
+						for (u32 q = (u32)lane; q < nwords; q += 64)
+							st32u(w.p + 4 * q, stage[q]);
+						w.p += 4 * nwords;
+						w.acc = stage[nwords]; /* bits of the partial word; zero above them */
+						w.n = nbits & 31;
+					}
+					pos += wv_readlane(incl_pos, 63);
+					wv_sync();
+					if ((u32)(w.p - out) > room)
+						fits = false;
+					prev_of = wv_readlane(of, 63);
+					continue;
+				}
 				for (u32 j = 0; j < k; j++) {
 					const u32 cj = wv_readlane(ccode, (int)j);
 					be_put(w, cj & 0xFFFFu, cj >> 16, lane);
