@@ -501,17 +501,27 @@ zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_tota
 					if (c.dsym != 0xFFFFFFFFu)
 						atomicAdd(&L.hist[BE_DIST + c.dsym], 1u);
 				}
-				/* literal bytes of this lane's sequence */
+				/* literal bytes of the batch, spread over the lanes (owner of literal t = last lane whose
+				 * first literal index is <= t; the code array is not built yet and lends its LDS) */
 				const u32 incl = wv_scan_incl(ll + ml);
 				const u32 lp = pos + incl - (ll + ml);
-				if (ll <= 64)
-					for (u32 k = 0; k < ll; k++)
-						atomicAdd(&L.hist[BE_LIT + src[lp + k]], 1u);
-				for (u64 lm = wv_ballot(ll > 64); lm; lm &= lm - 1) { /* long runs: the whole wave */
-					const int j = wv_ffs(lm) - 1;
-					const u32 a = wv_readlane(lp, j), cnt = wv_readlane(ll, j);
-					for (u32 k = (u32)lane; k < cnt; k += 64)
-						atomicAdd(&L.hist[BE_LIT + src[a + k]], 1u);
+				{
+					u32 *const a_pre = (u32 *)L.code, *const a_lp = a_pre + 64;
+					const u32 incl_ll = wv_scan_incl(ll);
+					const u32 T = wv_readlane(incl_ll, 63);
+					wv_sync();
+					a_pre[lane] = incl_ll - ll;
+					a_lp[lane] = lp;
+					wv_sync();
+					for (u32 t0 = 0; t0 < T; t0 += 64) {
+						const u32 t = t0 + (u32)lane;
+						u32 j = 0;
+						for (u32 st = 32; st; st >>= 1)
+							if (j + st < 64 && a_pre[j + st] <= t)
+								j += st;
+						if (t < T)
+							atomicAdd(&L.hist[BE_LIT + src[a_lp[j] + (t - a_pre[j])]], 1u);
+					}
 				}
 				pos += wv_readlane(incl, 63);
 				prev_of = wv_readlane(of, 63);
