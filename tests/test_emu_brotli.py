@@ -101,6 +101,8 @@ ENC = {
     "random": (cases.rnd(8000, 3), 65536),                 # does not shrink: uncompressed meta-block
     "two_blocks_two_chunks": (cases.text(140000, 7), 131072),
     "one_symbol_then_text": (b"z" * 5000 + cases.text(5000, 9), 65536),
+    # one command and one distance in the meta-block: both alphabets get a zero-bit code
+    "single_command": (bytes((b & 15) * 17 for b in cases.rnd(384, 5)) + b"\xff" * 616, 65536),
 }
 
 

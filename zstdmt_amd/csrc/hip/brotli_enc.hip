@@ -75,7 +75,7 @@ struct BeBits {
 };
 static __device__ __forceinline__ void be_put(BeBits &w, u32 v, u32 n, int lane)
 {
-	w.acc |= (u64)v << w.n;
+	w.acc |= (u64)(v & ((1u << n) - 1u)) << w.n; /* n <= 24; nothing of v beyond its n bits */
 	w.n += n;
 	if (w.n >= 32) {
 		if (lane == 0)
@@ -182,6 +182,8 @@ static __device__ u32 be_code_lengths(BEncLds &L, u32 base, u32 A, u32 *one_sym,
 static __device__ void be_assign_codes(BEncLds &L, u32 base, u32 A, int lane)
 {
 	u32 cnt = 0; /* lane l: number of symbols of length l */
+	for (u32 s = (u32)lane; s < A; s += 64)
+		L.code[base + s] = 0; /* symbols without a code (and the one symbol of a zero-bit code) */
 	for (u32 s0 = 0; s0 < A; s0 += 64) {
 		const u32 s = s0 + (u32)lane;
 		const u32 ln = s < A ? L.len[base + s] : 0;
@@ -270,6 +272,11 @@ static __device__ __forceinline__ void be_or_bits(u32 *stage, u32 at, u64 v, u32
 	if (w2)
 		atomicOr(&stage[wi + 2], w2);
 }
+#ifdef ZMT_EMU
+static inline bool getenv_serial() { return getenv("BE_SERIAL") != nullptr; }
+#else
+static __device__ __forceinline__ bool getenv_serial() { return false; }
+#endif
 #define BE_STAGE_WORDS 640u /* 20 480 bits: a batch of 64 commands is ~5 Kbit on text */
 
 /* ------------------------------------------------------------------ commands
@@ -479,6 +486,16 @@ zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_tota
 #undef BE_LOOKUP
 		wave_mem_fence();
 		const u32 tail_lits = bsize - anchor; /* literals after the last match */
+#ifdef ZMT_EMU
+		if (getenv("ZMT_EMU_DEBUG") && lane == 0) {
+			u32 p = 0;
+			for (u32 i = 0; i < ns; i++) {
+				fprintf(stderr, "S pos %u ll %u ml %u of %u\n", p + sq_ll[i], sq_ll[i], sq_ml[i], sq_of[i]);
+				p += sq_ll[i] + sq_ml[i];
+			}
+			fprintf(stderr, "tail %u\n", tail_lits);
+		}
+#endif
 
 		/* ------------------------------------------------ histograms */
 		for (u32 i = (u32)lane; i < BE_NSYM; i += 64)
@@ -639,7 +656,7 @@ zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_tota
 				const u32 incl_s = wv_scan_incl(tot);
 				const u32 S = w.n + incl_s - tot;
 				const u32 B = wv_readlane(incl_s, 63);
-				if (w.n + B + 96 <= BE_STAGE_WORDS * 32) {
+				if (!getenv_serial() && w.n + B + 96 <= BE_STAGE_WORDS * 32) {
 					const u32 nw = (w.n + B + 31) / 32 + 3;
 					for (u32 q = (u32)lane; q < nw; q += 64)
 						stage[q] = 0;
