@@ -204,6 +204,15 @@ static __device__ __forceinline__ u32 m_ld8(const InRing &R, u32 p)
 	return (p >= R.mbase && p - R.mbase < MWIN) ? (u32)R.mwin[p - R.mbase] : (u32)R.chunk[p];
 }
 
+/* forward compares right after ring_want(ip) / mside_prepare(match): the ip side [ip, ip + 68) is in
+ * the ring and the match side [m, m + 68) in the ring or in the window (wave-uniform which), so the
+ * per-lane residency tests of in_ld8 / m_ld8 are not needed */
+static __device__ __forceinline__ u32 in_fwd8(const InRing &R, u32 p) { return (u32)R.ring[p & (IRING - 1)]; }
+static __device__ __forceinline__ u32 m_fwd8(const InRing &R, u32 p)
+{
+	return R.mbase == 0xFFFFFFFFu ? (u32)R.ring[p & (IRING - 1)] : (u32)R.mwin[p - R.mbase];
+}
+
 /* cooperative literal copy chunk[a .. a+n) -> d, from the ring when it is there */
 static __device__ __forceinline__ void copy_literals(const InRing &R, u8 *d, u32 a, u32 n, int lane)
 {
@@ -323,6 +332,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		 * are in flight together. */
 		u32 fwd; /* equal bytes following the 4 that matched at ip */
 		{
+			ring_want(R, ip, lane); /* [ip, ip + 68) resident whatever the probe spacing was */
 			mside_prepare(R, match, lane);
 			u32 room = ip - anchor;
 			if (match - low < room)
@@ -333,7 +343,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			if ((u32)lane < nb)
 				eqb = in_ld8(R, ip - 1 - (u32)lane) == m_ld8(R, match - 1 - (u32)lane);
 			if ((u32)lane < flimit)
-				stopf = in_ld8(R, ip + MINMATCH + (u32)lane) != m_ld8(R, match + MINMATCH + (u32)lane);
+				stopf = in_fwd8(R, ip + MINMATCH + (u32)lane) != m_fwd8(R, match + MINMATCH + (u32)lane);
 			const u64 neb = ~wv_ballot(eqb);
 			const u64 smf = wv_ballot(stopf);
 			u32 back = neb ? (u32)wv_ffs(neb) - 1 : 64;
@@ -443,7 +453,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					const u32 lim = matchlimit - ip; /* > 4: ip < mflimit+1 */
 					bool stp = true;
 					if ((u32)lane < lim)
-						stp = in_ld8(R, ip + (u32)lane) != m_ld8(R, match + (u32)lane);
+						stp = in_fwd8(R, ip + (u32)lane) != m_fwd8(R, match + (u32)lane);
 					const u64 sm = wv_ballot(stp);
 					u32 eqn = sm ? (u32)wv_ffs(sm) - 1 : 64;
 					rm = eqn >= MINMATCH;
