@@ -263,7 +263,9 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					goto last_literals;
 				EPC(R, 7);
 				ring_want(R, cur0, lane);
-				const u64 x = valid ? in_ld64(R, cur) : 0;
+				/* the first 65 probes are consecutive positions: all inside the piece ring_want just made
+				 * resident, no per-lane residency test */
+				const u64 x = !valid ? 0 : (kbase + bsz <= 65) ? ld64u(R.ring + (cur & (IRING - 1))) : in_ld64(R, cur);
 				const u32 h = hash3<TM>(TM == T_U16 ? (u64)(u32)x : x);
 				wv_sync();
 				u32 cand = valid ? t_read<TM>(tlo, thi, h) : 0;
@@ -340,8 +342,16 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			const u32 nb = room < 64 ? room : 64;
 			const u32 flimit = matchlimit - (ip + MINMATCH);
 			bool eqb = false, stopf = true;
-			if ((u32)lane < nb)
-				eqb = in_ld8(R, ip - 1 - (u32)lane) == m_ld8(R, match - 1 - (u32)lane);
+			if ((u32)lane < nb) {
+				/* the bytes before ip are in the ring unless it was restarted less than nb bytes
+				 * ago; the bytes before the match are in the ring, or (up to 32 of them) in the
+				 * window -- wave-uniform tests, else the generic readers */
+				const u32 a = ip >= R.rlo + nb ? (u32)R.ring[(ip - 1 - (u32)lane) & (IRING - 1)] : in_ld8(R, ip - 1 - (u32)lane);
+				const u32 b = R.mbase == 0xFFFFFFFFu ? (u32)R.ring[(match - 1 - (u32)lane) & (IRING - 1)]
+					      : (nb <= 32 && match >= 32) ? (u32)R.mwin[match - 1 - (u32)lane - R.mbase]
+									  : m_ld8(R, match - 1 - (u32)lane);
+				eqb = a == b;
+			}
 			if ((u32)lane < flimit)
 				stopf = in_fwd8(R, ip + MINMATCH + (u32)lane) != m_fwd8(R, match + MINMATCH + (u32)lane);
 			const u64 neb = ~wv_ballot(eqb);
@@ -426,10 +436,13 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			ring_want(R, ip, lane);
 			{
 				/* T[h(ip-2)] = ip-2, then the immediate re-match test at ip */
-				const u64 x2 = wv_readfirst((u32)in_ld64(R, ip - 2)) |
-					       (u64)wv_readfirst((u32)(in_ld64(R, ip - 2) >> 32)) << 32;
-				const u64 x0 = wv_readfirst((u32)in_ld64(R, ip)) |
-					       (u64)wv_readfirst((u32)(in_ld64(R, ip) >> 32)) << 32;
+				/* [ip - 2, ip + 8) sits in the ring right after ring_want(ip) unless the ring was
+				 * restarted within the last two bytes (wave-uniform test) */
+				const bool near = ip >= R.rlo + 2;
+				const u64 r2 = near ? ld64u(R.ring + ((ip - 2) & (IRING - 1))) : in_ld64(R, ip - 2);
+				const u64 r0 = near ? ld64u(R.ring + (ip & (IRING - 1))) : in_ld64(R, ip);
+				const u64 x2 = wv_readfirst((u32)r2) | (u64)wv_readfirst((u32)(r2 >> 32)) << 32;
+				const u64 x0 = wv_readfirst((u32)r0) | (u64)wv_readfirst((u32)(r0 >> 32)) << 32;
 				const u32 h2 = hash3<TM>(TM == T_U16 ? (u64)(u32)x2 : x2);
 				const u32 h0 = hash3<TM>(TM == T_U16 ? (u64)(u32)x0 : x0);
 				/* reference order: insert ip-2, look up ip, insert ip.  The lookup is issued first
