@@ -36,6 +36,9 @@
 #define BE_MAXSEQ (BE_BLOCK / 4u)
 #define BE_WSCRATCH (3u * BE_MAXSEQ * 4u) /* per persistent wave: the three sequence arrays */
 #define BE_HASH(v) ((u32)((((v) << 16) * 0x9E3779B185EBCA87ull) >> (64 - BE_HLOG)))
+#ifndef BE_WAVES_PER_EU
+#define BE_WAVES_PER_EU 4
+#endif
 #define BE_MAXLEN 15u
 /* symbol space of the three alphabets inside the shared LDS arrays */
 #define BE_LIT 0u
@@ -329,7 +332,7 @@ static __device__ __forceinline__ BeCmd be_command(const BEncLds &L, u32 ins, u3
 	return c;
 }
 
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BE_WAVES_PER_EU, BE_WAVES_PER_EU)))
 zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
 		      u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch)
 {
