@@ -366,6 +366,7 @@ zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_tota
 			L.table[i] = 0;
 		wv_sync();
 		u32 ns = 0, anchor = 0, cursor = 0;
+		u32 r_ll = 0, r_ml = 0, r_of = 0;
 		const u32 steps = bsize >= BE_MINMATCH ? (bsize - BE_MINMATCH) / 64 + 1 : 0;
 /* All loads of the pipeline are unconditional (addresses clamped, results of invalid lanes ignored):
  * a load under an exec mask needs its destination initialised first, and that write would have to
@@ -472,12 +473,19 @@ zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_tota
 						if (ml > bsize - pj)
 							ml = bsize - pj;
 					}
-					if (lane == 0) {
-						sq_ll[ns] = pj - anchor;
-						sq_ml[ns] = ml;
-						sq_of[ns] = pj - cj;
+					/* sequences collect in registers (lane = index mod 64) and leave 64 at a time */
+					{
+						const bool me = (u32)lane == (ns & 63);
+						r_ll = me ? pj - anchor : r_ll;
+						r_ml = me ? ml : r_ml;
+						r_of = me ? pj - cj : r_of;
 					}
 					ns++;
+					if ((ns & 63) == 0) {
+						sq_ll[ns - 64 + (u32)lane] = r_ll;
+						sq_ml[ns - 64 + (u32)lane] = r_ml;
+						sq_of[ns - 64 + (u32)lane] = r_of;
+					}
 					anchor = cursor = pj + ml;
 					/* drop every candidate the match covers in one go */
 					mask = cursor - p0 >= 64 ? 0 : mask & ~((1ull << (cursor - p0)) - 1);
@@ -487,6 +495,11 @@ zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_tota
 		}
 #undef BE_LOADV
 #undef BE_LOOKUP
+		if ((u32)lane < (ns & 63)) { /* the sequences still in registers */
+			sq_ll[(ns & ~63u) + (u32)lane] = r_ll;
+			sq_ml[(ns & ~63u) + (u32)lane] = r_ml;
+			sq_of[(ns & ~63u) + (u32)lane] = r_of;
+		}
 		wave_mem_fence();
 		const u32 tail_lits = bsize - anchor; /* literals after the last match */
 #ifdef ZMT_EMU

@@ -740,6 +740,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			L.table[i] = 0;
 		wv_sync();
 		u32 ns = 0, anchor = 0, cursor = 0;
+		u32 r_ll = 0, r_ml = 0, r_of = 0;
 		const u32 steps = bsize >= ZE_MINMATCH ? (bsize - ZE_MINMATCH) / 64 + 1 : 0;
 /* All loads of the pipeline are unconditional (addresses clamped, results of invalid lanes ignored):
  * a load under an exec mask needs its destination initialised first, and that write would have to
@@ -854,12 +855,19 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 							tq += t_ - tx_; /* not charged to the parse phase */
 						}
 					}
-					if (lane == 0) {
-						sq_ll[ns] = pj - anchor;
-						sq_ml[ns] = ml;
-						sq_of[ns] = pj - cj;
+					/* sequences collect in registers (lane = index mod 64) and leave 64 at a time */
+					{
+						const bool me = (u32)lane == (ns & 63);
+						r_ll = me ? pj - anchor : r_ll;
+						r_ml = me ? ml : r_ml;
+						r_of = me ? pj - cj : r_of;
 					}
 					ns++;
+					if ((ns & 63) == 0) {
+						sq_ll[ns - 64 + (u32)lane] = r_ll;
+						sq_ml[ns - 64 + (u32)lane] = r_ml;
+						sq_of[ns - 64 + (u32)lane] = r_of;
+					}
 					anchor = cursor = pj + ml;
 					/* drop every candidate the match covers in one go */
 					mask = cursor - p0 >= 64 ? 0 : mask & ~((1ull << (cursor - p0)) - 1);
@@ -870,6 +878,11 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		}
 #undef ZE_LOADV
 #undef ZE_LOOKUP
+		if ((u32)lane < (ns & 63)) { /* the sequences still in registers */
+			sq_ll[(ns & ~63u) + (u32)lane] = r_ll;
+			sq_ml[(ns & ~63u) + (u32)lane] = r_ml;
+			sq_of[(ns & ~63u) + (u32)lane] = r_of;
+		}
 		wave_mem_fence();
 #ifdef ZMT_EMU
 		if (getenv("ZMT_EMU_DEBUG") && lane == 0) {
