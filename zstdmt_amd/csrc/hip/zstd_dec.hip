@@ -19,6 +19,7 @@
  *     matches that read this batch's own output resolve in watermark rounds, long copies are
  *     done by the whole wave.
  */
+#include <cstddef>
 #include "lz4_common.h"
 #include "lz4_frame.h"
 #include "match_copy.h"
@@ -51,6 +52,9 @@ template <int HCAP, int LLCAP, int OFCAP, int MLCAP> struct ZLdsT {
 };
 typedef ZLdsT<11, 9, 8, 9> ZLds;      /* everything RFC 8878 allows */
 typedef ZLdsT<10, 6, 5, 6> ZLdsSmall; /* predefined-size sequence tables, 10-bit literals */
+static_assert(offsetof(ZLdsSmall, sq) - offsetof(ZLdsSmall, below) == 1056 &&
+		      offsetof(ZLds, sq) - offsetof(ZLds, below) == 1056,
+	      "below | stage | sq are one region (per-lane stream windows)");
 
 enum { ZM_ERR = 0, ZM_A, ZM_B, ZM_C, ZM_D, ZM_E, ZM_F, ZM_G, ZM_H };
 
@@ -479,6 +483,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 	u32 rep0 = 1, rep1 = 4, rep2 = 8;
 	bool huf_ok = false;
 	int huf_log = 0;
+	u32 pre_left = 0, pre_lit = 0; /* blocks ahead whose literals are already decoded / where they start */
 	bool my_tab_ok = false; /* lanes 0..2: state of the LL / OF / ML table this lane builds */
 	bool my_tab_pre = false; /* ... and whether it currently holds the predefined distribution */
 	int my_tab_log = 0;
@@ -621,6 +626,191 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 					stc = ZBAD();
 					break;
 				}
+				bool lit_done = false;
+				if (ltype == 3 && pre_left) {
+					/* decoded together with the block that carried the tree (below) */
+					lit = lit_scratch + pre_lit;
+					pre_lit += regen;
+					pre_left--;
+					lit_done = true;
+				} else {
+					pre_left = 0;
+				}
+				/* ---- blocks that follow with `treeless` literals: all their streams at once ----
+				 * The device encoder writes one tree per 128 KiB unit and up to 15 more blocks that
+				 * reuse it; four lanes per block decode up to 64 streams side by side instead of 4.
+				 * Anything odd in a block ahead just ends the look-ahead there: the block is then
+				 * decoded (and judged) when its turn comes. */
+				if (ltype == 2 && nstreams == 4 && !last && lcsz >= tree + 10u) {
+					u32 *pre = (u32 *)L.w; /* the weights are in the table now */
+					wv_sync();
+					if (lane == 0) {
+						u32 n = 0, cum = regen, q = ip + bsize;
+						while (n < 15) {
+							if (flen - q < 8)
+								break;
+							const u8 *h = f + q;
+							const u32 bh2 = (u32)h[0] | (u32)h[1] << 8 | (u32)h[2] << 16;
+							const u32 bs2 = bh2 >> 3;
+							if (((bh2 >> 1) & 3) != 2 || bs2 > block_max || bs2 < 5 || flen - (q + 3) < bs2)
+								break;
+							const u64 v = (u64)h[3] | (u64)h[4] << 8 | (u64)h[5] << 16 | (u64)h[6] << 24 | (u64)h[7] << 32;
+							const u32 sf2 = (u32)(v >> 2) & 3;
+							if ((v & 3) != 3 || sf2 == 0)
+								break;
+							u32 rg, cs, hl2;
+							if (sf2 == 1) {
+								rg = (u32)(v >> 4) & 1023;
+								cs = (u32)(v >> 14) & 1023;
+								hl2 = 3;
+							} else if (sf2 == 2) {
+								rg = (u32)(v >> 4) & 16383;
+								cs = (u32)(v >> 18) & 16383;
+								hl2 = 4;
+							} else {
+								rg = (u32)(v >> 4) & 262143;
+								cs = (u32)(v >> 22) & 262143;
+								hl2 = 5;
+							}
+							if (rg == 0 || rg > block_max || hl2 + cs > bs2 || cs < 10 || cum + rg > Z_BLOCK_MAX)
+								break;
+							pre[4 * n] = q + 3 + hl2; /* jump table, as an offset into the frame */
+							pre[4 * n + 1] = cs;
+							pre[4 * n + 2] = rg;
+							pre[4 * n + 3] = cum;
+							cum += rg;
+							n++;
+							q += 3 + bs2;
+							if (bh2 & 1)
+								break;
+						}
+						L.misc[ZM_A] = n;
+					}
+					wv_sync();
+					u32 npre = L.misc[ZM_A];
+					if (npre) {
+						const u32 g = (u32)lane >> 2, sl = (u32)lane & 3;
+						bool dec = g <= npre, bad = false;
+						u32 jt = (u32)(src - f) + lhl + tree, cs = lcsz - tree, rg = regen, base = 0;
+						if (g && dec) {
+							jt = pre[4 * (g - 1)];
+							cs = pre[4 * (g - 1) + 1];
+							rg = pre[4 * (g - 1) + 2];
+							base = pre[4 * (g - 1) + 3];
+						}
+						u32 s_off = 0, s_len = 0, s_n = 0, s_dst = 0;
+						int ipos = 0;
+						if (dec) {
+							const u8 *jp = f + jt;
+							const u32 j1 = (u32)jp[0] | (u32)jp[1] << 8, j2 = (u32)jp[2] | (u32)jp[3] << 8,
+								  j3 = (u32)jp[4] | (u32)jp[5] << 8;
+							const u32 tot = cs - 6, q4 = (rg + 3) / 4;
+							if (j1 + j2 + j3 >= tot || 3 * q4 > rg) {
+								bad = true;
+							} else {
+								s_off = jt + 6 + (sl > 0 ? j1 : 0) + (sl > 1 ? j2 : 0) + (sl > 2 ? j3 : 0);
+								s_len = sl == 0 ? j1 : sl == 1 ? j2 : sl == 2 ? j3 : tot - j1 - j2 - j3;
+								s_n = sl < 3 ? q4 : rg - 3 * q4;
+								s_dst = base + sl * q4;
+								const u32 lastb = s_len ? f[s_off + s_len - 1] : 0;
+								if (s_len == 0 || lastb == 0)
+									bad = true;
+								else
+									ipos = 8 * (int)(s_len - 1) + hb32(lastb);
+							}
+						}
+						/* every lane keeps a 32-byte window of its own stream in LDS (over the
+						 * header stage and the sequence batch, both idle here): 16 symbols a round */
+						u8 *win = L.below + 40u * (u32)lane;
+						const int lg = huf_log;
+						const u32 hm = (1u << lg) - 1;
+						u32 done = 0;
+						while (wv_any(dec && !bad && done < s_n)) {
+							if (dec && !bad && done < s_n) {
+								const int whi = (ipos + 7) >> 3, iwlo = whi - 32;
+								const u8 *p = f + s_off + iwlo;
+								u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+								if (iwlo >= 0) {
+									w0 = ld64u(p);
+									w1 = ld64u(p + 8);
+									w2 = ld64u(p + 16);
+									w3 = ld64u(p + 24);
+								} else {
+									for (int k = 0; k < 8; k++) {
+										if (iwlo + k >= 0)
+											w0 |= (u64)p[k] << (8 * k);
+										if (iwlo + 8 + k >= 0)
+											w1 |= (u64)p[8 + k] << (8 * k);
+										if (iwlo + 16 + k >= 0)
+											w2 |= (u64)p[16 + k] << (8 * k);
+										if (iwlo + 24 + k >= 0)
+											w3 |= (u64)p[24 + k] << (8 * k);
+									}
+								}
+								*(u64 *)win = w0;
+								*(u64 *)(win + 8) = w1;
+								*(u64 *)(win + 16) = w2;
+								*(u64 *)(win + 24) = w3;
+								const u32 todo = s_n - done < 16 ? s_n - done : 16;
+								u8 *dst = lit_scratch + s_dst + done;
+								u32 i = 0;
+								for (; i + 8 <= todo && ipos >= 0; i += 8) {
+									u64 acc = 0;
+									ZMT_UNROLL
+									for (int hlf = 0; hlf < 2; hlf++) {
+										const int tb = (ipos - 1) >> 3;
+										const u64 word = ld64u(win + (tb - 7 - iwlo));
+										int cb = ipos - 8 * (tb - 7);
+										ZMT_UNROLL
+										for (int k = 0; k < 4; k++) {
+											const u32 e = L.huf[(u32)(word >> (cb - lg)) & hm];
+											cb -= (int)(e >> 8);
+											acc |= (u64)(e & 255) << (8 * (4 * hlf + k));
+										}
+										ipos = cb + 8 * (tb - 7);
+									}
+									st64g(dst + i, acc);
+								}
+								{
+									u64 c = 0;
+									int cb = 0;
+									for (; i < todo && ipos >= 0; i++) {
+										if (cb < lg) {
+											const int tb = (ipos - 1) >> 3;
+											c = ld64u(win + (tb - 7 - iwlo));
+											cb = ipos - 8 * (tb - 7);
+										}
+										const u32 e = L.huf[(u32)(c >> (cb - lg)) & hm];
+										const int nb = (int)(e >> 8);
+										cb -= nb;
+										ipos -= nb;
+										dst[i] = (u8)e;
+									}
+								}
+								if (ipos < 0)
+									bad = true;
+								done += todo;
+								if (!bad && done == s_n && ipos != 0)
+									bad = true;
+							}
+						}
+						const u64 bm = wv_ballot(dec && bad);
+						if (bm) {
+							const u32 gb = (u32)(wv_ffs(bm) - 1) >> 2;
+							if (gb == 0) {
+								stc = ZBAD();
+								break;
+							}
+							npre = gb - 1; /* the blocks from there on are decoded in their turn */
+						}
+						pre_left = npre;
+						pre_lit = regen;
+						lit_done = true;
+						wv_sync();
+						wave_mem_fence();
+					}
+				}
+				if (!lit_done) {
 				ZP(0);
 				/* ---- Huffman streams: lane s < nstreams decodes stream s ---- */
 				const u32 body = lhl + tree; /* offset of jump table / single stream in src */
@@ -749,6 +939,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 					break;
 				}
 				wave_mem_fence(); /* literals are read back by other lanes below */
+				} /* !lit_done */
 			}
 
 			ZP(1);
