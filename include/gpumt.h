@@ -202,6 +202,8 @@ int gpumt_brotli_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t
 				size_t slot_stride, uint32_t *d_rec_len, int stream);
 
 #define GPUMT_BROTLI_SCRATCH 825856u
+/* zstd decode: scratch per record (literals of one 128 KiB unit + 24576 sequences decoded ahead) */
+#define GPUMT_ZSTD_DEC_SCRATCH 327936u
 int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
 				  const uint32_t *d_rec_len, size_t nrec, void *d_out,
 				  const uint64_t *d_out_off, const uint32_t *d_out_cap,

@@ -165,7 +165,7 @@ void emu_zstd_probe(const u8 *stream, const u64 *rec_off, const u32 *rec_len, u3
 void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *rec_off, const u32 *rec_len,
 			       u32 nrec, u8 *out, const u64 *out_off, u32 *out_len, u32 *status)
 {
-	std::vector<u8> lit((size_t)nrec * (131072 + 256), 0xA5);
+	std::vector<u8> lit((size_t)nrec * 327936u, 0xA5); /* GPUMT_ZSTD_DEC_SCRATCH */
 	u8 *litp = lit.data();
 	std::vector<u32> ce(nrec, 0xA5A5A5A5u), cv(nrec, 0xA5A5A5A5u);
 	u32 *cep = ce.data(), *cvp = cv.data();

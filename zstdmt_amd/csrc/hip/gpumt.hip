@@ -696,7 +696,7 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 		return GPUMT_E_ARG;
 	if (use(h))
 		return GPUMT_E_HIP;
-	const size_t lit_bytes = nrec * (size_t)(131072 + 256);
+	const size_t lit_bytes = nrec * (size_t)GPUMT_ZSTD_DEC_SCRATCH;
 	if (want_scratch(h, 1, s, lit_bytes + nrec * 8 + 64))
 		return GPUMT_E_HIP;
 	u32 *chk_e = (u32 *)((u8 *)h->scratch[1][s] + lit_bytes), *chk_v = chk_e + nrec;

@@ -67,6 +67,8 @@ static inline int wv_ffs(u64 m) { return __builtin_ffsll((long long)m); } /* 1-b
 /* number of set bits of m below this lane */
 static inline u32 wv_mbcnt(u64 m) { return (u32)__builtin_popcountll(m & ((1ull << wv_lane()) - 1)); }
 static inline void wv_sleep() {}
+/* value of lane k (0..3) of this lane's group of four */
+static inline u32 wv_quad(u32 v, int k) { return wv_shfl(v, (wv_lane() & ~3) + k); }
 #define ZMT_UNROLL
 
 #else
@@ -101,6 +103,8 @@ static __device__ __forceinline__ u32 wv_mbcnt(u64 m)
 	return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0));
 }
 static __device__ __forceinline__ void wv_sleep() { __builtin_amdgcn_s_sleep(2); }
+/* value of lane k (constant 0..3) of this lane's group of four: one DPP quad_perm move */
+#define wv_quad(v, k) ((u32)__builtin_amdgcn_update_dpp(0, (int)(v), (k) * 0x55, 0xf, 0xf, true))
 #define ZMT_UNROLL _Pragma("unroll")
 #endif
 

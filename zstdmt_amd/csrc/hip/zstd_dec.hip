@@ -26,7 +26,9 @@
 
 #define ZMT_ZSTD_MAGIC 0xFD2FB528u
 #define Z_BLOCK_MAX 131072u
-#define Z_LITSLOT (Z_BLOCK_MAX + 256u) /* literal scratch per record (include/gpumt.h) */
+#define Z_SEQCAP 24576u /* sequences decoded ahead of their blocks, 8 bytes each (see `unit` below) */
+#define Z_LITSLOT (Z_BLOCK_MAX + 256u + 8u * Z_SEQCAP) /* scratch per record = GPUMT_ZSTD_DEC_SCRATCH */
+static_assert(Z_LITSLOT == 327936u, "GPUMT_ZSTD_DEC_SCRATCH in include/gpumt.h");
 #define Z_STAGE 1024u
 #define Z_CAP 64u /* longer literal runs / matches are copied by the whole wave */
 
@@ -484,6 +486,9 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 	bool huf_ok = false;
 	int huf_log = 0;
 	u32 pre_left = 0, pre_lit = 0; /* blocks ahead whose literals are already decoded / where they start */
+	u32 sq_left = 0, sq_pos = 0; /* blocks (this one first) whose sequences are decoded / where they start */
+	bool unit_head = false;
+	u64 *seq_scratch = (u64 *)(lit_scratch + Z_BLOCK_MAX + 256u);
 	bool my_tab_ok = false; /* lanes 0..2: state of the LL / OF / ML table this lane builds */
 	bool my_tab_pre = false; /* ... and whether it currently holds the predefined distribution */
 	int my_tab_log = 0;
@@ -677,7 +682,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 							pre[4 * n] = q + 3 + hl2; /* jump table, as an offset into the frame */
 							pre[4 * n + 1] = cs;
 							pre[4 * n + 2] = rg;
-							pre[4 * n + 3] = cum;
+							pre[4 * n + 3] = q + 3 + bs2; /* end of the block */
 							cum += rg;
 							n++;
 							q += 3 + bs2;
@@ -696,8 +701,8 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 							jt = pre[4 * (g - 1)];
 							cs = pre[4 * (g - 1) + 1];
 							rg = pre[4 * (g - 1) + 2];
-							base = pre[4 * (g - 1) + 3];
 						}
+						base = wv_scan_incl(sl == 0 && dec ? rg : 0u) - rg; /* literals of the blocks before mine */
 						u32 s_off = 0, s_len = 0, s_n = 0, s_dst = 0;
 						int ipos = 0;
 						if (dec) {
@@ -719,22 +724,25 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 									ipos = 8 * (int)(s_len - 1) + hb32(lastb);
 							}
 						}
-						/* every lane keeps a 32-byte window of its own stream in LDS (over the
-						 * header stage and the sequence batch, both idle here): 16 symbols a round */
+						/* every lane keeps a 40-byte window of its own stream in LDS (over the
+						 * header stage and the sequence batch, both idle here): 24 symbols a round
+						 * (the sixth group of four starts at most 5 x 44 bits = 28 bytes down and
+						 * reads 8 bytes from there) */
 						u8 *win = L.below + 40u * (u32)lane;
 						const int lg = huf_log;
 						const u32 hm = (1u << lg) - 1;
 						u32 done = 0;
 						while (wv_any(dec && !bad && done < s_n)) {
 							if (dec && !bad && done < s_n) {
-								const int whi = (ipos + 7) >> 3, iwlo = whi - 32;
+								const int whi = (ipos + 7) >> 3, iwlo = whi - 40;
 								const u8 *p = f + s_off + iwlo;
-								u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+								u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0;
 								if (iwlo >= 0) {
 									w0 = ld64u(p);
 									w1 = ld64u(p + 8);
 									w2 = ld64u(p + 16);
 									w3 = ld64u(p + 24);
+									w4 = ld64u(p + 32);
 								} else {
 									for (int k = 0; k < 8; k++) {
 										if (iwlo + k >= 0)
@@ -745,13 +753,16 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 											w2 |= (u64)p[16 + k] << (8 * k);
 										if (iwlo + 24 + k >= 0)
 											w3 |= (u64)p[24 + k] << (8 * k);
+										if (iwlo + 32 + k >= 0)
+											w4 |= (u64)p[32 + k] << (8 * k);
 									}
 								}
 								*(u64 *)win = w0;
 								*(u64 *)(win + 8) = w1;
 								*(u64 *)(win + 16) = w2;
 								*(u64 *)(win + 24) = w3;
-								const u32 todo = s_n - done < 16 ? s_n - done : 16;
+								*(u64 *)(win + 32) = w4;
+								const u32 todo = s_n - done < 24 ? s_n - done : 24;
 								u8 *dst = lit_scratch + s_dst + done;
 								u32 i = 0;
 								for (; i + 8 <= todo && ipos >= 0; i += 8) {
@@ -806,6 +817,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 						pre_left = npre;
 						pre_lit = regen;
 						lit_done = true;
+						unit_head = npre != 0;
 						wv_sync();
 						wave_mem_fence();
 					}
@@ -1011,6 +1023,10 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 			}
 			const u32 nseq = L.misc[ZM_D];
 			const u32 sq_hdr = L.misc[ZM_E];
+			/* all three tables predefined (what the device encoder writes) */
+			const bool all_pre = nseq && (L.misc[ZM_A] & 0xC0000000u) == 0x40000000u &&
+					     (L.misc[ZM_A + 1] & 0xC0000000u) == 0x40000000u &&
+					     (L.misc[ZM_A + 2] & 0xC0000000u) == 0x40000000u;
 			u32 lpos = 0; /* literals consumed */
 			if (nseq) {
 				/* ---- build the three tables on lanes 0..2 ---- */
@@ -1067,6 +1083,180 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 					break;
 				}
 				long pos = 8 * (long)(bs_len - 1) + hb32(lastb); /* unread bits, wave-uniform */
+				/* ---- unit: the sequences of this block and of the blocks looked at above ----
+				 * Their bitstreams are independent and, with predefined tables everywhere, read
+				 * through the same three tables: four lanes per block (LL / OF / ML state + one
+				 * idle) decode up to 16 blocks side by side into the record's scratch, 8 bytes a
+				 * sequence (ll | ml << 18 | offset value << 36); the blocks then only execute.
+				 * As with the literals, anything odd ends the unit before that block. */
+				if (unit_head) {
+					unit_head = false;
+					sq_left = 0;
+					if (all_pre && pre_left) {
+						const u32 *pre = (const u32 *)L.w;
+						const u32 g = (u32)lane >> 2, sl = (u32)lane & 3;
+						bool act = g <= pre_left, gbad = false;
+						u32 g_off = (u32)(src - f) + bs_off, g_len = bs_len, g_n = nseq;
+						if (g && act) {
+							const u32 s0 = pre[4 * (g - 1)] + pre[4 * (g - 1) + 1], bend = pre[4 * (g - 1) + 3];
+							g_n = 0;
+							if (bend - s0 >= 4) {
+								const u32 b0 = f[s0];
+								u32 p = 1;
+								g_n = b0;
+								if (b0 == 255) {
+									g_n = ((u32)f[s0 + 1] | (u32)f[s0 + 2] << 8) + 0x7F00u;
+									p = 3;
+								} else if (b0 >= 128) {
+									g_n = ((b0 - 128) << 8) + f[s0 + 1];
+									p = 2;
+								}
+								if (f[s0 + p] != 0)
+									g_n = 0; /* a table of its own */
+								g_off = s0 + p + 1;
+								if (g_off >= bend)
+									g_n = 0;
+								else
+									g_len = bend - g_off;
+							}
+							if (g_n == 0)
+								gbad = true;
+						}
+						int bp = 0; /* unread bits of my block's stream */
+						if (act && !gbad) {
+							const u32 lb = f[g_off + g_len - 1];
+							if (lb == 0)
+								gbad = true;
+							else
+								bp = 8 * (int)(g_len - 1) + hb32(lb);
+							if (bp < ll_log + of_log + ml_log)
+								gbad = true;
+						}
+						u32 ngrp = pre_left + 1;
+						{
+							const u64 bm = wv_ballot(act && gbad);
+							if (bm)
+								ngrp = (u32)(wv_ffs(bm) - 1) >> 2;
+						}
+						act = g < ngrp;
+						const u32 incl = wv_scan_incl(sl == 0 && act ? g_n : 0u);
+						{
+							const u64 om = wv_ballot(act && incl > Z_SEQCAP);
+							if (om)
+								ngrp = (u32)(wv_ffs(om) - 1) >> 2;
+						}
+						act = g < ngrp;
+						u64 *myseq = seq_scratch + (incl - g_n);
+						if (ngrp >= 2) {
+							const u32 *mytab = sl == 1 ? L.of : sl == 2 ? L.ml : L.ll;
+							const u32 mylog = sl == 0 ? (u32)ll_log : sl == 1 ? (u32)of_log : sl == 2 ? (u32)ml_log : 0u;
+							const u32 tmask = (1u << mylog) - 1;
+							const u32 e_of = sl == 1 ? 0u : ~0u, e_ml = sl == 0 ? ~0u : 0u;
+							const u32 s_ll = sl == 0 ? 0u : ~0u, s_ml = sl == 1 ? ~0u : 0u;
+							u8 *gwin = L.below + 160u * g; /* 160-byte window per block, 40 per lane */
+							u32 state = 0, done = 0;
+							bool first = true;
+							while (wv_any(act && done < g_n)) {
+								const int whi = (bp + 7) >> 3, wlo = whi - 160;
+								wv_sync();
+								if (act && done < g_n) {
+									const int rel = (int)g_off + wlo + 40 * (int)sl;
+									u64 w[5] = {0, 0, 0, 0, 0};
+									if (rel >= 0) {
+										ZMT_UNROLL
+										for (int j = 0; j < 5; j++)
+											w[j] = ld64u(f + rel + 8 * j);
+									} else {
+										for (int j = 0; j < 5; j++)
+											for (int k2 = 0; k2 < 8; k2++)
+												if (rel + 8 * j + k2 >= 0)
+													w[j] |= (u64)f[rel + 8 * j + k2] << (8 * k2);
+									}
+									ZMT_UNROLL
+									for (int j = 0; j < 5; j++)
+										*(u64 *)(gwin + 40u * sl + 8u * (u32)j) = w[j];
+								}
+								wv_sync();
+								const u8 *winb = gwin - wlo - 15; /* winb[b + 15] = byte b of my stream */
+								if (first) {
+									first = false;
+									const int tb = (bp - 1) >> 3;
+									const u64 w1 = ld64u(winb + tb), w0 = ld64u(winb + tb + 8);
+									const u32 skip = (u32)(8 * (tb + 1) - bp);
+									state = xbits(w0, w1, skip + (sl == 0 ? 0u : sl == 1 ? (u32)ll_log : (u32)(ll_log + of_log)),
+										      mylog);
+									bp -= ll_log + of_log + ml_log;
+								}
+								for (;;) {
+									/* eight sequences of every block; lane sl keeps 2 sl, 2 sl + 1 */
+									u64 r0 = 0, r1 = 0;
+									ZMT_UNROLL
+									for (int i = 0; i < 8; i++) {
+										const bool on = act && done + (u32)i < g_n;
+										int tb = (bp - 1) >> 3;
+										tb = tb < wlo + 15 ? wlo + 15 : tb; /* a stream gone bad stays inside its window */
+										const u64 w1 = ld64u(winb + tb), w0 = ld64u(winb + tb + 8);
+										const u32 cell = mytab[state & tmask];
+										const u32 skip = (u32)(8 * (tb + 1) - bp) & 127u;
+										const u32 nb = done + (u32)i + 1 == g_n ? 0u : ZC_NB(cell), ab = ZC_AB(cell);
+										const u32 pk = ab | nb << 8;
+										const u32 p_ll = wv_quad(pk, 0), p_of = wv_quad(pk, 1), p_ml = wv_quad(pk, 2);
+										const u32 a_ll = p_ll & 255, n_ll = p_ll >> 8, a_of = p_of & 255, n_of = p_of >> 8;
+										const u32 a_ml = p_ml & 255, n_ml = p_ml >> 8;
+										const u32 base3 = skip + a_of + a_ml + a_ll;
+										const u32 eo = skip + (a_of & e_of) + (a_ml & e_ml);
+										const u32 so = base3 + (n_ll & s_ll) + (n_ml & s_ml);
+										const u32 extra = xbits(w0, w1, eo, ab);
+										const u32 sbits = xbits(w0, w1, so, nb);
+										const u32 sym = ZC_SYM(cell);
+										const u32 val = sl == 0   ? (L.llx[sym < 36 ? sym : 0] & 0xFFFFFFu) + extra
+												: sl == 2 ? (L.mlx[sym < 53 ? sym : 0] & 0xFFFFFFu) + extra
+													  : (1u << (sym & 31)) + extra;
+										if (on && sl == 1 && sym > 27)
+											gbad = true; /* does not fit the packing: left to the block itself */
+										const u32 v_ll = wv_quad(val, 0), v_of = wv_quad(val, 1), v_ml = wv_quad(val, 2);
+										const u64 rcd = (u64)v_ll | (u64)v_ml << 18 | (u64)v_of << 36;
+										if ((u32)(i >> 1) == sl) {
+											if (i & 1)
+												r1 = rcd;
+											else
+												r0 = rcd;
+										}
+										state = on ? ZC_BASE(cell) + sbits : state;
+										bp -= on ? (int)(base3 - skip + n_ll + n_ml + n_of) : 0;
+									}
+									if (act && done + 2 * sl < g_n)
+										st64g((u8 *)(myseq + done + 2 * sl), r0);
+									if (act && done + 2 * sl + 1 < g_n)
+										st64g((u8 *)(myseq + done + 2 * sl + 1), r1);
+									if (act && done < g_n) {
+										done = g_n - done < 8 ? g_n : done + 8;
+										if (bp < 0 || (done == g_n && bp != 0))
+											gbad = true;
+										if (gbad)
+											act = false;
+									}
+									const bool more = act && done < g_n;
+									/* 8 x 76 more bits and the 16-byte read must stay inside the 160 bytes */
+									if (!wv_any(more) || wv_any(more && 8 * whi - bp > 544))
+										break;
+								}
+							}
+							wave_mem_fence();
+							{
+								const u64 bm = wv_ballot(gbad && g < ngrp);
+								if (bm) {
+									const u32 gb = (u32)(wv_ffs(bm) - 1) >> 2;
+									ngrp = gb < ngrp ? gb : ngrp;
+								}
+							}
+							sq_left = ngrp;
+							sq_pos = 0;
+							wv_sync();
+						}
+					}
+				}
+				const bool from_scr = sq_left != 0;
 				/* lanes 0 / 1 / 2 carry the LL / OF / ML state and decode their own code; the
 				 * loop below is wave-uniform (one LDS round trip per sequence): every lane reads
 				 * its state's cell and the same 128-bit window of the bitstream, the six field
@@ -1080,6 +1270,9 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 				u32 state = 0;
 				for (u32 sbase = 0; sbase < nseq && stc == ST_OK; sbase += 64) {
 					const u32 k = nseq - sbase < 64 ? nseq - sbase : 64;
+					const bool act0 = (u32)lane < k;
+					u32 ll = 0, ml = 0, ofv = 4;
+					if (!from_scr) {
 					/* window of the bitstream: 1 KiB ending at the byte of the next unread bit */
 					const long whi = (pos + 7) >> 3, wlo = whi - (long)Z_STAGE;
 					wv_sync();
@@ -1134,14 +1327,18 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 					wv_sync();
 					ZP(3);
 					/* ---- execute the k sequences ---- */
-					const bool act0 = (u32)lane < k;
-					u32 ll = 0, ml = 0, ofv = 4;
 					if (act0) {
 						const u64 q_ll = L.sq[0][lane], q_of = L.sq[1][lane], q_ml = L.sq[2][lane];
 						const u32 c_of = (u32)(q_of >> 32);
 						ll = (L.llx[(u32)(q_ll >> 32)] & 0xFFFFFFu) + (u32)q_ll;
 						ml = (L.mlx[(u32)(q_ml >> 32)] & 0xFFFFFFu) + (u32)q_ml;
 						ofv = c_of > 31 ? 0u : (1u << c_of) + (u32)q_of;
+					}
+					} else if (act0) {
+						const u64 v = seq_scratch[sq_pos + sbase + (u32)lane];
+						ll = (u32)v & 0x3FFFFu;
+						ml = (u32)(v >> 18) & 0x3FFFFu;
+						ofv = (u32)(v >> 36);
 					}
 					if (wv_any(act0 && ofv == 0)) {
 						stc = ZBAD(); /* offset code > 31 */
@@ -1255,6 +1452,10 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 				}
 				if (stc != ST_OK)
 					break;
+				if (from_scr) {
+					sq_pos += nseq;
+					sq_left--;
+				}
 			} else if (sq_hdr != bsize - sq0) {
 				stc = ZBAD();
 				break;
@@ -1270,6 +1471,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 				opos += restl;
 			}
 			wave_mem_fence();
+			unit_head = false;
 			ip += bsize;
 		}
 		if (last)
