@@ -1512,9 +1512,14 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 		status[rec] = stc;
 }
 
+#ifdef ZMT_EMU
+#define ZMT_WAVES4
+#else
+#define ZMT_WAVES4 __attribute__((amdgpu_waves_per_eu(4, 4))) /* 128 VGPRs: 16 waves per CU */
+#endif
 /* records whose status is `want` (GPUMT_ST_OK after the probe, or ST_NEEDS_GENERAL after the small
  * variant) are decoded; their status becomes OK / an error / ST_NEEDS_GENERAL (small variant only) */
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64) ZMT_WAVES4
 zmt_zstd_dec_small_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
 			  const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
 			  const u64 *__restrict__ out_off, u32 *__restrict__ out_len,
