@@ -2,9 +2,12 @@
 # Runs ON THE GPU BOX (through gpurun): the default bench line, the rocprofv3 kernel-trace summary of the
 # same command, and the two separate PMC passes (FETCH_SIZE, WRITE_SIZE).  Everything lands under
 # gpurun_out/; tools/pmc_summarize.py turns it into the files committed under profiles/.
-#   gpurun --timeout 900 -- 'bash tools/profile_round.sh'
+#   gpurun --timeout 900 -- 'bash tools/profile_round.sh'            (all three codecs)
+#   gpurun --timeout 400 -- 'bash tools/profile_round.sh zstd'       (one of lz4 | zstd | brotli)
+ONLY=${1:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
+if [ $ONLY = all ] || [ $ONLY = lz4 ]; then
 rm -rf $O/prof_stats $O/prof_fetch $O/prof_write
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- \
@@ -13,6 +16,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch -
     python bench.py --steps 1 --warmup 0 --no-cpu > $O/bench_fetch.json 2> $O/prof_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -- \
     python bench.py --steps 1 --warmup 0 --no-cpu > $O/bench_write.json 2> $O/prof_write.err
+cat $O/bench_default.json
+fi
+if [ $ONLY = all ] || [ $ONLY = zstd ]; then
 # configs[3]: zstd-mt level 1 (same workload text, 1 MiB chunks)
 rm -rf $O/prof_zstd_stats $O/prof_zstd_fetch $O/prof_zstd_write
 python bench.py --codec zstd > $O/bench_zstd.json 2> $O/bench_zstd.err
@@ -22,6 +28,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_zstd_fe
     python bench.py --codec zstd --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_zstd_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_zstd_write -- \
     python bench.py --codec zstd --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_zstd_write.err
+cat $O/bench_zstd.json
+fi
+if [ $ONLY = all ] || [ $ONLY = brotli ]; then
 # configs[4]: brotli-mt decompress (level-1 streams written by the reference build, 1 MiB chunks)
 rm -rf $O/prof_brotli_stats $O/prof_brotli_fetch $O/prof_brotli_write
 python bench.py --codec brotli > $O/bench_brotli.json 2> $O/bench_brotli.err
@@ -36,6 +45,5 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_brotli_
 rm -rf $O/prof_brotli_enc_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_brotli_enc_stats -- \
     python bench.py --codec brotli --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_brotli_enc_stats.err
-cat $O/bench_default.json
-cat $O/bench_zstd.json
 cat $O/bench_brotli.json
+fi
