@@ -137,3 +137,24 @@ def test_emu_checksummed_frames():
     bad[12 + len(fr) - 1] ^= 0x10           # last checksum byte of the first frame
     out, status = E.zstd_decompress(bytes(bad))
     assert status.tolist() == [5, 0, 0]     # GPUMT_ST_BAD_CHECKSUM
+
+
+def test_emu_corrupt_unit_streams():
+    """Streams of the device encoder form units (one tree, up to 16 blocks decoded side by side):
+    flips anywhere in such a record must leave the verdict -- and the content, when the stream stays
+    valid -- equal to the oracle's, whichever block the damage lands in."""
+    data = cases.text(200000, 21)
+    st = E.zstd_compress(data, 1 << 20)
+    assert E.zstd_decompress(st)[0] == data
+    rng = np.random.default_rng(11)
+    ro, rl = np.array([0], np.uint64), np.array([len(st)], np.uint32)
+    for pos in sorted(set(rng.integers(12, len(st), 40).tolist())):
+        bad = bytearray(st)
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        bad = bytes(bad)
+        want = H.oracle_zstdmt_decompress(bad, len(data) + 64)
+        out, status = E.zstd_decompress(bad, rec=(ro, rl))
+        if want is None:
+            assert status[0] != 0, f"flip at {pos}: oracle rejects, kernel accepted"
+        else:
+            assert status[0] == 0 and out == want, f"flip at {pos}"

@@ -80,6 +80,25 @@ def test_corrupt_streams_status(eng):
             assert status[0] == 0 and out == want
 
 
+def test_corrupt_unit_streams_status(eng):
+    """The same on a record of the device encoder, whose blocks are decoded a unit (one tree, up to
+    16 blocks) at a time: damage in any block leaves verdict and content equal to the oracle's."""
+    data = cases.text(600000, 21)
+    st, ro, rl = eng.compress_bytes(data, 1 << 20, codec="zstd")
+    assert len(rl) == 1
+    rng = np.random.default_rng(5)
+    for pos in sorted(set(rng.integers(12, len(st), 120).tolist())):
+        bad = bytearray(st)
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        bad = bytes(bad)
+        want = H.oracle_zstdmt_decompress(bad, len(data) + 64)
+        out, status = eng.decompress_bytes(bad, ro, rl, codec="zstd")
+        if want is None:
+            assert status[0] != 0, pos
+        else:
+            assert status[0] == 0 and out == want, pos
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_fuzz_encode_is_decompress_identical(eng, seed):
     import random
