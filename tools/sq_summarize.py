@@ -18,7 +18,8 @@ for codec in ("lz4", "zstd", "brotli"):
         files = glob.glob(os.path.join(go, f"sq_{codec}_{p}", "**", "*_counter_collection.csv"), recursive=True)
         if not files:
             continue
-        f = max(files, key=os.path.getsize)
+        newest = max(os.path.getmtime(x) for x in files)   # newest run, its largest file = the bench process
+        f = max((x for x in files if newest - os.path.getmtime(x) < 120), key=os.path.getsize)
         tot, n = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
         with open(f) as fh:
             for row in csv.DictReader(fh):
