@@ -13,27 +13,33 @@ static __device__ __forceinline__ void st64g(u8 *p, u64 v) { __builtin_memcpy(p,
 
 static __device__ __forceinline__ void g_copy(u8 *d, const u8 *s, u32 len)
 {
+	/* Lanes that take different branches run one after the other, and with in-order memory returns
+	 * every branch pays its own load -> store round trip: so three length classes only, each with
+	 * all of its loads issued before its first store. */
 	if (len >= 8) {
-		/* ends first: two loads cover up to 16 bytes, four up to 32 -- all issued before the
-		 * first store, so the common lengths cost one memory round trip; the middle of longer
-		 * runs (rare: Z_CAP is 64) goes piece by piece */
-		const u64 a = ld64u(s), b = ld64u(s + len - 8);
-		if (len > 16) {
-			const u64 c = ld64u(s + 8), e = ld64u(s + len - 16);
-			st64g(d + 8, c);
-			st64g(d + len - 16, e);
+		/* 8..32 bytes: four 8-byte pieces at 0, min(8, len-8), max(len,16)-16, len-8 (they overlap
+		 * for the shorter lengths); the middle of longer runs (rare: the caps are 64) piece by piece */
+		const u32 o1 = len - 8 < 8 ? len - 8 : 8, o2 = (len > 16 ? len : 16) - 16, o3 = len - 8;
+		const u64 a = ld64u(s), b = ld64u(s + o1), c = ld64u(s + o2), e = ld64u(s + o3);
+		if (len > 32) {
 			for (u32 i = 16; i + 16 < len; i += 8)
 				st64g(d + i, ld64u(s + i));
 		}
 		st64g(d, a);
-		st64g(d + len - 8, b);
+		st64g(d + o1, b);
+		st64g(d + o2, c);
+		st64g(d + o3, e);
 	} else if (len >= 4) {
 		const u32 a = ld32u(s), b = ld32u(s + len - 4);
 		st32u(d, a);
 		st32u(d + len - 4, b);
-	} else {
-		for (u32 i = 0; i < len; i++)
-			d[i] = s[i];
+	} else if (len) {
+		/* 1..3 bytes: first, middle, last */
+		const u32 h = len >> 1;
+		const u8 a = s[0], b = s[h], c = s[len - 1];
+		d[0] = a;
+		d[h] = b;
+		d[len - 1] = c;
 	}
 }
 

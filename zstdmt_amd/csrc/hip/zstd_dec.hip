@@ -1515,7 +1515,10 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 #ifdef ZMT_EMU
 #define ZMT_WAVES4
 #else
-#define ZMT_WAVES4 __attribute__((amdgpu_waves_per_eu(4, 4))) /* 128 VGPRs: 16 waves per CU */
+#ifndef ZD_WAVES
+#define ZD_WAVES 4 /* 128 VGPRs: 16 waves per CU */
+#endif
+#define ZMT_WAVES4 __attribute__((amdgpu_waves_per_eu(ZD_WAVES, ZD_WAVES)))
 #endif
 /* records whose status is `want` (GPUMT_ST_OK after the probe, or ST_NEEDS_GENERAL after the small
  * variant) are decoded; their status becomes OK / an error / ST_NEEDS_GENERAL (small variant only) */
