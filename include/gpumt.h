@@ -154,7 +154,8 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
  * d_out_len[i] is the exact content size for frames that state one (what the probe returns); for a
  * frame without a content size (streaming writers, plain .zst files) the caller passes a capacity
  * there and the decoder replaces it by the decoded size.
- * Internal scratch: 128 KiB + 264 B per record.
+ * Internal scratch: GPUMT_ZSTD_DEC_SCRATCH (320 KiB) per record of a launch slice (at most 16384
+ * records, 5 GiB) + 8 B per record.
  */
 /* Bytes one zstd record slot occupies: room for the record + frame header and one padded area per
  * 128 KiB block (the blocks are compressed independently and then moved together), rounded to 256. */

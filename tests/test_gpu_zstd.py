@@ -99,6 +99,16 @@ def test_corrupt_unit_streams_status(eng):
             assert status[0] == 0 and out == want, pos
 
 
+def test_more_records_than_one_launch_slice(eng):
+    """The decoder's per-record scratch is sized for 16 384 records; a batch beyond that goes in
+    slices (gpumt_zstd_decompress_batch) and every record still lands where it belongs."""
+    data = cases.text(20000 * 1024 + 77, 33)
+    st, ro, rl = eng.compress_bytes(data, 1024, codec="zstd")
+    assert len(rl) == 20001
+    out, status = eng.decompress_bytes(st, ro, rl, codec="zstd")
+    assert (status == 0).all() and out == data
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_fuzz_encode_is_decompress_identical(eng, seed):
     import random

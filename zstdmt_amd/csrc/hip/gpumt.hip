@@ -696,7 +696,11 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 		return GPUMT_E_ARG;
 	if (use(h))
 		return GPUMT_E_HIP;
-	const size_t lit_bytes = nrec * (size_t)GPUMT_ZSTD_DEC_SCRATCH;
+	/* per-record scratch (literals + sequences decoded ahead) is what bounds a launch: records go
+	 * in slices of at most ZD_SLICE (5 GiB of scratch), each slice still 4x the resident waves */
+	const size_t ZD_SLICE = 16384;
+	const size_t slice = nrec < ZD_SLICE ? nrec : ZD_SLICE;
+	const size_t lit_bytes = slice * (size_t)GPUMT_ZSTD_DEC_SCRATCH;
 	if (want_scratch(h, 1, s, lit_bytes + nrec * 8 + 64))
 		return GPUMT_E_HIP;
 	u32 *chk_e = (u32 *)((u8 *)h->scratch[1][s] + lit_bytes), *chk_v = chk_e + nrec;
@@ -705,23 +709,27 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
 	}
 	PROF0(11);
-	if (h->profile == 5) {
-		hipLaunchKernelGGL(zmt_zstd_dec_kernel_prof, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
-				   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
-				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1][s], d_status, chk_e, chk_v,
-				   0u, h->d_prof);
-	} else {
-		/* small-table variant first (16 waves per CU); records that need the full-size tables
-		 * come back with status 101 and are decoded by the general variant (12 waves per CU) */
-		const u32 want = h->zdec_variant == 1 ? 0u : 101u;
-		if (h->zdec_variant != 1)
-			hipLaunchKernelGGL(zmt_zstd_dec_small_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
-					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
-					   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1][s], d_status, chk_e,
-					   chk_v);
-		hipLaunchKernelGGL(zmt_zstd_dec_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
-				   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off, d_rec_len, (u32)nrec,
-				   (u8 *)d_out, d_out_off, d_out_len, (u8 *)h->scratch[1][s], d_status, chk_e, chk_v, want);
+	for (size_t b = 0; b < nrec; b += slice) {
+		const size_t m = nrec - b < slice ? nrec - b : slice;
+		if (h->profile == 5) {
+			hipLaunchKernelGGL(zmt_zstd_dec_kernel_prof, dim3((unsigned)m), dim3(64), 0, h->st[s],
+					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
+					   (u8 *)d_out, d_out_off + b, d_out_len + b, (u8 *)h->scratch[1][s], d_status + b,
+					   chk_e + b, chk_v + b, 0u, h->d_prof);
+		} else {
+			/* small-table variant first (16 waves per CU); records that need the full-size tables
+			 * come back with status 101 and are decoded by the general variant (12 waves per CU) */
+			const u32 want = h->zdec_variant == 1 ? 0u : 101u;
+			if (h->zdec_variant != 1)
+				hipLaunchKernelGGL(zmt_zstd_dec_small_kernel, dim3((unsigned)m), dim3(64), 0, h->st[s],
+						   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
+						   (u8 *)d_out, d_out_off + b, d_out_len + b, (u8 *)h->scratch[1][s],
+						   d_status + b, chk_e + b, chk_v + b);
+			hipLaunchKernelGGL(zmt_zstd_dec_kernel, dim3((unsigned)m), dim3(64), 0, h->st[s],
+					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
+					   (u8 *)d_out, d_out_off + b, d_out_len + b, (u8 *)h->scratch[1][s], d_status + b,
+					   chk_e + b, chk_v + b, want);
+		}
 	}
 	/* XXH64 content checksums, for the frames that carry one */
 	hipLaunchKernelGGL(zmt_xxh64_verify_kernel, dim3((unsigned)((nrec * 4 + 255) / 256)), dim3(256), 0,
