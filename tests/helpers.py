@@ -470,3 +470,15 @@ def liblz4_frame(data: bytes, block_id=7, linked=1, content_size=0, checksum=1, 
     n = lz.LZ4F_compressFrame(dst, cap, data, len(data), C.byref(pr))
     assert n <= cap
     return dst.raw[:n]
+
+
+def dense_sequences(n, lits=b"aaaabbcd"):
+    """7-byte words from a small dictionary with one literal between them: the densest sequence
+    lists the device zstd encoder writes; lits=None makes the literals incompressible (raw sections)."""
+    import random
+    rng = random.Random(77)
+    words = [bytes(rng.randrange(256) for _ in range(7)) for _ in range(48)]
+    out = bytearray()
+    while len(out) < n:
+        out += rng.choice(words) + bytes([rng.choice(lits) if lits else rng.randrange(256)])
+    return bytes(out[:n])

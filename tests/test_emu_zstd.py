@@ -89,18 +89,10 @@ ENC_CASES = {
     "four_high_symbols": (131072, lambda: bytes(200 + (b & 3) for b in cases.rnd(100000, 5))),
     # the densest units the device encoder can write (7-byte matches, one literal between them:
     # ~16 K sequences per 128 KiB) through the decoder's look-ahead scratch
-    "dense_sequences": (1 << 20, lambda: _dense_sequences(150000)),
+    "dense_sequences": (1 << 20, lambda: H.dense_sequences(150000)),
+    # the same with literals that do not compress: raw literal sections, the blocks still form units
+    "dense_sequences_raw_literals": (1 << 20, lambda: H.dense_sequences(300000, None)),
 }
-
-
-def _dense_sequences(n):
-    import random
-    rng = random.Random(77)
-    words = [bytes(rng.randrange(256) for _ in range(7)) for _ in range(48)]
-    out = bytearray()
-    while len(out) < n:
-        out += rng.choice(words) + bytes([rng.choice(b"aaaabbcd")])
-    return bytes(out[:n])
 
 
 @pytest.mark.parametrize("name", sorted(ENC_CASES))

@@ -99,6 +99,28 @@ def test_corrupt_unit_streams_status(eng):
             assert status[0] == 0 and out == want, pos
 
 
+@pytest.mark.parametrize("lits", [b"aaaabbcd", None])
+def test_dense_units_and_their_damage(eng, lits):
+    """Dense sequence lists with Huffman-coded and with raw literal sections (both form units in
+    the decoder): content, and verdict parity with the oracle under bit flips."""
+    data = H.dense_sequences(900000, lits)
+    st, ro, rl = eng.compress_bytes(data, 1 << 20, codec="zstd")
+    out, status = eng.decompress_bytes(st, ro, rl, codec="zstd")
+    assert (status == 0).all() and out == data
+    assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
+    rng = np.random.default_rng(9)
+    for pos in sorted(set(rng.integers(12, len(st), 60).tolist())):
+        bad = bytearray(st)
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        bad = bytes(bad)
+        want = H.oracle_zstdmt_decompress(bad, len(data) + 64)
+        out, status = eng.decompress_bytes(bad, ro, rl, codec="zstd")
+        if want is None:
+            assert status[0] != 0, pos
+        else:
+            assert status[0] == 0 and out == want, pos
+
+
 def test_more_records_than_one_launch_slice(eng):
     """The decoder's per-record scratch is sized for 16 384 records; a batch beyond that goes in
     slices (gpumt_zstd_decompress_batch) and every record still lands where it belongs."""

@@ -488,6 +488,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 	u32 pre_left = 0, pre_lit = 0; /* blocks ahead whose literals are already decoded / where they start */
 	u32 sq_left = 0, sq_pos = 0; /* blocks (this one first) whose sequences are decoded / where they start */
 	bool unit_head = false;
+	u32 unit_n = 0; /* blocks behind a unit head whose sequence sections are listed in L.w */
 	u64 *seq_scratch = (u64 *)(lit_scratch + Z_BLOCK_MAX + 256u);
 	bool my_tab_ok = false; /* lanes 0..2: state of the LL / OF / ML table this lane builds */
 	bool my_tab_pre = false; /* ... and whether it currently holds the predefined distribution */
@@ -609,6 +610,52 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 			const u8 *lit = lit_scratch;
 			if (ltype == 0) {
 				lit = src + lhl;
+				/* Raw literals (a unit whose literals did not compress): the blocks that follow the
+				 * same way still share the predefined sequence tables; list them for the unit-wide
+				 * sequence decode below (same records as the Huffman look-ahead writes) */
+				if (sq_left == 0 && !last) {
+					u32 *pre = (u32 *)L.w;
+					wv_sync();
+					if (lane == 0) {
+						u32 n = 0, q = ip + bsize;
+						while (n < 15) {
+							if (flen - q < 8)
+								break;
+							const u8 *h = f + q;
+							const u32 bh2 = (u32)h[0] | (u32)h[1] << 8 | (u32)h[2] << 16;
+							const u32 bs2 = bh2 >> 3;
+							if (((bh2 >> 1) & 3) != 2 || bs2 > block_max || bs2 < 5 || flen - (q + 3) < bs2)
+								break;
+							const u32 b0 = h[3], sf2 = (b0 >> 2) & 3;
+							if ((b0 & 3) != 0)
+								break;
+							u32 rg, hl2;
+							if (sf2 == 1) {
+								rg = (b0 | (u32)h[4] << 8) >> 4;
+								hl2 = 2;
+							} else if (sf2 == 3) {
+								rg = (b0 | (u32)h[4] << 8 | (u32)h[5] << 16) >> 4;
+								hl2 = 3;
+							} else {
+								rg = b0 >> 3;
+								hl2 = 1;
+							}
+							if (rg > block_max || hl2 + rg > bs2)
+								break;
+							pre[4 * n] = q + 3 + hl2;
+							pre[4 * n + 1] = rg;
+							pre[4 * n + 3] = q + 3 + bs2;
+							n++;
+							q += 3 + bs2;
+							if (bh2 & 1)
+								break;
+						}
+						L.misc[ZM_A] = n;
+					}
+					wv_sync();
+					unit_n = L.misc[ZM_A];
+					unit_head = unit_n != 0;
+				}
 			} else if (ltype == 1) {
 				const u8 v = (u8)uld8(src + lhl);
 				for (u32 i = (u32)lane * 8; i < regen + 8; i += 512)
@@ -818,6 +865,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 						pre_lit = regen;
 						lit_done = true;
 						unit_head = npre != 0;
+						unit_n = npre;
 						wv_sync();
 						wave_mem_fence();
 					}
@@ -1092,10 +1140,10 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 				if (unit_head) {
 					unit_head = false;
 					sq_left = 0;
-					if (all_pre && pre_left) {
+					if (all_pre && unit_n) {
 						const u32 *pre = (const u32 *)L.w;
 						const u32 g = (u32)lane >> 2, sl = (u32)lane & 3;
-						bool act = g <= pre_left, gbad = false;
+						bool act = g <= unit_n, gbad = false;
 						u32 g_off = (u32)(src - f) + bs_off, g_len = bs_len, g_n = nseq;
 						if (g && act) {
 							const u32 s0 = pre[4 * (g - 1)] + pre[4 * (g - 1) + 1], bend = pre[4 * (g - 1) + 3];
@@ -1132,7 +1180,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 							if (bp < ll_log + of_log + ml_log)
 								gbad = true;
 						}
-						u32 ngrp = pre_left + 1;
+						u32 ngrp = unit_n + 1;
 						{
 							const u64 bm = wv_ballot(act && gbad);
 							if (bm)
