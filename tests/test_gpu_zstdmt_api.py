@@ -262,6 +262,29 @@ def test_decompress_plain_zst_streams(lib, name):
 
 
 @pytest.mark.skipif(H.libzstd_frame(b"x") is None, reason="libzstd not on this box")
+def test_mt_records_without_content_size(lib):
+    """pzstd-style records whose frames were streamed (no Frame_Content_Size): the reference grows
+    its output buffer (lib/zstd-mt_decompress.c:499-522); here the block headers bound the content
+    and the decoder reports the size.  Mixed with sized frames and a checksummed one."""
+    parts = [cases.text(300000, 61), cases.rnd(4000, 62) + bytes(90000), cases.text(1 << 20, 63), b"tail"]
+    frames = [H.libzstd_frame(parts[0], 1, content_size=0), H.libzstd_frame(parts[1], 3, checksum=1, content_size=0),
+              H.libzstd_frame(parts[2], 1), H.libzstd_frame(parts[3], 1, content_size=0)]
+    st = b"".join(b"\x50\x2A\x4D\x18" + (4).to_bytes(4, "little") + len(f).to_bytes(4, "little") + f for f in frames)
+    rv, out, io, stats = H.zstdmt_decompress_via(lib, st, threads=4)
+    assert rv == 0 and out == b"".join(parts)
+    assert stats == (4, len(st), len(out))
+    assert io.writes == [len(p) for p in parts]          # one fn_write per frame, its decoded size
+    if H.have_zref():
+        rv_r, out_r, _, stats_r = H.zstdmt_decompress_via(H.zref(), st, threads=4)
+        assert rv_r == 0 and out_r == out and stats_r == stats
+    # damage inside the checksummed size-less frame is still an error (block syntax or XXH64)
+    dmg = bytearray(st)
+    dmg[12 + len(frames[0]) + 12 + len(frames[1]) // 2] ^= 0x10
+    rv, _, _, _ = H.zstdmt_decompress_via(lib, bytes(dmg), threads=4)
+    assert rv == ERR(E_LIB)
+
+
+@pytest.mark.skipif(H.libzstd_frame(b"x") is None, reason="libzstd not on this box")
 def test_plain_zst_errors(lib):
     a = cases.text(200000, 91)
     f = H.libzstd_frame(a, 3, checksum=1)

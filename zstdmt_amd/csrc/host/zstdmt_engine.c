@@ -312,6 +312,7 @@ struct dslot {
 	dbuf status; /* u32[n], D2H                                                           */
 	dbuf out;    /* decoded chunks, D2H                                                   */
 	size_t nrec, in_bytes, out_bytes;
+	int unsized; /* a frame of the batch states no content size: out_len holds capacities, read back */
 };
 
 struct ZSTDCB_DCtx_s {
@@ -393,9 +394,12 @@ static size_t d_read_header(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, uint32_t *csize
 	return 0;
 }
 
+static size_t zstd_frame_extent(const uint8_t *p, size_t n, uint64_t *bound, int *sized);
+
 static size_t d_read_batch(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s, int *eof)
 {
 	s->nrec = 0;
+	s->unsized = 0;
 	s->in_bytes = 0;
 	s->out_bytes = 0;
 	while (s->nrec < BATCH_MAXREC) {
@@ -452,8 +456,20 @@ static size_t d_read_batch(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s,
 		ctx->insize += b.size;
 		ctx->frames++;
 		osz = zstd_content_size(rec + 12, csize);
-		if (osz == ~(uint64_t)0 || osz > 0x7FFFFFFFull) {
-			/* no content size: never written by zstd-mt; the reference would grow its buffer */
+		if (osz == ~(uint64_t)0) {
+			/* No content size: never written by zstd-mt, but pzstd-style writers that stream
+			 * their frames do it, and the reference just grows its buffer (:499-522).  The block
+			 * headers bound the content; the decoder replaces the capacity by the size. */
+			uint64_t bound = 0;
+			int sized = 0;
+			if (!zstd_frame_extent(rec + 12, csize, &bound, &sized) || sized) {
+				zstdmt_errcode = GPUMT_ST_BAD_FRAME;
+				return ZSTDCB_ERROR(compression_library);
+			}
+			osz = bound;
+			s->unsized = 1;
+		}
+		if (osz > 0x7FFFFFFFull) {
 			zstdmt_errcode = GPUMT_ST_UNSUPPORTED;
 			return ZSTDCB_ERROR(compression_library);
 		}
@@ -488,6 +504,8 @@ static size_t d_launch(ZSTDCB_DCtx *ctx, struct dslot *s)
 					  (uint32_t *)s->status.d, ks);
 	rc |= gpumt_stream_wait(g, 2, ks);
 	rc |= gpumt_memcpy_d2h(g, s->status.h, s->status.d, s->nrec * 4, 2);
+	if (s->unsized) /* capacities -> decoded sizes */
+		rc |= gpumt_memcpy_d2h(g, m_out_len(s, 0), m_out_len(s, 1), s->nrec * 4, 2);
 	if (s->out_bytes)
 		rc |= gpumt_memcpy_d2h(g, s->out.h, s->out.d, s->out_bytes, 2);
 	return rc ? ZSTDCB_ERROR(compression_library) : 0;
