@@ -17,7 +17,12 @@
  *     the wave then executes the 64 sequences in parallel: prefix sums give output and literal
  *     positions, every lane copies its own literals and match (8-byte unaligned global accesses),
  *     matches that read this batch's own output resolve in watermark rounds, long copies are
- *     done by the whole wave.
+ *     done by the whole wave;
+ *   - units: a block with a Huffman tree (or raw literals) followed by blocks with treeless (raw)
+ *     literals and predefined sequence tables -- what the device encoder writes per 128 KiB -- is
+ *     decoded side by side: up to 64 Huffman streams on 64 lanes, then up to 16 sequence
+ *     bitstreams on 16 x (LL, OF, ML) lanes into the record's scratch; the blocks then only
+ *     execute.  Anything else ends the unit and takes the per-block path above.
  */
 #include <cstddef>
 #include "lz4_common.h"
