@@ -23,6 +23,7 @@ void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
 void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *, u32 *, unsigned long long *, u32);
 void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, const u32 *, u32 *);
+void zmt_dec_gather_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, u32 *);
 void zmt_lz4_dec_batch(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u32 *);
 void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 void zmt_scan_kernel(const u32 *, u32, u64 *);
@@ -143,9 +144,14 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 			for (u32 r = 0; r < nrec; r++)
 				fprintf(stderr, "rec %u status=%u nblk=%u\n", r, status[r], rnb[r]);
 		}
-		emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{256, 1, 1}, [=]() {
-			zmt_dec_copy_kernel(stream, stream_bytes, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bixp, bntp, bolp, status);
-		});
+		if (variant == 4)
+			emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
+				zmt_dec_gather_kernel(stream, stream_bytes, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
+			});
+		else
+			emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{256, 1, 1}, [=]() {
+				zmt_dec_copy_kernel(stream, stream_bytes, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bixp, bntp, bolp, status);
+			});
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
 			zmt_lz4_dec_serial(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp, 100u);
 		});

@@ -12,7 +12,7 @@ from cases import CASES, KNOWN_HEX, rnd, text
 pytestmark = pytest.mark.gpu
 
 # decoder kernel variants under test (include/gpumt.h gpumt_set_variant "lz4_dec")
-VARIANTS = [0, 1, 2]   # 0 split pipeline (default), 1 serial, 2 fused batch kernel
+VARIANTS = [0, 1, 2, 4]   # 0 split pipeline, 1 serial, 2 fused batch kernel, 4 gather copy stage
 
 with open(os.path.join(H.GOLDEN_DIR, "manifest.json")) as _f:
     MAN = json.load(_f)["cases"]

@@ -34,7 +34,7 @@ for v in variants:
     st = eng.download(d_st, nrec * 4, np.uint32)
     ok = bool((eng.download(d_out, n) == hb).all())
     print(f"variant {v}: kernel {ms:.3f} ms  ({n/1e6/ms:.1f} GB/s out)  errors={int((st!=0).sum())} data_ok={ok}")
-    if v == 0:
+    if v in (0, 4):
         for xf in ([int(x) for x in os.environ.get("K2X", "0").split(",")] if os.environ.get("K2PROF") else []):
             eng.set_variant("k2x", xf)
             eng.set_variant("profile", 2)
@@ -43,13 +43,22 @@ for v in variants:
             L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); w = max(c[6], 1); st_ = max(c[4], 1)
             print(f"   K2 prof xflags={xf}: parse_ms={eng.timer_ms(14):.3f} waves={c[6]} steps/wave={c[4]/w:.0f} cycles/step total={c[0]/st_:.0f} refill={c[1]/st_:.0f} token={c[2]/st_:.0f} drain={c[3]/st_:.0f} slowloads/step={c[5]/st_:.2f} | token split: read={c[10]/st_:.0f} lit={c[11]/st_:.0f} ml+state={c[12]/st_:.0f} emit={c[2]/st_:.0f}")
             eng.set_variant("profile", 1); eng.set_variant("k2x", 0)
-        if os.environ.get("K3PROF"):
+        if os.environ.get("K3PROF") and v == 0:
             eng.set_variant("profile", 3)
             cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
             eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
             L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); nbat = nrec * 2 * 86
             nm = ["fields", "scan+cuts+reserve", "far-issue", "literals", "far-commit", "rounds", "flush", "loop/other"]
             print("   K3 prof (cycles per ~batch): " + ", ".join(f"{nm[i]}={c[i]/nbat:.0f}" for i in range(8)) + f" total={c[8]/nbat:.0f}")
+            eng.set_variant("profile", 1)
+        if os.environ.get("K3PROF") and v == 4:
+            eng.set_variant("profile", 3)
+            cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
+            eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
+            L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); rows = max(c[10], 1)
+            nm = ["step", "commit", "lookup", "bytes", "global", "write+sync", "fix", "carry+drain"]
+            print("   gather prof (cycles per row): " + ", ".join(f"{nm[i]}={c[i]/rows:.0f}" for i in range(8)) +
+                  f" total={c[8]/rows:.0f} | rows={c[10]} steps={c[11]} rows/step={c[10]/max(c[11],1):.2f} fixpasses/row={c[12]/rows:.2f} fences/wave={c[13]/max(c[9],1):.1f} cycles/step={c[0]/max(c[11],1):.0f}")
             eng.set_variant("profile", 1)
         print("   split: frames %.3f ms, parse %.3f ms, copy %.3f ms, xxh %.3f ms" % (eng.timer_ms(13), eng.timer_ms(14), eng.timer_ms(15), eng.timer_ms(12)))
     if v == 3:

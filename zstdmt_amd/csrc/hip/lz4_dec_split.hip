@@ -221,6 +221,16 @@ static __device__ __forceinline__ u32 ring_off(u32 g, u32 rb)
 	return d < P_RING ? d : d - P_RING;
 }
 
+/* four bytes at ring offset o (any alignment) as two ALIGNED dword reads + a funnel shift: a
+ * misaligned ds_read_b32 is replayed lane by lane on gfx950 (64 LDS cycles per wave instruction,
+ * tools/ubench/lds_ops.hip), an aligned one costs 2.5.  The 16-byte mirror behind the ring keeps
+ * the second dword inside the row. */
+static __device__ __forceinline__ u32 ring_ld32(const u8 *ring, u32 o)
+{
+	const u32 *w = (const u32 *)(ring + (o & ~3u));
+	return wv_alignbyte(w[1], w[0], o & 3);
+}
+
 extern "C" __global__ void __launch_bounds__(64)
 zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 		     const u64 *__restrict__ blk_coff, const u32 *__restrict__ blk_csize,
@@ -347,7 +357,7 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 		if (!done) {
 			const u32 gp = boff + pos;
 			const bool in1 = gp + 4 <= ghi && gp + P_RING >= ghi;
-			const u32 w = ld32u(myring + (in1 ? ring_off(gp, rb) : 0)); /* may run into the mirror */
+			const u32 w = ring_ld32(myring, in1 ? ring_off(gp, rb) : 0); /* may run into the mirror */
 			const u32 tokb = w & 255;
 			const bool lx = (tokb >> 4) == 15;
 			const u32 b1 = (w >> 8) & 255;
@@ -355,7 +365,7 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 			const u32 lend = pos + 1 + (lx ? 1 : 0) + lit;
 			const u32 g2 = boff + lend;
 			const bool in2 = g2 + 4 <= ghi && g2 + P_RING >= ghi;
-			const u32 w2 = ld32u(myring + (in2 ? ring_off(g2, rb) : 0));
+			const u32 w2 = ring_ld32(myring, in2 ? ring_off(g2, rb) : 0);
 			{ u64 t_ = KT(); c_t1 += t_ - tk0; tk0 = t_; }
 			const bool mx = (tokb & 15) == 15;
 			const u32 b2 = (w2 >> 16) & 255;

@@ -139,6 +139,49 @@ static __device__ __forceinline__ u32 wv_scan_incl(u32 v)
 }
 #endif
 
+/* inclusive prefix maximum (unsigned) over the 64 lanes; lane-1's value with `fill` for lane 0;
+ * bytes sh.. of the 64-bit value hi:lo (sh = 0..3) */
+#ifdef ZMT_EMU
+static inline u32 wv_scan_max_incl(u32 v)
+{
+	int l = wv_lane();
+	for (int d = 1; d < 64; d <<= 1) {
+		u32 o = wv_shfl(v, l - d);
+		if (l >= d && o > v)
+			v = o;
+	}
+	return v;
+}
+static inline u32 wv_shr1(u32 v, u32 fill)
+{
+	int l = wv_lane();
+	u32 o = wv_shfl(v, l - 1);
+	return l ? o : fill;
+}
+static inline u32 wv_alignbyte(u32 hi, u32 lo, u32 sh) { return (u32)((((u64)hi << 32) | lo) >> (8 * (sh & 3))); }
+#else
+static __device__ __forceinline__ u32 wv_umax(u32 a, u32 b) { return a > b ? a : b; }
+static __device__ __forceinline__ u32 wv_scan_max_incl(u32 v)
+{
+	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false)); /* row_shr:1 */
+	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false)); /* row_shr:2 */
+	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false)); /* row_shr:4 */
+	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false)); /* row_shr:8 */
+	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false)); /* row_bcast:15 */
+	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false)); /* row_bcast:31 */
+	return v;
+}
+/* wave_shr:1 (gfx9 DPP): lane l receives lane l-1's value, lane 0 keeps `fill` */
+static __device__ __forceinline__ u32 wv_shr1(u32 v, u32 fill)
+{
+	return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
+}
+static __device__ __forceinline__ u32 wv_alignbyte(u32 hi, u32 lo, u32 sh)
+{
+	return (u32)__builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+#endif
+
 /* unaligned little-endian accesses (gfx950 global memory handles misaligned dwords natively) */
 static __device__ __forceinline__ u32 ld32u(const u8 *p)
 {
