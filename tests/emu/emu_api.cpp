@@ -23,6 +23,7 @@ void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
 void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *, u32 *, unsigned long long *, u32);
 void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, const u32 *, u32 *);
+void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *, u32 *);
 void zmt_dec_gather_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, u32 *);
 void zmt_lz4_dec_batch(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u32 *);
 void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
@@ -106,6 +107,9 @@ void emu_lz4_probe_sizes(const u8 *stream, const u64 *rec_off, const u32 *rec_le
 	emu::launch(dim3{1, 1, 1}, dim3{1024, 1, 1}, [=]() { zmt_scan_kernel(out_len, nrec, out_off); });
 }
 
+static int g_parse_variant = 0; /* 0 = lane-per-block kernel (default), 3 = zmt_dec_parse3_kernel */
+void emu_set_parse_variant(int v) { g_parse_variant = v; }
+
 void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, const u64 *rec_off,
 			      const u32 *rec_len, u32 nrec, u8 *out, u64 out_bytes, const u64 *out_off,
 			      u32 *out_len, u32 *status)
@@ -135,9 +139,14 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 		emu::launch(dim3{(nrec + 255) / 256, 1, 1}, dim3{256, 1, 1}, [=]() {
 			zmt_dec_frames_kernel(stream, rec_off, rec_len, nrec, out_len, blk0p, bcop, bcsp, rnbp, rflp, status, cep, cvp);
 		});
-		emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
-			zmt_dec_parse_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bixp, bntp, bolp, nullptr, 0);
-		});
+		if (g_parse_variant == 3)
+			emu::launch(dim3{(u32)((nblk_max + 3) / 4), 1, 1}, dim3{256, 1, 1}, [=]() {
+				zmt_dec_parse3_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bixp, bntp, bolp);
+			});
+		else
+			emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
+				zmt_dec_parse_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bixp, bntp, bolp, nullptr, 0);
+			});
 		if (getenv("ZMT_EMU_DEBUG")) {
 			for (size_t b = 0; b < blk0[nrec]; b++)
 				fprintf(stderr, "blk %zu coff=%llu csize=%x ntok=%u olen=%u\n", b, (unsigned long long)bco[b], bcs[b], bnt[b], bol[b]);

@@ -71,9 +71,10 @@ def walk_records(stream: bytes):
     return np.array(offs, np.uint64), np.array(lens, np.uint32)
 
 
-def decompress(stream: bytes, variant: int = 0, rec=None):
-    """-> (content bytes, status[n])"""
+def decompress(stream: bytes, variant: int = 0, rec=None, parse: int = 0):
+    """-> (content bytes, status[n]); parse 0 = lane-per-block token walk, 3 = zmt_dec_parse3_kernel"""
     L = lib()
+    L.emu_set_parse_variant(C.c_int(parse))
     ro, rl = rec if rec is not None else walk_records(stream)
     nrec = len(ro)
     sbuf = np.frombuffer(stream + b"\0" * 512, np.uint8).copy()

@@ -39,7 +39,7 @@ def test_emu_compress_bit_exact(name, variant):
     assert H.sha256(stream) == MAN[name]["out_sha256"]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])
 @pytest.mark.parametrize("name", SMALL)
 def test_emu_decompress(name, variant):
     chunk, thunk = CASES[name]
@@ -50,7 +50,17 @@ def test_emu_decompress(name, variant):
     assert out == data
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("name", ["text_128k", "text_64k_p20", "lcg_128k", "zeros_70000", "period_65535", "mixed_text_rnd", "hello_5", "empty"])
+def test_emu_decompress_parse3(name):
+    """the wave-per-block token kernel (lz4_dec_parse.hip) in front of the gather copy stage"""
+    chunk, thunk = CASES[name]
+    data = thunk()
+    out, status = E.decompress(H.oracle_compress(data, chunk), 4, parse=3)
+    assert status.tolist() == [0] * len(status)
+    assert out == data
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 4])
 @pytest.mark.parametrize("mutate,code", [("magic", 2), ("hc", 2), ("blocksize", 3), ("checksum", 5),
                                          ("skipmagic", 1), ("skiplen", 1), ("offset0", 3)])
 def test_emu_corrupt_streams(mutate, code, variant):

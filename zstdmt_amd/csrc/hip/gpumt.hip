@@ -37,6 +37,8 @@ __global__ void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, 
 __global__ void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
 				    const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 				    const u32 *, const u32 *, const u32 *, u32 *);
+__global__ void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *, u32 *,
+				      u32 *, u32 *);
 __global__ void zmt_dec_gather_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
 				      const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 				      const u32 *, const u32 *, u32 *);
@@ -87,6 +89,7 @@ struct gpumt_ctx {
 					   * batches launched on different streams can overlap */
 	size_t scratch_bytes[2][GPUMT_NSTREAMS];
 	int dec_variant;
+	int parse_variant; /* 0 = zmt_dec_parse3_kernel (16-byte loads, several tokens per load), 1 = LDS-ring design */
 	int enc_variant; /* 0 = v3 (LDS input ring, small batches, 17-bit table), 1 = v1, 2 = v2 */
 	unsigned long long *d_prof; /* 16 phase counters of the profiling decoder */
 	int xflags;  /* experiment switches of the parse kernel (developer) */
@@ -569,6 +572,11 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 				   (const u64 *)blk0, bco, bcs, rnb, rfl, d_status, ce, cv);
 		PROF1(13);
 		PROF0(14);
+		if (h->parse_variant == 3 && h->profile != 2)
+			hipLaunchKernelGGL(zmt_dec_parse3_kernel, dim3((unsigned)((nblk_max + 3) / 4)), dim3(256), 0,
+					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
+					   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bix, bnt, bol);
+		else
 		hipLaunchKernelGGL(zmt_dec_parse_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
 				   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
 				   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bix, bnt, bol,
@@ -864,6 +872,9 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	if (!strcmp(what, "lz4_dec")) {
 		prev = h->dec_variant;
 		h->dec_variant = variant;
+	} else if (!strcmp(what, "lz4_parse")) {
+		prev = h->parse_variant;
+		h->parse_variant = variant;
 	} else if (!strcmp(what, "lz4_enc")) {
 		prev = h->enc_variant;
 		h->enc_variant = variant;

@@ -746,7 +746,7 @@ copy_body(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_bas
 			{
 				/* fast path, branch-free: two LDS dword reads; a 255 continuation byte or a
 				 * sequence outside the staged window takes the generic path (rare) */
-				const u32 w = ld32u(cb + (staged ? qr : 0));
+				const u32 w = ring_ld32(cb, staged ? qr : 0); /* aligned pair + funnel shift (see ring_ld32) */
 				const u32 tokb = w & 255;
 				const bool lx = (tokb >> 4) == 15;
 				const u32 b1 = (w >> 8) & 255;
@@ -754,7 +754,7 @@ copy_body(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_bas
 				const u32 h = q + 1 + (lx ? 1 : 0);
 				const u32 lend = h + l_;
 				const bool st2 = staged && lend - cs0 + 4 <= CSTAGE;
-				const u32 w2 = ld32u(cb + (st2 ? lend - cs0 : 0));
+				const u32 w2 = ring_ld32(cb, st2 ? lend - cs0 : 0);
 				const bool mx = (tokb & 15) == 15;
 				const u32 b2 = (w2 >> 16) & 255;
 				const bool fast = staged && !(lx && b1 == 255) && (is_last || (st2 && !(mx && b2 == 255)));
