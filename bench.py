@@ -1,27 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- lz4-mt hot path on MI355X: compress + decompress of the synthetic enwik-style buffer.
+"""bench.py -- the lz4-mt / zstd-mt / brotli-mt hot path on MI355X, device-resident, with roofline.
 
-Workload (BASELINE.json configs[1]): lz4-mt level 1, 8 GiB enwik-style synthetic text per GPU,
-128 KiB chunks (65 536 chunks -> 65 536 records).  One "step" = one full pass of the hot path over
-that buffer, inputs already resident in HBM:
+Default run (what the driver times): BASELINE.json configs[1] -- lz4-mt level 1, 8 GiB enwik-style
+synthetic text, 128 KiB chunks (65 536 records).  One "step" = one full pass of the hot path over the
+buffer, inputs already resident in HBM:
 
     compress_batch (XXH32 of every chunk + bit-exact LZ4 frame encode into per-chunk slots)
     -> compact (scan of record sizes + ordered pack into the MT stream)
     -> probe_sizes (content-size fields + scan)
     -> decompress_batch (frame decode + XXH32 content-checksum verification)
 
-value = uncompressed MB (1e6 B) round-tripped per second, whole job (all ranks).  Per-direction
-rates, per-kernel HIP-event times and the HBM roofline of the kernels are carried alongside.
+`value` = uncompressed MB (1e6 B) round-tripped per second, whole job (all ranks).  Per-direction
+rates, per-kernel HIP-event times and the HBM roofline of the kernels ride along, and -- on the
+default single-GPU run -- short legs of the other BASELINE configs under "configs": zstd-mt level 1
+(configs[3]), brotli-mt decompress (configs[4]) and the PCIe-inclusive drop-in APIs (LZ4MT_* /
+ZSTDCB_* / BROTLIMT_* with memcpy callbacks), each with its own roofline / cpu_baseline.
 
-Multi-GPU: chunks are independent, so each rank takes its own 8 GiB shard (weak scaling); the only
-exchange is the all-gather of per-rank stream sizes that gives every rank its offset in the final
-stream (frame reassembly); `--gather` additionally times the RCCL gather of the compressed
-segments to rank 0 (reported separately).
+Multi-GPU (`--gpus N`): bench.py starts N ranks itself (torch.distributed.run, one process per GPU,
+RCCL) unless it already runs under a launcher (RANK in the environment, which is how the driver
+starts it).  Chunks are independent, so rank r takes the contiguous chunk range shard_range(...) of
+ONE `--gib` buffer (`--scaling strong`, the default: BASELINE's metric is one 8 GiB job at 1/2/4/8
+GPUs) or its own `--gib` buffer (`--scaling weak`).  The only exchange on the path is the all-gather
+of the per-rank segment sizes (-> byte offsets of the segments in the final stream, included in the
+timed region); `--gather` additionally times the RCCL gather of the segments to rank 0 and reports
+it as gather_ms / value_with_gather, never as `value`.
+`--mode decompress` = configs[2] (decompress only: the records are written untimed, then timed).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -34,6 +43,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK = 8.0e12        # B/s, MI355X spec (MI355X_MICROARCH.md)
 HBM_COPY = 6.29e12       # measured float4 copy ceiling, same guide
 SEED = 20260926
+TRAFFIC_FILE = os.path.join("profiles", "pmc_traffic.json")
 
 
 def parse():
@@ -41,19 +51,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--gib", type=float, default=8.0, help="uncompressed GiB per GPU")
+    ap.add_argument("--gib", type=float, default=8.0,
+                    help="uncompressed GiB: of the whole job (--scaling strong) or per GPU (weak)")
     ap.add_argument("--codec", choices=("lz4", "zstd", "brotli"), default="lz4",
                     help="lz4 = BASELINE configs[1] (the metric's config); zstd = configs[3], zstd-mt level 1; "
                          "brotli = configs[4], brotli-mt decompress of level-1 streams at 1 MiB chunks")
-    ap.add_argument("--chunk", type=int, default=0, help="0 = 128 KiB for lz4 (configs[1]), 1 MiB for zstd (level-1 default)")
+    ap.add_argument("--mode", choices=("roundtrip", "decompress"), default="roundtrip",
+                    help="decompress = BASELINE configs[2]: only the decompress leg is timed")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--chunk", type=int, default=0, help="0 = 128 KiB for lz4 (configs[1]), 1 MiB for zstd / brotli")
     ap.add_argument("--dec-variant", type=int, default=0)
     ap.add_argument("--enc-variant", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-mib", type=int, default=2048, help="cpu_baseline sample size")
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of segments")
-    ap.add_argument("--verify", action="store_true", help="download and compare the round trip")
+    ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of segments to rank 0")
+    ap.add_argument("--no-verify", dest="verify", action="store_false",
+                    help="skip the byte-for-byte comparison of the round trip (on by default)")
+    ap.add_argument("--only", action="store_true", help="main leg only: no zstd / brotli / api legs under 'configs'")
+    ap.add_argument("--extra-gib", type=float, default=2.0, help="size of the extra legs of the default run")
     ap.add_argument("--no-encoder", action="store_true",
                     help="--codec brotli: skip the device-encoder leg (profiling runs of the decoder alone)")
+    ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="start the ranks, report who runs where (gloo, no GPU touched) and exit")
     return ap.parse_args()
 
 
@@ -63,11 +83,26 @@ def tools():
     return t
 
 
-def cpu_baseline(args):
-    """oracle/_ref (reference sources + liblz4) if present, else the oracle port; bounded sample."""
+def spawn(args):
+    """--gpus N without a launcher: start N ranks of this script on this node (one per GPU)."""
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(codec, chunk, cpu_mib):
+    """oracle/_ref (reference sources + the image's codec library) if present, else the oracle port;
+    bounded sample, rank 0 at N=1 only."""
     exe = os.path.join(ROOT, "oracle", "cpu_bench")
-    zstd = args.codec == "zstd"
-    brotli = args.codec == "brotli"
+    zstd = codec == "zstd"
+    brotli = codec == "brotli"
     ref = os.path.join(ROOT, "oracle", "_ref", "libbrotlimt_ref.so" if brotli else
                        "libzstdmt_ref.so" if zstd else "liblz4mt_ref.so")
     if not os.path.exists(exe):
@@ -78,77 +113,118 @@ def cpu_baseline(args):
     kind = "reference" if os.path.exists(ref) else "port"
     if (zstd or brotli) and kind == "port":
         return {"value": None, "unit": "MB/s", "cores": threads, "kind": "reference",
-                "error": f"{os.path.basename(ref)} not present (the {args.codec} oracle has no compressor)"}
-    n = args.cpu_mib << 20
+                "error": f"{os.path.basename(ref)} not present (the {codec} oracle has no compressor)"}
+    n = cpu_mib << 20
     try:
         out = subprocess.check_output([exe, "reference-brotli" if brotli else "reference-zstd" if zstd else kind,
                                        ref if kind == "reference" else "-", str(n),
-                                       str(args.chunk), str(threads), str(SEED)], timeout=600)
+                                       str(chunk), str(threads), str(SEED)], timeout=600)
         r = json.loads(out)
     except Exception as e:  # report, never hide
         return {"value": None, "unit": "MB/s", "cores": threads, "kind": kind, "error": repr(e)}
     if brotli:
         return {"value": r["decompress_MBps"], "unit": "MB/s", "cores": threads, "kind": kind,
                 "compress_MBps": r["compress_MBps"], "decompress_MBps": r["decompress_MBps"], "host_cpus": cores,
-                "sample": f"{args.cpu_mib} MiB of the same synthetic text, {args.chunk}-byte chunks, level 1: "
+                "sample": f"{cpu_mib} MiB of the same synthetic text, {chunk}-byte chunks, level 1: "
                           f"BROTLIMT_decompressDCtx of the stream BROTLIMT_compressCCtx wrote, memcpy "
                           f"callbacks, T={threads}"}
     return {"value": r["roundtrip_MBps"], "unit": "MB/s", "cores": threads, "kind": kind,
             "compress_MBps": r["compress_MBps"], "decompress_MBps": r["decompress_MBps"],
             "host_cpus": cores,
-            "sample": f"{args.cpu_mib} MiB of the same synthetic text, {args.chunk}-byte chunks, "
+            "sample": f"{cpu_mib} MiB of the same synthetic text, {chunk}-byte chunks, "
                       f"{'ZSTDCB' if zstd else 'LZ4MT'}_compressCCtx+decompressDCtx (level 1) with memcpy "
                       f"callbacks, T={threads}"}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or "RANK" in os.environ:
-        # launched by torch.distributed.run: one process per GPU, RCCL ("nccl") process group.
-        # torch must be imported BEFORE the native library so both share one HIP runtime.
+class Ctx:
+    """what every leg needs: engine, rank layout, process group"""
+
+    def __init__(self, args, eng, rank, world, dist):
+        self.args, self.eng, self.rank, self.world, self.dist = args, eng, rank, world, dist
+
+    def barrier(self):
+        self.eng.sync()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.eng.sync()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
         import torch
-        import torch.distributed as dist_
-        dist = dist_
-        torch.cuda.set_device(local)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        t = torch.tensor([x], device="cuda", dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
-    import zstdmt_amd as z
-    eng = z.Engine(local)
-    L, h = eng.L, eng.h
-    eng.set_variant("lz4_dec", args.dec_variant)
-    eng.set_variant("lz4_enc", args.enc_variant)
-    eng.set_variant("profile", 1)
+    def sum_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], device="cuda", dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
 
-    zstd = args.codec == "zstd"
-    if args.codec == "brotli":
-        return bench_brotli(args, eng, rank, world, dist)
-    if not args.chunk:
-        args.chunk = (1 << 20) if zstd else 131072
-    n = int(args.gib * (1 << 30)) // args.chunk * args.chunk
-    chunk = args.chunk
-    nrec = eng.record_count(n, chunk)
-    stride = eng.zstd_slot_stride(chunk) if zstd else eng.slot_stride(chunk)
+    def all_true(self, ok):
+        return self.sum_over_ranks(0.0 if ok else 1.0) == 0.0
 
-    # ---- synthetic input, generated on the host in 256 MiB pieces, uploaded once ----
+
+def traffic_table(gib, chunk, want_chunk):
+    """PMC HBM traffic per launch from the committed summary of separate rocprofv3 --pmc passes
+    (tools/profile_round.sh): valid for the 8 GiB single-GPU shape only."""
+    tf = os.path.join(ROOT, TRAFFIC_FILE)
+    if os.path.exists(tf) and abs(gib - 8.0) < 1e-9 and chunk == want_chunk:
+        with open(tf) as f:
+            return json.load(f).get("per_launch_bytes_8gib", {})
+    return {}
+
+
+def shard(args, world, rank, chunk):
+    """-> (bytes of this rank, offset of this rank in the synthetic corpus, total bytes of the job)"""
+    total = int(args.gib * (1 << 30)) // chunk * chunk
+    if world == 1:
+        return total, 0, total
+    if args.scaling == "weak":
+        return total, rank * total, total * world
+    from zstdmt_amd.shard import shard_range
+    lo, hi = shard_range(total // chunk, rank, world)
+    return (hi - lo) * chunk, lo * chunk, total
+
+
+def generate(ctx, n, corpus_off):
+    """synthetic text, generated on the host in 256 MiB pieces, uploaded once"""
+    eng, L = ctx.eng, ctx.eng.L
     d_in = eng.alloc(n + 64)
     piece = 256 << 20
-    hbuf = np.empty(min(piece, n), np.uint8)
+    hbuf = np.empty(min(piece, max(n, 1)), np.uint8)
     T = tools()
-    gen_threads = max(1, (os.cpu_count() or 1) // max(1, world))
+    gen_threads = max(1, (os.cpu_count() or 1) // max(1, ctx.world))
     t0 = time.time()
     for off in range(0, n, piece):
         m = min(piece, n - off)
-        # each rank generates a different part of the (conceptually world*n byte) corpus
-        T.zmt_gen_text(hbuf.ctypes.data, m, SEED, rank * n + off, gen_threads)
-        eng._ck(L.gpumt_memcpy_h2d(h, d_in.ptr + off, hbuf.ctypes.data, m, 0), "h2d")
+        T.zmt_gen_text(hbuf.ctypes.data, m, SEED, corpus_off + off, gen_threads)
+        eng._ck(L.gpumt_memcpy_h2d(eng.h, d_in.ptr + off, hbuf.ctypes.data, m, 0), "h2d")
         eng.sync(0)
-    gen_s = time.time() - t0
+    return d_in, time.time() - t0
 
+
+def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True, main=True):
+    """configs[1] (lz4), configs[2] (lz4 --mode decompress), configs[3] (zstd)"""
+    args, eng, rank, world, dist = ctx.args, ctx.eng, ctx.rank, ctx.world, ctx.dist
+    zstd = codec == "zstd"
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    chunk = args.chunk if (args.chunk and main) else ((1 << 20) if zstd else 131072)
+    saved_gib = args.gib
+    if gib_args is not None:
+        args.gib = gib_args
+    n, corpus_off, total_n = shard(args, world, rank, chunk)
+    gib = args.gib
+    args.gib = saved_gib
+    dec_only = args.mode == "decompress" and main
+    nrec = eng.record_count(n, chunk)
+    stride = eng.zstd_slot_stride(chunk) if zstd else eng.slot_stride(chunk)
+
+    d_in, gen_s = generate(ctx, n, corpus_off)
     d_slots = eng.alloc(nrec * stride)
     d_rl = eng.alloc(nrec * 4)
     d_ro = eng.alloc((nrec + 1) * 8)
@@ -157,8 +233,9 @@ def main():
     d_oo = eng.alloc((nrec + 1) * 8)
     d_st = eng.alloc(nrec * 4)
     d_out = eng.alloc(n + 64)
+    bufs = [d_in, d_slots, d_rl, d_ro, d_stream, d_ol, d_oo, d_st, d_out]
 
-    def step():
+    def compress():
         eng.timer_start(1)
         if zstd:
             eng.zstd_compress(d_in, n, chunk, d_slots, stride, d_rl)
@@ -168,6 +245,8 @@ def main():
         eng.timer_start(2)
         eng.lz4_compact(d_slots, stride, d_rl, nrec, d_stream, d_ro)
         eng.timer_stop(2)
+
+    def decompress():
         eng.timer_start(3)
         if zstd:
             eng.zstd_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo, d_st)
@@ -177,195 +256,149 @@ def main():
             eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st)
         eng.timer_stop(3)
 
-    def barrier():
-        eng.sync()
-        if dist is not None:
-            dist.barrier()
-        eng.sync()
+    seg_off = [0]
 
-    for _ in range(args.warmup):
+    def step():
+        if not dec_only:
+            compress()
+        decompress()
+        if dist is not None and not dec_only:
+            # frame reassembly: every rank learns the byte offset of its segment in the final stream
+            from zstdmt_amd.shard import exchange_segment_sizes
+            eng.sync(0)
+            total_c = int(eng.download(d_ro, 8, np.uint64, offset=nrec * 8)[0])
+            _sizes, seg_off[0] = exchange_segment_sizes(total_c, device="cuda")
+
+    if dec_only:
+        compress()                     # the records to decode: written once, untimed
+        eng.sync()
+    for _ in range(warmup):
         step()
-    barrier()
+    ctx.barrier()
     acc = {}
+    slots = (("compress", 1), ("compact", 2), ("decompress", 3), ("k_lz4_enc", 9),
+             ("k_scan_compact", 10), ("k_lz4_dec", 11))
+    if not zstd:
+        slots += (("k_xxh32_c", 8), ("k_xxh32_d", 12), ("k_dec_frames", 13), ("k_dec_parse", 14),
+                  ("k_dec_copy", 15))
+    if dec_only:
+        slots = tuple(s for s in slots if s[0] not in ("compress", "compact", "k_lz4_enc", "k_scan_compact", "k_xxh32_c"))
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
         eng.sync(0)
-        # slots 1-3: API-level legs; 8..13: individual kernels (profile mode)
-        slots = (("compress", 1), ("compact", 2), ("decompress", 3), ("k_lz4_enc", 9),
-                 ("k_scan_compact", 10), ("k_lz4_dec", 11))
-        if not zstd:
-            slots += (("k_xxh32_c", 8), ("k_xxh32_d", 12), ("k_dec_frames", 13), ("k_dec_parse", 14),
-                      ("k_dec_copy", 15))
+        # slots 1-3: API-level legs; 8..15: individual kernels (HIP events on the launching stream)
         for name, slot in slots:
             acc[name] = acc.get(name, 0.0) + eng.timer_ms(slot)
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tw = torch.tensor([wall], device="cuda")
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
+    ctx.barrier()
+    wall = ctx.max_over_ranks(time.perf_counter() - t0)
 
-    ms = {k: v / args.steps for k, v in acc.items()}
+    ms = {k: v / steps for k, v in acc.items()}
     total_c = int(eng.download(d_ro, 8, np.uint64, offset=nrec * 8)[0])
     status = eng.download(d_st, nrec * 4, np.uint32)
-    bad = int((status != 0).sum())
-
-    # ---- frame reassembly across ranks: sizes all-gather (-> offsets), optional bulk gather ----
-    gather_ms = None
-    seg_off = 0
-    if dist is not None:
-        from zstdmt_amd.shard import exchange_segment_sizes
-        sizes, seg_off = exchange_segment_sizes(total_c, device="cuda")
-        if args.gather:
-            gather_ms = rccl_gather(eng, dist, d_stream, sizes, rank, world)
-
-    ok = True
+    bad = int(ctx.sum_over_ranks(float((status != 0).sum())))
+    ok = None
     if args.verify:
-        a = eng.download(d_in, n)
-        b = eng.download(d_out, n)
-        ok = bool((a == b).all())
+        ok = ctx.all_true(eng.equal(d_in, d_out, n))
 
+    gather_ms = None
+    if dist is not None and args.gather and main:
+        from zstdmt_amd.shard import exchange_segment_sizes
+        sizes, _ = exchange_segment_sizes(n if dec_only else total_c, device="cuda")
+        gather_ms = rccl_gather(eng, dist, d_out if dec_only else d_stream, sizes, rank, world)
+    Cb_all = ctx.sum_over_ranks(float(total_c))
+    for b in bufs:
+        b.free()
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
 
-    U = float(n)
+    U = float(n)                       # this rank's bytes: kernel times below are this rank's
     Cb = float(total_c)
-    alg = U + Cb                              # algorithmic bytes either direction
-    t_c = (ms["compress"] + ms["compact"]) * 1e-3
+    alg = U + Cb                       # algorithmic bytes either direction
+    U_all = float(total_n)
+    step_s = wall / steps
     t_d = ms["decompress"] * 1e-3
-    if zstd:
-        return report_zstd(args, eng, world, wall, ms, U, Cb, nrec, chunk, bad, ok, gen_s, seg_off, gather_ms, dist)
-    kern = {}
-    split = args.dec_variant == 0
-    ntok_bytes = 0.0   # token list written by the parse kernel and read by the copy kernel
-    for k, byt in (("k_xxh32_c", U), ("k_lz4_enc", U + Cb), ("k_scan_compact", 2 * Cb),
-                   ("k_lz4_dec", U + Cb), ("k_xxh32_d", U), ("k_dec_frames", 0.0),
-                   ("k_dec_parse", Cb), ("k_dec_copy", U + Cb)):
-        if k.startswith("k_dec_") and not split:
-            continue
-        t = ms[k] * 1e-3
-        kern[k] = {"ms": round(ms[k], 4), "alg_bytes": byt,
-                   "GBps": round(byt / t / 1e9, 2) if t > 0 else None}
-    dom = max(("k_lz4_enc", "k_lz4_dec", "k_xxh32_c", "k_xxh32_d", "k_scan_compact"),
-              key=lambda k: ms[k])
-    traffic = {}
-    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tf):
-        with open(tf) as f:
-            traffic = json.load(f).get("per_launch_bytes_8gib", {})
+    t_c = (ms["compress"] + ms["compact"]) * 1e-3 if not dec_only else None
+    want_chunk = (1 << 20) if zstd else 131072
+    traffic = traffic_table(gib if world == 1 else -1, chunk, want_chunk)
+    split = args.dec_variant in (0, 4)
 
-    def roof(k):
-        t = ms[k] * 1e-3
-        a = kern[k]["alg_bytes"] / t / 1e9
-        kname = {"k_lz4_enc": {0: "zmt_lz4_enc3_p17_kernel" if 65536 < chunk <= 131072 else
-                                   ("zmt_lz4_enc3_u16_kernel" if chunk <= 65536 else "zmt_lz4_enc3_u32_kernel"),
-                               1: "zmt_lz4_enc_v1_kernel", 2: "zmt_lz4_enc_kernel"}[args.enc_variant],
-                 "k_lz4_dec": ("zmt_dec_frames+parse+copy_kernel" if split else "zmt_lz4_dec_*"),
-                 "k_xxh32_c": "zmt_xxh32_kernel", "k_xxh32_d": "zmt_xxh32_kernel",
-                 "k_scan_compact": "zmt_compact_kernel", "k_dec_copy": "zmt_dec_copy_kernel",
-                 "k_dec_parse": "zmt_dec_parse_kernel"}[k]
-        return {"kernel": kname,
-                "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+    def roof(kname, t_ms, alg_bytes, pmc_names):
+        t = t_ms * 1e-3
+        a = alg_bytes / t / 1e9 if t > 0 else 0.0
+        tr = [traffic.get(k) for k in pmc_names if traffic.get(k) is not None]
+        return {"kernel": kname, "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(a * 1e9 / HBM_PEAK, 5), "frac_of_copy_ceiling": round(a * 1e9 / HBM_COPY, 5),
-                "alg_bytes_per_launch": kern[k]["alg_bytes"], "avg_launch_ms": round(ms[k], 4),
-                "traffic": (traffic.get(kname) if abs(args.gib - 8.0) < 1e-9 else None)}
+                "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t_ms, 4),
+                "traffic": sum(tr) if tr else None,
+                "traffic_source": (TRAFFIC_FILE + " (separate rocprofv3 --pmc passes of this command, not this run)")
+                if tr else None}
 
-    step_s = wall / args.steps
+    kern = {k: {"ms": round(v, 4)} for k, v in ms.items() if k.startswith("k_")}
+    if zstd:
+        name, what = "zstd-mt level 1", "zstd-mt -1"
+        r_enc = None if dec_only else roof("zmt_zstd_enc_kernel(+assemble)", ms["k_lz4_enc"], alg,
+                                           ("zmt_zstd_enc_kernel", "zmt_zstd_assemble_kernel"))
+        r_dec = roof("zmt_zstd_dec_small_kernel(+zmt_zstd_dec_kernel for frames with full-size tables)",
+                     ms["k_lz4_dec"], alg, ("zmt_zstd_dec_small_kernel", "zmt_zstd_dec_kernel"))
+    else:
+        name, what = "lz4-mt", "lz4-mt -1"
+        ek = {0: "zmt_lz4_enc3_p17_kernel" if 65536 < chunk <= 131072 else
+              ("zmt_lz4_enc3_u16_kernel" if chunk <= 65536 else "zmt_lz4_enc3_u32_kernel"),
+              1: "zmt_lz4_enc_v1_kernel", 2: "zmt_lz4_enc_kernel"}[args.enc_variant]
+        r_enc = None if dec_only else roof(ek, ms["k_lz4_enc"], alg, (ek,))
+        r_dec = roof("zmt_dec_frames+parse+copy_kernel" if split else "zmt_lz4_dec_*", ms["k_lz4_dec"], alg,
+                     ("zmt_dec_frames_kernel", "zmt_dec_parse_kernel", "zmt_dec_copy_kernel") if split else ())
+    dom = r_dec if (dec_only or ms["k_lz4_dec"] >= ms.get("k_lz4_enc", 0.0)) else r_enc
     res = {
-        "metric": "MB/s compress+decompress, 8 GiB synthetic, lz4-mt; % HBM roofline",
-        "value": round(world * U / 1e6 / step_s, 1),
+        "metric": (f"MB/s decompress, 8 GiB synthetic, {name}; % HBM roofline" if dec_only else
+                   f"MB/s compress+decompress, 8 GiB synthetic, {name}; % HBM roofline"),
+        "value": round(U_all / 1e6 / step_s, 1),
         "unit": "MB/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(step_s * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"lz4-mt -1, {args.gib:g} GiB enwik-style synthetic per GPU, "
-                               f"{chunk // 1024} KiB chunks, device-resident compress+decompress",
-                   "chunk": chunk, "records_per_gpu": nrec, "level": 1,
-                   "ratio": round(U / Cb, 4), "dec_variant": args.dec_variant,
+        "config": {"workload": f"{what}{' decompress-only' if dec_only else ''}, {U_all / (1 << 30):g} GiB enwik-style "
+                               f"synthetic ({'whole job' if args.scaling == 'strong' or world == 1 else 'per GPU x ' + str(world)}), "
+                               f"{chunk // 1024} KiB chunks, device-resident",
+                   "chunk": chunk, "records_per_gpu": nrec, "records": int(total_n // chunk), "level": 1,
+                   "ratio": round(ctx_ratio(U_all, Cb_all), 4), "dec_variant": args.dec_variant,
                    "parallelism": f"chunk-sharded x{world}"},
-        "compress_MBps": round(world * U / 1e6 / t_c, 1),
-        "decompress_MBps": round(world * U / 1e6 / t_d, 1),
-        "roofline": roof(dom),
-        "roofline_decompress": roof("k_lz4_dec"),
-        "roofline_decompress_copy_kernel": roof("k_dec_copy") if split else None,
+        "decompress_MBps": round(U / 1e6 / t_d * world, 1),
+        "roofline": dom,
+        "roofline_decompress": r_dec,
         "roofline_decompress_path": {
-            "what": "decode + XXH32 verify kernels together", "achieved": round(alg / t_d / 1e9, 2),
-            "unit": "GB/s", "frac": round(alg / t_d / HBM_PEAK, 5)},
+            "what": "probe + decode + checksum-verify kernels together (HIP events around the leg)",
+            "achieved": round(alg / t_d / 1e9, 2), "unit": "GB/s", "frac": round(alg / t_d / HBM_PEAK, 5)},
         "kernels": kern,
-        "decode_errors": bad, "roundtrip_verified": ok if args.verify else None,
+        "decode_errors": bad, "roundtrip_verified": ok,
         "gen_s": round(gen_s, 2), "device": eng.name,
-        "segment_offset_rank0": seg_off, "gather_ms": gather_ms,
+        "segment_offset_rank0": seg_off[0], "gather_ms": gather_ms,
     }
-    if not args.no_cpu:
-        res["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if not dec_only:
+        res["compress_MBps"] = round(U / 1e6 / t_c * world, 1)
+        res["roofline_compress"] = r_enc
+    if zstd:
+        res["config"]["parity"] = "decompress-identical (SURVEY 8a C4)"
+    elif split:
+        res["roofline_decompress_copy_kernel"] = roof("zmt_dec_copy_kernel", ms["k_dec_copy"], alg, ("zmt_dec_copy_kernel",))
+        res["roofline_decompress_parse_kernel"] = roof("zmt_dec_parse_kernel", ms["k_dec_parse"], Cb, ("zmt_dec_parse_kernel",))
+    if gather_ms is not None:
+        res["value_with_gather"] = round(U_all / 1e6 / (step_s + gather_ms * 1e-3), 1)
+    if cpu and not args.no_cpu and world == 1:
+        res["cpu_baseline"] = cpu_baseline(codec, chunk, args.cpu_mib)
+    return res
 
 
-def report_zstd(args, eng, world, wall, ms, U, Cb, nrec, chunk, bad, ok, gen_s, seg_off, gather_ms, dist):
-    """BASELINE configs[3]: zstd-mt level 1.  Kernels: zmt_zstd_enc_kernel + zmt_zstd_assemble_kernel
-    (timer slot 9), zmt_zstd_dec_kernel (slot 11); algorithmic bytes U + C either direction."""
-    alg = U + Cb
-    t_c = (ms["compress"] + ms["compact"]) * 1e-3
-    t_d = ms["decompress"] * 1e-3
-    step_s = wall / args.steps
-
-    traffic = {}
-    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tf) and abs(args.gib - 8.0) < 1e-9 and chunk == 1 << 20:
-        with open(tf) as f:
-            traffic = json.load(f).get("per_launch_bytes_8gib", {})
-
-    def roof(name, t_ms, pmc):
-        a = alg / (t_ms * 1e-3) / 1e9
-        tr = [traffic.get(k) for k in pmc if traffic.get(k) is not None]
-        return {"kernel": name, "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s", "frac": round(a * 1e9 / HBM_PEAK, 5),
-                "frac_of_copy_ceiling": round(a * 1e9 / HBM_COPY, 5), "alg_bytes_per_launch": alg,
-                "avg_launch_ms": round(t_ms, 4), "traffic": sum(tr) if tr else None}
-
-    enc = roof("zmt_zstd_enc_kernel(+assemble)", ms["k_lz4_enc"], ("zmt_zstd_enc_kernel", "zmt_zstd_assemble_kernel"))
-    dec = roof("zmt_zstd_dec_small_kernel(+zmt_zstd_dec_kernel for frames with full-size tables)", ms["k_lz4_dec"],
-               ("zmt_zstd_dec_small_kernel", "zmt_zstd_dec_kernel"))
-    res = {
-        "metric": "MB/s compress+decompress, 8 GiB synthetic, zstd-mt level 1; % HBM roofline",
-        "value": round(world * U / 1e6 / step_s, 1), "unit": "MB/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(step_s * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"zstd-mt -1, {args.gib:g} GiB enwik-style synthetic per GPU, "
-                               f"{chunk // 1024} KiB chunks, device-resident compress+decompress",
-                   "chunk": chunk, "records_per_gpu": nrec, "level": 1, "ratio": round(U / Cb, 4),
-                   "parity": "decompress-identical (SURVEY 8a C4)", "parallelism": f"chunk-sharded x{world}"},
-        "compress_MBps": round(world * U / 1e6 / t_c, 1),
-        "decompress_MBps": round(world * U / 1e6 / t_d, 1),
-        "roofline": enc if ms["k_lz4_enc"] >= ms["k_lz4_dec"] else dec,
-        "roofline_compress": enc, "roofline_decompress": dec,
-        "kernels": {"k_zstd_enc": {"ms": round(ms["k_lz4_enc"], 4)}, "k_scan_compact": {"ms": round(ms["k_scan_compact"], 4)},
-                    "k_zstd_dec": {"ms": round(ms["k_lz4_dec"], 4)}},
-        "decode_errors": bad, "roundtrip_verified": ok if args.verify else None,
-        "gen_s": round(gen_s, 2), "device": eng.name,
-        "segment_offset_rank0": seg_off, "gather_ms": gather_ms,
-    }
-    if not args.no_cpu:
-        res["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+def ctx_ratio(u, c):
+    return u / c if c else 0.0
 
 
 def reference_brotli_stream(data, chunk, level, threads):
     """The workload's input: `data` compressed by the REFERENCE's brotli-mt (oracle/_ref, SURVEY 8d
-    "cfg5: the same text compressed by own/oracle brotli at 1 MiB chunks").  The device has no brotli
-    encoder yet, so the compressed input can only come from the reference build; this is input
-    preparation on the host, outside the timed region."""
+    "cfg5: the same text compressed by own/oracle brotli at 1 MiB chunks").  Input preparation on the
+    host, outside the timed region; the device encoder's streams are timed as well (device_encoder)."""
     so = os.path.join(ROOT, "oracle", "_ref", "libbrotlimt_ref.so")
     lib = C.CDLL(so)
 
@@ -409,17 +442,25 @@ def reference_brotli_stream(data, chunk, level, threads):
     return b"".join(out)
 
 
-def bench_brotli(args, eng, rank, world, dist):
+def bench_brotli(ctx, gib_args=None, steps=None, warmup=None, cpu=True, main=True):
     """BASELINE configs[4]: brotli-mt decompress.  Input: level-1 streams of the synthetic text at
     1 MiB chunks (the reference's default chunk for level 1, lib/brotli-mt_compress.c:105-109), written
     by the reference build; one step = gpumt_brotli_decompress_batch over all records of the rank,
     input and output resident in HBM.  value = uncompressed MB/s (decompress only: there is no
-    compression on this path)."""
+    compression on this path).  Ranks take contiguous record ranges of the job (strong) or a
+    replica each (weak)."""
     import struct
+    args, eng, rank, world, dist = ctx.args, ctx.eng, ctx.rank, ctx.world, ctx.dist
     L, h = eng.L, eng.h
-    chunk = args.chunk or (1 << 20)
-    args.chunk = chunk
-    n = int(args.gib * (1 << 30)) // chunk * chunk
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
+    chunk = (args.chunk if main else 0) or (1 << 20)
+    saved_gib = args.gib
+    if gib_args is not None:
+        args.gib = gib_args
+    n, corpus_off, total_n = shard(args, world, rank, chunk)
+    gib = args.gib
+    args.gib = saved_gib
     base_n = min(n, 1 << 30) // chunk * chunk          # compressed once on the host, replicated in HBM
     reps = (n + base_n - 1) // base_n
     n = base_n * reps
@@ -427,7 +468,7 @@ def bench_brotli(args, eng, rank, world, dist):
     threads = min(os.cpu_count() or 1, 128) // max(1, world) or 1
     t0 = time.time()
     text = np.empty(base_n, np.uint8)
-    T.zmt_gen_text(text.ctypes.data, base_n, SEED, rank * base_n, threads)
+    T.zmt_gen_text(text.ctypes.data, base_n, SEED, corpus_off, threads)
     stream = reference_brotli_stream(text, chunk, 1, threads)
     # record table (what the host engine parses while reading, lib/brotli-mt_decompress.c:187-284)
     ro, rl, cap = [], [], []
@@ -457,36 +498,26 @@ def bench_brotli(args, eng, rank, world, dist):
     d_ro, d_rl, d_oo, d_oc = eng.upload(rec_off), eng.upload(rec_len), eng.upload(out_off), eng.upload(out_cap)
     d_ol, d_st = eng.alloc(nrec * 4), eng.alloc(nrec * 4)
     d_out = eng.alloc(total_cap + 64)
+    bufs = [d_stream, d_ro, d_rl, d_oo, d_oc, d_ol, d_st, d_out]
 
     def step():
         eng.timer_start(3)
         eng.brotli_decompress(d_stream, d_ro, d_rl, nrec, d_out, d_oo, d_oc, d_ol, d_st)
         eng.timer_stop(3)
 
-    def barrier():
-        eng.sync()
-        if dist is not None:
-            dist.barrier()
-        eng.sync()
-
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    barrier()
+    ctx.barrier()
     acc = {"decompress": 0.0, "k_brotli_dec": 0.0}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
         eng.sync(0)
         acc["decompress"] += eng.timer_ms(3)
         acc["k_brotli_dec"] += eng.timer_ms(12)
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tw = torch.tensor([wall], device="cuda")
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
-    ms = {k: v / args.steps for k, v in acc.items()}
+    ctx.barrier()
+    wall = ctx.max_over_ranks(time.perf_counter() - t0)
+    ms = {k: v / steps for k, v in acc.items()}
     status = eng.download(d_st, nrec * 4, np.uint32)
     olen = eng.download(d_ol, nrec * 4, np.uint32)
     bad = int((status != 0).sum())
@@ -496,12 +527,15 @@ def bench_brotli(args, eng, rank, world, dist):
     if ok:
         got = eng.download(d_out, base_n)              # capacities == chunk sizes for full chunks
         ok = bool((got == text).all()) if int(out_off[nb]) == base_n else None
+    ok_all = ctx.all_true(bool(ok)) if ok is not None else None
+    bad_all = int(ctx.sum_over_ranks(float(bad)))
     # ---- the device encoder on the same text (not part of `value`: configs[4] is decompress) ----
     own = None
     try:
-        if args.no_encoder:
-            raise RuntimeError("skipped (--no-encoder)")
+        if args.no_encoder or not main or world > 1:
+            raise RuntimeError("skipped")
         d_text = eng.alloc(n + 64)
+        bufs.append(d_text)
         for r in range(reps):
             eng._ck(L.gpumt_memcpy_h2d(h, d_text.ptr + r * base_n, text.ctypes.data, base_n, 0), "h2d")
         eng.sync(0)
@@ -510,6 +544,7 @@ def bench_brotli(args, eng, rank, world, dist):
         d_slots = eng.alloc(nrec_c * stride)
         d_cl, d_co = eng.alloc(nrec_c * 4), eng.alloc((nrec_c + 1) * 8)
         d_cs = eng.alloc(nrec_c * stride)
+        bufs += [d_slots, d_cl, d_co, d_cs]
         for it in range(2):
             eng.timer_start(1)
             eng.brotli_compress(d_text, n, chunk, d_slots, stride, d_cl)
@@ -525,6 +560,7 @@ def bench_brotli(args, eng, rank, world, dist):
         cap2 = np.full(nrec_c, chunk, np.uint32)
         oo2 = np.arange(nrec_c + 1, dtype=np.uint64) * np.uint64(chunk)
         d_oo2, d_oc2 = eng.upload(oo2), eng.upload(cap2)
+        bufs += [d_ro2, d_rl2, d_oo2, d_oc2]
         for it in range(2):
             eng.timer_start(2)
             eng.brotli_decompress(d_cs, d_ro2, d_rl2, nrec_c, d_out, d_oo2, d_oc2, d_ol, d_st)
@@ -534,63 +570,82 @@ def bench_brotli(args, eng, rank, world, dist):
         st2 = eng.download(d_st, nrec_c * 4, np.uint32)
         ok2 = bool((st2 == 0).all()) and bool((eng.download(d_out, base_n) == text).all())
         own = {"what": "zmt_brotli_enc_kernel(+assemble+compact) on the same text, and the decode of its streams",
-               "compress_ms": round(t_enc, 3), "compress_MBps": round(world * n / 1e6 / (t_enc * 1e-3), 1),
+               "compress_ms": round(t_enc, 3), "compress_MBps": round(n / 1e6 / (t_enc * 1e-3), 1),
                "ratio": round(n / c_own, 4), "decompress_ms": round(t_dec, 3),
-               "decompress_MBps": round(world * n / 1e6 / (t_dec * 1e-3), 1), "roundtrip_verified": ok2}
+               "decompress_MBps": round(n / 1e6 / (t_dec * 1e-3), 1), "roundtrip_verified": ok2}
     except Exception as e:  # report, never hide
-        own = {"error": repr(e)}
+        own = {"skipped": True} if str(e) == "skipped" else {"error": repr(e)}
+    U_all = ctx.sum_over_ranks(U)
+    for b in bufs:
+        b.free()
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
     Cb = float(sum(rl) + 16 * nb) * reps
     alg = U + Cb
-    step_s = wall / args.steps
+    step_s = wall / steps
     t_k = ms["k_brotli_dec"] * 1e-3
     a = alg / t_k / 1e9
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tf) and abs(args.gib - 8.0) < 1e-9 and chunk == 1 << 20:
-        with open(tf) as f:
-            traffic = json.load(f).get("per_launch_bytes_8gib", {}).get("zmt_brotli_dec_kernel")
+    traffic = traffic_table(gib if world == 1 else -1, chunk, 1 << 20).get("zmt_brotli_dec_kernel")
     res = {
         "metric": "MB/s decompress, 8 GiB synthetic, brotli-mt (level-1 streams); % HBM roofline",
-        "value": round(world * U / 1e6 / step_s, 1), "unit": "MB/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(U_all / 1e6 / step_s, 1), "unit": "MB/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(step_s * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"brotli-mt decompress, {n / (1 << 30):g} GiB enwik-style synthetic per GPU, "
+        "config": {"workload": f"brotli-mt decompress, {U_all / (1 << 30):g} GiB enwik-style synthetic "
+                               f"({'whole job' if args.scaling == 'strong' or world == 1 else 'per GPU x ' + str(world)}), "
                                f"{chunk // 1024} KiB chunks compressed at level 1 by the reference build "
-                               f"({base_n >> 20} MiB compressed on the host, replicated x{reps} in HBM), "
+                               f"({base_n >> 20} MiB compressed on the host per rank, replicated x{reps} in HBM), "
                                f"device-resident decode",
                    "chunk": chunk, "records_per_gpu": nrec, "level": 1, "ratio": round(U / Cb, 4),
                    "parallelism": f"record-sharded x{world}"},
-        "decompress_MBps": round(world * U / 1e6 / (ms["decompress"] * 1e-3), 1),
+        "decompress_MBps": round(U / 1e6 / (ms["decompress"] * 1e-3) * world, 1),
         "roofline": {"kernel": "zmt_brotli_dec_kernel", "bound": "hbm", "achieved": round(a, 2),
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(a * 1e9 / HBM_PEAK, 5),
                      "frac_of_copy_ceiling": round(a * 1e9 / HBM_COPY, 5), "alg_bytes_per_launch": alg,
-                     "avg_launch_ms": round(ms["k_brotli_dec"], 4), "traffic": traffic},
+                     "avg_launch_ms": round(ms["k_brotli_dec"], 4), "traffic": traffic,
+                     "traffic_source": (TRAFFIC_FILE + " (separate rocprofv3 --pmc passes, not this run)")
+                     if traffic else None},
         "kernels": {"k_brotli_dec": {"ms": round(ms["k_brotli_dec"], 4)}},
         "device_encoder": own,
-        "decode_errors": bad, "roundtrip_verified": ok,
+        "decode_errors": bad_all, "roundtrip_verified": ok_all,
         "gen_s": round(gen_s, 2), "device": eng.name,
     }
-    if not args.no_cpu:
-        res["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if cpu and not args.no_cpu and world == 1:
+        res["cpu_baseline"] = cpu_baseline("brotli", chunk, args.cpu_mib)
+    return res
 
 
-def rccl_gather(eng, dist, d_stream, sizes, rank, world):
-    """gatherv of the per-rank compressed segments to rank 0 over RCCL (zstdmt_amd.shard), timed."""
+def bench_api(mib):
+    """PCIe-inclusive rates of the drop-in APIs (LZ4MT_* / ZSTDCB_* / BROTLIMT_* compressCCtx and
+    decompressDCtx with memcpy callbacks, round trip checked) -- zstdmt_amd/bin/api_bench, the same
+    measurement oracle/cpu_bench makes for the reference libraries."""
+    exe = os.path.join(ROOT, "zstdmt_amd", "bin", "api_bench")
+    lib = os.path.join(ROOT, "zstdmt_amd", "lib", "libzstdmt_amd.so")
+    out = {}
+    for codec, chunk in (("lz4", 131072), ("zstd", 1 << 20), ("brotli", 1 << 20)):
+        try:
+            t0 = time.time()
+            txt = subprocess.check_output([exe, codec, str(mib << 20), str(chunk), lib], timeout=300,
+                                          stderr=subprocess.DEVNULL)
+            r = json.loads(txt.decode().strip().splitlines()[-1])
+            r["seconds"] = round(time.time() - t0, 1)
+            r["roundtrip_verified"] = True       # api_bench exits non-zero on a mismatch
+            out[codec] = r
+        except Exception as e:  # report, never hide
+            out[codec] = {"error": repr(e)}
+    return out
+
+
+def rccl_gather(eng, dist, d_buf, sizes, rank, world):
+    """gatherv of the per-rank segments to rank 0 over RCCL (zstdmt_amd.shard), timed."""
     import torch
     from zstdmt_amd.shard import gather_segments
     mine = int(sizes[rank])
     # RCCL wants torch tensors: stage the segment into a torch-owned buffer (D2D copy, untimed)
     seg = torch.empty(mine, dtype=torch.uint8, device="cuda")
-    eng._ck(eng.L.gpumt_memcpy_d2d(eng.h, seg.data_ptr(), d_stream.ptr, mine, 0), "d2d")
+    eng._ck(eng.L.gpumt_memcpy_d2d(eng.h, seg.data_ptr(), d_buf.ptr, mine, 0), "d2d")
     eng.sync(0)
     dist.barrier()
     torch.cuda.synchronize()
@@ -599,6 +654,92 @@ def rccl_gather(eng, dist, d_stream, sizes, rank, world):
     torch.cuda.synchronize()
     dist.barrier()
     return round((time.perf_counter() - t0) * 1e3, 3)
+
+
+def dry_run(args, rank, local, world, dist):
+    """ranks report where they would run; no GPU is touched (CPU test of the launch path)"""
+    from zstdmt_amd.shard import shard_range
+    chunk = args.chunk or ((1 << 20) if args.codec != "lz4" else 131072)
+    nch = int(args.gib * (1 << 30)) // chunk
+    lo, hi = shard_range(nch, rank, world) if args.scaling == "strong" else (0, nch)
+    me = {"rank": rank, "local_rank": local, "device": local, "chunks": [lo, hi], "pid": os.getpid()}
+    ranks = [None] * world
+    if dist is not None:
+        dist.all_gather_object(ranks, me)
+    else:
+        ranks = [me]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "scaling": args.scaling, "codec": args.codec,
+                          "mode": args.mode, "ranks": ranks}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1 or "RANK" in os.environ:
+        # one process per GPU, RCCL ("nccl") process group.  torch must be imported BEFORE the native
+        # library so both share one HIP runtime.
+        import torch
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.dry_run:
+            dist.init_process_group("gloo")
+            return dry_run(args, rank, local, world, dist)
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif args.dry_run:
+        return dry_run(args, rank, local, world, None)
+
+    os.environ["GPUMT_DEVICE"] = str(local)       # the drop-in APIs of this process use this rank's GPU
+    import zstdmt_amd as z
+    eng = z.Engine(local)
+    eng.set_variant("lz4_dec", args.dec_variant)
+    eng.set_variant("lz4_enc", args.enc_variant)
+    eng.set_variant("profile", 1)
+    ctx = Ctx(args, eng, rank, world, dist)
+
+    if args.codec == "brotli":
+        res = bench_brotli(ctx)
+    else:
+        res = bench_lz4_zstd(ctx, args.codec)
+
+    default_run = (world == 1 and args.codec == "lz4" and args.mode == "roundtrip" and not args.only)
+    if rank == 0 and default_run:
+        # the other BASELINE configs, short, in the same line
+        cfgs = {}
+        try:
+            cfgs["zstd-mt level 1 (configs[3])"] = bench_lz4_zstd(ctx, "zstd", gib_args=args.extra_gib, steps=2,
+                                                                  warmup=1, main=False)
+        except Exception as e:
+            cfgs["zstd-mt level 1 (configs[3])"] = {"error": repr(e)}
+        try:
+            cfgs["brotli-mt decompress (configs[4])"] = bench_brotli(ctx, gib_args=args.extra_gib, steps=2,
+                                                                     warmup=1, main=False)
+        except Exception as e:
+            cfgs["brotli-mt decompress (configs[4])"] = {"error": repr(e)}
+        eng.close()
+        api = bench_api(int(args.extra_gib * 1024))
+        for codec, leg in (("lz4", res), ("zstd", cfgs["zstd-mt level 1 (configs[3])"]),
+                           ("brotli", cfgs["brotli-mt decompress (configs[4])"])):
+            cb = (leg or {}).get("cpu_baseline") or {}
+            if isinstance(api.get(codec), dict) and cb.get("compress_MBps"):
+                api[codec]["cpu_reference"] = {"compress_MBps": cb["compress_MBps"],
+                                               "decompress_MBps": cb["decompress_MBps"],
+                                               "threads": cb.get("cores"), "kind": cb.get("kind")}
+        cfgs["drop-in API, PCIe-inclusive (LZ4MT_*/ZSTDCB_*/BROTLIMT_* with memcpy callbacks)"] = api
+        res["configs"] = cfgs
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -59,6 +59,9 @@ typedef struct gpumt_ctx gpumt_ctx;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
 int  gpumt_device_count(void);
+/* device: HIP device index, or GPUMT_DEVICE_DEFAULT = the index in the environment variable
+ * GPUMT_DEVICE (0 when unset) -- what the LZ4MT_* / ZSTDCB_* / BROTLIMT_* contexts use */
+#define GPUMT_DEVICE_DEFAULT (-1)
 int  gpumt_open(int device, gpumt_ctx **out);
 void gpumt_close(gpumt_ctx *h);
 const char *gpumt_last_error(gpumt_ctx *h);

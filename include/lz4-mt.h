@@ -8,12 +8,18 @@
  * unchanged and links to libzstdmt_amd.so instead of the pthread library.
  *
  * Differences that a caller can observe are listed in INTEGRATION.md:
- *   - `threads` is validated (1..LZ4MT_THREAD_MAX) but the work runs on the GPU; callbacks are
- *     invoked from the calling thread, one at a time;
+ *   - `threads` is validated (1..LZ4MT_THREAD_MAX) but the work runs on the GPU (the device named by
+ *     the environment variable GPUMT_DEVICE, default 0).  Threading contract of the callbacks: fn_read
+ *     is called from ONE library thread (the reader) and fn_write from ONE other library thread (the
+ *     writer); a read and a write may run at the same time, two reads or two writes never do -- the
+ *     reference's own contract (lib/lz4-mt_compress.c:256-277 vs :301-303).  With threads == 1
+ *     LZ4MT_decompressDCtx runs every callback on the calling thread, as the reference does
+ *     (lib/lz4-mt_decompress.c:528-534);
  *   - levels 1-2 (LZ4 "fast") run on the device and are bit-identical to the reference;
  *     levels 3-12 (LZ4HC) are not implemented: LZ4MT_compressCCtx returns
  *     LZ4MT_error_compressionParameter_unsupported for such a context;
- *   - plain .lz4 input (no skippable frames) is not decoded (reference: st_decompress).
+ *   - plain .lz4 input (no skippable frames; reference: st_decompress, lib/lz4-mt_decompress.c:391-483)
+ *     is decoded on the device as well: the frames are split on the host and handed over in batches.
  */
 #ifndef LZ4MT_H
 #define LZ4MT_H

@@ -99,6 +99,30 @@ size_t ZSTDCB_GetInsizeDCtx(ZSTDCB_DCtx *ctx);
 size_t ZSTDCB_GetOutsizeDCtx(ZSTDCB_DCtx *ctx);
 void ZSTDCB_freeDCtx(ZSTDCB_DCtx *ctx);
 
+/* ---- the names /root/reference/lib/README.md:36-76 documents (ZSTDMT_*): exported aliases of the ZSTDCB_* entry
+ * points above, same signatures, for callers written against that README ---------------------------- */
+typedef ZSTDCB_Buffer ZSTDMT_Buffer;
+typedef ZSTDCB_RdWr_t ZSTDMT_RdWr_t;
+typedef ZSTDCB_CCtx ZSTDMT_CCtx;
+typedef ZSTDCB_DCtx ZSTDMT_DCtx;
+#define ZSTDMT_THREAD_MAX ZSTDCB_THREAD_MAX
+#define ZSTDMT_LEVEL_MIN ZSTDCB_LEVEL_MIN
+#define ZSTDMT_LEVEL_MAX ZSTDCB_LEVEL_MAX
+extern unsigned ZSTDMT_isError(size_t code);
+extern const char *ZSTDMT_getErrorString(size_t code);
+ZSTDMT_CCtx *ZSTDMT_createCCtx(int threads, int level, int inputsize);
+size_t ZSTDMT_compressCCtx(ZSTDMT_CCtx *ctx, ZSTDMT_RdWr_t *rdwr);
+size_t ZSTDMT_GetFramesCCtx(ZSTDMT_CCtx *ctx);
+size_t ZSTDMT_GetInsizeCCtx(ZSTDMT_CCtx *ctx);
+size_t ZSTDMT_GetOutsizeCCtx(ZSTDMT_CCtx *ctx);
+void ZSTDMT_freeCCtx(ZSTDMT_CCtx *ctx);
+ZSTDMT_DCtx *ZSTDMT_createDCtx(int threads, int inputsize);
+size_t ZSTDMT_decompressDCtx(ZSTDMT_DCtx *ctx, ZSTDMT_RdWr_t *rdwr);
+size_t ZSTDMT_GetFramesDCtx(ZSTDMT_DCtx *ctx);
+size_t ZSTDMT_GetInsizeDCtx(ZSTDMT_DCtx *ctx);
+size_t ZSTDMT_GetOutsizeDCtx(ZSTDMT_DCtx *ctx);
+void ZSTDMT_freeDCtx(ZSTDMT_DCtx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

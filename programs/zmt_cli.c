@@ -6,7 +6,8 @@
  * statistics line, :970-977 timing line), so that BASELINE.json's configurations can be typed as
  * written ("lz4-mt -1 -T4 FILE").  One source, the codec is chosen at build time (-DZMT_ZSTD, -DZMT_BROTLI) like
  * the reference does with programs/lz4-mt.c / programs/zstd-mt.c; the personality (compress /
- * decompress / cat) follows argv[0].  Not implemented: -l (listing), -L, -C.
+ * decompress / cat) follows argv[0].  -l lists compressed / uncompressed sizes (and crc32 + mtime with -v, -C
+ * switches the crc off) in the reference's layout (programs/main.c:383-418).
  */
 #include <errno.h>
 #include <stdio.h>
@@ -15,6 +16,7 @@
 #include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/time.h>
+#include <time.h>
 #include <unistd.h>
 
 #if defined(ZMT_BROTLI)
@@ -23,6 +25,7 @@
 #define UNZIP "unbrotli-mt"
 #define ZCAT "brotlicat-mt"
 #define SUFFIX ".brot"
+#define METHOD "brotli"
 #define LEVEL_DEF 3
 #define LEVEL_MIN BROTLIMT_LEVEL_MIN
 #define LEVEL_MAX BROTLIMT_LEVEL_MAX
@@ -36,6 +39,7 @@ typedef BROTLIMT_RdWr_t MT_RdWr_t;
 #define UNZIP "unzstd-mt"
 #define ZCAT "zstdcat-mt"
 #define SUFFIX ".zst"
+#define METHOD "zstd"
 #define LEVEL_DEF 3
 #define LEVEL_MIN ZSTDCB_LEVEL_MIN
 #define LEVEL_MAX ZSTDCB_LEVEL_MAX
@@ -49,6 +53,7 @@ typedef ZSTDCB_RdWr_t MT_RdWr_t;
 #define UNZIP "unlz4-mt"
 #define ZCAT "lz4cat-mt"
 #define SUFFIX ".lz4"
+#define METHOD "lz4"
 #define LEVEL_DEF 1 /* the reference defaults to 3 (LZ4HC, programs/lz4-mt.c:19); HC is not on the device */
 #define LEVEL_MIN LZ4MT_LEVEL_MIN
 #define LEVEL_MAX LZ4MT_LEVEL_MAX
@@ -58,12 +63,35 @@ typedef LZ4MT_Buffer MT_Buffer;
 typedef LZ4MT_RdWr_t MT_RdWr_t;
 #endif
 
-enum { M_COMPRESS, M_DECOMPRESS, M_TEST };
+enum { M_COMPRESS, M_DECOMPRESS, M_TEST, M_LIST };
 
 static int o_mode = M_COMPRESS, o_level = LEVEL_DEF, o_threads = 0, o_chunk = 0, o_iter = 1;
-static int o_stdout, o_force, o_keep, o_quiet, o_verbose, o_timings;
+static int o_stdout, o_force, o_keep, o_quiet, o_verbose = 1, o_timings; /* verbose: 1 default, -v adds, as the reference */
 static const char *o_out, *o_suffix = SUFFIX;
 static int exit_code;
+/* -l: what the callbacks saw (programs/main.c:172-200) */
+static int o_nocrc;
+static unsigned long long l_read, l_written;
+static unsigned int l_crc;
+
+static unsigned int crc32_update(const unsigned char *buf, size_t size, unsigned int crc)
+{
+	static unsigned int table[256];
+	static int init;
+	if (!init) {
+		for (unsigned int b = 0; b < 256; b++) {
+			unsigned int r = b;
+			for (int i = 0; i < 8; i++)
+				r = (r & 1) ? (r >> 1) ^ 0xEDB88320U : r >> 1;
+			table[b] = r;
+		}
+		init = 1;
+	}
+	crc = ~crc;
+	while (size--)
+		crc = table[(*buf++ ^ crc) & 0xFF] ^ (crc >> 8);
+	return ~crc;
+}
 
 static void die(const char *msg, const char *arg)
 {
@@ -80,11 +108,19 @@ static int rd(void *arg, MT_Buffer *b)
 	if (got != b->size && ferror(f))
 		return -1;
 	b->size = got;
+	if (o_mode == M_LIST)
+		l_read += got;
 	return 0;
 }
 static int wr(void *arg, MT_Buffer *b)
 {
 	FILE *f = (FILE *)arg;
+	if (o_mode == M_LIST) {
+		if (o_verbose > 1 && !o_nocrc)
+			l_crc = crc32_update((const unsigned char *)b->buf, b->size, l_crc);
+		l_written += b->size;
+		return 0;
+	}
 	if (!f)
 		return 0; /* -t: discard */
 	return fwrite(b->buf, 1, b->size, f) == b->size ? 0 : -1;
@@ -100,6 +136,8 @@ static void usage(void)
 	       "  -f    overwrite existing files\n"
 	       "  -o F  write output to file F ('-' = stdout)\n"
 	       "  -k    keep input files\n"
+	       "  -l    list compressed / uncompressed sizes (-v: method, crc32, date; -C: no crc32)\n"
+	       "  -L    display the license     \n"
 	       "  -q    quiet     -v    verbose     -h    this help     -V    version\n"
 	       "  -S X  suffix of compressed files (default \"%s\")\n"
 	       "  -T N  number of threads (validated, 1-%d; the work runs on the GPU)\n"
@@ -178,6 +216,43 @@ static void do_file(const char *name)
 		return;
 	}
 	outname[0] = 0;
+	if (o_mode == M_LIST) {
+		/* decode to nowhere, count (reference: MODE_LIST writes to /dev/null, main.c:932-937) */
+		static int first_row = 1;
+		struct stat stt;
+		time_t mt = time(NULL);
+		l_read = l_written = 0;
+		l_crc = 0;
+		if (in != stdin && fstat(fileno(in), &stt) == 0)
+			mt = stt.st_mtime;
+		err = run(in, NULL);
+		if (in != stdin)
+			fclose(in);
+		if (first_row && o_verbose > 1)
+			printf("%8s %8s %10s %8s %20s %20s %7s %s\n", "method", "crc32", "date", "time", "compressed",
+			       "uncompressed", "ratio", "uncompressed_name");
+		else if (first_row)
+			printf("%20s %20s %7s %s\n", "compressed", "uncompressed", "ratio", "uncompressed_name");
+		first_row = 0;
+		if (err) {
+			if (!o_quiet)
+				fprintf(stderr, "%s: %s: %s\n", PROGNAME, name, err);
+			exit_code = 1;
+			if (o_verbose > 1)
+				printf("%8s %8s %10s %8s %20s %20s %7s %s\n", "-", "-", "-", "-", "-", "-", "-", name);
+			else
+				printf("%20s %20s %7s %s\n", "-", "-", "-", name);
+		} else if (o_verbose > 1) {
+			char tb[30];
+			strftime(tb, sizeof tb, "%Y-%m-%d %H:%M:%S", localtime(&mt));
+			printf("%8s %08x %12s %20llu %20llu %6.2f%% %s\n", METHOD, l_crc, tb, l_read, l_written,
+			       l_written ? 100 - (double)l_read * 100 / (double)l_written : 0.0, name);
+		} else {
+			printf("%20llu %20llu %6.2f%% %s\n", l_read, l_written,
+			       l_written ? 100 - (double)l_read * 100 / (double)l_written : 0.0, name);
+		}
+		return;
+	}
 	if (o_mode == M_TEST) {
 		out = NULL;
 	} else if (to_stdout) {
@@ -229,7 +304,7 @@ static void do_file(const char *name)
 		exit_code = 1;
 		return;
 	}
-	if (o_verbose && !o_quiet)
+	if (o_verbose > 1 && !o_quiet)
 		fprintf(stderr, "%s: %s\n", name, o_mode == M_TEST ? "OK" : "done");
 	if (outname[0] && !o_keep && !o_out && in != stdin && o_mode != M_TEST)
 		remove(name);
@@ -263,18 +338,23 @@ int main(int argc, char **argv)
 		case 'o': o_out = optarg; break;
 		case 'h': usage(); break;
 		case 'k': o_keep = 1; break;
-		case 'q': o_quiet = 1; break;
+		case 'q': o_quiet = 1; o_verbose = 0; break;
 		case 'S': o_suffix = optarg; break;
 		case 't': o_mode = M_TEST; break;
-		case 'v': o_verbose = 1; break;
+		case 'v': o_verbose++; break;
 		case 'V': printf("%s (zstdmt_amd, MI355X)\n", PROGNAME); return 0;
 		case 'T': o_threads = atoi(optarg); break;
 		case 'b': o_chunk = atoi(optarg) * 1024 * 1024; break;
 		case 'i': o_iter = atoi(optarg); break;
 		case 'B': o_timings = 1; break;
-		case 'l': case 'L': case 'C':
-			die("option not implemented in this front end", NULL);
-			break;
+		case 'l': o_mode = M_LIST; o_keep = 1; break;
+		case 'C': o_nocrc = 1; break;
+		case 'L':
+			printf("%s (zstdmt_amd, MI355X): command line front end of libzstdmt_amd.so.\n"
+			       "Written for this repository; the option letters and report layouts follow the\n"
+			       "BSD-licensed zstdmt tools (https://github.com/mcmilk/zstdmt), whose code it does not contain.\n",
+			       PROGNAME);
+			return 0;
 		default:
 			usage();
 		}
@@ -293,7 +373,7 @@ int main(int argc, char **argv)
 	if (optind >= argc) {
 		if (o_iter != 1)
 			die("You can not use stdin together with the -i option.", NULL);
-		if (o_mode != M_TEST && !o_out && !o_force && isatty(fileno(stdout)))
+		if (o_mode < M_TEST && !o_out && !o_force && isatty(fileno(stdout)))
 			die("refusing to write binary data to a terminal (use -f or -c)", NULL);
 		do_file("-");
 	} else {

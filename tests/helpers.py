@@ -193,6 +193,8 @@ class MemIO:
         self.out = []
         self.reads = []
         self.writes = []
+        self.read_threads = set()    # threading.get_ident() of every fn_read / fn_write call
+        self.write_threads = set()
         self.lock = threading.Lock()
         self.fail_read_at = fail_read_at
         self.fail_write_at = fail_write_at
@@ -205,6 +207,7 @@ class MemIO:
     def _read(self, _arg, bufp):
         b = bufp.contents
         with self.lock:
+            self.read_threads.add(threading.get_ident())
             if self.fail_read_at is not None and len(self.reads) >= self.fail_read_at:
                 return self.read_rv
             want = b.size
@@ -219,6 +222,7 @@ class MemIO:
     def _write(self, _arg, bufp):
         b = bufp.contents
         with self.lock:
+            self.write_threads.add(threading.get_ident())
             if self.fail_write_at is not None and len(self.writes) >= self.fail_write_at:
                 return self.write_rv
             self.out.append(C.string_at(b.buf, b.size))

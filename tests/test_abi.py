@@ -12,7 +12,7 @@ def _declared(header):
     txt = open(os.path.join(H.ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     txt = re.sub(r"^\s*#\s*define[^\n]*$", "", txt, flags=re.M)   # function-like macros are not symbols
-    return sorted(set(re.findall(r"\b((?:gpumt|LZ4MT|ZSTDCB|BROTLIMT)_[A-Za-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b((?:gpumt|LZ4MT|ZSTDCB|ZSTDMT|BROTLIMT)_[A-Za-z0-9_]+)\s*\(", txt)))
 
 
 @pytest.fixture(scope="module")

@@ -233,3 +233,17 @@ def test_context_reuse(lib):
         assert lib.BROTLIMT_decompressDCtx(ctx, C.byref(io.rdwr)) == 0
         assert H.sha256(io.result()) == MAN[name]["in_sha256"]
     lib.BROTLIMT_freeDCtx(ctx)
+
+
+def test_chunk_not_a_multiple_of_64k(lib):
+    """inputsize = 100 000: the hint of a full chunk must cover it (the reference truncates
+    inputsize >> 16 and then cannot decode its own records); ours rounds up, so both decoders
+    accept what BROTLIMT_compressCCtx of this library writes."""
+    data = cases.text(350000, 7)
+    rv, st, _, _ = H.brotlimt_compress_via(lib, data, 100000, threads=2, level=1)
+    assert rv == 0
+    rv, out, _, _ = H.brotlimt_decompress_via(lib, st)
+    assert rv == 0 and out == data
+    if H.have_bref():
+        rv, out, _, _ = H.brotlimt_decompress_via(H.bref(), st)
+        assert rv == 0 and out == data

@@ -124,3 +124,36 @@ def test_brotli_decompress_personalities(tmp_path):
     z = run([brotli, "-1", "-c"], data).stdout
     assert len(z) < len(data) and H.oracle_brotlimt_decompress(z, len(data) + 65536) == data
     assert run([brotli, "-d", "-c"], z).stdout == data
+
+
+def test_list_mode(tmp_path):
+    """-l: sizes and ratio in the reference's layout (programs/main.c:383-418); -lv adds method, crc32
+    of the content and the file date, -C switches the crc off; the file stays."""
+    import zlib
+    data = cases.text(300000, 5)
+    f = tmp_path / "t.txt"
+    f.write_bytes(data)
+    run([LZ4, "-1", "-k", str(f)])
+    z = tmp_path / "t.txt.lz4"
+    csz = z.stat().st_size
+    p = run([LZ4, "-l", str(z)])
+    lines = p.stdout.decode().splitlines()
+    assert lines[0].split() == ["compressed", "uncompressed", "ratio", "uncompressed_name"]
+    cols = lines[1].split()
+    assert int(cols[0]) == csz and int(cols[1]) == len(data) and cols[3] == str(z)
+    assert abs(float(cols[2].rstrip("%")) - (100 - csz * 100 / len(data))) < 0.01
+    assert z.exists()
+    p = run([LZ4, "-l", "-v", str(z)])
+    lines = p.stdout.decode().splitlines()
+    assert lines[0].split()[:2] == ["method", "crc32"]
+    cols = lines[1].split()
+    assert cols[0] == "lz4" and int(cols[1], 16) == (zlib.crc32(data) & 0xFFFFFFFF)
+    p = run([LZ4, "-l", "-v", "-C", str(z)])
+    assert p.stdout.decode().splitlines()[1].split()[1] == "00000000"
+    # a damaged file lists as dashes and fails
+    bad = bytearray(z.read_bytes())
+    bad[40] ^= 0xFF
+    zb = tmp_path / "bad.lz4"
+    zb.write_bytes(bytes(bad))
+    p = run([LZ4, "-l", str(zb)], check=False)
+    assert p.returncode != 0 and p.stdout.decode().splitlines()[1].split()[:3] == ["-", "-", "-"]

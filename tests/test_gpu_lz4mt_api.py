@@ -218,3 +218,19 @@ def test_plain_lz4_errors(lib):
     assert rv == ERR(E_LIB) or out != a                # damaged tokens: rejected, or caught by the checksum
     rv, _, _, _ = H.lz4mt_decompress_via(lib, H.liblz4_frame(a, block_checksum=1))
     assert rv == ERR(E_LIB)                             # block checksums: not on the device
+
+
+def test_callback_threads(lib):
+    """threads == 1: every decompress callback runs on the calling thread (reference:
+    lib/lz4-mt_decompress.c:528-534); otherwise one reader and one writer thread of the library."""
+    import threading
+    data = text(5 * 131072 + 99)
+    rv, stream, _, _ = H.lz4mt_compress_via(lib, data, 131072, threads=2)
+    assert not lib.LZ4MT_isError(rv)
+    me = threading.get_ident()
+    rv, out, io, _ = H.lz4mt_decompress_via(lib, stream, threads=1)
+    assert not lib.LZ4MT_isError(rv) and out == data
+    assert io.read_threads == {me} and io.write_threads == {me}
+    rv, out, io, _ = H.lz4mt_decompress_via(lib, stream, threads=4)
+    assert not lib.LZ4MT_isError(rv) and out == data
+    assert len(io.write_threads) == 1 and me not in io.write_threads

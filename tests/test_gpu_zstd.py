@@ -178,3 +178,23 @@ def test_checksummed_frames(eng):
     bad[12 + len(frames[0]) - 2] ^= 0x01
     out, status = eng.decompress_bytes(bytes(bad), ro, rl, codec="zstd")
     assert status.tolist() == [5, 0, 0, 0]
+
+
+def test_chunk_beyond_128_mib_has_a_window_descriptor(eng):
+    """A single-segment frame of more than 128 MiB is refused by libzstd's streaming decoder (window
+    above 2^27), which is what the reference's pt_decompress runs: such chunks get a 128 KiB
+    Window_Descriptor instead, and the reference library must decode them."""
+    import ctypes as C
+    T = C.CDLL(os.path.join(H.ROOT, "zstdmt_amd", "lib", "libzmt_tools.so"))
+    T.zmt_gen_text.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int]
+    n = (129 << 20) + 4321
+    buf = np.empty(n, np.uint8)
+    T.zmt_gen_text(buf.ctypes.data, n, 20260926, 0, 8)
+    data = buf.tobytes()
+    st, ro, rl = eng.compress_bytes(data, n, codec="zstd")
+    assert len(rl) == 1 and st[12:16] == b"\x28\xb5\x2f\xfd" and st[16] == 0x80 and st[17] == 0x38
+    out, status = eng.decompress_bytes(st, ro, rl, codec="zstd")
+    assert (status == 0).all() and out == data
+    if H.have_zref():
+        rv, back, _, _ = H.zstdmt_decompress_via(H.zref(), st)
+        assert rv == 0 and back == data

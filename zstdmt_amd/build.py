@@ -84,6 +84,11 @@ def build(force=False, verbose=True):
             dst = os.path.join(bindir, ln)
             if not os.path.lexists(dst):
                 os.symlink(name, dst)
+    # PCIe-inclusive API benchmark (tools/api_bench.c): bench.py's "drop-in API" leg
+    ab = os.path.join(bindir, "api_bench")
+    absrc = os.path.join(ROOT, "tools", "api_bench.c")
+    if force or _stale(ab, [absrc, tsrc]):
+        _run(["gcc", "-O2", "-pthread", absrc, tsrc, "-o", ab, "-ldl", "-lm"])
     return lib
 
 

@@ -829,8 +829,11 @@ zmt_brotli_assemble_kernel(u64 n, u32 chunk, u32 nrec, u32 blk_per_rec, u8 *__re
 			slot[at++] = 0x03; /* ISLAST, ISLASTEMPTY */
 		}
 		const u32 csz = at - 16;
-		/* hint: 64 KiB units of output the decoder must provide (:294-304) */
-		const u32 hint = clen < chunk ? (clen >> 16) + 1 : chunk >> 16;
+		/* hint: 64 KiB units of output the decoder must provide (:294-304).  The reference writes
+		 * inputsize >> 16 for a full chunk, which is one unit short when inputsize is not a multiple
+		 * of 64 KiB (its own decoder then rejects the record): round up -- a larger hint stays
+		 * decodable by the reference, and for multiples of 64 KiB the value is the reference's. */
+		const u32 hint = clen < chunk ? (clen >> 16) + 1 : (chunk + 65535u) >> 16;
 		slot[0] = 0x50; slot[1] = 0x2A; slot[2] = 0x4D; slot[3] = 0x18;
 		slot[4] = 8; slot[5] = 0; slot[6] = 0; slot[7] = 0;
 		slot[8] = (u8)csz; slot[9] = (u8)(csz >> 8); slot[10] = (u8)(csz >> 16); slot[11] = (u8)(csz >> 24);

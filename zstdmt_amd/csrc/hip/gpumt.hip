@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -167,7 +168,15 @@ int gpumt_open(int device, gpumt_ctx **out)
 	if (!out)
 		return GPUMT_E_ARG;
 	*out = NULL;
-	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+		return GPUMT_E_NODEVICE;
+	if (device == GPUMT_DEVICE_DEFAULT) {
+		/* the drop-in APIs (LZ4MT_* ...) have no device argument: GPUMT_DEVICE selects the GPU of
+		 * the contexts a process creates (one process per GPU, like the ranks of bench.py) */
+		const char *e = getenv("GPUMT_DEVICE");
+		device = (e && *e) ? atoi(e) : 0;
+	}
+	if (device < 0 || device >= n)
 		return GPUMT_E_NODEVICE;
 	h = (gpumt_ctx *)calloc(1, sizeof *h);
 	if (!h)
@@ -246,21 +255,84 @@ void gpumt_free(gpumt_ctx *h, void *p)
 	if (h && p && !use(h))
 		(void)hipFree(p);
 }
+/*
+ * Pinned host memory costs ~0.3 s per GiB to allocate and to free (page pinning), which used to be
+ * most of a drop-in API call on a few GiB: freed staging buffers are therefore kept in a
+ * process-wide cache and handed to the next context that asks (a decompress context after a
+ * compress context, the next file of the CLI, the next call of a long-running caller).  The cache
+ * is bounded (GPUMT_PINNED_CACHE_MB, default 8192); hipHostMallocPortable makes a buffer usable by
+ * the contexts of every device.
+ */
+#define PIN_CACHE_SLOTS 64
+static struct {
+	pthread_mutex_t mu;
+	void *p[PIN_CACHE_SLOTS];
+	size_t cap[PIN_CACHE_SLOTS];
+	size_t total, limit;
+	int init;
+} g_pin = {PTHREAD_MUTEX_INITIALIZER, {0}, {0}, 0, 0, 0};
+
+struct pin_hdr { /* in front of every pinned buffer: its capacity */
+	size_t cap;
+	size_t pad[7];
+};
+
 void *gpumt_host_alloc(gpumt_ctx *h, size_t bytes)
 {
 	void *p = NULL;
 	if (!h || use(h))
 		return NULL;
+	if (!bytes)
+		bytes = 1;
+	pthread_mutex_lock(&g_pin.mu);
+	if (!g_pin.init) {
+		const char *e = getenv("GPUMT_PINNED_CACHE_MB");
+		g_pin.limit = (size_t)(e && *e ? strtoull(e, 0, 10) : 8192) << 20;
+		g_pin.init = 1;
+	}
+	{
+		int best = -1;
+		for (int i = 0; i < PIN_CACHE_SLOTS; i++)
+			if (g_pin.p[i] && g_pin.cap[i] >= bytes && g_pin.cap[i] <= bytes + bytes / 2 + (1u << 20) &&
+			    (best < 0 || g_pin.cap[i] < g_pin.cap[best]))
+				best = i;
+		if (best >= 0) {
+			p = g_pin.p[best];
+			g_pin.total -= g_pin.cap[best];
+			g_pin.p[best] = NULL;
+		}
+	}
+	pthread_mutex_unlock(&g_pin.mu);
+	if (p)
+		return p;
 	/* non-coherent = CPU-cached pinned memory: the callbacks memcpy in and out of it at full host
 	 * speed; visibility is established by the stream synchronisation the engine does anyway */
-	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocNonCoherent) != hipSuccess)
+	if (hipHostMalloc(&p, bytes + sizeof(struct pin_hdr), hipHostMallocNonCoherent | hipHostMallocPortable) !=
+	    hipSuccess)
 		return NULL;
-	return p;
+	((struct pin_hdr *)p)->cap = bytes;
+	return (u8 *)p + sizeof(struct pin_hdr);
 }
 void gpumt_host_free(gpumt_ctx *h, void *p)
 {
-	if (h && p && !use(h))
-		(void)hipHostFree(p);
+	if (!h || !p)
+		return;
+	struct pin_hdr *hd = (struct pin_hdr *)((u8 *)p - sizeof(struct pin_hdr));
+	const size_t cap = hd->cap;
+	pthread_mutex_lock(&g_pin.mu);
+	if (g_pin.total + cap <= g_pin.limit) {
+		for (int i = 0; i < PIN_CACHE_SLOTS; i++)
+			if (!g_pin.p[i]) {
+				g_pin.p[i] = p;
+				g_pin.cap[i] = cap;
+				g_pin.total += cap;
+				p = NULL;
+				break;
+			}
+	}
+	pthread_mutex_unlock(&g_pin.mu);
+	if (p && !use(h))
+		(void)hipHostFree(hd);
 }
 
 #define STREAM_OK(s) ((s) >= 0 && (s) < GPUMT_NSTREAMS)

@@ -1154,7 +1154,12 @@ zmt_zstd_assemble_kernel(u64 n, u32 chunk, u32 nrec, u32 blk_per_rec, u8 *__rest
 	const u32 clen = (u32)(n - cstart < chunk ? n - cstart : chunk);
 	u8 *slot = slots + (u64)rec * stride;
 	const u32 fcs_len = clen < 256 ? 1u : clen < 65536 + 256 ? 2u : 4u;
-	const u32 fh = 4 + 1 + fcs_len;
+	/* A single-segment header makes Window_Size = content size; libzstd's streaming decoder (what the
+	 * reference's pt_decompress uses, lib/zstd-mt_decompress.c:464) refuses windows above 2^27.  No
+	 * match of this encoder leaves its 128 KiB block, so chunks beyond 128 MiB get a Window_Descriptor
+	 * of 128 KiB and a 4-byte content size instead. */
+	const bool with_wd = clen > (128u << 20);
+	const u32 fh = 4 + 1 + fcs_len + (with_wd ? 1u : 0u);
 	u32 at = 12 + fh;
 	const u32 nb = clen ? (clen + ZE_BLOCK - 1) / ZE_BLOCK : 0;
 	for (u32 b = 0; b < nb; b++) {
@@ -1207,9 +1212,13 @@ zmt_zstd_assemble_kernel(u64 n, u32 chunk, u32 nrec, u32 blk_per_rec, u8 *__rest
 			f[4] = 0x20 | 1u << 6;
 			f[5] = (u8)(clen - 256);
 			f[6] = (u8)((clen - 256) >> 8);
-		} else {
+		} else if (!with_wd) {
 			f[4] = 0x20 | 2u << 6;
 			f[5] = (u8)clen; f[6] = (u8)(clen >> 8); f[7] = (u8)(clen >> 16); f[8] = (u8)(clen >> 24);
+		} else {
+			f[4] = 2u << 6; /* 4-byte content size, Window_Descriptor follows */
+			f[5] = 0x38;    /* exponent 7, mantissa 0: 2^17 */
+			f[6] = (u8)clen; f[7] = (u8)(clen >> 8); f[8] = (u8)(clen >> 16); f[9] = (u8)(clen >> 24);
 		}
 		rec_len[rec] = at;
 	}

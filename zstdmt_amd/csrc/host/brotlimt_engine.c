@@ -101,7 +101,7 @@ BROTLIMT_CCtx *BROTLIMT_createCCtx(int threads, int level, int inputsize)
 	ctx->threads = threads;
 	ctx->level = level;
 	ctx->inputsize = inputsize ? inputsize : 1024 * 1024 * (level ? level : 1); /* :105-109 */
-	if (gpumt_open(0, &ctx->gpu) != GPUMT_OK) {
+	if (gpumt_open(GPUMT_DEVICE_DEFAULT, &ctx->gpu) != GPUMT_OK) {
 		free(ctx); /* no device: fail loudly, there is no CPU path */
 		return NULL;
 	}
@@ -292,7 +292,7 @@ BROTLIMT_DCtx *BROTLIMT_createDCtx(int threads, int inputsize)
 		return NULL;
 	ctx->threads = threads;
 	ctx->inputsize = inputsize ? inputsize : 1024 * 64; /* brotli-mt_decompress.c:110-113 */
-	if (gpumt_open(0, &ctx->gpu) != GPUMT_OK) {
+	if (gpumt_open(GPUMT_DEVICE_DEFAULT, &ctx->gpu) != GPUMT_OK) {
 		free(ctx);
 		return NULL;
 	}
@@ -388,8 +388,11 @@ static size_t d_read_batch(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *io, struct dslot
 		if (s->in_bytes + (size_t)csize + 512 > s->in.cap) {
 			dbuf old = s->in;
 			memset(&s->in, 0, sizeof s->in);
-			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + (size_t)csize + 512, 1, 1))
+			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + (size_t)csize + 512, 1, 1)) {
+				dbuf_free(ctx->gpu, &s->in);
+				s->in = old; /* keep the slot as it was: freeCtx releases it */
 				return BROTLIMT_ERROR(memory_allocation);
+			}
 			memcpy(s->in.h, old.h, s->in_bytes);
 			dbuf_free(ctx->gpu, &old);
 		}
@@ -513,7 +516,8 @@ size_t BROTLIMT_decompressDCtx(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *rdwr)
 	ctx->have_hdr = 0;
 	ctx->budget = BATCH_MIN;
 	ctx->io = rdwr;
-	err = mt_pipe_run(&ops, ctx);
+	/* threads == 1: every callback on the calling thread, as the reference (its single-thread path) */
+	err = ctx->threads == 1 ? mt_pipe_run_inline(&ops, ctx) : mt_pipe_run(&ops, ctx);
 	gpumt_device_sync(ctx->gpu);
 	return err;
 }

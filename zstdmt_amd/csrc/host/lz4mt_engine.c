@@ -103,7 +103,7 @@ LZ4MT_CCtx *LZ4MT_createCCtx(int threads, int level, int inputsize)
 	ctx->level = level;
 	ctx->threads = threads;
 	ctx->inputsize = inputsize ? inputsize : 1024 * 1024 * 4; /* lz4-mt_compress.c:111-114 */
-	if (gpumt_open(0, &ctx->gpu) != GPUMT_OK) {
+	if (gpumt_open(GPUMT_DEVICE_DEFAULT, &ctx->gpu) != GPUMT_OK) {
 		free(ctx); /* no device: fail loudly, there is no CPU path */
 		return NULL;
 	}
@@ -308,7 +308,7 @@ LZ4MT_DCtx *LZ4MT_createDCtx(int threads, int inputsize)
 		return NULL;
 	ctx->threads = threads;
 	ctx->inputsize = inputsize ? inputsize : 1024 + 1024 * 4; /* sic, lz4-mt_decompress.c:115 */
-	if (gpumt_open(0, &ctx->gpu) != GPUMT_OK) {
+	if (gpumt_open(GPUMT_DEVICE_DEFAULT, &ctx->gpu) != GPUMT_OK) {
 		free(ctx);
 		return NULL;
 	}
@@ -411,8 +411,11 @@ static size_t d_read_batch(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, struct dslot *s, i
 			/* a single record larger than the slot: grow (nothing is in flight in this slot) */
 			dbuf old = s->in;
 			memset(&s->in, 0, sizeof s->in);
-			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + 12 + (size_t)csize + 512, 1, 1))
+			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + 12 + (size_t)csize + 512, 1, 1)) {
+				dbuf_free(ctx->gpu, &s->in);
+				s->in = old; /* keep the slot as it was: freeCtx releases it */
 				return ERROR(memory_allocation);
+			}
 			memcpy(s->in.h, old.h, s->in_bytes);
 			dbuf_free(ctx->gpu, &old);
 		}
@@ -759,7 +762,8 @@ size_t LZ4MT_decompressDCtx(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *rdwr)
 	ctx->io = rdwr;
 	ctx->have_hdr = 0;
 	ctx->budget = BATCH_MIN;
-	err = mt_pipe_run(&ops, ctx);
+	/* threads == 1: every callback on the calling thread, as the reference (its single-thread path) */
+	err = ctx->threads == 1 ? mt_pipe_run_inline(&ops, ctx) : mt_pipe_run(&ops, ctx);
 	gpumt_device_sync(ctx->gpu);
 	return err;
 }

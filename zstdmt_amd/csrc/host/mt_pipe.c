@@ -184,3 +184,22 @@ size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
 	pthread_mutex_destroy(&p.mu);
 	return err;
 }
+
+size_t mt_pipe_run_inline(const mt_pipe_ops *ops, void *arg)
+{
+	for (long b = 0;; b++) {
+		const int s = (int)(b % MT_NSLOT);
+		int has_data = 0, eof = 0;
+		size_t err = ops->fill(arg, s, &has_data, &eof);
+		if (err)
+			return err;
+		if (has_data) {
+			if ((err = ops->launch(arg, s)) != 0 || (err = ops->complete(arg, s)) != 0 ||
+			    (err = ops->drain(arg, s)) != 0)
+				return err;
+		}
+		if (eof || !has_data)
+			break;
+	}
+	return 0;
+}

@@ -34,4 +34,9 @@ typedef struct {
 
 size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg);
 
+/* The same batches, every role on the calling thread, one batch at a time: what the reference does
+ * for a decompress context with threads == 1 (lib/lz4-mt_decompress.c:528-534 calls pt_decompress
+ * directly, so fn_read and fn_write run on the caller's thread). */
+size_t mt_pipe_run_inline(const mt_pipe_ops *ops, void *arg);
+
 #endif

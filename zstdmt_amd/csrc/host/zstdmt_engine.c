@@ -138,7 +138,7 @@ ZSTDCB_CCtx *ZSTDCB_createCCtx(int threads, int level, int inputsize)
 	ctx->level = level;
 	ctx->threads = threads;
 	ctx->inputsize = inputsize ? inputsize : 1 << (window_log[level] + 1);
-	if (gpumt_open(0, &ctx->gpu) != GPUMT_OK) {
+	if (gpumt_open(GPUMT_DEVICE_DEFAULT, &ctx->gpu) != GPUMT_OK) {
 		free(ctx); /* no device: fail loudly, there is no CPU path */
 		return NULL;
 	}
@@ -338,7 +338,7 @@ ZSTDCB_DCtx *ZSTDCB_createDCtx(int threads, int inputsize)
 		return NULL;
 	ctx->threads = threads;
 	ctx->inputsize = inputsize ? inputsize : 1024 * 512; /* zstd-mt_decompress.c:125-128 */
-	if (gpumt_open(0, &ctx->gpu) != GPUMT_OK) {
+	if (gpumt_open(GPUMT_DEVICE_DEFAULT, &ctx->gpu) != GPUMT_OK) {
 		free(ctx);
 		return NULL;
 	}
@@ -427,8 +427,11 @@ static size_t d_read_batch(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s,
 		if (s->in_bytes + 12 + (size_t)csize + 512 > s->in.cap) {
 			dbuf old = s->in;
 			memset(&s->in, 0, sizeof s->in);
-			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + 12 + (size_t)csize + 512, 1, 1))
+			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + 12 + (size_t)csize + 512, 1, 1)) {
+				dbuf_free(ctx->gpu, &s->in);
+				s->in = old; /* keep the slot as it was: freeCtx releases it */
 				return ZSTDCB_ERROR(memory_allocation);
+			}
 			memcpy(s->in.h, old.h, s->in_bytes);
 			dbuf_free(ctx->gpu, &old);
 		}
@@ -856,7 +859,25 @@ size_t ZSTDCB_decompressDCtx(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 	}
 	ctx->budget = BATCH_MIN;
 	ctx->io = rdwr;
-	err = mt_pipe_run(&ops, ctx);
+	/* threads == 1: every callback on the calling thread, as the reference (its single-thread path) */
+	err = ctx->threads == 1 ? mt_pipe_run_inline(&ops, ctx) : mt_pipe_run(&ops, ctx);
 	gpumt_device_sync(ctx->gpu);
 	return err;
 }
+
+/* ---- ZSTDMT_* : the names of /root/reference/lib/README.md:36-76, aliases of the entry points above ---- */
+#define ZMT_ALIAS(ret, name, args) ret ZSTDMT_##name args __attribute__((alias("ZSTDCB_" #name)))
+ZMT_ALIAS(unsigned, isError, (size_t));
+ZMT_ALIAS(const char *, getErrorString, (size_t));
+ZMT_ALIAS(ZSTDCB_CCtx *, createCCtx, (int, int, int));
+ZMT_ALIAS(size_t, compressCCtx, (ZSTDCB_CCtx *, ZSTDCB_RdWr_t *));
+ZMT_ALIAS(size_t, GetFramesCCtx, (ZSTDCB_CCtx *));
+ZMT_ALIAS(size_t, GetInsizeCCtx, (ZSTDCB_CCtx *));
+ZMT_ALIAS(size_t, GetOutsizeCCtx, (ZSTDCB_CCtx *));
+ZMT_ALIAS(void, freeCCtx, (ZSTDCB_CCtx *));
+ZMT_ALIAS(ZSTDCB_DCtx *, createDCtx, (int, int));
+ZMT_ALIAS(size_t, decompressDCtx, (ZSTDCB_DCtx *, ZSTDCB_RdWr_t *));
+ZMT_ALIAS(size_t, GetFramesDCtx, (ZSTDCB_DCtx *));
+ZMT_ALIAS(size_t, GetInsizeDCtx, (ZSTDCB_DCtx *));
+ZMT_ALIAS(size_t, GetOutsizeDCtx, (ZSTDCB_DCtx *));
+ZMT_ALIAS(void, freeDCtx, (ZSTDCB_DCtx *));

@@ -76,6 +76,36 @@ class Engine:
             self.sync(stream)
         return out.view(dtype)
 
+    def equal(self, d_a, d_b, nbytes, piece=128 << 20):
+        """byte-for-byte comparison of two device buffers: both are copied to pinned host memory in
+        pieces and compared there (bench.py's round-trip verification)"""
+        nbytes = int(nbytes)
+        if nbytes == 0:
+            return True
+        piece = min(piece, nbytes)
+        self.L.gpumt_host_alloc.restype = C.c_void_p
+        ha = self.L.gpumt_host_alloc(self.h, piece)
+        hb = self.L.gpumt_host_alloc(self.h, piece)
+        if not ha or not hb:
+            raise NativeError("gpumt_host_alloc failed")
+        libc = C.CDLL(None)
+        libc.memcmp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        same = True
+        try:
+            for off in range(0, nbytes, piece):
+                m = min(piece, nbytes - off)
+                self._ck(self.L.gpumt_memcpy_d2h(self.h, C.c_void_p(ha), d_a.ptr + off, m, 2), "d2h")
+                self._ck(self.L.gpumt_memcpy_d2h(self.h, C.c_void_p(hb), d_b.ptr + off, m, 3), "d2h")
+                self.sync(2)
+                self.sync(3)
+                if libc.memcmp(ha, hb, m) != 0:
+                    same = False
+                    break
+        finally:
+            self.L.gpumt_host_free(self.h, C.c_void_p(ha))
+            self.L.gpumt_host_free(self.h, C.c_void_p(hb))
+        return same
+
     def sync(self, stream=None):
         if stream is None:
             self._ck(self.L.gpumt_device_sync(self.h), "device_sync")
