@@ -30,10 +30,10 @@
 extern "C" {
 #endif
 
-/* streams 0..3: kernels / H2D / small D2H / bulk D2H of the host engines' pipeline; 4..7: one extra
+/* streams 0..3: kernels / H2D / small D2H / bulk D2H of the host engines' pipeline; 4..11: one extra
  * kernel stream per batch slot, so that the batches of a pipeline overlap on the device (every
  * launching stream has its own internal scratch) */
-#define GPUMT_NSTREAMS 8
+#define GPUMT_NSTREAMS 16
 
 enum {
 	GPUMT_OK = 0,
@@ -84,7 +84,7 @@ int   gpumt_stream_wait(gpumt_ctx *h, int waiter, int signaler);
  * far on `stream`; gpumt_mark_sync(id) blocks the calling host thread until that point is reached
  * (and nothing queued later).  Thread-safe: one thread may wait on a marker while another queues
  * work. */
-#define GPUMT_NMARKS 8
+#define GPUMT_NMARKS 16
 int   gpumt_mark(gpumt_ctx *h, int id, int stream);
 int   gpumt_mark_sync(gpumt_ctx *h, int id);
 /* raw hipStream_t of a stream index, for callers that interoperate (e.g. RCCL via torch) */

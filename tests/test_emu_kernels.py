@@ -39,7 +39,7 @@ def test_emu_compress_bit_exact(name, variant):
     assert H.sha256(stream) == MAN[name]["out_sha256"]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5])
 @pytest.mark.parametrize("name", SMALL)
 def test_emu_decompress(name, variant):
     chunk, thunk = CASES[name]
@@ -60,7 +60,7 @@ def test_emu_decompress_parse3(name):
     assert out == data
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5])
 @pytest.mark.parametrize("mutate,code", [("magic", 2), ("hc", 2), ("blocksize", 3), ("checksum", 5),
                                          ("skipmagic", 1), ("skiplen", 1), ("offset0", 3)])
 def test_emu_corrupt_streams(mutate, code, variant):

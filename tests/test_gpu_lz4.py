@@ -12,7 +12,7 @@ from cases import CASES, KNOWN_HEX, rnd, text
 pytestmark = pytest.mark.gpu
 
 # decoder kernel variants under test (include/gpumt.h gpumt_set_variant "lz4_dec")
-VARIANTS = [0, 1, 2, 4]   # 0 split pipeline, 1 serial, 2 fused batch kernel, 4 gather copy stage
+VARIANTS = [0, 1, 2, 4, 5]   # 0 split pipeline, 1 serial, 2 fused batch kernel, 4 gather copy stage, 5 copy2
 
 with open(os.path.join(H.GOLDEN_DIR, "manifest.json")) as _f:
     MAN = json.load(_f)["cases"]

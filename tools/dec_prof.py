@@ -34,7 +34,7 @@ for v in variants:
     st = eng.download(d_st, nrec * 4, np.uint32)
     ok = bool((eng.download(d_out, n) == hb).all())
     print(f"variant {v}: kernel {ms:.3f} ms  ({n/1e6/ms:.1f} GB/s out)  errors={int((st!=0).sum())} data_ok={ok}")
-    if v in (0, 4):
+    if v in (0, 4, 5):
         for xf in ([int(x) for x in os.environ.get("K2X", "0").split(",")] if os.environ.get("K2PROF") else []):
             eng.set_variant("k2x", xf)
             eng.set_variant("profile", 2)
@@ -50,6 +50,14 @@ for v in variants:
             L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); nbat = nrec * 2 * 86
             nm = ["fields", "scan+cuts+reserve", "far-issue", "literals", "far-commit", "rounds", "flush", "loop/other"]
             print("   K3 prof (cycles per ~batch): " + ", ".join(f"{nm[i]}={c[i]/nbat:.0f}" for i in range(8)) + f" total={c[8]/nbat:.0f}")
+            eng.set_variant("profile", 1)
+        if os.environ.get("K3PROF") and v == 5:
+            eng.set_variant("profile", 3)
+            cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
+            eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
+            L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); nbat = max(c[12], 1)
+            nm = ["land", "fields", "scan+check", "cuts+reserve+classify", "far-issue", "literals", "slot+sync", "match-r1", "rounds", "flush", "loop/prefetch"]
+            print("   copy2 prof (cycles per batch): " + ", ".join(f"{nm[i]}={c[i]/nbat:.0f}" for i in range(11)) + f" total={c[11]/nbat:.0f} batches={c[12]}")
             eng.set_variant("profile", 1)
         if os.environ.get("K3PROF") and v == 4:
             eng.set_variant("profile", 3)

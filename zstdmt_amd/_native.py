@@ -11,7 +11,8 @@ class NativeError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "lib", "libzstdmt_amd.so")
+    # ZMT_LIB: developer override (A/B builds of the kernels, tools/variant_build.sh)
+    return os.environ.get("ZMT_LIB") or os.path.join(HERE, "lib", "libzstdmt_amd.so")
 
 
 # name -> (restype, argtypes)   -- every symbol include/gpumt.h declares

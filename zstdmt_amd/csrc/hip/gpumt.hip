@@ -40,6 +40,12 @@ __global__ void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, con
 				    const u32 *, const u32 *, const u32 *, u32 *);
 __global__ void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *, u32 *,
 				      u32 *, u32 *);
+__global__ void zmt_dec_copy2_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
+				     const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
+				     const u32 *, const u32 *, u32 *);
+__global__ void zmt_dec_copy2_kernel_prof(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
+					  const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
+					  const u32 *, const u32 *, u32 *, unsigned long long *);
 __global__ void zmt_dec_gather_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
 				      const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 				      const u32 *, const u32 *, u32 *);
@@ -620,7 +626,7 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 	CARVE(bix, u32, ntok_max / 64 + 2)
 	CARVE(tok, u16, ntok_max)
 #undef CARVE
-	const bool split = (h->dec_variant == 0 || h->dec_variant == 4);
+	const bool split = (h->dec_variant == 0 || h->dec_variant == 4 || h->dec_variant == 5);
 	if (h->profile >= 2 && !h->d_prof) {
 		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
@@ -655,7 +661,19 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 				   h->profile == 2 ? h->d_prof : (unsigned long long *)NULL, (u32)h->xflags);
 		PROF1(14);
 		PROF0(15);
-		if (h->dec_variant == 4 && h->profile == 3)
+		if (h->dec_variant == 5 && h->profile == 3)
+			hipLaunchKernelGGL(zmt_dec_copy2_kernel_prof, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0, h->st[s],
+					   (const u8 *)d_stream, (u64)stream_bytes, n, (u8 *)d_out, d_out_off,
+					   d_out_len, (const u64 *)blk0, (const u64 *)bco, (const u32 *)bcs,
+					   (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, (const u32 *)bnt,
+					   (const u32 *)bol, d_status, h->d_prof);
+		else if (h->dec_variant == 5)
+			hipLaunchKernelGGL(zmt_dec_copy2_kernel, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0, h->st[s],
+					   (const u8 *)d_stream, (u64)stream_bytes, n, (u8 *)d_out, d_out_off,
+					   d_out_len, (const u64 *)blk0, (const u64 *)bco, (const u32 *)bcs,
+					   (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, (const u32 *)bnt,
+					   (const u32 *)bol, d_status);
+		else if (h->dec_variant == 4 && h->profile == 3)
 			hipLaunchKernelGGL(zmt_dec_gather_kernel_prof, dim3(n), dim3(64), 0, h->st[s],
 					   (const u8 *)d_stream, (u64)stream_bytes, n, (u8 *)d_out, d_out_off,
 					   d_out_len, (const u64 *)blk0, (const u64 *)bco, (const u32 *)bcs,

@@ -239,7 +239,9 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 		     unsigned long long *prof, u32 xflags)
 {
 	__shared__ __attribute__((aligned(16))) u8 ring_lds[64 * P_RSTRIDE];
+#ifndef P_DIRECT_TOK
 	__shared__ __attribute__((aligned(16))) u8 tile_lds[64 * P_TSTRIDE];
+#endif
 	const int lane = wv_lane();
 	const u32 gb = blockIdx.x * 64 + (u32)lane;
 	const u64 nblk = *nblk_ptr;
@@ -272,7 +274,9 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 	const u32 trel = (u32)(tbase - tmin);
 	const u8 *src = stream + coff;
 	u8 *const myring = ring_lds + (u32)lane * P_RSTRIDE;
+#ifndef P_DIRECT_TOK
 	u16 *const mytile = (u16 *)(tile_lds + (u32)lane * P_TSTRIDE);
+#endif
 
 	u32 pos = 0, opos = 0, n = 0;
 	/* ring bookkeeping in "g" coordinates: g = boff + block position = stream offset - abase,
@@ -433,14 +437,23 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 		}
 		{ u64 t_ = KT(); c_t3 += t_ - tk0; tk0 = t_; }
 		if (emit) {
+#ifdef P_DIRECT_TOK
+			/* no LDS tile: the position goes straight to the list (2-byte scattered stores: nothing
+			 * waits for them, consecutive ones of a lane fall into the same L2 line) */
+			tok[tmin + trel + n] = (u16)my_pos;
+			if ((n & 63) == 0)
+				bidx[((tmin + trel) >> 6) + (n >> 6)] = my_opos;
+#else
 			mytile[n & 63] = (u16)my_pos;
 			if ((n & 63) == 0)
 				bx_pending = my_opos;
+#endif
 			n++;
 		}
 		{ u64 t_ = KT(); c_token += t_ - tk0; tk0 = t_; }
 		/* ---------------- drain the token tile (every 64 steps, and at the end) -------- */
 		const bool all_done = !wv_any(!done);
+#ifndef P_DIRECT_TOK
 		if ((step & 63) == 63 || all_done) {
 			wv_sync();
 			/* lanes that emitted in this window own tile rows worth writing */
@@ -463,6 +476,10 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 				bidx[((tmin + trel) >> 6) + (first >> 6)] = bx_pending;
 			wv_sync();
 		}
+#else
+		(void)bx_pending;
+		(void)dpiece;
+#endif
 		{ u64 t_ = KT(); c_drain += t_ - tk0; tk0 = t_; }
 		if (all_done) {
 #ifndef ZMT_EMU

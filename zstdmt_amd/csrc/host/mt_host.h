@@ -20,7 +20,17 @@
  * context, so repeated calls on one context do not pay for them again.
  */
 #define BATCH_MIN ((size_t)64 << 20)
-#define BATCH_BYTES ((size_t)256 << 20)
+#define BATCH_BYTES (zmt_batch_bytes())
+static inline size_t zmt_batch_bytes(void)
+{
+	static size_t v;
+	if (!v) {
+		const char *e = getenv("GPUMT_BATCH_MB"); /* developer knob: device batch size */
+		size_t mb = e && *e ? (size_t)strtoull(e, 0, 10) : 256;
+		v = (mb < 16 ? 16 : mb > 2048 ? 2048 : mb) << 20;
+	}
+	return v;
+}
 #define BATCH_MAXREC 8192
 
 static inline uint32_t rd32(const uint8_t *p)

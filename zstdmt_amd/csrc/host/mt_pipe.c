@@ -2,6 +2,18 @@
 #include "mt_pipe.h"
 
 #include <pthread.h>
+#include <stdlib.h>
+
+int mt_nslot(void)
+{
+	static int n;
+	if (!n) {
+		const char *e = getenv("GPUMT_SLOTS");
+		int v = e && *e ? atoi(e) : 4;
+		n = v < 2 ? 2 : v > MT_NSLOT ? MT_NSLOT : v;
+	}
+	return n;
+}
 
 enum { S_FREE, S_FILLED, S_DONE };
 
@@ -11,6 +23,7 @@ typedef struct {
 	pthread_mutex_t mu;
 	pthread_cond_t cv;
 	int state[MT_NSLOT];
+	int nslot;
 	size_t err;        /* first error, sticky */
 	long n_filled;     /* batches the reader has produced */
 	long n_done;       /* batches whose results are in host memory */
@@ -31,7 +44,7 @@ static void *reader_main(void *a)
 {
 	pipe_t *p = (pipe_t *)a;
 	for (long b = 0;; b++) {
-		const int s = (int)(b % MT_NSLOT);
+		const int s = (int)(b % p->nslot);
 		int has_data = 0, eof = 0;
 		size_t err;
 		pthread_mutex_lock(&p->mu);
@@ -69,7 +82,7 @@ static void *writer_main(void *a)
 {
 	pipe_t *p = (pipe_t *)a;
 	for (long b = 0;; b++) {
-		const int s = (int)(b % MT_NSLOT);
+		const int s = (int)(b % p->nslot);
 		size_t err;
 		int stop;
 		pthread_mutex_lock(&p->mu);
@@ -95,7 +108,7 @@ static void *writer_main(void *a)
 /* wait until the slot is done being filled; 1 = go, 0 = no more batches / error */
 static int wait_filled(pipe_t *p, long b)
 {
-	const int s = (int)(b % MT_NSLOT);
+	const int s = (int)(b % p->nslot);
 	int go;
 	pthread_mutex_lock(&p->mu);
 	while (!(p->state[s] == S_FILLED && b < p->n_filled) && !p->err && !(p->reader_over && b >= p->n_filled))
@@ -108,7 +121,7 @@ static int wait_filled(pipe_t *p, long b)
 static void mark_done(pipe_t *p, long b)
 {
 	pthread_mutex_lock(&p->mu);
-	p->state[b % MT_NSLOT] = S_DONE;
+	p->state[b % p->nslot] = S_DONE;
 	p->n_done = b + 1;
 	pthread_cond_broadcast(&p->cv);
 	pthread_mutex_unlock(&p->mu);
@@ -123,6 +136,7 @@ size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
 
 	p.ops = ops;
 	p.arg = arg;
+	p.nslot = mt_nslot();
 	p.err = 0;
 	p.n_filled = p.n_done = 0;
 	p.reader_over = p.device_over = 0;
@@ -150,7 +164,7 @@ size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
 		for (;;) {
 			const int go = wait_filled(&p, b);
 			if (go) {
-				err = ops->launch(arg, (int)(b % MT_NSLOT));
+				err = ops->launch(arg, (int)(b % p.nslot));
 				if (err) {
 					fail(&p, err);
 					break;
@@ -158,8 +172,8 @@ size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
 				b++;
 			}
 			err = 0;
-			while (done < b && (!go || b - done >= MT_NSLOT - 1)) {
-				err = ops->complete(arg, (int)(done % MT_NSLOT));
+			while (done < b && (!go || b - done >= p.nslot - 1)) {
+				err = ops->complete(arg, (int)(done % p.nslot));
 				if (err)
 					break;
 				mark_done(&p, done);
@@ -188,7 +202,7 @@ size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
 size_t mt_pipe_run_inline(const mt_pipe_ops *ops, void *arg)
 {
 	for (long b = 0;; b++) {
-		const int s = (int)(b % MT_NSLOT);
+		const int s = (int)(b % 2);
 		int has_data = 0, eof = 0;
 		size_t err = ops->fill(arg, s, &has_data, &eof);
 		if (err)

@@ -21,7 +21,11 @@
 
 #include <stddef.h>
 
-#define MT_NSLOT 4
+#define MT_NSLOT 8 /* slots a context owns; the pipeline uses the first mt_nslot() of them */
+
+/* slots in use: GPUMT_SLOTS (2..MT_NSLOT), default 4 -- more slots keep more batches on the device at
+ * once (the wave-per-record decoders are latency-bound per record) at the price of pinned memory */
+int mt_nslot(void);
 
 typedef struct {
 	/* fill: *has_data = 0 when the input ended before anything was read into the slot; *eof = 1
