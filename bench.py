@@ -61,7 +61,6 @@ def parse():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--chunk", type=int, default=0, help="0 = 128 KiB for lz4 (configs[1]), 1 MiB for zstd / brotli")
     ap.add_argument("--dec-variant", type=int, default=0)
-    ap.add_argument("--enc-variant", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-mib", type=int, default=2048, help="cpu_baseline sample size")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of segments to rank 0")
@@ -321,7 +320,7 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
     t_c = (ms["compress"] + ms["compact"]) * 1e-3 if not dec_only else None
     want_chunk = (1 << 20) if zstd else 131072
     traffic = traffic_table(gib if world == 1 else -1, chunk, want_chunk)
-    split = args.dec_variant in (0, 4)
+    split = args.dec_variant == 0
 
     def roof(kname, t_ms, alg_bytes, pmc_names):
         t = t_ms * 1e-3
@@ -343,12 +342,11 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
                      ms["k_lz4_dec"], alg, ("zmt_zstd_dec_small_kernel", "zmt_zstd_dec_kernel"))
     else:
         name, what = "lz4-mt", "lz4-mt -1"
-        ek = {0: "zmt_lz4_enc3_p17_kernel" if 65536 < chunk <= 131072 else
-              ("zmt_lz4_enc3_u16_kernel" if chunk <= 65536 else "zmt_lz4_enc3_u32_kernel"),
-              1: "zmt_lz4_enc_v1_kernel", 2: "zmt_lz4_enc_kernel"}[args.enc_variant]
+        ek = ("zmt_lz4_enc3_p17_kernel" if 65536 < chunk <= 131072 else
+              ("zmt_lz4_enc3_u16_kernel" if chunk <= 65536 else "zmt_lz4_enc3_u32_kernel"))
         r_enc = None if dec_only else roof(ek, ms["k_lz4_enc"], alg, (ek,))
-        r_dec = roof("zmt_dec_frames+parse+copy_kernel" if split else "zmt_lz4_dec_*", ms["k_lz4_dec"], alg,
-                     ("zmt_dec_frames_kernel", "zmt_dec_parse_kernel", "zmt_dec_copy_kernel") if split else ())
+        r_dec = roof("zmt_dec_frames+parse+copy2_kernel" if split else "zmt_lz4_dec_serial", ms["k_lz4_dec"], alg,
+                     ("zmt_dec_frames_kernel", "zmt_dec_parse_kernel", "zmt_dec_copy2_kernel") if split else ())
     dom = r_dec if (dec_only or ms["k_lz4_dec"] >= ms.get("k_lz4_enc", 0.0)) else r_enc
     res = {
         "metric": (f"MB/s decompress, 8 GiB synthetic, {name}; % HBM roofline" if dec_only else
@@ -382,7 +380,7 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
     if zstd:
         res["config"]["parity"] = "decompress-identical (SURVEY 8a C4)"
     elif split:
-        res["roofline_decompress_copy_kernel"] = roof("zmt_dec_copy_kernel", ms["k_dec_copy"], alg, ("zmt_dec_copy_kernel",))
+        res["roofline_decompress_copy_kernel"] = roof("zmt_dec_copy2_kernel", ms["k_dec_copy"], alg, ("zmt_dec_copy2_kernel",))
         res["roofline_decompress_parse_kernel"] = roof("zmt_dec_parse_kernel", ms["k_dec_parse"], Cb, ("zmt_dec_parse_kernel",))
     if gather_ms is not None:
         res["value_with_gather"] = round(U_all / 1e6 / (step_s + gather_ms * 1e-3), 1)
@@ -702,7 +700,6 @@ def main():
     import zstdmt_amd as z
     eng = z.Engine(local)
     eng.set_variant("lz4_dec", args.dec_variant)
-    eng.set_variant("lz4_enc", args.enc_variant)
     eng.set_variant("profile", 1)
     ctx = Ctx(args, eng, rank, world, dist)
 

@@ -13,8 +13,6 @@ typedef uint64_t u64;
 
 extern "C" {
 void zmt_xxh32_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, const u32 *, const u32 *, u32 *);
-void zmt_lz4_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
-void zmt_lz4_enc_v1_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
 void zmt_lz4_enc3_u16_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
 void zmt_lz4_enc3_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
 void zmt_lz4_enc3_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
@@ -22,11 +20,7 @@ void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u
 void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
 void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *, u32 *, unsigned long long *, u32);
-void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, const u32 *, u32 *);
-void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *, u32 *);
-void zmt_dec_copy2_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, u32 *);
-void zmt_dec_gather_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, u32 *);
-void zmt_lz4_dec_batch(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u32 *);
+void zmt_dec_copy2_kernel(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, u32 *);
 void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 void zmt_scan_kernel(const u32 *, u32, u64 *);
 void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
@@ -58,9 +52,6 @@ void emu_xxh32_batch(const u8 *base, const u64 *off, const u32 *len, u32 n, u32 
 		    [=]() { zmt_xxh32_kernel(base, off, len, n, out, nullptr, nullptr, nullptr); });
 }
 
-static int g_enc_variant = 0;
-void emu_set_enc_variant(int v) { g_enc_variant = v; }
-
 void emu_lz4_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len)
 {
 	u32 nrec = n ? (u32)((n + chunk - 1) / chunk) : 1;
@@ -72,13 +63,7 @@ void emu_lz4_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 strid
 	}
 	emu_xxh32_batch(in, off.data(), len.data(), nrec, chk.data());
 	const u32 *chkp = chk.data();
-	if (g_enc_variant == 1) {
-		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
-			    [=]() { zmt_lz4_enc_v1_kernel(in, n, chunk, nrec, slots, stride, rec_len, chkp); });
-	} else if (g_enc_variant == 2) {
-		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
-			    [=]() { zmt_lz4_enc_kernel(in, n, chunk, nrec, slots, stride, rec_len, chkp); });
-	} else if (chunk <= 65536) {
+	if (chunk <= 65536) {
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
 			    [=]() { zmt_lz4_enc3_u16_kernel(in, n, chunk, 0, nrec, slots, stride, rec_len, chkp, nullptr); });
 	} else {
@@ -108,9 +93,6 @@ void emu_lz4_probe_sizes(const u8 *stream, const u64 *rec_off, const u32 *rec_le
 	emu::launch(dim3{1, 1, 1}, dim3{1024, 1, 1}, [=]() { zmt_scan_kernel(out_len, nrec, out_off); });
 }
 
-static int g_parse_variant = 0; /* 0 = lane-per-block kernel (default), 3 = zmt_dec_parse3_kernel */
-void emu_set_parse_variant(int v) { g_parse_variant = v; }
-
 void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, const u64 *rec_off,
 			      const u32 *rec_len, u32 nrec, u8 *out, u64 out_bytes, const u64 *out_off,
 			      u32 *out_len, u32 *status)
@@ -120,10 +102,6 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 	if (variant == 1) {
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
 			zmt_lz4_dec_serial(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp, 0xFFFFFFFFu);
-		});
-	} else if (variant == 2) {
-		emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{256, 1, 1}, [=]() {
-			zmt_lz4_dec_batch(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp);
 		});
 	} else {
 		size_t nblk_max = out_bytes / 65536 + nrec + 1;
@@ -140,32 +118,18 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 		emu::launch(dim3{(nrec + 255) / 256, 1, 1}, dim3{256, 1, 1}, [=]() {
 			zmt_dec_frames_kernel(stream, rec_off, rec_len, nrec, out_len, blk0p, bcop, bcsp, rnbp, rflp, status, cep, cvp);
 		});
-		if (g_parse_variant == 3)
-			emu::launch(dim3{(u32)((nblk_max + 3) / 4), 1, 1}, dim3{256, 1, 1}, [=]() {
-				zmt_dec_parse3_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bixp, bntp, bolp);
-			});
-		else
-			emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
-				zmt_dec_parse_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bixp, bntp, bolp, nullptr, 0);
-			});
+		emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
+			zmt_dec_parse_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bixp, bntp, bolp, nullptr, 0);
+		});
 		if (getenv("ZMT_EMU_DEBUG")) {
 			for (size_t b = 0; b < blk0[nrec]; b++)
 				fprintf(stderr, "blk %zu coff=%llu csize=%x ntok=%u olen=%u\n", b, (unsigned long long)bco[b], bcs[b], bnt[b], bol[b]);
 			for (u32 r = 0; r < nrec; r++)
 				fprintf(stderr, "rec %u status=%u nblk=%u\n", r, status[r], rnb[r]);
 		}
-		if (variant == 5)
-			emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{256, 1, 1}, [=]() {
-				zmt_dec_copy2_kernel(stream, stream_bytes, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
-			});
-		else if (variant == 4)
-			emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
-				zmt_dec_gather_kernel(stream, stream_bytes, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
-			});
-		else
-			emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{256, 1, 1}, [=]() {
-				zmt_dec_copy_kernel(stream, stream_bytes, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bixp, bntp, bolp, status);
-			});
+		emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{256, 1, 1}, [=]() {
+			zmt_dec_copy2_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
+		});
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
 			zmt_lz4_dec_serial(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp, 100u);
 		});

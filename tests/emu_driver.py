@@ -36,10 +36,9 @@ def xxh32_batch(buf: np.ndarray, off: np.ndarray, length: np.ndarray) -> np.ndar
     return out
 
 
-def compress(data: bytes, chunk: int, variant: int = 0):
-    """-> (stream bytes, rec_off[n+1], rec_len[n]); variant 0 = v3 (default), 1 = v1, 2 = v2"""
+def compress(data: bytes, chunk: int):
+    """-> (stream bytes, rec_off[n+1], rec_len[n])"""
     L = lib()
-    L.emu_set_enc_variant(C.c_int(variant))
     n = len(data)
     nrec = max(1, (n + chunk - 1) // chunk)
     stride = L.emu_lz4_slot_stride(chunk)
@@ -71,10 +70,9 @@ def walk_records(stream: bytes):
     return np.array(offs, np.uint64), np.array(lens, np.uint32)
 
 
-def decompress(stream: bytes, variant: int = 0, rec=None, parse: int = 0):
-    """-> (content bytes, status[n]); parse 0 = lane-per-block token walk, 3 = zmt_dec_parse3_kernel"""
+def decompress(stream: bytes, variant: int = 0, rec=None):
+    """-> (content bytes, status[n]); variant 0 = frames + parse + copy2 kernels, 1 = serial decoder"""
     L = lib()
-    L.emu_set_parse_variant(C.c_int(parse))
     ro, rl = rec if rec is not None else walk_records(stream)
     nrec = len(ro)
     sbuf = np.frombuffer(stream + b"\0" * 512, np.uint8).copy()

@@ -12,7 +12,7 @@ from cases import CASES, KNOWN_HEX, rnd, text
 pytestmark = pytest.mark.gpu
 
 # decoder kernel variants under test (include/gpumt.h gpumt_set_variant "lz4_dec")
-VARIANTS = [0, 1, 2, 4, 5]   # 0 split pipeline, 1 serial, 2 fused batch kernel, 4 gather copy stage, 5 copy2
+VARIANTS = [0, 1]   # 0 = frames + parse + copy2 pipeline (default), 1 = serial wave-per-record decoder
 
 with open(os.path.join(H.GOLDEN_DIR, "manifest.json")) as _f:
     MAN = json.load(_f)["cases"]
@@ -26,16 +26,11 @@ def eng():
     e.close()
 
 
-@pytest.mark.parametrize("enc", [0, 1, 2])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_compress_golden(eng, name, enc):
+def test_compress_golden(eng, name):
     chunk, thunk = CASES[name]
     data = thunk()
-    eng.set_variant("lz4_enc", enc)
-    try:
-        stream, rec_off, rec_len = eng.compress_bytes(data, chunk)
-    finally:
-        eng.set_variant("lz4_enc", 0)
+    stream, rec_off, rec_len = eng.compress_bytes(data, chunk)
     e = MAN[name]
     assert len(stream) == e["out_len"]
     assert H.sha256(stream) == e["out_sha256"]
@@ -68,7 +63,6 @@ def test_fuzz_vs_oracle(eng, seed):
     from test_oracle_vs_ref import _mix
     rng = random.Random(1000 + seed)
     n = rng.randrange(1, 3_000_000)
-    eng.set_variant("lz4_enc", seed % 3)
     chunk = rng.choice([65536, 131072, 131072, 100000, 262144, 1 << 20])
     data = _mix(rng, n)
     want = H.oracle_compress(data, chunk)
@@ -79,7 +73,6 @@ def test_fuzz_vs_oracle(eng, seed):
         out, status = eng.decompress_bytes(stream, ro, rl)
         eng.set_variant("lz4_dec", 0)
         assert not status.any() and out == data
-    eng.set_variant("lz4_enc", 0)
 
 
 def test_config1_random_64m(eng):

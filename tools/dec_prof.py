@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import zstdmt_amd as z
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "2", "3"])]
+variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "1"])]
 eng = z.Engine(0); L, h = eng.L, eng.h
 T = C.CDLL(os.path.join(ROOT, "zstdmt_amd", "lib", "libzmt_tools.so"))
 T.zmt_gen_text.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int]
@@ -34,7 +34,7 @@ for v in variants:
     st = eng.download(d_st, nrec * 4, np.uint32)
     ok = bool((eng.download(d_out, n) == hb).all())
     print(f"variant {v}: kernel {ms:.3f} ms  ({n/1e6/ms:.1f} GB/s out)  errors={int((st!=0).sum())} data_ok={ok}")
-    if v in (0, 4, 5):
+    if v == 0:
         for xf in ([int(x) for x in os.environ.get("K2X", "0").split(",")] if os.environ.get("K2PROF") else []):
             eng.set_variant("k2x", xf)
             eng.set_variant("profile", 2)
@@ -47,34 +47,8 @@ for v in variants:
             eng.set_variant("profile", 3)
             cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
             eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
-            L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); nbat = nrec * 2 * 86
-            nm = ["fields", "scan+cuts+reserve", "far-issue", "literals", "far-commit", "rounds", "flush", "loop/other"]
-            print("   K3 prof (cycles per ~batch): " + ", ".join(f"{nm[i]}={c[i]/nbat:.0f}" for i in range(8)) + f" total={c[8]/nbat:.0f}")
-            eng.set_variant("profile", 1)
-        if os.environ.get("K3PROF") and v == 5:
-            eng.set_variant("profile", 3)
-            cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
-            eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
             L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); nbat = max(c[12], 1)
             nm = ["land", "fields", "scan+check", "cuts+reserve+classify", "far-issue", "literals", "slot+sync", "match-r1", "rounds", "flush", "loop/prefetch"]
             print("   copy2 prof (cycles per batch): " + ", ".join(f"{nm[i]}={c[i]/nbat:.0f}" for i in range(11)) + f" total={c[11]/nbat:.0f} batches={c[12]}")
             eng.set_variant("profile", 1)
-        if os.environ.get("K3PROF") and v == 4:
-            eng.set_variant("profile", 3)
-            cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
-            eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
-            L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); rows = max(c[10], 1)
-            nm = ["step", "commit", "lookup", "bytes", "global", "write+sync", "fix", "carry+drain"]
-            print("   gather prof (cycles per row): " + ", ".join(f"{nm[i]}={c[i]/rows:.0f}" for i in range(8)) +
-                  f" total={c[8]/rows:.0f} | rows={c[10]} steps={c[11]} rows/step={c[10]/max(c[11],1):.2f} fixpasses/row={c[12]/rows:.2f} fences/wave={c[13]/max(c[9],1):.1f} cycles/step={c[0]/max(c[11],1):.0f}")
-            eng.set_variant("profile", 1)
         print("   split: frames %.3f ms, parse %.3f ms, copy %.3f ms, xxh %.3f ms" % (eng.timer_ms(13), eng.timer_ms(14), eng.timer_ms(15), eng.timer_ms(12)))
-    if v == 3:
-        L.gpumt_debug_counters(h, cnt, 16)
-        c = list(cnt)
-        nb = max(c[9], 1)
-        print(f"  batches={c[9]} seqs/batch={c[10]/nb:.1f} waves={nrec}")
-        tot = c[11]
-        for i in (0, 1, 2, 3, 4, 5, 6, 7, 8):
-            print(f"  {names[i]:22s} {c[i]/nb:9.0f} cyc/batch  {100*c[i]/tot:5.1f}%")
-        print(f"  {'total/wave':22s} {tot/nrec:9.0f} cycles; per batch {tot/nb:.0f}")

@@ -20,8 +20,6 @@ typedef uint64_t u64;
 extern "C" {
 __global__ void zmt_xxh32_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, const u32 *,
 				 const u32 *, u32 *);
-__global__ void zmt_lz4_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
-__global__ void zmt_lz4_enc_v1_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *);
 __global__ void zmt_lz4_enc3_u16_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
 					unsigned long long *);
 __global__ void zmt_lz4_enc3_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
@@ -35,23 +33,12 @@ __global__ void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32,
 				      const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
 __global__ void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *,
 				     u32 *, u32 *, u32 *, unsigned long long *, u32);
-__global__ void zmt_dec_copy_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
-				    const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
-				    const u32 *, const u32 *, const u32 *, u32 *);
-__global__ void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *, u32 *,
-				      u32 *, u32 *);
-__global__ void zmt_dec_copy2_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
+__global__ void zmt_dec_copy2_kernel(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *,
 				     const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 				     const u32 *, const u32 *, u32 *);
-__global__ void zmt_dec_copy2_kernel_prof(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
+__global__ void zmt_dec_copy2_kernel_prof(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *,
 					  const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 					  const u32 *, const u32 *, u32 *, unsigned long long *);
-__global__ void zmt_dec_gather_kernel(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
-				      const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
-				      const u32 *, const u32 *, u32 *);
-__global__ void zmt_dec_gather_kernel_prof(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
-					   const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
-					   const u32 *, const u32 *, u32 *, unsigned long long *);
 __global__ void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 __global__ void zmt_brotli_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 __global__ void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *,
@@ -70,13 +57,6 @@ __global__ void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u
 __global__ void zmt_zstd_enc_kernel_prof(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *, unsigned long long *);
 __global__ void zmt_zstd_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 __global__ void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
-__global__ void zmt_dec_copy_kernel_prof(const u8 *, u64, u32, u8 *, const u64 *, const u32 *, const u64 *,
-					 const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
-					 const u32 *, const u32 *, const u32 *, u32 *, unsigned long long *);
-__global__ void zmt_lz4_dec_batch(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
-				  const u32 *, u32 *, u32 *, u32 *);
-__global__ void zmt_lz4_dec_batch_prof(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
-				       const u32 *, u32 *, u32 *, u32 *, unsigned long long *);
 __global__ void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 __global__ void zmt_scan_kernel(const u32 *, u32, u64 *);
 __global__ void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
@@ -96,8 +76,6 @@ struct gpumt_ctx {
 					   * batches launched on different streams can overlap */
 	size_t scratch_bytes[2][GPUMT_NSTREAMS];
 	int dec_variant;
-	int parse_variant; /* 0 = zmt_dec_parse3_kernel (16-byte loads, several tokens per load), 1 = LDS-ring design */
-	int enc_variant; /* 0 = v3 (LDS input ring, small batches, 17-bit table), 1 = v1, 2 = v2 */
 	unsigned long long *d_prof; /* 16 phase counters of the profiling decoder */
 	int xflags;  /* experiment switches of the parse kernel (developer) */
 	int profile; /* record events in timer slots 8.. around individual kernels */
@@ -525,15 +503,7 @@ int gpumt_lz4_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t ch
 		}
 		eprof = h->d_prof;
 	}
-	if (h->enc_variant == 1) {
-		hipLaunchKernelGGL(zmt_lz4_enc_v1_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
-				   (const u8 *)d_in, (u64)n, (u32)chunk, (u32)nrec, (u8 *)d_slots,
-				   (u64)slot_stride, d_rec_len, (const u32 *)chk);
-	} else if (h->enc_variant == 2) {
-		hipLaunchKernelGGL(zmt_lz4_enc_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
-				   (const u8 *)d_in, (u64)n, (u32)chunk, (u32)nrec, (u8 *)d_slots,
-				   (u64)slot_stride, d_rec_len, (const u32 *)chk);
-	} else if (chunk <= 65536) {
+	if (chunk <= 65536) {
 		/* every record is a single independent block: byU16 table */
 		hipLaunchKernelGGL(zmt_lz4_enc3_u16_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
 				   (const u8 *)d_in, (u64)n, (u32)chunk, 0u, (u32)nrec, (u8 *)d_slots,
@@ -626,7 +596,7 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 	CARVE(bix, u32, ntok_max / 64 + 2)
 	CARVE(tok, u16, ntok_max)
 #undef CARVE
-	const bool split = (h->dec_variant == 0 || h->dec_variant == 4 || h->dec_variant == 5);
+	const bool split = (h->dec_variant == 0);
 	if (h->profile >= 2 && !h->d_prof) {
 		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
@@ -650,72 +620,36 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 				   (const u64 *)blk0, bco, bcs, rnb, rfl, d_status, ce, cv);
 		PROF1(13);
 		PROF0(14);
-		if (h->parse_variant == 3 && h->profile != 2)
-			hipLaunchKernelGGL(zmt_dec_parse3_kernel, dim3((unsigned)((nblk_max + 3) / 4)), dim3(256), 0,
-					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
-					   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bix, bnt, bol);
-		else
 		hipLaunchKernelGGL(zmt_dec_parse_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
 				   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
 				   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bix, bnt, bol,
 				   h->profile == 2 ? h->d_prof : (unsigned long long *)NULL, (u32)h->xflags);
 		PROF1(14);
 		PROF0(15);
-		if (h->dec_variant == 5 && h->profile == 3)
+		/* (running the XXH32 verification of record slices on a second stream while the next slice
+		 * is copied was measured: the partial last round of every slice costs more than the overlap
+		 * gains, 12.2 vs 10.5 + 1.5 ms per 8 GiB) */
+		if (h->profile == 3)
 			hipLaunchKernelGGL(zmt_dec_copy2_kernel_prof, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0, h->st[s],
-					   (const u8 *)d_stream, (u64)stream_bytes, n, (u8 *)d_out, d_out_off,
+					   (const u8 *)d_stream, (u64)stream_bytes, 0u, n, (u8 *)d_out, d_out_off,
 					   d_out_len, (const u64 *)blk0, (const u64 *)bco, (const u32 *)bcs,
 					   (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, (const u32 *)bnt,
 					   (const u32 *)bol, d_status, h->d_prof);
-		else if (h->dec_variant == 5)
-			hipLaunchKernelGGL(zmt_dec_copy2_kernel, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0, h->st[s],
-					   (const u8 *)d_stream, (u64)stream_bytes, n, (u8 *)d_out, d_out_off,
-					   d_out_len, (const u64 *)blk0, (const u64 *)bco, (const u32 *)bcs,
-					   (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, (const u32 *)bnt,
-					   (const u32 *)bol, d_status);
-		else if (h->dec_variant == 4 && h->profile == 3)
-			hipLaunchKernelGGL(zmt_dec_gather_kernel_prof, dim3(n), dim3(64), 0, h->st[s],
-					   (const u8 *)d_stream, (u64)stream_bytes, n, (u8 *)d_out, d_out_off,
-					   d_out_len, (const u64 *)blk0, (const u64 *)bco, (const u32 *)bcs,
-					   (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, (const u32 *)bnt,
-					   (const u32 *)bol, d_status, h->d_prof);
-		else if (h->dec_variant == 4)
-			hipLaunchKernelGGL(zmt_dec_gather_kernel, dim3(n), dim3(64), 0, h->st[s],
-					   (const u8 *)d_stream, (u64)stream_bytes, n, (u8 *)d_out, d_out_off,
-					   d_out_len, (const u64 *)blk0, (const u64 *)bco, (const u32 *)bcs,
-					   (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, (const u32 *)bnt,
-					   (const u32 *)bol, d_status);
-		else if (h->profile == 3)
-			hipLaunchKernelGGL(zmt_dec_copy_kernel_prof, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0,
-					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, n, (u8 *)d_out,
-					   d_out_off, d_out_len, (const u64 *)blk0, (const u64 *)bco,
-					   (const u32 *)bcs, (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok,
-					   (const u32 *)bix, (const u32 *)bnt, (const u32 *)bol, d_status, h->d_prof);
 		else
-			hipLaunchKernelGGL(zmt_dec_copy_kernel, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0,
-					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, n, (u8 *)d_out,
-					   d_out_off, d_out_len, (const u64 *)blk0, (const u64 *)bco,
-					   (const u32 *)bcs, (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok,
-					   (const u32 *)bix, (const u32 *)bnt, (const u32 *)bol, d_status);
+			hipLaunchKernelGGL(zmt_dec_copy2_kernel, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0, h->st[s],
+					   (const u8 *)d_stream, (u64)stream_bytes, 0u, n, (u8 *)d_out, d_out_off,
+					   d_out_len, (const u64 *)blk0, (const u64 *)bco, (const u32 *)bcs,
+					   (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, (const u32 *)bnt,
+					   (const u32 *)bol, d_status);
 		PROF1(15);
 		/* records the fast path does not cover (block size > 64 KiB, odd block counts) */
 		hipLaunchKernelGGL(zmt_lz4_dec_serial, dim3(n), dim3(64), 0, h->st[s], (const u8 *)d_stream,
 				   d_rec_off, d_rec_len, n, (u8 *)d_out, d_out_off, d_out_len, d_status, ce,
 				   cv, 100u);
-	} else if (h->dec_variant == 3) {
-		if (!h->d_prof)
-			CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
-		hipLaunchKernelGGL(zmt_lz4_dec_batch_prof, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0,
-				   h->st[s], (const u8 *)d_stream, d_rec_off, d_rec_len, n, (u8 *)d_out,
-				   d_out_off, d_out_len, d_status, ce, cv, h->d_prof);
-	} else if (h->dec_variant == 1) {
+	} else {
 		hipLaunchKernelGGL(zmt_lz4_dec_serial, dim3(n), dim3(64), 0, h->st[s], (const u8 *)d_stream,
 				   d_rec_off, d_rec_len, n, (u8 *)d_out, d_out_off, d_out_len, d_status, ce,
 				   cv, 0xFFFFFFFFu);
-	} else {
-		hipLaunchKernelGGL(zmt_lz4_dec_batch, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0,
-				   h->st[s], (const u8 *)d_stream, d_rec_off, d_rec_len, n, (u8 *)d_out,
-				   d_out_off, d_out_len, d_status, ce, cv);
 	}
 	PROF1(11);
 	PROF0(12);
@@ -962,12 +896,6 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	if (!strcmp(what, "lz4_dec")) {
 		prev = h->dec_variant;
 		h->dec_variant = variant;
-	} else if (!strcmp(what, "lz4_parse")) {
-		prev = h->parse_variant;
-		h->parse_variant = variant;
-	} else if (!strcmp(what, "lz4_enc")) {
-		prev = h->enc_variant;
-		h->enc_variant = variant;
 	} else if (!strcmp(what, "k2x")) {
 		prev = h->xflags;
 		h->xflags = variant;

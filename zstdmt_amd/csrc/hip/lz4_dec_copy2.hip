@@ -225,7 +225,7 @@ static __device__ __forceinline__ void c2_match(u8 *win, u32 dofs, const u8 *sb,
 
 template <bool PROF>
 static __device__ __forceinline__ void
-c2_body(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_base,
+c2_body(const u8 *__restrict__ stream, u64 stream_bytes, u32 rec0, u32 nrec, u8 *out_base,
 	const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
 	const u64 *__restrict__ blk0, const u64 *__restrict__ blk_coff,
 	const u32 *__restrict__ blk_csize, const u32 *__restrict__ rec_nblk,
@@ -238,7 +238,7 @@ c2_body(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_base,
 	const u64 t_begin = tq;
 	u64 nbatch = 0;
 	const u32 wave = threadIdx.x >> 6;
-	const u32 rec = blockIdx.x * 4 + wave;
+	const u32 rec = rec0 + blockIdx.x * 4 + wave; /* records [rec0, nrec) of the batch */
 	if (rec >= nrec)
 		return;
 	if (wv_readfirst(status[rec]) != ST_OK)
@@ -564,7 +564,7 @@ c2_body(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_base,
 }
 
 extern "C" __global__ void __launch_bounds__(256) C2_ATTR
-zmt_dec_copy2_kernel(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_base,
+zmt_dec_copy2_kernel(const u8 *__restrict__ stream, u64 stream_bytes, u32 rec0, u32 nrec, u8 *out_base,
 		     const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
 		     const u64 *__restrict__ blk0, const u64 *__restrict__ blk_coff,
 		     const u32 *__restrict__ blk_csize, const u32 *__restrict__ rec_nblk,
@@ -573,13 +573,13 @@ zmt_dec_copy2_kernel(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, 
 		     u32 *__restrict__ status)
 {
 	__shared__ __attribute__((aligned(16))) u8 lds[4 * C2_LDS_WAVE];
-	c2_body<false>(stream, stream_bytes, nrec, out_base, out_off, out_len, blk0, blk_coff, blk_csize, rec_nblk,
+	c2_body<false>(stream, stream_bytes, rec0, nrec, out_base, out_off, out_len, blk0, blk_coff, blk_csize, rec_nblk,
 		       rec_flags, tok, blk_ntok, blk_olen, status, nullptr, lds);
 }
 
 #ifndef ZMT_EMU
 extern "C" __global__ void __launch_bounds__(256) /* no register cap: the counters need room */
-zmt_dec_copy2_kernel_prof(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_base,
+zmt_dec_copy2_kernel_prof(const u8 *__restrict__ stream, u64 stream_bytes, u32 rec0, u32 nrec, u8 *out_base,
 			  const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
 			  const u64 *__restrict__ blk0, const u64 *__restrict__ blk_coff,
 			  const u32 *__restrict__ blk_csize, const u32 *__restrict__ rec_nblk,
@@ -588,7 +588,7 @@ zmt_dec_copy2_kernel_prof(const u8 *__restrict__ stream, u64 stream_bytes, u32 n
 			  u32 *__restrict__ status, unsigned long long *prof)
 {
 	__shared__ __attribute__((aligned(16))) u8 lds[4 * C2_LDS_WAVE];
-	c2_body<true>(stream, stream_bytes, nrec, out_base, out_off, out_len, blk0, blk_coff, blk_csize, rec_nblk,
+	c2_body<true>(stream, stream_bytes, rec0, nrec, out_base, out_off, out_len, blk0, blk_coff, blk_csize, rec_nblk,
 		      rec_flags, tok, blk_ntok, blk_olen, status, prof, lds);
 }
 #endif

@@ -1,7 +1,7 @@
 /*
- * lz4_dec_split.hip -- LZ4 frame decoder as a three-kernel pipeline ("split" variant, default).
+ * lz4_dec_split.hip -- LZ4 frame decoder, first two kernels of the three-kernel pipeline.
  *
- * Same contract as the other decoders (replaces LZ4F_decompress at
+ * Same contract as the serial decoder (replaces LZ4F_decompress at
  * /root/reference/lib/lz4-mt_decompress.c:349-362 for every record of a batch).
  *
  * Why split: finding where the tokens are is a serial pointer chase per block (each token's
@@ -12,16 +12,10 @@
  *   K1 zmt_dec_frames_kernel  thread per record: record + frame header checks, block-header walk
  *                             -> block table (offset, size, stored flag), expected checksum.
  *   K2 zmt_dec_parse_kernel   lane per block: serial token walk -> u16 token positions (2 B per
- *                             sequence) and the output offset of every 64th sequence.
- *   K3 zmt_dec_copy_kernel    wave per record: 64 sequences per step.  Lane k loads token k's
- *                             fields, a DPP prefix sum yields output positions, literals and
- *                             matches are copied with unaligned 8-byte LDS accesses into a sliding
- *                             8 KiB LDS output window (older sources: global memory), dependent
- *                             matches resolve in watermark rounds, the window drains to HBM as
- *                             coalesced 16-byte stores.  Lengths > 64 and stored blocks take a
- *                             wave-cooperative path.
+ *                             sequence), block decoded sizes.
+ *   K3 zmt_dec_copy2_kernel   (lz4_dec_copy2.hip) wave per record: 64 sequences per step.
  *
- * Extra HBM traffic vs the fused kernels: the token list, 2 B per sequence written by K2 and read
+ * Extra HBM traffic vs a fused kernel: the token list, 2 B per sequence written by K2 and read
  * by K3 (about +20 % of the algorithmic bytes on enwik-like text).
  * Frames whose block size exceeds 64 KiB are flagged for the serial kernel (never produced by
  * lz4-mt; LZ4F allows them).
@@ -29,24 +23,10 @@
 #include "lz4_common.h"
 #include "lz4_frame.h"
 
-#ifndef WIN
-#define WIN 8192u      /* LDS output window per wave */
-#endif
-#ifndef WIN_KEEP
-#define WIN_KEEP 4096u /* history kept when the window slides */
-#endif
-#define CAP_LEN 64u
-#define SPAN_MAX 2048u
-#define CSTAGE 1024u /* compressed bytes staged in LDS per batch */
-#define CSLACK 32u
-#ifndef COPY_WAVES_PER_SIMD
-#define COPY_WAVES_PER_SIMD 4 /* caps VGPRs at 128: four 256-thread workgroups per CU (LDS: 4 x 36 KiB) */
-#endif
 #define ST_NEEDS_SERIAL 100u /* internal: record is decoded by zmt_lz4_dec_serial afterwards */
 #define BLK_STORED 0x80000000u
 #define BLK_EMPTY 0xFFFFFFFFu
 
-static __device__ __forceinline__ void st64u(u8 *p, u64 v) { __builtin_memcpy(p, &v, 8); }
 
 /* token-list base (in u16 entries) of global block gb whose compressed bytes start at stream
  * offset coff: disjoint per block because a block of c bytes holds at most c/3 + 1 sequences */
@@ -517,495 +497,3 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 		}
 	}
 }
-
-/* ------------------------------------------------------------------------------------- K3 */
-static __device__ __forceinline__ void copy_units(u8 *d, const u8 *s, u32 len, bool slop)
-{
-	if (len >= 8) {
-		for (u32 i = 0; i + 8 < len; i += 8)
-			st64u(d + i, ld64u(s + i));
-		st64u(d + len - 8, ld64u(s + len - 8));
-	} else if (len >= 4) {
-		u32 a = ld32u(s), b = ld32u(s + len - 4);
-		st32u(d, a);
-		st32u(d + len - 4, b);
-	} else if (len) {
-		if (slop) {
-			st32u(d, ld32u(s));
-		} else {
-			for (u32 i = 0; i < len; i++)
-				d[i] = s[i];
-		}
-	}
-}
-
-static __device__ __forceinline__ void win_match(u8 *d, u32 off, u32 ml)
-{
-	const u8 *s = d - off;
-	if (ml >= 4 && (off >= 8 || off >= ml)) {
-		copy_units(d, s, ml, false);
-	} else {
-		u32 j = 0;
-		for (u32 i = 0; i < ml; i++) {
-			d[i] = s[j];
-			if (++j == off)
-				j = 0;
-		}
-	}
-}
-
-struct CopyState {
-	u32 opos, flushed, valid_from, wbase, fenced;
-};
-
-static __device__ __forceinline__ void flush_to(CopyState &st, const u8 *win, u8 *out, u32 upto, int lane)
-{
-	u32 f = st.flushed;
-	if (upto <= f)
-		return;
-	const u8 *w = win - st.wbase;
-	u32 head = (16 - (f & 15)) & 15;
-	if (head > upto - f)
-		head = upto - f;
-	if ((u32)lane < head)
-		out[f + lane] = w[f + lane];
-	f += head;
-	u32 body_end = f + ((upto - f) & ~15u);
-	for (u32 pos = f + 16 * (u32)lane; pos < body_end; pos += 1024) {
-		const u8 *r = w + pos;
-		u64 a = *(const u64 *)r, b = *(const u64 *)(r + 8);
-		st64u(out + pos, a);
-		st64u(out + pos + 8, b);
-	}
-	if ((u32)lane < upto - body_end)
-		out[body_end + lane] = w[body_end + lane];
-	st.flushed = upto;
-}
-
-static __device__ __forceinline__ void win_slide(CopyState &st, u8 *win, int lane)
-{
-	u32 nb = st.opos > WIN_KEEP ? (st.opos - WIN_KEEP) & ~15u : 0;
-	if (nb < st.wbase)
-		nb = st.wbase;
-	if (st.valid_from >= st.opos || nb - st.wbase >= WIN) {
-		st.wbase = nb;
-		return;
-	}
-	u32 delta = nb - st.wbase, keep = st.opos - nb;
-	wv_sync();
-	for (u32 o = 0; o < keep; o += 1024) {
-		u32 i = o + 16 * (u32)lane;
-		u64 a = 0, b = 0;
-		if (i < keep) {
-			a = *(const u64 *)(win + delta + i);
-			b = *(const u64 *)(win + delta + i + 8);
-		}
-		wv_sync();
-		if (i < keep) {
-			*(u64 *)(win + i) = a;
-			*(u64 *)(win + i + 8) = b;
-		}
-	}
-	wv_sync();
-	st.wbase = nb;
-}
-static __device__ __forceinline__ void win_reserve(CopyState &st, u8 *win, u32 end, int lane)
-{
-	if (end - st.wbase > WIN)
-		win_slide(st, win, lane);
-}
-
-/* cooperative copy of one long sequence straight to global memory (fields are wave-uniform) */
-static __device__ void long_sequence(const u8 *lsrc, u32 lit, u32 off, u32 ml, u8 *out, CopyState &st,
-				     const u8 *win, int lane)
-{
-	flush_to(st, win, out, st.opos, lane);
-	u32 opos = st.opos;
-	wave_copy(out + opos, lsrc, lit, lane);
-	opos += lit;
-	if (ml) {
-		wave_mem_fence();
-		const u8 *m = out + opos - off;
-		u8 *d = out + opos;
-		if (off >= ml) {
-			u32 i = 0;
-			if (ml >= 512) {
-				u32 n4 = ml & ~255u;
-				for (i = (u32)lane * 4; i < n4; i += 256)
-					st32u(d + i, ld32u(m + i));
-				i = n4;
-			}
-			for (i += (u32)lane; i < ml; i += 64)
-				d[i] = m[i];
-		} else {
-			for (u32 i = (u32)lane; i < ml; i += 64)
-				d[i] = m[i % off];
-		}
-		opos += ml;
-	}
-	wave_mem_fence();
-	st.opos = opos;
-	st.flushed = opos;
-	st.fenced = opos;
-	st.valid_from = opos;
-}
-
-template <bool PROF>
-static __device__ __forceinline__ void
-copy_body(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_base,
-		    const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
-		    const u64 *__restrict__ blk0, const u64 *__restrict__ blk_coff,
-		    const u32 *__restrict__ blk_csize, const u32 *__restrict__ rec_nblk,
-		    const u32 *__restrict__ rec_flags, const u16 *__restrict__ tok,
-		    const u32 *__restrict__ bidx, const u32 *__restrict__ blk_ntok,
-		    const u32 *__restrict__ blk_olen, u32 *__restrict__ status,
-		    unsigned long long *prof, u8 *lds)
-{
-	const int lane = wv_lane();
-	const u32 wave = threadIdx.x >> 6;
-	const u32 rec = blockIdx.x * 4 + wave;
-	if (rec >= nrec)
-		return;
-	if (wv_readfirst(status[rec]) != ST_OK)
-		return;
-	u8 *win = lds + wave * (WIN + CSTAGE + CSLACK);
-	u8 *cb = win + WIN; /* staged compressed bytes of the current batch */
-	u8 *out = out_base + out_off[rec];
-	const u32 cap = out_len[rec];
-	const u64 b0 = blk0[rec];
-	const u32 nb = wv_readfirst(rec_nblk[rec]);
-	const bool indep = wv_readfirst(rec_flags[rec]) & 1;
-	u32 stc = ST_OK;
-	CopyState st;
-	st.opos = st.flushed = st.valid_from = st.wbase = st.fenced = 0;
-	u64 pc[PROF ? 8 : 1] = {0}, tq = PROF ? KT() : 0, t_begin3 = tq;
-#define PC(i) do { if (PROF) { u64 t_ = KT(); pc[PROF ? (i) : 0] += t_ - tq; tq = t_; } } while (0)
-
-	for (u32 bi = 0; bi < nb && stc == ST_OK; bi++) {
-		const u32 gb = (u32)(b0 + bi);
-		const u32 cs = wv_readfirst(blk_csize[gb]);
-		const u64 coff = blk_coff[gb];
-		const u8 *src = stream + coff;
-		const u32 olen = wv_readfirst(blk_olen[gb]);
-		const u32 bstart = st.opos;
-		if (olen == 0xFFFFFFFFu || cap - bstart < olen) {
-			stc = ST_BAD_BLOCK;
-			break;
-		}
-		if (cs & BLK_STORED) {
-			u32 bsz = cs & 0x7FFFFFFFu;
-			flush_to(st, win, out, st.opos, lane);
-			wave_copy(out + st.opos, src, bsz, lane);
-			st.opos += bsz;
-			st.flushed = st.opos;
-			st.valid_from = st.opos;
-			continue;
-		}
-		const u32 ntok = wv_readfirst(blk_ntok[gb]);
-		const u64 tbase = tok_base(coff, gb);
-		const u32 low = indep ? bstart : 0;
-		/*
-		 * Software pipeline over the block's batches: token positions (and the batch's output
-		 * offset) are loaded two batches ahead, the batch's compressed bytes -- one coalesced
-		 * 1 KiB window starting at its first token -- one batch ahead, so the global-memory
-		 * latency of both is covered by the copy work of the batch before.
-		 */
-		const u16 *tk = tok + tbase;
-		const u32 *bx = bidx + (tbase >> 6);
-#define TOK_LOAD(T0) (((T0) + (u32)lane < ntok) ? (u32)tk[(T0) + lane] : 0u)
-#define STAGE_LOAD(CS0, A, B)                                                                     \
-	do {                                                                                       \
-		/* may run up to 31 bytes past the block, hence past stream_bytes: the stream      \
-		 * allocation carries 256 bytes of slack (include/gpumt.h) */                       \
-		const u32 o_ = (CS0) + 16u * (u32)lane;                                            \
-		(A) = 0;                                                                           \
-		(B) = 0;                                                                           \
-		if (o_ < cs + 8) {                                                                 \
-			(A) = ld64u(src + o_);                                                     \
-			(B) = ld64u(src + o_ + 8);                                                 \
-		}                                                                                  \
-	} while (0)
-		u32 q_cur = TOK_LOAD(0), q_nxt = TOK_LOAD(64);
-		u32 b_cur = ntok ? bx[0] : 0, b_nxt = ntok > 64 ? bx[1] : 0;
-		u64 ca, cbv;
-		STAGE_LOAD(0, ca, cbv);
-		u32 cs_cur = 0; /* block position of cb[0] */
-		for (u32 t0 = 0; t0 < ntok && stc == ST_OK; t0 += 64) {
-			const u32 k = ntok - t0 < 64 ? ntok - t0 : 64;
-			PC(7);
-			/* land this batch's staged bytes, then put the next loads in flight */
-			wv_sync();
-			*(u64 *)(cb + 16u * (u32)lane) = ca;
-			*(u64 *)(cb + 16u * (u32)lane + 8) = cbv;
-			wv_sync();
-			const u32 q = q_cur;
-			const u32 bofs = wv_readfirst(b_cur);
-			const u32 cs0 = cs_cur;
-			{
-				const u32 q_nn = TOK_LOAD(t0 + 128);
-				const u32 b_nn = (t0 + 128 < ntok) ? bx[(t0 >> 6) + 2] : 0;
-				const u32 cs_n = wv_readlane(q_nxt, 0); /* first token of the next batch */
-				if (t0 + 64 < ntok)
-					STAGE_LOAD(cs_n, ca, cbv);
-				cs_cur = cs_n;
-				q_cur = q_nxt;
-				q_nxt = q_nn;
-				b_cur = b_nxt;
-				b_nxt = b_nn;
-			}
-			const bool act0 = (u32)lane < k;
-			const bool is_last = act0 && t0 + (u32)lane == ntok - 1;
-			/* ---- fields of sequence t0+lane: from the staged window when the whole
-			 * (ordinary) sequence lies inside it, else straight from global memory ---- */
-			u32 lit = 0, ml = 0, off = 1, lsrc = 0;
-			const u32 qr = q - cs0;
-			bool staged = qr + 80 <= CSTAGE;
-			{
-				/* fast path, branch-free: two LDS dword reads; a 255 continuation byte or a
-				 * sequence outside the staged window takes the generic path (rare) */
-				const u32 w = ring_ld32(cb, staged ? qr : 0); /* aligned pair + funnel shift (see ring_ld32) */
-				const u32 tokb = w & 255;
-				const bool lx = (tokb >> 4) == 15;
-				const u32 b1 = (w >> 8) & 255;
-				const u32 l_ = (tokb >> 4) + (lx ? b1 : 0);
-				const u32 h = q + 1 + (lx ? 1 : 0);
-				const u32 lend = h + l_;
-				const bool st2 = staged && lend - cs0 + 4 <= CSTAGE;
-				const u32 w2 = ring_ld32(cb, st2 ? lend - cs0 : 0);
-				const bool mx = (tokb & 15) == 15;
-				const u32 b2 = (w2 >> 16) & 255;
-				const bool fast = staged && !(lx && b1 == 255) && (is_last || (st2 && !(mx && b2 == 255)));
-				if (act0 && fast) {
-					lit = l_;
-					lsrc = h;
-					if (!is_last) {
-						off = w2 & 0xFFFF;
-						ml = (tokb & 15) + (mx ? b2 : 0) + 4;
-					}
-				}
-				if (act0 && !fast) {
-					/* generic: straight from global memory (K2 validated the chain) */
-					const u32 tk = src[q];
-					u32 l2 = tk >> 4, h2 = q + 1;
-					if (l2 == 15) {
-						u32 b;
-						do {
-							b = src[h2++];
-							l2 += b;
-						} while (b == 255);
-					}
-					lit = l2;
-					lsrc = h2;
-					if (!is_last) {
-						u32 m = h2 + l2;
-						off = ld16u(src + m);
-						m += 2;
-						ml = tk & 15;
-						if (ml == 15) {
-							u32 b;
-							do {
-								b = src[m++];
-								ml += b;
-							} while (b == 255);
-						}
-						ml += 4;
-					}
-					staged = false; /* literals of this sequence come from global memory too */
-				}
-			}
-			PC(0);
-			const u32 len = lit + ml;
-			const u32 incl = wv_scan_incl(len);
-			const u32 bpos = bstart + bofs;
-			const u32 op = bpos + incl - len;
-			const u32 mpos = op + lit;
-			const u32 src_pos = mpos - off;
-			const u32 eff = ml < off ? ml : off;
-			/* K2 summed the same lengths: positions are consistent by construction */
-			if (wv_any(act0 && !is_last && (off == 0 || off > mpos - low))) {
-				stc = ST_BAD_BLOCK;
-				break;
-			}
-			/* sub-batches: runs of ordinary sequences; long ones, the block's final
-			 * literal-only sequence and (rarely) sources straddling the window / global
-			 * frontier are handled one at a time by long_sequence() */
-			u64 cutm = wv_ballot(act0 && (lit > CAP_LEN || ml > CAP_LEN || is_last || !staged));
-			u32 lo = 0;
-			while (lo < k) {
-				const u64 rest = cutm & ~((1ull << lo) - 1);
-				u32 hi = rest ? (u32)wv_ffs(rest) - 1 : k;
-				if (hi > lo) {
-					/* ---------- ordinary sequences [lo, hi) ---------- */
-					const u32 sub_start = wv_readlane(op, (int)lo);
-					{
-						/* at most SPAN_MAX bytes per step */
-						u64 over = wv_ballot((u32)lane >= lo && (u32)lane < hi &&
-								     op + len - sub_start > SPAN_MAX);
-						if (over)
-							hi = (u32)wv_ffs(over) - 1; /* > lo: one sequence is <= 128 B */
-					}
-					st.opos = sub_start; /* == end of whatever came before */
-					win_reserve(st, win, wv_readlane(op + len, (int)(hi - 1)), lane);
-					const u32 near_lo = st.valid_from > st.wbase ? st.valid_from : st.wbase;
-					{
-						u64 oddm = wv_ballot((u32)lane >= lo && (u32)lane < hi &&
-								     src_pos < near_lo && src_pos + eff > st.flushed);
-						if (oddm) {
-							u32 l1 = (u32)wv_ffs(oddm) - 1;
-							cutm |= 1ull << l1;
-							if (l1 == lo)
-								continue; /* handled as a single sequence below */
-							hi = l1;
-						}
-					}
-					const bool act = (u32)lane >= lo && (u32)lane < hi;
-					const u32 sub_end = wv_readlane(op + len, (int)(hi - 1));
-					u8 *const w0 = win - st.wbase;
-					const bool is_far = act && src_pos < near_lo;
-					PC(1);
-					/* far sources: loads first, one round trip */
-					u64 fv[8];
-					const bool far_plain = is_far && off >= ml;
-					u32 far_trips = 0;
-					{
-						u32 need = is_far ? src_pos + eff : 0;
-						if (wv_any(need > st.fenced)) {
-							wave_mem_fence();
-							st.fenced = st.flushed;
-						}
-						if (wv_any(far_plain)) {
-							/* widest far match in 8-byte units (1..8), by bisection on ballots */
-							const u32 tr = far_plain ? (ml + 7) >> 3 : 0;
-							u32 mxt = wv_any(tr > 4) ? 4 : 0;
-							mxt += wv_any(tr > mxt + 2) ? 2 : 0;
-							mxt += wv_any(tr > mxt + 1) ? 1 : 0;
-							mxt += wv_any(tr > mxt) ? 1 : 0;
-							far_trips = mxt;
-							const u8 *g = out + src_pos;
-							ZMT_UNROLL
-							for (u32 t = 0; t < 8; t++) {
-								fv[t] = 0;
-								if (t < far_trips && far_plain && ml > 8 * t) {
-									u32 o = 8 * t + 8 <= ml ? 8 * t : (ml >= 8 ? ml - 8 : 0);
-									fv[t] = ld64u(g + o);
-								}
-							}
-						}
-					}
-					PC(2);
-					if (act)
-						copy_units(w0 + op, cb + (lsrc - cs0), lit, true);
-					PC(3);
-					if (far_trips) {
-						ZMT_UNROLL
-						for (u32 t = 0; t < 8; t++) {
-							if (t < far_trips && far_plain && ml > 8 * t) {
-								u8 *d = w0 + mpos;
-								if (ml >= 8) {
-									u32 o = 8 * t + 8 <= ml ? 8 * t : ml - 8;
-									st64u(d + o, fv[t]);
-								} else {
-									st32u(d, (u32)fv[0]);
-									st32u(d + ml - 4, (u32)(fv[0] >> (8 * (ml - 4))));
-								}
-							}
-						}
-					}
-					if (is_far && !far_plain) {
-						copy_units(w0 + mpos, out + src_pos, off, false);
-						win_match(w0 + mpos + off, off, ml - off);
-					}
-					wv_sync();
-					PC(4);
-					/* near matches, watermark rounds */
-					{
-						bool fin = !(act && !is_far);
-						for (;;) {
-							u64 unf = wv_ballot(!fin);
-							if (!unf)
-								break;
-							u32 first = (u32)wv_ffs(unf) - 1;
-							u32 W = wv_readlane(mpos, (int)first);
-							bool ready = !fin && src_pos + eff <= W;
-							if (ready) {
-								win_match(w0 + mpos, off, ml);
-								fin = true;
-							}
-							wv_sync();
-						}
-					}
-					PC(5);
-					st.opos = sub_end;
-					{
-						u32 end = sub_end & ~15u;
-						if (end > st.flushed)
-							flush_to(st, win, out, end, lane);
-					}
-					lo = hi;
-				}
-				if (lo < k && ((cutm >> lo) & 1)) {
-					/* ---------- one long (or final literal-only) sequence ---------- */
-					const u32 l_lit = wv_readlane(lit, (int)lo), l_ml = wv_readlane(ml, (int)lo);
-					const u32 l_off = wv_readlane(off, (int)lo), l_src = wv_readlane(lsrc, (int)lo);
-					st.opos = wv_readlane(op, (int)lo);
-					long_sequence(src + l_src, l_lit, l_off, l_ml, out, st, win, lane);
-					lo++;
-				}
-			}
-		}
-		if (stc == ST_OK && st.opos != bstart + olen)
-			stc = ST_BAD_BLOCK;
-	}
-	PC(6);
-	flush_to(st, win, out, st.opos, lane);
-#ifndef ZMT_EMU
-	if (PROF && prof && lane == 0) {
-		for (int i = 0; i < (PROF ? 8 : 1); i++)
-			atomicAdd(prof + i, (unsigned long long)pc[i]);
-		atomicAdd(prof + 8, (unsigned long long)(KT() - t_begin3));
-		atomicAdd(prof + 9, 1ull);
-	}
-#endif
-	if (stc == ST_OK && st.opos != cap)
-		stc = ST_SIZE_MISMATCH;
-	if (lane == 0 && stc != ST_OK)
-		status[rec] = stc;
-}
-
-#ifdef ZMT_EMU
-#define COPY_ATTR
-#else
-#define COPY_ATTR __attribute__((amdgpu_waves_per_eu(COPY_WAVES_PER_SIMD, COPY_WAVES_PER_SIMD)))
-#endif
-
-extern "C" __global__ void __launch_bounds__(256) COPY_ATTR
-zmt_dec_copy_kernel(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_base,
-		    const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
-		    const u64 *__restrict__ blk0, const u64 *__restrict__ blk_coff,
-		    const u32 *__restrict__ blk_csize, const u32 *__restrict__ rec_nblk,
-		    const u32 *__restrict__ rec_flags, const u16 *__restrict__ tok,
-		    const u32 *__restrict__ bidx, const u32 *__restrict__ blk_ntok,
-		    const u32 *__restrict__ blk_olen, u32 *__restrict__ status)
-{
-	__shared__ __attribute__((aligned(16))) u8 lds[4 * (WIN + CSTAGE + CSLACK)];
-	copy_body<false>(stream, stream_bytes, nrec, out_base, out_off, out_len, blk0, blk_coff,
-			 blk_csize, rec_nblk, rec_flags, tok, bidx, blk_ntok, blk_olen, status, nullptr, lds);
-}
-
-#ifndef ZMT_EMU
-/* same kernel with per-phase cycle counters (developer tool) */
-extern "C" __global__ void __launch_bounds__(256)
-zmt_dec_copy_kernel_prof(const u8 *__restrict__ stream, u64 stream_bytes, u32 nrec, u8 *out_base,
-			 const u64 *__restrict__ out_off, const u32 *__restrict__ out_len,
-			 const u64 *__restrict__ blk0, const u64 *__restrict__ blk_coff,
-			 const u32 *__restrict__ blk_csize, const u32 *__restrict__ rec_nblk,
-			 const u32 *__restrict__ rec_flags, const u16 *__restrict__ tok,
-			 const u32 *__restrict__ bidx, const u32 *__restrict__ blk_ntok,
-			 const u32 *__restrict__ blk_olen, u32 *__restrict__ status,
-			 unsigned long long *prof)
-{
-	__shared__ __attribute__((aligned(16))) u8 lds[4 * (WIN + CSTAGE + CSLACK)];
-	copy_body<true>(stream, stream_bytes, nrec, out_base, out_off, out_len, blk0, blk_coff,
-			blk_csize, rec_nblk, rec_flags, tok, bidx, blk_ntok, blk_olen, status, prof, lds);
-}
-#endif
