@@ -85,3 +85,21 @@ def test_emu_corrupt_streams(mutate, code, variant):
     out, status = E.decompress(bytes(s), variant, rec=rec)
     assert status.tolist() == [code, 0]
     assert out[131072:] == data[131072:]   # the healthy record still decodes
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_emu_block_checksum_and_dictid_frames(variant):
+    """frames with block checksums / a dictionary id (liblz4-written fixtures): the pipeline hands them
+    to the wave-per-record decoder, which verifies every block's XXH32"""
+    d = os.path.join(H.GOLDEN_DIR, "lz4f_flags")
+    man = json.load(open(os.path.join(d, "manifest.json")))["cases"]
+    for name, e in man.items():
+        rec = open(os.path.join(d, name + ".rec"), "rb").read()
+        out, status = E.decompress(rec, variant)
+        assert status.tolist() == [0], (name, status)
+        assert H.sha256(out) == e["content_sha256"], name
+        if e["flg"] & 0x10:
+            bad = bytearray(rec)
+            bad[12 + 40] ^= 0x01
+            _, status = E.decompress(bytes(bad), variant, rec=E.walk_records(rec))
+            assert status.tolist() == [5], (name, status)   # GPUMT_ST_BAD_CHECKSUM

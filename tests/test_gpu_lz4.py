@@ -161,3 +161,28 @@ def test_xxh32_batch(eng):
     eng._ck(eng.L.gpumt_xxh32_batch(eng.h, d_buf.ptr, d_off.ptr, d_len.ptr, len(lens), d_h.ptr, 0), "xxh")
     got = eng.download(d_h, len(lens) * 4, np.uint32).tolist()
     assert got == [xxhash.xxh32(b, seed=0).intdigest() for b in blobs]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_block_checksum_and_dictid_frames(eng, variant):
+    """LZ4F features lz4-mt never writes but liblz4 decodes (fixtures written by liblz4 1.9.3,
+    tests/golden/gen_golden_lz4f_flags.py): block checksums are verified on the device, a dictionary
+    id is skipped; a damaged block reports GPUMT_ST_BAD_CHECKSUM."""
+    import emu_driver as E
+    d = os.path.join(H.GOLDEN_DIR, "lz4f_flags")
+    man = json.load(open(os.path.join(d, "manifest.json")))["cases"]
+    eng.set_variant("lz4_dec", variant)
+    try:
+        for name, e in man.items():
+            rec = open(os.path.join(d, name + ".rec"), "rb").read()
+            ro, rl = E.walk_records(rec)
+            out, status = eng.decompress_bytes(rec, ro, rl)
+            assert status.tolist() == [0], (name, status)
+            assert H.sha256(out) == e["content_sha256"], name
+            if e["flg"] & 0x10:
+                bad = bytearray(rec)
+                bad[12 + 40] ^= 0x01
+                _, status = eng.decompress_bytes(bytes(bad), ro, rl)
+                assert status.tolist() == [5], (name, status)
+    finally:
+        eng.set_variant("lz4_dec", 0)

@@ -114,3 +114,24 @@ def test_oracle_rejects_corrupt(mutate):
         s[q + lit] = 0
         s[q + lit + 1] = 0
     assert H.oracle_decompress(bytes(s), len(data)) is None
+
+
+def _flag_cases():
+    import json
+    d = os.path.join(H.GOLDEN_DIR, "lz4f_flags")
+    man = json.load(open(os.path.join(d, "manifest.json")))["cases"]
+    return d, man
+
+
+def test_oracle_decodes_block_checksum_and_dictid_frames():
+    """LZ4F features lz4-mt never writes but liblz4 accepts (fixtures written by liblz4 1.9.3,
+    tests/golden/gen_golden_lz4f_flags.py): the oracle decodes them and rejects a damaged block."""
+    d, man = _flag_cases()
+    for name, e in man.items():
+        rec = open(os.path.join(d, name + ".rec"), "rb").read()
+        out = H.oracle_decompress(rec, e["content_len"] + 64)
+        assert out is not None and len(out) == e["content_len"] and H.sha256(out) == e["content_sha256"], name
+        if e["flg"] & 0x10:
+            bad = bytearray(rec)
+            bad[12 + 40] ^= 0x01
+            assert H.oracle_decompress(bytes(bad), e["content_len"] + 64) is None, name

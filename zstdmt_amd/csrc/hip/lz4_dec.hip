@@ -82,6 +82,28 @@ static __device__ u32 decode_block_serial(const u8 *src, u32 slen, u8 *out, u32 
 	}
 }
 
+/* XXH32 (seed 0) of [p, p + len) by one wave: lanes 0..3 carry the four accumulators over the
+ * 16-byte stripes, lane 0 folds the tail; the result is wave-uniform */
+static __device__ u32 wave_xxh32(const u8 *p, u32 len, int lane)
+{
+	u32 v = 0;
+	if (len >= 16 && lane < 4) {
+		u32 acc = (lane == 0) ? XP1 + XP2 : (lane == 1) ? XP2 : (lane == 2) ? 0u : 0u - XP1;
+		const u8 *q = p + lane * 4;
+		for (u32 s = 0, ns = len >> 4; s < ns; s++) {
+			acc = xxh_round(acc, ld32u(q));
+			q += 16;
+		}
+		v = rotl32(acc, (lane == 0) ? 1 : (lane == 1) ? 7 : (lane == 2) ? 12 : 18);
+	}
+	v += wv_shfl(v, lane ^ 1);
+	v += wv_shfl(v, lane ^ 2);
+	u32 h = (len >= 16 ? v : XP5) + len;
+	if (lane == 0)
+		h = xxh_tail(h, p + (len & ~15u), len & 15);
+	return wv_readlane(h, 0);
+}
+
 extern "C" __global__ void __launch_bounds__(64)
 zmt_lz4_dec_serial(const u8 *__restrict__ stream, const u64 *__restrict__ rec_off,
 		   const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
@@ -129,8 +151,12 @@ zmt_lz4_dec_serial(const u8 *__restrict__ stream, const u64 *__restrict__ rec_of
 		if (bh == 0)
 			break;
 		bsz = bh & 0x7FFFFFFFu;
-		if (bsz > fi.blkmax || flen - ip < bsz) {
+		if (bsz > fi.blkmax || flen - ip < bsz || (fi.has_bcheck && flen - ip - bsz < 4)) {
 			st = ST_BAD_BLOCK;
+			goto done;
+		}
+		if (fi.has_bcheck && wave_xxh32(r + ip, bsz, lane) != uld32(r + ip + bsz)) {
+			st = ST_BAD_CHECKSUM; /* LZ4F_ERROR_blockChecksum_invalid */
 			goto done;
 		}
 		if (bh & 0x80000000u) {
@@ -150,7 +176,7 @@ zmt_lz4_dec_serial(const u8 *__restrict__ stream, const u64 *__restrict__ rec_of
 			}
 			opos = np;
 		}
-		ip += bsz;
+		ip += bsz + (fi.has_bcheck ? 4u : 0u);
 	}
 	/* a frame that states its content size must produce exactly that (= out_len); one that does not
 	 * (plain .lz4 files of the lz4 tool; never lz4-mt) was given a capacity and reports its size */

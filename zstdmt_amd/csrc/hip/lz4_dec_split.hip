@@ -91,7 +91,7 @@ zmt_dec_frames_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 		return;
 	}
 	if ((flg & 0x10) || (flg & 0x01)) {
-		status[rec] = ST_UNSUPPORTED;
+		status[rec] = ST_NEEDS_SERIAL; /* block checksums / dictionary id: the wave-per-record decoder */
 		return;
 	}
 	indep = (flg >> 5) & 1;
@@ -284,7 +284,14 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 		 * eight lanes with one 16-byte load each: a load instruction serves 8 blocks and touches
 		 * 8 lines (the texture path costs per line, not per byte).  Software-pipelined: units
 		 * requested in one round land in LDS at the start of the next round. */
-		if ((step & 7) == 0 || step < 4) { /* start-up: three back-to-back rounds fill the ring */
+#ifdef P_URGENT
+		/* a lane whose parse position has run past what its ring holds (a long literal run) would
+		 * take the global-memory path for every token until the next scheduled round: top up now */
+		const bool urgent = wv_any(!done && boff + pos + P_URGENT > ghi && ghi < boff + cs);
+#else
+		const bool urgent = false;
+#endif
+		if ((step & 7) == 0 || step < 4 || urgent) { /* start-up: three back-to-back rounds fill the ring */
 			if (pendm) {
 				wv_sync();
 				ZMT_UNROLL

@@ -22,6 +22,7 @@ struct FrameInfo {
 	u32 hdr;       /* header bytes */
 	u32 blkmax;
 	u32 has_csize, has_ccheck, indep;
+	u32 has_bcheck; /* every block is followed by the XXH32 of its stored bytes */
 	u64 csize;
 };
 
@@ -35,17 +36,19 @@ static __device__ u32 parse_frame_header(const u8 *f, u32 flen, FrameInfo &fi)
 	bd = uld8(f + 5);
 	if ((flg >> 6) != 1 || (flg & 0x02) || (bd & 0x8F) || (bd >> 4) < 4)
 		return ST_BAD_FRAME;
-	if ((flg & 0x10) || (flg & 0x01))
-		return ST_UNSUPPORTED; /* block checksums / dictID: valid LZ4F, never emitted by lz4-mt */
+	/* block checksums and a dictionary id are valid LZ4F that lz4-mt never writes; liblz4 (behind
+	 * lib/lz4-mt_decompress.c:349-362) decodes both -- the id is informational when no dictionary is
+	 * attached -- and so does the wave-per-record decoder */
+	fi.has_bcheck = (flg >> 4) & 1;
 	fi.indep = (flg >> 5) & 1;
 	fi.has_csize = (flg >> 3) & 1;
 	fi.has_ccheck = (flg >> 2) & 1;
 	fi.blkmax = 1u << (8 + 2 * (bd >> 4));
-	hdr = 7 + (fi.has_csize ? 8 : 0);
+	hdr = 7 + (fi.has_csize ? 8 : 0) + ((flg & 0x01) ? 4 : 0);
 	if (flen < hdr)
 		return ST_BAD_FRAME;
 	{
-		u8 d[10];
+		u8 d[14];
 		for (u32 i = 0; i < hdr - 5; i++)
 			d[i] = (u8)uld8(f + 4 + i);
 		if (uld8(f + hdr - 1) != ((xxh32_short(d, hdr - 5) >> 8) & 0xFF))

@@ -558,7 +558,7 @@ static size_t lz4_frame_extent(const uint8_t *p, size_t n, uint64_t *bound, int 
 	if ((flg >> 6) != 1 || bsid < 4 || n < hp)
 		return 0;
 	blkmax = 1ull << (8 + 2 * bsid); /* 4 -> 64 KiB ... 7 -> 4 MiB */
-	*supported = !(bchk || has_dict); /* block checksums / dictionaries: not on the device */
+	*supported = 1; /* block checksums are verified and a dictionary id skipped by the frame-serial kernel */
 	for (;;) {
 		uint32_t bh, bsz;
 		if (n - hp < 4)
