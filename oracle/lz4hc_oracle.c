@@ -1,0 +1,398 @@
+/*
+ * lz4hc_oracle.c -- TEST INFRASTRUCTURE ONLY: CPU restatement of the LZ4 "HC" block encoder the
+ * reference reaches for levels 3..12 (LZ4F_compressFrame with compressionLevel >= 3, call site
+ * /root/reference/lib/lz4-mt_compress.c:141-146 + :281; the CLI's default level is 3,
+ * /root/reference/programs/lz4-mt.c:19).
+ *
+ * The algorithm lives in liblz4's lz4hc.c, a third-party dependency that is NOT in /root/reference
+ * (programs/Makefile:9 pins v1.9.4; this image carries the binary of v1.9.3 only).  What follows
+ * restates the published hash-chain parser of that file for the levels whose search is a plain chain
+ * walk -- 3..8: 4, 8, 16, 32, 64, 128 attempts; level 9 adds the repeated-pattern analysis and
+ * 10..12 the optimal parser, not restated -- and is pinned byte for byte against the reference build
+ * (oracle/_ref/liblz4mt_ref.so, tests/test_oracle_vs_ref.py) and the committed fixtures
+ * (tests/golden/lz4hc).  Frame container: lz4_oracle.c.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "zmt_oracle.h"
+
+#define HC_HASH_LOG 15
+#define HC_MAXD 65536u
+#define HC_DIST_MAX 65535u
+#define HC_MINMATCH 4
+#define HC_MFLIMIT 12
+#define HC_LASTLITERALS 5
+#define HC_OPTIMAL_ML 18 /* (ML_MASK - 1) + MINMATCH */
+#define HC_BASE 65536u   /* index of the chunk's first byte (LZ4HC_init_internal starts at 64 KB) */
+
+typedef struct {
+	uint32_t hash[1u << HC_HASH_LOG];
+	uint16_t chain[HC_MAXD];
+	const uint8_t *src;     /* chunk start: byte at index i is src[i - HC_BASE] */
+	uint32_t next_to_update;
+} zo_hc;
+
+static uint32_t rd32(const uint8_t *p)
+{
+	return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+static uint32_t rd16(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; }
+static uint32_t hc_hash(const uint8_t *p) { return (rd32(p) * 2654435761u) >> (32 - HC_HASH_LOG); }
+
+static unsigned hc_count(const uint8_t *a, const uint8_t *b, const uint8_t *alimit)
+{
+	const uint8_t *s = a;
+	while (a < alimit && *a == *b) {
+		a++;
+		b++;
+	}
+	return (unsigned)(a - s);
+}
+
+/* LZ4HC_Insert: every position below `target` enters the hash chains */
+static void hc_insert(zo_hc *h, uint32_t target)
+{
+	uint32_t idx = h->next_to_update;
+	while (idx < target) {
+		const uint32_t hv = hc_hash(h->src + (idx - HC_BASE));
+		uint32_t delta = idx - h->hash[hv];
+		if (delta > HC_DIST_MAX)
+			delta = HC_DIST_MAX;
+		h->chain[idx & (HC_MAXD - 1)] = (uint16_t)delta;
+		h->hash[hv] = idx;
+		idx++;
+	}
+	h->next_to_update = target;
+}
+
+/* LZ4HC_InsertAndGetWiderMatch without pattern analysis / chain swap (levels 3..8).
+ * ip, low, high are positions in the chunk; returns the longest length found (> longest on entry),
+ * match position in *mpos and the (possibly moved back) start in *spos. */
+static int hc_wider(zo_hc *h, uint32_t ip, uint32_t low_limit, uint32_t high_limit, int longest,
+		    uint32_t *mpos, uint32_t *spos, int max_attempts)
+{
+	const uint8_t *const s = h->src;
+	const uint32_t ip_index = ip + HC_BASE;
+	const uint32_t lowest = (HC_BASE + HC_DIST_MAX + 1 > ip_index) ? HC_BASE : ip_index - HC_DIST_MAX;
+	const int look_back = (int)(ip - low_limit);
+	const uint32_t pattern = rd32(s + ip);
+	int attempts = max_attempts;
+	uint32_t match_index;
+
+	hc_insert(h, ip_index);
+	match_index = h->hash[hc_hash(s + ip)];
+	while (match_index >= lowest && attempts > 0) {
+		const uint32_t m = match_index - HC_BASE; /* chunk position of the candidate */
+		attempts--;
+		if (rd16(s + low_limit + longest - 1) == rd16(s + m - look_back + longest - 1)) {
+			if (rd32(s + m) == pattern) {
+				int back = 0, ml;
+				if (look_back) {
+					/* LZ4HC_countBack: not before the search start, not before the chunk */
+					const int min_i = (int)low_limit - (int)ip;
+					const int min_m = -(int)m;
+					const int min = min_i > min_m ? min_i : min_m;
+					while (back > min && s[ip + back - 1] == s[m + back - 1])
+						back--;
+				}
+				ml = HC_MINMATCH + (int)hc_count(s + ip + HC_MINMATCH, s + m + HC_MINMATCH, s + high_limit);
+				ml -= back;
+				if (ml > longest) {
+					longest = ml;
+					*mpos = (uint32_t)((int)m + back);
+					*spos = (uint32_t)((int)ip + back);
+				}
+			}
+		}
+		match_index -= h->chain[match_index & (HC_MAXD - 1)];
+	}
+	return longest;
+}
+
+/* LZ4HC_encodeSequence; returns 1 when the output limit is hit */
+static int hc_encode(const uint8_t *s, uint32_t *ip, uint8_t **op, uint32_t *anchor, int ml, uint32_t mpos,
+		     uint8_t *oend)
+{
+	uint8_t *const token = (*op)++;
+	size_t length = (size_t)(*ip - *anchor);
+	if (*op + (length / 255) + length + (2 + 1 + HC_LASTLITERALS) > oend)
+		return 1;
+	if (length >= 15) {
+		size_t len = length - 15;
+		*token = 15 << 4;
+		for (; len >= 255; len -= 255)
+			*(*op)++ = 255;
+		*(*op)++ = (uint8_t)len;
+	} else {
+		*token = (uint8_t)(length << 4);
+	}
+	memcpy(*op, s + *anchor, length);
+	*op += length;
+	(*op)[0] = (uint8_t)(*ip - mpos);
+	(*op)[1] = (uint8_t)((*ip - mpos) >> 8);
+	*op += 2;
+	length = (size_t)ml - HC_MINMATCH;
+	if (*op + (length / 255) + (1 + HC_LASTLITERALS) > oend)
+		return 1;
+	if (length >= 15) {
+		*token += 15;
+		length -= 15;
+		for (; length >= 510; length -= 510) {
+			*(*op)++ = 255;
+			*(*op)++ = 255;
+		}
+		if (length >= 255) {
+			length -= 255;
+			*(*op)++ = 255;
+		}
+		*(*op)++ = (uint8_t)length;
+	} else {
+		*token += (uint8_t)length;
+	}
+	*ip += (uint32_t)ml;
+	*anchor = *ip;
+	return 0;
+}
+
+/* LZ4HC_compress_hashChain over chunk positions [start, start + n), output capacity cap
+ * (limitedOutput): compressed size or 0 */
+static size_t hc_block(zo_hc *h, uint32_t start, uint32_t n, uint8_t *dst, size_t cap, int max_attempts)
+{
+	const uint8_t *const s = h->src;
+	uint32_t ip = start, anchor = start;
+	const uint32_t iend = start + n;
+	const uint32_t mflimit = iend - HC_MFLIMIT, matchlimit = iend - HC_LASTLITERALS;
+	uint8_t *op = dst, *const oend = dst + cap;
+	int ml0, ml, ml2, ml3;
+	uint32_t start0, ref0, ref = 0, start2 = 0, ref2 = 0, start3 = 0, ref3 = 0;
+
+	if (n < HC_MFLIMIT + 1)
+		goto last_literals;
+	while (ip <= mflimit) {
+		{
+			uint32_t dummy = ip;
+			ml = hc_wider(h, ip, ip, matchlimit, HC_MINMATCH - 1, &ref, &dummy, max_attempts);
+		}
+		if (ml < HC_MINMATCH) {
+			ip++;
+			continue;
+		}
+		start0 = ip;
+		ref0 = ref;
+		ml0 = ml;
+search2:
+		if (ip + (uint32_t)ml <= mflimit)
+			ml2 = hc_wider(h, ip + (uint32_t)ml - 2, ip + 0, matchlimit, ml, &ref2, &start2, max_attempts);
+		else
+			ml2 = ml;
+		if (ml2 == ml) { /* no better match: encode ML1 */
+			if (hc_encode(s, &ip, &op, &anchor, ml, ref, oend))
+				return 0;
+			continue;
+		}
+		if (start0 < ip) { /* first match was skipped at least once */
+			if (start2 < ip + (uint32_t)ml0) { /* squeezing ML1 between ML0 (original ML1) and ML2 */
+				ip = start0;
+				ref = ref0;
+				ml = ml0;
+			}
+		}
+		if (start2 - ip < 3) { /* first match too small: removed */
+			ml = ml2;
+			ip = start2;
+			ref = ref2;
+			goto search2;
+		}
+search3:
+		if (start2 - ip < HC_OPTIMAL_ML) {
+			int correction;
+			int new_ml = ml;
+			if (new_ml > HC_OPTIMAL_ML)
+				new_ml = HC_OPTIMAL_ML;
+			if (ip + (uint32_t)new_ml > start2 + (uint32_t)ml2 - HC_MINMATCH)
+				new_ml = (int)(start2 - ip) + ml2 - HC_MINMATCH;
+			correction = new_ml - (int)(start2 - ip);
+			if (correction > 0) {
+				start2 += (uint32_t)correction;
+				ref2 += (uint32_t)correction;
+				ml2 -= correction;
+			}
+		}
+		if (start2 + (uint32_t)ml2 <= mflimit)
+			ml3 = hc_wider(h, start2 + (uint32_t)ml2 - 3, start2, matchlimit, ml2, &ref3, &start3, max_attempts);
+		else
+			ml3 = ml2;
+		if (ml3 == ml2) { /* no better match: encode ML1 and ML2 */
+			if (start2 < ip + (uint32_t)ml)
+				ml = (int)(start2 - ip);
+			if (hc_encode(s, &ip, &op, &anchor, ml, ref, oend))
+				return 0;
+			ip = start2;
+			if (hc_encode(s, &ip, &op, &anchor, ml2, ref2, oend))
+				return 0;
+			continue;
+		}
+		if (start3 < ip + (uint32_t)ml + 3) { /* not enough space for match 2: remove it */
+			if (start3 >= ip + (uint32_t)ml) { /* Seq1 can be written now; Seq3 becomes Seq1 */
+				if (start2 < ip + (uint32_t)ml) {
+					const int correction = (int)(ip + (uint32_t)ml - start2);
+					start2 += (uint32_t)correction;
+					ref2 += (uint32_t)correction;
+					ml2 -= correction;
+					if (ml2 < HC_MINMATCH) {
+						start2 = start3;
+						ref2 = ref3;
+						ml2 = ml3;
+					}
+				}
+				if (hc_encode(s, &ip, &op, &anchor, ml, ref, oend))
+					return 0;
+				ip = start3;
+				ref = ref3;
+				ml = ml3;
+				start0 = start2;
+				ref0 = ref2;
+				ml0 = ml2;
+				goto search2;
+			}
+			start2 = start3;
+			ref2 = ref3;
+			ml2 = ml3;
+			goto search3;
+		}
+		/* three ascending matches: write the first one */
+		if (start2 < ip + (uint32_t)ml) {
+			if (start2 - ip < HC_OPTIMAL_ML) {
+				int correction;
+				if (ml > HC_OPTIMAL_ML)
+					ml = HC_OPTIMAL_ML;
+				if (ip + (uint32_t)ml > start2 + (uint32_t)ml2 - HC_MINMATCH)
+					ml = (int)(start2 - ip) + ml2 - HC_MINMATCH;
+				correction = ml - (int)(start2 - ip);
+				if (correction > 0) {
+					start2 += (uint32_t)correction;
+					ref2 += (uint32_t)correction;
+					ml2 -= correction;
+				}
+			} else {
+				ml = (int)(start2 - ip);
+			}
+		}
+		if (hc_encode(s, &ip, &op, &anchor, ml, ref, oend))
+			return 0;
+		ip = start2;
+		ref = ref2;
+		ml = ml2;
+		start2 = start3;
+		ref2 = ref3;
+		ml2 = ml3;
+		goto search3;
+	}
+last_literals:
+	{
+		const size_t run = (size_t)(iend - anchor);
+		const size_t lit_len = (run + 255 - 15) / 255;
+		if (op + 1 + lit_len + run > oend)
+			return 0;
+		if (run >= 15) {
+			size_t acc = run - 15;
+			*op++ = 15 << 4;
+			for (; acc >= 255; acc -= 255)
+				*op++ = 255;
+			*op++ = (uint8_t)acc;
+		} else {
+			*op++ = (uint8_t)(run << 4);
+		}
+		memcpy(op, s + anchor, run);
+		op += run;
+	}
+	return (size_t)(op - dst);
+}
+
+static int hc_attempts(int level)
+{
+	static const int a[] = {2, 2, 2, 4, 8, 16, 32, 64, 128};
+	return level >= 0 && level <= 8 ? a[level] : 0;
+}
+
+int zo_lz4hc_level_supported(int level) { return level >= 3 && level <= 8; }
+
+/* one LZ4 frame as LZ4F_compressFrame writes it for the prefs of lz4-mt at an HC level: same
+ * container as zo_lz4f_compress (lz4_oracle.c), blocks from the HC parser with one context per frame
+ * (linked blocks: the chains run on across the chunk's blocks) */
+size_t zo_lz4f_compress_hc(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int level)
+{
+	uint8_t *op = dst;
+	size_t pos;
+	const int single = (n <= ZO_BLOCK_MAX);
+	const uint8_t flg = (uint8_t)(0x40 | (single ? 0x20 : 0) | (n ? 0x08 : 0) | 0x04);
+	const size_t hdr = n ? 15 : 7;
+	zo_hc *h;
+
+	if (!zo_lz4hc_level_supported(level) || cap < zo_lz4f_bound(n))
+		return (size_t)-1;
+	h = (zo_hc *)calloc(1, sizeof *h);
+	if (!h)
+		return (size_t)-1;
+	h->src = src;
+	h->next_to_update = HC_BASE;
+	op[0] = 0x04; op[1] = 0x22; op[2] = 0x4D; op[3] = 0x18;
+	op[4] = flg;
+	op[5] = 0x40;
+	if (n) {
+		uint64_t v = n;
+		for (int i = 0; i < 8; i++)
+			op[6 + i] = (uint8_t)(v >> (8 * i));
+	}
+	op[hdr - 1] = (uint8_t)(zo_xxh32(op + 4, hdr - 5, 0) >> 8);
+	op += hdr;
+	for (pos = 0; pos < n; pos += ZO_BLOCK_MAX) {
+		const size_t len = n - pos < ZO_BLOCK_MAX ? n - pos : ZO_BLOCK_MAX;
+		const size_t c = hc_block(h, (uint32_t)pos, (uint32_t)len, op + 4, len - 1, hc_attempts(level));
+		uint32_t bh;
+		if (c == 0) { /* did not shrink: stored block; the chains keep what the attempt inserted */
+			bh = (uint32_t)len | 0x80000000u;
+			memcpy(op + 4, src + pos, len);
+		} else {
+			bh = (uint32_t)c;
+		}
+		op[0] = (uint8_t)bh; op[1] = (uint8_t)(bh >> 8); op[2] = (uint8_t)(bh >> 16); op[3] = (uint8_t)(bh >> 24);
+		op += 4 + (bh & 0x7FFFFFFFu);
+	}
+	op[0] = op[1] = op[2] = op[3] = 0; /* end mark */
+	op += 4;
+	{
+		const uint32_t x = zo_xxh32(src, n, 0);
+		op[0] = (uint8_t)x; op[1] = (uint8_t)(x >> 8); op[2] = (uint8_t)(x >> 16); op[3] = (uint8_t)(x >> 24);
+		op += 4;
+	}
+	free(h);
+	return (size_t)(op - dst);
+}
+
+/* the MT stream at an HC level (record framing as zo_lz4mt_compress) */
+size_t zo_lz4mt_compress_level(const uint8_t *src, size_t n, size_t chunk, uint8_t *dst, size_t cap, int level)
+{
+	size_t pos = 0, out = 0;
+	int first = 1;
+	if (level < 3)
+		return zo_lz4mt_compress(src, n, chunk, dst, cap);
+	while (pos < n || first) {
+		const size_t len = n - pos < chunk ? n - pos : chunk;
+		size_t c;
+		if (cap - out < zo_lz4f_bound(len) + 12)
+			return (size_t)-1;
+		c = zo_lz4f_compress_hc(src + pos, len, dst + out + 12, cap - out - 12, level);
+		if (c == (size_t)-1)
+			return (size_t)-1;
+		dst[out + 0] = 0x50; dst[out + 1] = 0x2A; dst[out + 2] = 0x4D; dst[out + 3] = 0x18;
+		dst[out + 4] = 4; dst[out + 5] = dst[out + 6] = dst[out + 7] = 0;
+		dst[out + 8] = (uint8_t)c; dst[out + 9] = (uint8_t)(c >> 8);
+		dst[out + 10] = (uint8_t)(c >> 16); dst[out + 11] = (uint8_t)(c >> 24);
+		out += 12 + c;
+		pos += len;
+		first = 0;
+	}
+	return out;
+}

@@ -82,6 +82,10 @@ uint64_t zo_lz4f_content_size(const uint8_t *frame, size_t slen);
  */
 size_t zo_lz4mt_compress(const uint8_t *src, size_t n, size_t chunk, uint8_t *dst, size_t cap);
 size_t zo_lz4mt_compress_bound(size_t n, size_t chunk);
+/* LZ4 "HC" levels (lz4hc_oracle.c): hash-chain parser, levels 3..8 */
+int zo_lz4hc_level_supported(int level);
+size_t zo_lz4f_compress_hc(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int level);
+size_t zo_lz4mt_compress_level(const uint8_t *src, size_t n, size_t chunk, uint8_t *dst, size_t cap, int level);
 
 /* Inverse: walk the records (12-byte skippable header each), decode every frame.
  * Returns content bytes, (size_t)-1 on malformed input, (size_t)-2 if cap too small. */

@@ -55,6 +55,8 @@ def oracle():
         lib.zo_lz4mt_compress_mt.argtypes = [C.c_void_p, sz, sz, C.c_void_p, sz, C.c_int]
         lib.zo_lz4mt_decompress_mt.restype = sz
         lib.zo_lz4mt_decompress_mt.argtypes = [C.c_void_p, sz, C.c_void_p, sz, C.c_int]
+        lib.zo_lz4mt_compress_level.restype = sz
+        lib.zo_lz4mt_compress_level.argtypes = [C.c_void_p, sz, sz, C.c_void_p, sz, C.c_int]
         lib.zo_xxh64.restype = C.c_uint64
         lib.zo_xxh64.argtypes = [p8, sz, C.c_uint64]
         lib.zo_zstd_frame_content_size.restype = C.c_uint64
@@ -81,6 +83,16 @@ def oracle_compress(data: bytes, chunk: int) -> bytes:
     cap = lib.zo_lz4mt_compress_bound(len(data), chunk)
     out = C.create_string_buffer(cap)
     n = lib.zo_lz4mt_compress(data, len(data), chunk, out, cap)
+    assert n != SIZE_ERR
+    return out.raw[:n]
+
+
+def oracle_compress_level(data: bytes, chunk: int, level: int) -> bytes:
+    """lz4-mt stream at `level`: 1-2 = LZ4 fast (lz4_oracle.c), 3-8 = LZ4 HC hash chain (lz4hc_oracle.c)"""
+    lib = oracle()
+    cap = len(data) + len(data) // 64 + (len(data) // max(chunk, 1) + 2) * 64 + 1024
+    out = C.create_string_buffer(cap)
+    n = lib.zo_lz4mt_compress_level(data, len(data), chunk, out, cap, level)
     assert n != SIZE_ERR
     return out.raw[:n]
 

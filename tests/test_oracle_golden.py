@@ -135,3 +135,23 @@ def test_oracle_decodes_block_checksum_and_dictid_frames():
             bad = bytearray(rec)
             bad[12 + 40] ^= 0x01
             assert H.oracle_decompress(bytes(bad), e["content_len"] + 64) is None, name
+
+
+with open(os.path.join(H.GOLDEN_DIR, "lz4hc", "manifest.json")) as _f:
+    HCMAN = json.load(_f)["cases"]
+
+
+@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("name", sorted(HCMAN))
+def test_oracle_hc_matches_reference_golden(name, level):
+    """LZ4 HC levels 3..8 (lz4hc_oracle.c) against digests of what the reference wrote
+    (tests/golden/gen_golden_lz4hc.py)."""
+    chunk, thunk = CASES[name]
+    data = thunk()
+    e = HCMAN[name]["levels"][str(level)]
+    assert H.sha256(data) == HCMAN[name]["in_sha256"]
+    s = H.oracle_compress_level(data, chunk, level)
+    assert len(s) == e["out_len"] and H.sha256(s) == e["out_sha256"]
+    if "out_hex" in e:
+        assert s.hex() == e["out_hex"]
+    assert H.oracle_decompress(s, max(len(data), 65536)) == data

@@ -78,3 +78,27 @@ def test_mt_variants_agree():
     back = C.create_string_buffer(len(data))
     m = lib.zo_lz4mt_decompress_mt(s, len(s), back, len(data), 4)
     assert m == len(data) and back.raw == data
+
+
+@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_compress_hc_bit_exact(seed, level):
+    """LZ4 HC levels whose search is a plain hash-chain walk (lz4hc_oracle.c) against the reference
+    library (liblz4 1.9.3 behind lib/lz4-mt_compress.c:281), incl. linked blocks and stored blocks."""
+    rng = random.Random(7000 + 31 * seed + level)
+    n = rng.choice([0, 1, 12, 13, 14, 65536, 65537, 131072, 131073, rng.randrange(1, 500000),
+                    rng.randrange(1, 500000)])
+    chunk = rng.choice([65536, 131072, 131072, 100000, 262144, 1 << 20])
+    data = _mix(rng, n)
+    rv, s_ref, _, _ = H.lz4mt_compress_via(H.ref(), data, chunk, threads=rng.choice([1, 3]), level=level)
+    assert rv == 0
+    assert H.oracle_compress_level(data, chunk, level) == s_ref
+    assert H.oracle_decompress(s_ref, max(n, 65536)) == data
+
+
+@pytest.mark.parametrize("level", [3, 8])
+def test_hc_text_and_runs(level):
+    data = text(700000, 21) + bytes(200000) + (text(97, 22) * 3000) + rnd(90000, 23) + text(150000, 24)
+    for chunk in (131072, 4 << 20):
+        rv, s_ref, _, _ = H.lz4mt_compress_via(H.ref(), data, chunk, threads=2, level=level)
+        assert rv == 0 and H.oracle_compress_level(data, chunk, level) == s_ref
