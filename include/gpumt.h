@@ -6,6 +6,7 @@
  * through these calls, exactly where the reference's worker threads call into liblz4:
  *
  *   gpumt_lz4_compress_batch   replaces  LZ4F_compressFrame    @ lib/lz4-mt_compress.c:281  (C2)
+ *   gpumt_lz4_compress_batch_level  the same call with prefs.compressionLevel >= 3 (HC, :141-146)
  *                                        + header emit          @ lib/lz4-mt_compress.c:294-298 (F5)
  *   gpumt_lz4_slot_stride      replaces  LZ4F_compressFrameBound@ lib/lz4-mt_compress.c:232,244 (C1)
  *   gpumt_lz4_compact          replaces  pt_write ordering      @ lib/lz4-mt_compress.c:178-205 (F4)
@@ -111,6 +112,20 @@ size_t gpumt_lz4_record_count(size_t n, size_t chunk);
  */
 int gpumt_lz4_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk,
 			     void *d_slots, size_t slot_stride, uint32_t *d_rec_len, int stream);
+
+/*
+ * The same with lz4-mt's compression level (prefs.compressionLevel, lib/lz4-mt_compress.c:141-146):
+ * 1..2 = LZ4 fast (what gpumt_lz4_compress_batch does), 3..8 = LZ4 HC hash-chain parser with
+ * 4..128 searches per position (liblz4 1.9.3 lz4hc.c), byte-identical to the reference at that
+ * level.  Levels 9..12 (pattern analysis / optimal parser) are not implemented: GPUMT_E_ARG.
+ * HC keeps a 256 KiB table set per wave in internal scratch (at most GPUMT_LZ4HC_WAVES of them).
+ */
+#define GPUMT_LZ4HC_SCRATCH 262144u
+#define GPUMT_LZ4HC_WAVES 4096u
+int gpumt_lz4_level_supported(int level);
+int gpumt_lz4_compress_batch_level(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk,
+				   void *d_slots, size_t slot_stride, uint32_t *d_rec_len, int level,
+				   int stream);
 
 /*
  * Ordered concatenation: d_rec_off[i] = sum of d_rec_len[0..i), d_rec_off[nrec] = total, and the

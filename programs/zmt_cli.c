@@ -54,7 +54,7 @@ typedef ZSTDCB_RdWr_t MT_RdWr_t;
 #define ZCAT "lz4cat-mt"
 #define SUFFIX ".lz4"
 #define METHOD "lz4"
-#define LEVEL_DEF 1 /* the reference defaults to 3 (LZ4HC, programs/lz4-mt.c:19); HC is not on the device */
+#define LEVEL_DEF 3 /* programs/lz4-mt.c:19 (LZ4HC) */
 #define LEVEL_MIN LZ4MT_LEVEL_MIN
 #define LEVEL_MAX LZ4MT_LEVEL_MAX
 #define THREAD_MAX LZ4MT_THREAD_MAX

@@ -16,6 +16,7 @@ void zmt_xxh32_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, const u3
 void zmt_lz4_enc3_u16_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
 void zmt_lz4_enc3_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
 void zmt_lz4_enc3_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
+void zmt_lz4hc_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *, u8 *, int);
 void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u32 *, u32 *, u32 *, u32);
 void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
@@ -76,6 +77,25 @@ void emu_lz4_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 strid
 		emu::launch(dim3{1, 1, 1}, dim3{64, 1, 1},
 			    [=]() { zmt_lz4_enc3_u16_kernel(in, n, chunk, nrec - 1, nrec, slots, stride, rec_len, chkp, nullptr); });
 	}
+}
+
+void emu_lz4hc_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, int level)
+{
+	u32 nrec = n ? (u32)((n + chunk - 1) / chunk) : 1;
+	std::vector<u64> off(nrec);
+	std::vector<u32> len(nrec), chk(nrec);
+	for (u32 i = 0; i < nrec; i++) {
+		off[i] = (u64)i * chunk;
+		len[i] = (u32)std::min<u64>(chunk, n - off[i]);
+	}
+	emu_xxh32_batch(in, off.data(), len.data(), nrec, chk.data());
+	const u32 *chkp = chk.data();
+	/* fewer waves than records on purpose: the persistent loop and the table reset are exercised */
+	const u32 grid = nrec > 2 ? (nrec + 1) / 2 : nrec;
+	std::vector<u8> scratch((size_t)grid * 262144, 0xA5);
+	u8 *sc = scratch.data();
+	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1},
+		    [=]() { zmt_lz4hc_enc_kernel(in, n, chunk, nrec, slots, stride, rec_len, chkp, sc, 1 << (level - 1)); });
 }
 
 void emu_lz4_compact(const u8 *slots, u64 stride, const u32 *rec_len, u32 nrec, u8 *stream, u64 *rec_off)

@@ -36,7 +36,7 @@ def xxh32_batch(buf: np.ndarray, off: np.ndarray, length: np.ndarray) -> np.ndar
     return out
 
 
-def compress(data: bytes, chunk: int):
+def compress(data: bytes, chunk: int, level: int = 1):
     """-> (stream bytes, rec_off[n+1], rec_len[n])"""
     L = lib()
     n = len(data)
@@ -45,8 +45,12 @@ def compress(data: bytes, chunk: int):
     inp = np.frombuffer(data + b"\0" * 16, np.uint8).copy()   # slack: hash reads 8 bytes
     slots = np.full(nrec * stride, 0xEE, np.uint8)
     rec_len = np.zeros(nrec, np.uint32)
-    L.emu_lz4_compress_batch(_p(inp), C.c_uint64(n), C.c_uint32(chunk), _p(slots),
-                             C.c_uint64(stride), _p(rec_len))
+    if level >= 3:
+        L.emu_lz4hc_compress_batch(_p(inp), C.c_uint64(n), C.c_uint32(chunk), _p(slots),
+                                   C.c_uint64(stride), _p(rec_len), C.c_int(level))
+    else:
+        L.emu_lz4_compress_batch(_p(inp), C.c_uint64(n), C.c_uint32(chunk), _p(slots),
+                                 C.c_uint64(stride), _p(rec_len))
     rec_off = np.zeros(nrec + 1, np.uint64)
     stream = np.full(int(rec_len.sum()) + 16, 0xDD, np.uint8)
     L.emu_lz4_compact(_p(slots), C.c_uint64(stride), _p(rec_len), C.c_uint32(nrec), _p(stream),

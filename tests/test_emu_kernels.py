@@ -36,6 +36,31 @@ def test_emu_compress_bit_exact(name):
     assert H.sha256(stream) == MAN[name]["out_sha256"]
 
 
+def _hc_inputs():
+    t = text(9000)
+    return {
+        "empty": (65536, b""),
+        "abc_12": (65536, b"abcabcabcabc"),
+        "abc_13": (65536, b"abcabcabcabca"),
+        "text_9000": (65536, t),
+        "zeros_70000": (131072, bytes(70000)),                  # linked second block, long match
+        "period_7": (65536, (b"abcdefg" * 1500)[:10000]),       # overlapping matches
+        "rnd_3000": (65536, rnd(3000, 5)),                      # does not shrink: stored block
+        "text_rnd_text": (65536, t[:3000] + rnd(1500, 9) + t[:3000]),
+        "text_4x2500": (2500, t + t[:1000]),                    # ragged chunks, persistent grid of 2
+        "lazy_shapes": (65536, b"".join(t[i * 37:i * 37 + 60 + i % 40] + t[:i % 23] for i in range(120))),
+    }
+
+
+@pytest.mark.parametrize("level", [3, 5, 8])
+@pytest.mark.parametrize("name", sorted(_hc_inputs()))
+def test_emu_hc_compress_bit_exact(name, level):
+    """lz4_enc_hc.hip on the emulator against the LZ4HC oracle (levels 3..8 = hash chain)."""
+    chunk, data = _hc_inputs()[name]
+    stream, rec_off, rec_len = E.compress(data, chunk, level)
+    assert stream == H.oracle_compress_level(data, chunk, level)
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("name", SMALL)
 def test_emu_decompress(name, variant):

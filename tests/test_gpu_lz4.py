@@ -75,6 +75,54 @@ def test_fuzz_vs_oracle(eng, seed):
         assert not status.any() and out == data
 
 
+with open(os.path.join(H.GOLDEN_DIR, "lz4hc", "manifest.json")) as _f:
+    HCMAN = json.load(_f)
+
+
+@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8])
+def test_hc_compress_golden(eng, level):
+    """LZ4HC levels 3..8 against the digests the reference build wrote (tests/golden/gen_golden_lz4hc.py)."""
+    n = 0
+    for name, e in HCMAN["cases"].items():
+        chunk, thunk = CASES[name]
+        want = e["levels"].get(str(level))
+        if want is None:
+            continue
+        stream, ro, rl = eng.compress_bytes(thunk(), chunk, level=level)
+        assert (len(stream), H.sha256(stream)) == (want["out_len"], want["out_sha256"]), name
+        n += 1
+    assert n >= 20
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_hc_fuzz_vs_oracle(eng, seed):
+    import random
+    from test_oracle_vs_ref import _mix
+    rng = random.Random(7000 + seed)
+    n = rng.randrange(1, 2_000_000)
+    chunk = rng.choice([65536, 131072, 100000, 262144, 1 << 20])
+    level = rng.choice([3, 4, 5, 6, 7, 8])
+    data = _mix(rng, n)
+    stream, ro, rl = eng.compress_bytes(data, chunk, level=level)
+    assert stream == H.oracle_compress_level(data, chunk, level)
+    out, status = eng.decompress_bytes(stream, ro, rl)
+    assert not status.any() and out == data
+
+
+def test_hc_many_chunks_persistent_grid(eng):
+    """More chunks than GPUMT_LZ4HC_WAVES: every wave resets its tables and takes several chunks."""
+    data = text(40 << 20)
+    chunk = 16384
+    stream, ro, rl = eng.compress_bytes(data, chunk, level=3)
+    assert len(rl) == 2560
+    for i in (0, 1, 2047, 2048, 2559):
+        rec = stream[int(ro[i]):int(ro[i]) + int(rl[i])]
+        assert rec == H.oracle_compress_level(data[i * chunk:(i + 1) * chunk], chunk, 3)
+    out, status = eng.decompress_bytes(stream, ro, rl)
+    assert not status.any() and out == data
+    assert eng.L.gpumt_lz4_level_supported(8) == 1 and eng.L.gpumt_lz4_level_supported(9) == 0
+
+
 def test_config1_random_64m(eng):
     """BASELINE config 1 shape: 64 MiB of PRNG bytes, default 4 MiB chunks -> 16 frames of 64 stored
     blocks; output = input + 16*(12+15+64*4+4+4) bytes."""

@@ -75,6 +75,22 @@ def test_callback_trace_equals_reference(lib, name):
     assert io_o.reads == io_r.reads and io_o.writes == io_r.writes
 
 
+@pytest.mark.parametrize("level", [3, 4, 6, 8])
+def test_hc_levels_match_oracle_and_reference(lib, level):
+    """Levels 3..8 (LZ4HC hash chain, the CLI default is 3): same bytes as the oracle, and as the
+    reference library where it is built; the stream decodes back."""
+    data = text(700000) + rnd(70000, 3) + bytes(200000) + text(300000)[::-1]
+    chunk = 262144
+    rv, stream, io, stats = H.lz4mt_compress_via(lib, data, chunk, threads=3, level=level)
+    assert rv == 0
+    assert stream == H.oracle_compress_level(data, chunk, level)
+    if H.have_ref():
+        rv_r, s_r, _, st_r = H.lz4mt_compress_via(H.ref(), data, chunk, threads=1, level=level)
+        assert rv_r == 0 and s_r == stream and st_r == stats
+    rv, out, _, _ = H.lz4mt_decompress_via(lib, stream, threads=2)
+    assert rv == 0 and out == data
+
+
 def test_large_pipeline_many_batches(lib):
     """> 2 device batches each way (64 MiB per batch): exercises the double-buffered pipeline."""
     data = text(200 << 20)
@@ -107,8 +123,8 @@ def test_create_argument_checks(lib):
     io = H.MemIO(b"x")
     assert lib.LZ4MT_compressCCtx(None, C.byref(io.rdwr)) == ERR(E_PARAM)
     assert lib.LZ4MT_decompressDCtx(None, C.byref(io.rdwr)) == ERR(E_PARAM)
-    # LZ4HC levels: context is created, compression reports the parameter as unsupported
-    rv, _, _, _ = H.lz4mt_compress_via(lib, b"abc", 131072, threads=1, level=3)
+    # LZ4HC levels 9-12: context is created, compression reports the parameter as unsupported
+    rv, _, _, _ = H.lz4mt_compress_via(lib, b"abc", 131072, threads=1, level=9)
     assert rv == ERR(E_PARAM) and lib.LZ4MT_isError(rv)
     assert lib.LZ4MT_getErrorString(rv) == b"Compression parameter is out of bound"
     assert not lib.LZ4MT_isError(0)
@@ -216,8 +232,13 @@ def test_plain_lz4_errors(lib):
     dmg[len(f) // 2 + 1] ^= 0xFF
     rv, out, _, _ = H.lz4mt_decompress_via(lib, bytes(dmg))
     assert rv == ERR(E_LIB) or out != a                # damaged tokens: rejected, or caught by the checksum
-    rv, _, _, _ = H.lz4mt_decompress_via(lib, H.liblz4_frame(a, block_checksum=1))
-    assert rv == ERR(E_LIB)                             # block checksums: not on the device
+    bc = H.liblz4_frame(a, block_checksum=1)            # block checksums are verified on the device
+    rv, out, _, _ = H.lz4mt_decompress_via(lib, bc)
+    assert rv == 0 and out == a
+    dmg = bytearray(bc)
+    dmg[len(bc) // 2] ^= 0x01
+    rv, _, _, _ = H.lz4mt_decompress_via(lib, bytes(dmg))
+    assert rv == ERR(E_LIB)
 
 
 def test_callback_threads(lib):

@@ -43,6 +43,8 @@ GPUMT_SYMBOLS = {
     "gpumt_lz4_slot_stride": (_sz, [_sz]),
     "gpumt_lz4_record_count": (_sz, [_sz, _sz]),
     "gpumt_lz4_compress_batch": (_i, [_vp, _vp, _sz, _sz, _vp, _sz, _u32p, _i]),
+    "gpumt_lz4_compress_batch_level": (_i, [_vp, _vp, _sz, _sz, _vp, _sz, _u32p, _i, _i]),
+    "gpumt_lz4_level_supported": (_i, [_i]),
     "gpumt_lz4_compact": (_i, [_vp, _vp, _sz, _u32p, _sz, _vp, _u64p, _i]),
     "gpumt_lz4_probe_sizes": (_i, [_vp, _vp, _u64p, _u32p, _sz, _u32p, _u64p, _i]),
     "gpumt_lz4_decompress_batch": (_i, [_vp, _vp, _sz, _u64p, _u32p, _sz, _vp, _sz, _u64p, _u32p, _u32p, _i]),

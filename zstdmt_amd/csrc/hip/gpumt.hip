@@ -24,6 +24,7 @@ __global__ void zmt_lz4_enc3_u16_kernel(const u8 *, u64, u32, u32, u32, u8 *, u6
 					unsigned long long *);
 __global__ void zmt_lz4_enc3_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
 					unsigned long long *);
+__global__ void zmt_lz4hc_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *, u8 *, int);
 __global__ void zmt_lz4_enc3_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
 					unsigned long long *);
 __global__ void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
@@ -81,6 +82,7 @@ struct gpumt_ctx {
 	int profile; /* record events in timer slots 8.. around individual kernels */
 	int num_cus;
 	int zenc_waves; /* resident waves of the persistent zstd encoder kernel (whole device) */
+	int hc_waves;     /* developer: grid of the LZ4HC encoder (0 = GPUMT_LZ4HC_WAVES) */
 	int zdec_variant; /* 0 = small-table kernel, then general; 1 = general only */
 	int bdec_waves;   /* resident waves of the persistent brotli decoder kernel (whole device) */
 	int benc_waves;   /* ... of the brotli encoder kernel */
@@ -475,14 +477,26 @@ int gpumt_xxh32_batch(gpumt_ctx *h, const void *d_base, const uint64_t *d_off,
 int gpumt_lz4_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk,
 			     void *d_slots, size_t slot_stride, uint32_t *d_rec_len, int s)
 {
+	return gpumt_lz4_compress_batch_level(h, d_in, n, chunk, d_slots, slot_stride, d_rec_len, 1, s);
+}
+
+int gpumt_lz4_level_supported(int level) { return level >= 1 && level <= 8; }
+
+int gpumt_lz4_compress_batch_level(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk,
+				   void *d_slots, size_t slot_stride, uint32_t *d_rec_len, int level, int s)
+{
 	size_t nrec = gpumt_lz4_record_count(n, chunk);
 	if (!h || !STREAM_OK(s) || chunk == 0 || chunk > 0x40000000u || nrec > 0x3FFFFFFFu ||
-	    slot_stride < gpumt_lz4_slot_stride(chunk))
+	    slot_stride < gpumt_lz4_slot_stride(chunk) || !gpumt_lz4_level_supported(level))
 		return GPUMT_E_ARG;
 	if (use(h))
 		return GPUMT_E_HIP;
-	/* scratch: off[nrec] u64 | len[nrec] u32 | chk[nrec] u32 */
-	if (want_scratch(h, 0, s, nrec * 16))
+	/* scratch: off[nrec] u64 | len[nrec] u32 | chk[nrec] u32 | (HC) one table set per wave */
+	const bool hc = level >= 3;
+	const size_t hc_max = h->hc_waves > 0 ? (size_t)h->hc_waves : GPUMT_LZ4HC_WAVES;
+	const size_t hc_grid = nrec < hc_max ? nrec : hc_max;
+	const size_t hc_base = (nrec * 16 + 255) & ~(size_t)255;
+	if (want_scratch(h, 0, s, hc ? hc_base + hc_grid * GPUMT_LZ4HC_SCRATCH : nrec * 16))
 		return GPUMT_E_HIP;
 	u64 *off = (u64 *)h->scratch[0][s];
 	u32 *len = (u32 *)(off + nrec);
@@ -503,7 +517,13 @@ int gpumt_lz4_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t ch
 		}
 		eprof = h->d_prof;
 	}
-	if (chunk <= 65536) {
+	if (hc) {
+		/* levels 3..8: hash-chain parser, nbSearches = 1 << (level - 1) (liblz4 clTable) */
+		hipLaunchKernelGGL(zmt_lz4hc_enc_kernel, dim3((unsigned)hc_grid), dim3(64), 0, h->st[s],
+				   (const u8 *)d_in, (u64)n, (u32)chunk, (u32)nrec, (u8 *)d_slots,
+				   (u64)slot_stride, d_rec_len, (const u32 *)chk,
+				   (u8 *)h->scratch[0][s] + hc_base, 1 << (level - 1));
+	} else if (chunk <= 65536) {
 		/* every record is a single independent block: byU16 table */
 		hipLaunchKernelGGL(zmt_lz4_enc3_u16_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
 				   (const u8 *)d_in, (u64)n, (u32)chunk, 0u, (u32)nrec, (u8 *)d_slots,
@@ -899,6 +919,9 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	} else if (!strcmp(what, "k2x")) {
 		prev = h->xflags;
 		h->xflags = variant;
+	} else if (!strcmp(what, "hc_waves")) {
+		prev = h->hc_waves;
+		h->hc_waves = variant;
 	} else if (!strcmp(what, "zstd_dec")) {
 		prev = h->zdec_variant;
 		h->zdec_variant = variant;

@@ -1,0 +1,438 @@
+/*
+ * lz4_enc_hc.hip -- LZ4 frame encoder for the "HC" levels 3..8 of lz4-mt, bit-exact.
+ *
+ * The reference hands levels >= 3 to LZ4F_compressFrame's HC path (prefs.compressionLevel,
+ * /root/reference/lib/lz4-mt_compress.c:141-146, call :281; the CLI default is level 3,
+ * /root/reference/programs/lz4-mt.c:19).  For levels 3..8 that is liblz4's hash-chain parser: every
+ * position enters a 32 K-entry hash table + 64 K-entry chain of 16-bit deltas, a search walks at
+ * most 4 / 8 / 16 / 32 / 64 / 128 chain links, and a lazy evaluation over up to three overlapping
+ * matches decides what is emitted (oracle/lz4hc_oracle.c restates it and is pinned against the
+ * reference build).  Level 9 (repeated-pattern analysis) and 10..12 (optimal parser) are not here.
+ *
+ * The parse is inherently serial per chunk (what is found depends on everything inserted before),
+ * so the unit of parallelism is the chunk: one wave per chunk on a persistent grid, tables in a
+ * 256 KiB global scratch area per wave.  The wave's lanes are used where the algorithm has width:
+ *   - insertion of up to 64 consecutive positions at once: hashes in parallel, positions that share
+ *     a hash inside the batch are chained to each other in lane order exactly as the serial loop
+ *     would (ballot per distinct hash), the last one of each hash updates the table;
+ *   - match length and backward extension compare 64 bytes per step (ballot + ffs);
+ *   - literals and stored blocks are copied by the whole wave.
+ * Control flow (chain walk, lazy evaluation) is wave-uniform.  Throughput is far below the level-1
+ * encoder and below the host library (dependent global-memory round trips per chain link); it
+ * exists so that the default level of the reference CLI is served on the device, bit for bit.
+ */
+#include "lz4_common.h"
+
+#define HC_HASH_LOG 15
+#define HC_MAXD 65536u
+#define HC_DIST_MAX 65535u
+#define HC_BASE 65536u
+#define HC_MINMATCH 4u
+#define HC_MFLIMIT 12u
+#define HC_LASTLITERALS 5u
+#define HC_OPTIMAL_ML 18
+#define HC_SCRATCH (32768u * 4u + HC_MAXD * 2u) /* == GPUMT_LZ4HC_SCRATCH */
+
+struct HcState {
+	u32 *hash;
+	u16 *chain;
+	const u8 *src;
+	u32 next_to_update;
+};
+
+static __device__ __forceinline__ u32 hc_hash(u32 v) { return (v * 2654435761u) >> (32 - HC_HASH_LOG); }
+
+/* wave-uniform loads of table entries (every lane issues the same address) */
+static __device__ __forceinline__ u32 hc_uld_hash(const HcState &H, u32 hv) { return wv_readfirst(H.hash[hv]); }
+static __device__ __forceinline__ u32 hc_uld_chain(const HcState &H, u32 idx)
+{
+	return wv_readfirst((u32)H.chain[idx & (HC_MAXD - 1)]);
+}
+
+/* LZ4HC_Insert: positions [next_to_update, target) enter the chains, 64 at a time */
+static __device__ void hc_insert(HcState &H, u32 target, int lane)
+{
+	while (H.next_to_update < target) {
+		const u32 base = H.next_to_update;
+		const u32 cnt = target - base < 64u ? target - base : 64u;
+		const bool act = (u32)lane < cnt;
+		const u32 idx = base + (u32)lane;
+		const u32 hv = act ? hc_hash(ld32u(H.src + (idx - HC_BASE))) : 0x10000u + (u32)lane;
+		const u32 prev = act ? H.hash[hv] : 0u;
+		/* lanes of the batch that share a hash: chained in lane order, the last one owns the table */
+		u32 pred = 64;
+		bool last = true;
+		u64 todo = wv_ballot(act);
+		while (todo) {
+			const int f = wv_ffs(todo) - 1;
+			const u32 hvf = wv_readlane(hv, f);
+			const u64 same = wv_ballot(act && hv == hvf);
+			if (act && hv == hvf) {
+				const u64 below = same & ((1ull << lane) - 1ull);
+				pred = below ? 63u - (u32)__builtin_clzll(below) : 64u;
+				last = (lane == 63) || ((same >> (lane + 1)) == 0);
+			}
+			todo &= ~same;
+		}
+		if (act) {
+			const u32 from = pred < 64u ? base + pred : prev;
+			u32 delta = idx - from;
+			if (delta > HC_DIST_MAX)
+				delta = HC_DIST_MAX;
+			H.chain[idx & (HC_MAXD - 1)] = (u16)delta;
+			if (last)
+				H.hash[hv] = idx;
+		}
+		H.next_to_update = base + cnt;
+		wv_sync(); /* the next batch and the search read what other lanes stored */
+	}
+}
+
+/* number of equal bytes of a[0..) and b[0..), at most `limit` (wave-uniform arguments and result) */
+static __device__ u32 hc_count(const u8 *a, const u8 *b, u32 limit, int lane)
+{
+	u32 done = 0;
+	for (;;) {
+		const u32 i = done + (u32)lane;
+		const bool stop = i >= limit || a[i] != b[i];
+		const u64 sm = wv_ballot(stop);
+		if (sm) {
+			const u32 r = done + (u32)wv_ffs(sm) - 1;
+			return r < limit ? r : limit;
+		}
+		done += 64;
+	}
+}
+
+/* LZ4HC_countBack: how far (as a negative number, >= min) the match extends backwards */
+static __device__ int hc_count_back(const u8 *s, u32 ip, u32 m, int min, int lane)
+{
+	const u32 room = (u32)(-min);
+	u32 done = 0;
+	for (;;) {
+		const u32 i = done + (u32)lane;
+		const bool stop = i >= room || s[ip - 1 - i] != s[m - 1 - i];
+		const u64 sm = wv_ballot(stop);
+		if (sm) {
+			u32 r = done + (u32)wv_ffs(sm) - 1;
+			if (r > room)
+				r = room;
+			return -(int)r;
+		}
+		done += 64;
+	}
+}
+
+/* LZ4HC_InsertAndGetWiderMatch (no pattern analysis, no chain swap: levels 3..8) */
+static __device__ int hc_wider(HcState &H, u32 ip, u32 low_limit, u32 high_limit, int longest, u32 *mpos,
+			       u32 *spos, int max_attempts, int lane)
+{
+	const u8 *const s = H.src;
+	const u32 ip_index = ip + HC_BASE;
+	const u32 lowest = (HC_BASE + HC_DIST_MAX + 1 > ip_index) ? HC_BASE : ip_index - HC_DIST_MAX;
+	const int look_back = (int)(ip - low_limit);
+	const u32 pattern = uld32(s + ip);
+	int attempts = max_attempts;
+
+	hc_insert(H, ip_index, lane);
+	u32 match_index = hc_uld_hash(H, hc_hash(pattern));
+	while (match_index >= lowest && attempts > 0) {
+		const u32 m = match_index - HC_BASE;
+		attempts--;
+		if (uld16(s + low_limit + (u32)longest - 1) == uld16(s + m - (u32)look_back + (u32)longest - 1)) {
+			if (uld32(s + m) == pattern) {
+				int back = 0;
+				if (look_back) {
+					const int min_i = -look_back, min_m = -(int)m;
+					back = hc_count_back(s, ip, m, min_i > min_m ? min_i : min_m, lane);
+				}
+				int ml = (int)HC_MINMATCH +
+					 (int)hc_count(s + ip + HC_MINMATCH, s + m + HC_MINMATCH, high_limit - (ip + HC_MINMATCH), lane);
+				ml -= back;
+				if (ml > longest) {
+					longest = ml;
+					*mpos = (u32)((int)m + back);
+					*spos = (u32)((int)ip + back);
+				}
+			}
+		}
+		match_index -= hc_uld_chain(H, match_index);
+	}
+	return longest;
+}
+
+/* LZ4HC_encodeSequence: 1 when the output limit is hit.  op / oend are offsets into dst. */
+static __device__ int hc_encode(const u8 *s, u8 *dst, u32 *ip, u32 *op, u32 *anchor, int ml, u32 mpos, u32 oend,
+				int lane)
+{
+	const u32 tokpos = (*op)++;
+	u32 length = *ip - *anchor, token;
+	if (*op + (length / 255) + length + (2 + 1 + HC_LASTLITERALS) > oend)
+		return 1;
+	if (length >= 15) {
+		u32 len = length - 15;
+		token = 15u << 4;
+		const u32 n255 = len / 255;
+		for (u32 i = (u32)lane; i < n255; i += 64)
+			dst[*op + i] = 255;
+		if (lane == 0)
+			dst[*op + n255] = (u8)(len - n255 * 255);
+		*op += n255 + 1;
+	} else {
+		token = length << 4;
+	}
+	wave_copy(dst + *op, s + *anchor, length, lane);
+	*op += length;
+	if (lane == 0) {
+		dst[*op] = (u8)(*ip - mpos);
+		dst[*op + 1] = (u8)((*ip - mpos) >> 8);
+	}
+	*op += 2;
+	length = (u32)ml - HC_MINMATCH;
+	if (*op + (length / 255) + (1 + HC_LASTLITERALS) > oend)
+		return 1;
+	if (length >= 15) {
+		token += 15;
+		length -= 15;
+		/* the reference writes pairs of 255 then singles: the bytes are n x 255 followed by the rest */
+		const u32 n255 = length / 255;
+		for (u32 i = (u32)lane; i < n255; i += 64)
+			dst[*op + i] = 255;
+		if (lane == 0)
+			dst[*op + n255] = (u8)(length - n255 * 255);
+		*op += n255 + 1;
+	} else {
+		token += length;
+	}
+	if (lane == 0)
+		dst[tokpos] = (u8)token;
+	*ip += (u32)ml;
+	*anchor = *ip;
+	return 0;
+}
+
+/* LZ4HC_compress_hashChain over chunk positions [start, start + n) into dst[0, cap): size or 0 */
+static __device__ u32 hc_block(HcState &H, u32 start, u32 n, u8 *dst, u32 cap, int max_attempts, int lane)
+{
+	const u8 *const s = H.src;
+	u32 ip = start, anchor = start;
+	const u32 iend = start + n;
+	const u32 mflimit = iend - HC_MFLIMIT, matchlimit = iend - HC_LASTLITERALS;
+	u32 op = 0;
+	const u32 oend = cap;
+	int ml0, ml, ml2, ml3;
+	u32 start0, ref0, ref = 0, start2 = 0, ref2 = 0, start3 = 0, ref3 = 0;
+
+	if (n < HC_MFLIMIT + 1)
+		goto last_literals;
+	while (ip <= mflimit) {
+		{
+			u32 dummy = ip;
+			ml = hc_wider(H, ip, ip, matchlimit, (int)HC_MINMATCH - 1, &ref, &dummy, max_attempts, lane);
+		}
+		if (ml < (int)HC_MINMATCH) {
+			ip++;
+			continue;
+		}
+		start0 = ip;
+		ref0 = ref;
+		ml0 = ml;
+search2:
+		if (ip + (u32)ml <= mflimit)
+			ml2 = hc_wider(H, ip + (u32)ml - 2, ip, matchlimit, ml, &ref2, &start2, max_attempts, lane);
+		else
+			ml2 = ml;
+		if (ml2 == ml) {
+			if (hc_encode(s, dst, &ip, &op, &anchor, ml, ref, oend, lane))
+				return 0;
+			continue;
+		}
+		if (start0 < ip) {
+			if (start2 < ip + (u32)ml0) {
+				ip = start0;
+				ref = ref0;
+				ml = ml0;
+			}
+		}
+		if (start2 - ip < 3) {
+			ml = ml2;
+			ip = start2;
+			ref = ref2;
+			goto search2;
+		}
+search3:
+		if (start2 - ip < (u32)HC_OPTIMAL_ML) {
+			int new_ml = ml;
+			if (new_ml > HC_OPTIMAL_ML)
+				new_ml = HC_OPTIMAL_ML;
+			if (ip + (u32)new_ml > start2 + (u32)ml2 - HC_MINMATCH)
+				new_ml = (int)(start2 - ip) + ml2 - (int)HC_MINMATCH;
+			const int correction = new_ml - (int)(start2 - ip);
+			if (correction > 0) {
+				start2 += (u32)correction;
+				ref2 += (u32)correction;
+				ml2 -= correction;
+			}
+		}
+		if (start2 + (u32)ml2 <= mflimit)
+			ml3 = hc_wider(H, start2 + (u32)ml2 - 3, start2, matchlimit, ml2, &ref3, &start3, max_attempts, lane);
+		else
+			ml3 = ml2;
+		if (ml3 == ml2) {
+			if (start2 < ip + (u32)ml)
+				ml = (int)(start2 - ip);
+			if (hc_encode(s, dst, &ip, &op, &anchor, ml, ref, oend, lane))
+				return 0;
+			ip = start2;
+			if (hc_encode(s, dst, &ip, &op, &anchor, ml2, ref2, oend, lane))
+				return 0;
+			continue;
+		}
+		if (start3 < ip + (u32)ml + 3) {
+			if (start3 >= ip + (u32)ml) {
+				if (start2 < ip + (u32)ml) {
+					const int correction = (int)(ip + (u32)ml - start2);
+					start2 += (u32)correction;
+					ref2 += (u32)correction;
+					ml2 -= correction;
+					if (ml2 < (int)HC_MINMATCH) {
+						start2 = start3;
+						ref2 = ref3;
+						ml2 = ml3;
+					}
+				}
+				if (hc_encode(s, dst, &ip, &op, &anchor, ml, ref, oend, lane))
+					return 0;
+				ip = start3;
+				ref = ref3;
+				ml = ml3;
+				start0 = start2;
+				ref0 = ref2;
+				ml0 = ml2;
+				goto search2;
+			}
+			start2 = start3;
+			ref2 = ref3;
+			ml2 = ml3;
+			goto search3;
+		}
+		if (start2 < ip + (u32)ml) {
+			if (start2 - ip < (u32)HC_OPTIMAL_ML) {
+				if (ml > HC_OPTIMAL_ML)
+					ml = HC_OPTIMAL_ML;
+				if (ip + (u32)ml > start2 + (u32)ml2 - HC_MINMATCH)
+					ml = (int)(start2 - ip) + ml2 - (int)HC_MINMATCH;
+				const int correction = ml - (int)(start2 - ip);
+				if (correction > 0) {
+					start2 += (u32)correction;
+					ref2 += (u32)correction;
+					ml2 -= correction;
+				}
+			} else {
+				ml = (int)(start2 - ip);
+			}
+		}
+		if (hc_encode(s, dst, &ip, &op, &anchor, ml, ref, oend, lane))
+			return 0;
+		ip = start2;
+		ref = ref2;
+		ml = ml2;
+		start2 = start3;
+		ref2 = ref3;
+		ml2 = ml3;
+		goto search3;
+	}
+last_literals:
+	{
+		const u32 run = iend - anchor;
+		const u32 lit_len = (run + 255 - 15) / 255;
+		if (op + 1 + lit_len + run > oend)
+			return 0;
+		if (run >= 15) {
+			const u32 acc = run - 15, n255 = acc / 255;
+			if (lane == 0)
+				dst[op] = 15u << 4;
+			op++;
+			for (u32 i = (u32)lane; i < n255; i += 64)
+				dst[op + i] = 255;
+			if (lane == 0)
+				dst[op + n255] = (u8)(acc - n255 * 255);
+			op += n255 + 1;
+		} else {
+			if (lane == 0)
+				dst[op] = (u8)(run << 4);
+			op++;
+		}
+		wave_copy(dst + op, s + anchor, run, lane);
+		op += run;
+	}
+	return op;
+}
+
+/*
+ * Persistent grid: wave w takes records w, w + gridDim.x, ...; scratch + w * HC_SCRATCH holds its
+ * hash table and chain.  Record layout as the level-1 encoder writes it (lz4_enc3.hip).
+ */
+extern "C" __global__ void __launch_bounds__(64)
+zmt_lz4hc_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nrec, u8 *__restrict__ slots,
+		     u64 slot_stride, u32 *__restrict__ rec_len, const u32 *__restrict__ chk,
+		     u8 *__restrict__ scratch, int max_attempts)
+{
+	const int lane = wv_lane();
+	HcState H;
+	H.hash = (u32 *)(scratch + (u64)blockIdx.x * HC_SCRATCH);
+	H.chain = (u16 *)(scratch + (u64)blockIdx.x * HC_SCRATCH + 32768u * 4u);
+	for (u32 rec = blockIdx.x; rec < nrec; rec += gridDim.x) {
+		const u64 start = (u64)rec * chunk;
+		const u32 len = (u32)((n - start) < (u64)chunk ? (n - start) : (u64)chunk);
+		const u8 *src = in + start;
+		u8 *dst = slots + (u64)rec * slot_stride;
+		const bool single = len <= ZMT_BLOCK;
+		const u32 hdr = len ? 15 : 7;
+		u32 op = 12 + hdr;
+		if (lane == 0) {
+			u8 d[10];
+			st32u(dst, ZMT_SKIP_MAGIC);
+			st32u(dst + 4, 4);
+			st32u(dst + 12, ZMT_LZ4F_MAGIC);
+			d[0] = (u8)(0x40 | (single ? 0x20 : 0) | (len ? 0x08 : 0) | 0x04);
+			d[1] = 0x40;
+			for (int i = 0; i < 8; i++)
+				d[2 + i] = (i < 4) ? (u8)(len >> (8 * i)) : 0;
+			for (u32 i = 0; i < hdr - 5; i++)
+				dst[16 + i] = d[i];
+			dst[12 + hdr - 1] = (u8)(xxh32_short(d, hdr - 5) >> 8);
+		}
+		/* a fresh context per frame: empty hash table (the chain needs no clearing: an entry is
+		 * written before it can be reached) */
+		for (u32 i = (u32)lane * 4; i < 32768u; i += 256) {
+			H.hash[i] = 0;
+			H.hash[i + 1] = 0;
+			H.hash[i + 2] = 0;
+			H.hash[i + 3] = 0;
+		}
+		wv_sync();
+		H.src = src;
+		H.next_to_update = HC_BASE;
+		for (u32 pos = 0; pos < len; pos += ZMT_BLOCK) {
+			const u32 blen = len - pos < ZMT_BLOCK ? len - pos : ZMT_BLOCK;
+			u32 c = hc_block(H, pos, blen, dst + op + 4, blen - 1, max_attempts, lane);
+			u32 bh = c;
+			if (c == 0) { /* did not shrink: stored; the chains keep what the attempt inserted */
+				wave_copy(dst + op + 4, src + pos, blen, lane);
+				c = blen;
+				bh = blen | 0x80000000u;
+			}
+			if (lane == 0)
+				st32u(dst + op, bh);
+			op += 4 + c;
+		}
+		if (lane == 0) {
+			st32u(dst + op, 0);
+			st32u(dst + op + 4, chk[rec]);
+			st32u(dst + 8, op + 8 - 12);
+			rec_len[rec] = op + 8;
+		}
+		wv_sync();
+	}
+}

@@ -177,7 +177,7 @@ static size_t c_launch(LZ4MT_CCtx *ctx, struct cslot *s)
 	if (s->n)
 		rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, s->n, 1);
 	rc |= gpumt_stream_wait(g, ks, 1);
-	rc |= gpumt_lz4_compress_batch(g, s->in.d, s->n, chunk, s->slots.d, stride, d_len, ks);
+	rc |= gpumt_lz4_compress_batch_level(g, s->in.d, s->n, chunk, s->slots.d, stride, d_len, ctx->level, ks);
 	rc |= gpumt_lz4_compact(g, s->slots.d, stride, d_len, s->nrec, s->stream.d, d_off, ks);
 	rc |= gpumt_stream_wait(g, 2, ks);
 	rc |= gpumt_memcpy_d2h(g, s->meta.h, s->meta.d, ((s->nrec * 4 + 15) & ~(size_t)15) + (s->nrec + 1) * 8, 2);
@@ -265,8 +265,8 @@ size_t LZ4MT_compressCCtx(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *rdwr)
 
 	if (!ctx)
 		return ERROR(compressionParameter_unsupported); /* lz4-mt_compress.c:317-318 */
-	if (ctx->level > 2)
-		return ERROR(compressionParameter_unsupported); /* LZ4HC: not on the device yet */
+	if (!gpumt_lz4_level_supported(ctx->level)) /* 9..12: pattern analysis / optimal parser */
+		return ERROR(compressionParameter_unsupported);
 	ctx->io = rdwr;
 	ctx->maxrec = BATCH_MIN / (size_t)ctx->inputsize;
 	if (ctx->maxrec < 1)

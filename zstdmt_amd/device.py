@@ -133,9 +133,10 @@ class Engine:
     def record_count(self, n, chunk):
         return self.L.gpumt_lz4_record_count(n, chunk)
 
-    def lz4_compress(self, d_in, n, chunk, d_slots, stride, d_rec_len, stream=0):
-        self._ck(self.L.gpumt_lz4_compress_batch(self.h, d_in.ptr, n, chunk, d_slots.ptr, stride,
-                                                 d_rec_len.ptr, stream), "lz4_compress_batch")
+    def lz4_compress(self, d_in, n, chunk, d_slots, stride, d_rec_len, stream=0, level=1):
+        self._ck(self.L.gpumt_lz4_compress_batch_level(self.h, d_in.ptr, n, chunk, d_slots.ptr, stride,
+                                                       d_rec_len.ptr, level, stream),
+                 "lz4_compress_batch_level")
 
     def lz4_compact(self, d_slots, stride, d_rec_len, nrec, d_stream, d_rec_off, stream=0):
         self._ck(self.L.gpumt_lz4_compact(self.h, d_slots.ptr, stride, d_rec_len.ptr, nrec,
@@ -212,7 +213,7 @@ class Engine:
         return recs, status
 
     # ---- convenience round trips on host bytes (tests) ----------------------------------------
-    def compress_bytes(self, data: bytes, chunk: int, codec="lz4"):
+    def compress_bytes(self, data: bytes, chunk: int, codec="lz4", level=1):
         """-> (stream bytes, rec_off[n+1] u64, rec_len[n] u32)"""
         n = len(data)
         nrec = self.record_count(n, chunk)
@@ -227,7 +228,7 @@ class Engine:
             elif codec == "brotli":
                 self.brotli_compress(d_in, n, chunk, d_slots, stride, d_len)
             else:
-                self.lz4_compress(d_in, n, chunk, d_slots, stride, d_len)
+                self.lz4_compress(d_in, n, chunk, d_slots, stride, d_len, level=level)
             rec_len = self.download(d_len, nrec * 4, np.uint32)
             total = int(rec_len.astype(np.uint64).sum())
             d_stream = self.alloc(total + 64)
