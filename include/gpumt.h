@@ -69,6 +69,9 @@ const char *gpumt_last_error(gpumt_ctx *h);
 const char *gpumt_device_name(gpumt_ctx *h);
 
 /* ---- memory / transfers / sync ------------------------------------------------------------ */
+/* Freed buffers go to process-wide caches (device: GPUMT_DEVICE_CACHE_MB, pinned host:
+ * GPUMT_PINNED_CACHE_MB, 16384 each by default; 0 disables) and from there to the next allocation of a
+ * similar size, without a device-wide wait: free a buffer only when no queued work uses it. */
 void *gpumt_malloc(gpumt_ctx *h, size_t bytes);
 void  gpumt_free(gpumt_ctx *h, void *dptr);
 void *gpumt_host_alloc(gpumt_ctx *h, size_t bytes);          /* pinned */
@@ -76,6 +79,11 @@ void  gpumt_host_free(gpumt_ctx *h, void *hptr);
 int   gpumt_memcpy_h2d(gpumt_ctx *h, void *dst, const void *src, size_t n, int stream);
 int   gpumt_memcpy_d2h(gpumt_ctx *h, void *dst, const void *src, size_t n, int stream);
 int   gpumt_memcpy_d2d(gpumt_ctx *h, void *dst, const void *src, size_t n, int stream);
+/* Device -> pinned host memory (from gpumt_host_alloc) by a kernel on `stream`: min(n, *d_n) bytes when
+ * d_n (a uint64 in device memory, e.g. the total gpumt_lz4_compact leaves at d_rec_off[nrec]) is
+ * given, else n.  Both addresses 16-byte aligned.  What the host engines use for results: the size
+ * stays on the device and batches on different streams overlap (see pack.hip). */
+int   gpumt_push_host(gpumt_ctx *h, void *dst_host, const void *src, size_t n, const uint64_t *d_n, int stream);
 int   gpumt_memset(gpumt_ctx *h, void *dst, int byte, size_t n, int stream);
 int   gpumt_stream_sync(gpumt_ctx *h, int stream);
 int   gpumt_device_sync(gpumt_ctx *h);

@@ -30,6 +30,7 @@ GPUMT_SYMBOLS = {
     "gpumt_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz, _i]),
     "gpumt_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz, _i]),
     "gpumt_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz, _i]),
+    "gpumt_push_host": (_i, [_vp, _vp, _vp, _sz, _vp, _i]),
     "gpumt_memset": (_i, [_vp, _vp, _i, _sz, _i]),
     "gpumt_stream_sync": (_i, [_vp, _i]),
     "gpumt_device_sync": (_i, [_vp]),

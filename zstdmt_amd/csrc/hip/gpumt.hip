@@ -24,6 +24,7 @@ __global__ void zmt_lz4_enc3_u16_kernel(const u8 *, u64, u32, u32, u32, u8 *, u6
 					unsigned long long *);
 __global__ void zmt_lz4_enc3_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
 					unsigned long long *);
+__global__ void zmt_push_host_kernel(const u8 *, u8 *, u64, const u64 *);
 __global__ void zmt_lz4hc_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *, u8 *, int);
 __global__ void zmt_lz4_enc3_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
 					unsigned long long *);
@@ -121,18 +122,25 @@ static int use(gpumt_ctx *h)
 	return GPUMT_OK;
 }
 
+static void *dev_alloc(gpumt_ctx *h, size_t bytes);
+static void dev_free(gpumt_ctx *h, void *p);
+
 static int want_scratch(gpumt_ctx *h, int k, int s, size_t bytes)
 {
 	if (bytes <= h->scratch_bytes[k][s])
 		return GPUMT_OK;
 	if (h->scratch[k][s]) {
 		CK(hipDeviceSynchronize());
-		CK(hipFree(h->scratch[k][s]));
+		dev_free(h, h->scratch[k][s]);
 		h->scratch[k][s] = NULL;
 		h->scratch_bytes[k][s] = 0;
 	}
 	bytes = (bytes + 0xFFFFF) & ~(size_t)0xFFFFF;
-	CK(hipMalloc(&h->scratch[k][s], bytes));
+	h->scratch[k][s] = dev_alloc(h, bytes);
+	if (!h->scratch[k][s]) {
+		snprintf(h->err, sizeof h->err, "device scratch of %zu bytes: out of memory", bytes);
+		return GPUMT_E_HIP;
+	}
 	h->scratch_bytes[k][s] = bytes;
 	return GPUMT_OK;
 }
@@ -154,6 +162,11 @@ int gpumt_open(int device, gpumt_ctx **out)
 	if (!out)
 		return GPUMT_E_ARG;
 	*out = NULL;
+	/* The host engines keep several batches in flight on streams of their own; with the runtime's
+	 * default of 4 hardware queues those streams share queues and wait for each other's kernels
+	 * (measured: tools/ubench/pipe_overlap.hip).  Effective when this is the first HIP call of the
+	 * process (the CLI, the drop-in APIs); a process that initialises HIP earlier exports it itself. */
+	setenv("GPU_MAX_HW_QUEUES", "16", 0);
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
 		return GPUMT_E_NODEVICE;
 	if (device == GPUMT_DEVICE_DEFAULT) {
@@ -211,7 +224,7 @@ void gpumt_close(gpumt_ctx *h)
 	for (int k = 0; k < 2; k++)
 		for (int i = 0; i < GPUMT_NSTREAMS; i++)
 			if (h->scratch[k][i])
-				(void)hipFree(h->scratch[k][i]);
+				dev_free(h, h->scratch[k][i]);
 	for (int i = 0; i < NTIMERS; i++) {
 		(void)hipEventDestroy(h->t0[i]);
 		(void)hipEventDestroy(h->t1[i]);
@@ -227,26 +240,119 @@ void gpumt_close(gpumt_ctx *h)
 const char *gpumt_last_error(gpumt_ctx *h) { return h ? h->err : "no handle"; }
 const char *gpumt_device_name(gpumt_ctx *h) { return h ? h->name : ""; }
 
-void *gpumt_malloc(gpumt_ctx *h, size_t bytes)
+/*
+ * Device buffers of a context (batch slots, per-wave scratch) are GiB-sized and hipMalloc / hipFree of
+ * that size cost tens of milliseconds each -- 0.86 s of a 1.3 s BROTLIMT_decompressDCtx call on 8 GiB
+ * were first-use allocations (GPUMT_TRACE).  Like the pinned staging buffers below, freed device
+ * buffers therefore stay in a process-wide cache (per device, bounded by GPUMT_DEVICE_CACHE_MB,
+ * default 16384) for the next context of the process.
+ */
+#define DEV_CACHE_SLOTS 192
+static struct {
+	pthread_mutex_t mu;
+	void *p[DEV_CACHE_SLOTS];
+	size_t cap[DEV_CACHE_SLOTS];
+	int dev[DEV_CACHE_SLOTS];
+	int used[DEV_CACHE_SLOTS];
+	size_t idle, limit;
+	int init;
+} g_dev = {PTHREAD_MUTEX_INITIALIZER, {0}, {0}, {0}, {0}, 0, 0, 0};
+
+static void *dev_alloc(gpumt_ctx *h, size_t bytes)
 {
 	void *p = NULL;
+	int slot = -1;
+	if (!bytes)
+		bytes = 1;
+	pthread_mutex_lock(&g_dev.mu);
+	if (!g_dev.init) {
+		const char *e = getenv("GPUMT_DEVICE_CACHE_MB");
+		g_dev.limit = (size_t)(e && *e ? strtoull(e, 0, 10) : 16384) << 20;
+		g_dev.init = 1;
+	}
+	{
+		int best = -1;
+		for (int i = 0; i < DEV_CACHE_SLOTS; i++)
+			if (g_dev.p[i] && !g_dev.used[i] && g_dev.dev[i] == h->device && g_dev.cap[i] >= bytes &&
+			    g_dev.cap[i] <= bytes + bytes / 2 + (1u << 20) && (best < 0 || g_dev.cap[i] < g_dev.cap[best]))
+				best = i;
+		if (best >= 0) {
+			g_dev.used[best] = 1;
+			g_dev.idle -= g_dev.cap[best];
+			p = g_dev.p[best];
+		}
+	}
+	pthread_mutex_unlock(&g_dev.mu);
+	if (p)
+		return p;
+	if (hipMalloc(&p, bytes) != hipSuccess) {
+		/* out of memory with idle buffers in the cache: give them back and try once more */
+		pthread_mutex_lock(&g_dev.mu);
+		for (int i = 0; i < DEV_CACHE_SLOTS; i++)
+			if (g_dev.p[i] && !g_dev.used[i] && g_dev.dev[i] == h->device) {
+				(void)hipFree(g_dev.p[i]);
+				g_dev.idle -= g_dev.cap[i];
+				g_dev.p[i] = NULL;
+			}
+		pthread_mutex_unlock(&g_dev.mu);
+		if (hipMalloc(&p, bytes) != hipSuccess)
+			return NULL;
+	}
+	pthread_mutex_lock(&g_dev.mu);
+	for (int i = 0; i < DEV_CACHE_SLOTS && slot < 0; i++)
+		if (!g_dev.p[i])
+			slot = i;
+	if (slot >= 0) { /* tracked: its size is known when it comes back (untracked ones are simply freed) */
+		g_dev.p[slot] = p;
+		g_dev.cap[slot] = bytes;
+		g_dev.dev[slot] = h->device;
+		g_dev.used[slot] = 1;
+	}
+	pthread_mutex_unlock(&g_dev.mu);
+	return p;
+}
+static void dev_free(gpumt_ctx *h, void *p)
+{
+	int keep = 0, slot = -1;
+	pthread_mutex_lock(&g_dev.mu);
+	for (int i = 0; i < DEV_CACHE_SLOTS && slot < 0; i++)
+		if (g_dev.p[i] == p && g_dev.used[i])
+			slot = i;
+	if (slot >= 0) {
+		if (g_dev.idle + g_dev.cap[slot] <= g_dev.limit) {
+			keep = 1;
+			g_dev.idle += g_dev.cap[slot];
+			g_dev.used[slot] = 0;
+		} else {
+			g_dev.p[slot] = NULL;
+			g_dev.used[slot] = 0;
+		}
+	}
+	pthread_mutex_unlock(&g_dev.mu);
+	(void)h;
+	if (!keep)
+		(void)hipFree(p);
+}
+
+void *gpumt_malloc(gpumt_ctx *h, size_t bytes)
+{
 	if (!h || use(h))
 		return NULL;
-	if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess)
-		return NULL;
-	return p;
+	return dev_alloc(h, bytes);
 }
 void gpumt_free(gpumt_ctx *h, void *p)
 {
+	/* the buffer must be idle: it may go to the cache and from there to another context without the
+	 * device-wide wait hipFree implies */
 	if (h && p && !use(h))
-		(void)hipFree(p);
+		dev_free(h, p);
 }
 /*
  * Pinned host memory costs ~0.3 s per GiB to allocate and to free (page pinning), which used to be
  * most of a drop-in API call on a few GiB: freed staging buffers are therefore kept in a
  * process-wide cache and handed to the next context that asks (a decompress context after a
  * compress context, the next file of the CLI, the next call of a long-running caller).  The cache
- * is bounded (GPUMT_PINNED_CACHE_MB, default 8192); hipHostMallocPortable makes a buffer usable by
+ * is bounded (GPUMT_PINNED_CACHE_MB, default 16384); hipHostMallocPortable makes a buffer usable by
  * the contexts of every device.
  */
 #define PIN_CACHE_SLOTS 64
@@ -273,7 +379,7 @@ void *gpumt_host_alloc(gpumt_ctx *h, size_t bytes)
 	pthread_mutex_lock(&g_pin.mu);
 	if (!g_pin.init) {
 		const char *e = getenv("GPUMT_PINNED_CACHE_MB");
-		g_pin.limit = (size_t)(e && *e ? strtoull(e, 0, 10) : 8192) << 20;
+		g_pin.limit = (size_t)(e && *e ? strtoull(e, 0, 10) : 16384) << 20;
 		g_pin.init = 1;
 	}
 	{
@@ -339,6 +445,27 @@ int gpumt_memcpy_d2h(gpumt_ctx *h, void *dst, const void *src, size_t n, int s)
 	if (use(h))
 		return GPUMT_E_HIP;
 	CK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, h->st[s]));
+	return GPUMT_OK;
+}
+int gpumt_push_host(gpumt_ctx *h, void *dst_host, const void *src, size_t n, const uint64_t *d_n, int s)
+{
+	void *dp = NULL;
+	if (!h || !STREAM_OK(s) || ((uintptr_t)dst_host & 15) || ((uintptr_t)src & 15))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	if (!n)
+		return GPUMT_OK;
+	CK(hipHostGetDevicePointer(&dp, dst_host, 0));
+	const size_t nv = n >> 4;
+	unsigned grid = (unsigned)((nv + 255) / 256);
+	if (grid > 512)
+		grid = 512; /* a few waves per CU saturate the host link and leave the rest to the codec kernels */
+	if (grid < 1)
+		grid = 1;
+	hipLaunchKernelGGL(zmt_push_host_kernel, dim3(grid), dim3(256), 0, h->st[s], (const u8 *)src, (u8 *)dp, (u64)n,
+			   (const u64 *)d_n);
+	CK(hipGetLastError());
 	return GPUMT_OK;
 }
 int gpumt_memcpy_d2d(gpumt_ctx *h, void *dst, const void *src, size_t n, int s)

@@ -98,3 +98,27 @@ zmt_iota_kernel(u64 *__restrict__ off, u32 *__restrict__ len, u64 n, u64 chunk, 
 	off[i] = o;
 	len[i] = (u32)(n - o < chunk ? n - o : chunk);
 }
+
+/*
+ * Results leave the device through a kernel that stores into pinned host memory (dst is the host
+ * buffer's device-visible address), on the stream of the kernels that produced them.  Two things
+ * this buys over hipMemcpyAsync after a host-side wait (measured, tools/ubench/pipe_overlap.hip): the
+ * byte count can stay on the device (n_dev: e.g. the total of a scan), so the host does not have to
+ * wake up between the kernels and the copy; and batches launched on different streams really
+ * overlap -- with the runtime's copy issued from the completing thread the next batches' input
+ * copies did not start before it, i.e. the pipeline ran one batch at a time.
+ * src and dst 16-byte aligned; bytes = min(n, *n_dev) when n_dev is given.
+ */
+extern "C" __global__ void __launch_bounds__(256)
+zmt_push_host_kernel(const u8 *__restrict__ src, u8 *__restrict__ dst, u64 n, const u64 *__restrict__ n_dev)
+{
+	if (n_dev && *n_dev < n)
+		n = *n_dev;
+	const u64 nv = n >> 4;
+	const u32x4 *s4 = (const u32x4 *)src;
+	u32x4 *d4 = (u32x4 *)dst;
+	for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < nv; i += (u64)gridDim.x * 256)
+		d4[i] = s4[i];
+	if (blockIdx.x == 0 && threadIdx.x < (u32)(n & 15))
+		dst[(nv << 4) + threadIdx.x] = src[(nv << 4) + threadIdx.x];
+}

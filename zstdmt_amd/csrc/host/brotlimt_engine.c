@@ -170,8 +170,11 @@ static size_t c_launch(BROTLIMT_CCtx *ctx, struct cslot *s)
 	rc |= gpumt_stream_wait(g, ks, 1);
 	rc |= gpumt_brotli_compress_batch(g, s->in.d, s->n, chunk, s->slots.d, stride, d_len, ks);
 	rc |= gpumt_lz4_compact(g, s->slots.d, stride, d_len, s->nrec, s->stream.d, d_off, ks);
-	rc |= gpumt_stream_wait(g, 2, ks);
-	rc |= gpumt_memcpy_d2h(g, s->meta.h, s->meta.d, ((s->nrec * 4 + 15) & ~(size_t)15) + (s->nrec + 1) * 8, 2);
+	/* sizes, offsets and the packed records go to the pinned mirrors from the slot's own stream, the
+	 * byte count of the records read on the device (d_off[nrec]): no host round trip in between, and
+	 * the batches of the pipeline overlap (gpumt_push_host) */
+	rc |= gpumt_push_host(g, s->meta.h, s->meta.d, ((s->nrec * 4 + 15) & ~(size_t)15) + (s->nrec + 1) * 8, NULL, ks);
+	rc |= gpumt_push_host(g, s->stream.h, s->stream.d, s->stream.cap & ~(size_t)15, d_off + s->nrec, ks);
 	return rc ? BROTLIMT_ERROR(frame_compress) : 0;
 }
 
@@ -202,7 +205,7 @@ static size_t cp_launch(void *a, int si)
 {
 	BROTLIMT_CCtx *ctx = (BROTLIMT_CCtx *)a;
 	size_t err = c_launch(ctx, &ctx->s[si]);
-	if (!err && gpumt_mark(ctx->gpu, si, 2))
+	if (!err && gpumt_mark(ctx->gpu, si, 4 + si))
 		err = BROTLIMT_ERROR(frame_compress);
 	return err;
 }
@@ -218,8 +221,6 @@ static size_t cp_complete(void *a, int si)
 		return BROTLIMT_ERROR(frame_compress);
 	total = (size_t)off[s->nrec];
 	if (total > s->stream.cap)
-		return BROTLIMT_ERROR(frame_compress);
-	if (gpumt_memcpy_d2h(g, s->stream.h, s->stream.d, total, 3) || gpumt_stream_sync(g, 3))
 		return BROTLIMT_ERROR(frame_compress);
 	return 0;
 }
@@ -357,6 +358,15 @@ static size_t d_read_header(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *io, uint32_t *c
 	return 0;
 }
 
+/*
+ * One wave decodes one record, and a 1 MiB record keeps it busy for ~165 ms whatever else runs, so
+ * the device is only full with thousands of records in flight: the output budget of a batch grows
+ * to four times the common batch size (1 GiB by default = 1 024 records of the level-1 chunk size).
+ * Compressed bytes a batch may hold: the budget plus an eighth (records that did not shrink).
+ */
+#define D_BATCH_BYTES (4 * BATCH_BYTES)
+#define D_IN_LIMIT(budget) ((budget) + ((budget) >> 3))
+
 static size_t d_read_batch(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *io, struct dslot *s, int *eof)
 {
 	s->nrec = 0;
@@ -378,7 +388,7 @@ static size_t d_read_batch(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *io, struct dslot
 				break;
 		}
 		cap = (size_t)hint << 16;
-		if (s->nrec && (s->in_bytes + (size_t)csize > s->in.cap - 512 || s->out_bytes + cap > ctx->budget)) {
+		if (s->nrec && (s->in_bytes + (size_t)csize > D_IN_LIMIT(ctx->budget) || s->out_bytes + cap > ctx->budget)) {
 			ctx->have_hdr = 1;
 			ctx->hdr_csize = csize;
 			ctx->hdr_hint = hint;
@@ -386,9 +396,14 @@ static size_t d_read_batch(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *io, struct dslot
 		}
 		ctx->have_hdr = 0;
 		if (s->in_bytes + (size_t)csize + 512 > s->in.cap) {
+			/* the record buffer starts at half the output budget (text shrinks more than 2:1) and
+			 * doubles when a batch needs more */
 			dbuf old = s->in;
+			size_t want = s->in_bytes + (size_t)csize + 512;
+			if (want < 2 * old.cap)
+				want = 2 * old.cap;
 			memset(&s->in, 0, sizeof s->in);
-			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + (size_t)csize + 512, 1, 1)) {
+			if (dbuf_want(ctx->gpu, &s->in, want, 1, 1)) {
 				dbuf_free(ctx->gpu, &s->in);
 				s->in = old; /* keep the slot as it was: freeCtx releases it */
 				return BROTLIMT_ERROR(memory_allocation);
@@ -444,12 +459,12 @@ static size_t dp_fill(void *a, int si, int *has_data, int *eof)
 	BROTLIMT_DCtx *ctx = (BROTLIMT_DCtx *)a;
 	struct dslot *s = &ctx->s[si];
 	size_t err;
-	if (dbuf_want(ctx->gpu, &s->in, ctx->budget + (ctx->budget >> 3) + 4096, 1, 1) ||
+	if (dbuf_want(ctx->gpu, &s->in, (ctx->budget >> 1) + 4096, 1, 1) ||
 	    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1))
 		return BROTLIMT_ERROR(memory_allocation);
 	err = d_read_batch(ctx, ctx->io, s, eof);
 	*has_data = s->nrec > 0;
-	if (ctx->budget < BATCH_BYTES)
+	if (ctx->budget < D_BATCH_BYTES)
 		ctx->budget *= 4;
 	return err;
 }

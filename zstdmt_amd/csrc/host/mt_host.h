@@ -53,7 +53,8 @@ static inline int dbuf_want(gpumt_ctx *g, dbuf *b, size_t bytes, int pinned, int
 {
 	if (bytes <= b->cap)
 		return 0;
-	gpumt_device_sync(g);
+	/* the caller owns an idle slot (its last batch is drained), so nothing on the device uses the old
+	 * buffers: no device-wide wait here -- it would stall the batches of the other slots in flight */
 	if (b->d)
 		gpumt_free(g, b->d);
 	if (b->h)

@@ -2,7 +2,16 @@
 #include "mt_pipe.h"
 
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 int mt_nslot(void)
 {
@@ -29,6 +38,8 @@ typedef struct {
 	long n_done;       /* batches whose results are in host memory */
 	int reader_over;   /* the reader will produce no further batch */
 	int device_over;   /* the device role will complete no further batch */
+	/* GPUMT_TRACE=1: seconds each role spent working / waiting for a slot (stderr at the end) */
+	double t_fill, t_fill_wait, t_drain, t_drain_wait, t_launch, t_complete, t_dev_wait;
 } pipe_t;
 
 static void fail(pipe_t *p, size_t err)
@@ -47,6 +58,7 @@ static void *reader_main(void *a)
 		const int s = (int)(b % p->nslot);
 		int has_data = 0, eof = 0;
 		size_t err;
+		double t0 = now_s(), t1;
 		pthread_mutex_lock(&p->mu);
 		while (p->state[s] != S_FREE && !p->err)
 			pthread_cond_wait(&p->cv, &p->mu);
@@ -54,7 +66,10 @@ static void *reader_main(void *a)
 		pthread_mutex_unlock(&p->mu);
 		if (err)
 			break;
+		t1 = now_s();
+		p->t_fill_wait += t1 - t0;
 		err = p->ops->fill(p->arg, s, &has_data, &eof);
+		p->t_fill += now_s() - t1;
 		if (err) {
 			fail(p, err);
 			break;
@@ -85,6 +100,7 @@ static void *writer_main(void *a)
 		const int s = (int)(b % p->nslot);
 		size_t err;
 		int stop;
+		double t0 = now_s(), t1;
 		pthread_mutex_lock(&p->mu);
 		while (p->state[s] != S_DONE && !p->err && !(p->device_over && b >= p->n_done))
 			pthread_cond_wait(&p->cv, &p->mu);
@@ -92,7 +108,10 @@ static void *writer_main(void *a)
 		pthread_mutex_unlock(&p->mu);
 		if (stop)
 			break;
+		t1 = now_s();
+		p->t_drain_wait += t1 - t0;
 		err = p->ops->drain(p->arg, s);
+		p->t_drain += now_s() - t1;
 		if (err) {
 			fail(p, err);
 			break;
@@ -140,6 +159,10 @@ size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
 	p.err = 0;
 	p.n_filled = p.n_done = 0;
 	p.reader_over = p.device_over = 0;
+	p.t_fill = p.t_fill_wait = p.t_drain = p.t_drain_wait = p.t_launch = p.t_complete = p.t_dev_wait = 0;
+	const double t_begin = now_s();
+	const char *trace_env = getenv("GPUMT_TRACE");
+	const int trace = trace_env && *trace_env ? atoi(trace_env) : 0;
 	for (int i = 0; i < MT_NSLOT; i++)
 		p.state[i] = S_FREE;
 	pthread_mutex_init(&p.mu, NULL);
@@ -162,9 +185,16 @@ size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
 	{
 		long done = 0; /* batches [done, b) are launched and not completed */
 		for (;;) {
+			double t0 = now_s(), t1;
 			const int go = wait_filled(&p, b);
+			t1 = now_s();
+			p.t_dev_wait += t1 - t0;
 			if (go) {
 				err = ops->launch(arg, (int)(b % p.nslot));
+				p.t_launch += now_s() - t1;
+				if (trace > 1)
+					fprintf(stderr, "[mt_pipe] %8.3f ms launch(%ld) took %.3f ms, waited %.3f ms for input\n",
+						(t1 - t_begin) * 1e3, b, (now_s() - t1) * 1e3, (t1 - t0) * 1e3);
 				if (err) {
 					fail(&p, err);
 					break;
@@ -173,7 +203,12 @@ size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
 			}
 			err = 0;
 			while (done < b && (!go || b - done >= p.nslot - 1)) {
+				t0 = now_s();
 				err = ops->complete(arg, (int)(done % p.nslot));
+				p.t_complete += now_s() - t0;
+				if (trace > 1)
+					fprintf(stderr, "[mt_pipe] %8.3f ms complete(%ld) took %.3f ms\n", (t0 - t_begin) * 1e3, done,
+						(now_s() - t0) * 1e3);
 				if (err)
 					break;
 				mark_done(&p, done);
@@ -194,6 +229,14 @@ size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
 	pthread_join(rt, NULL);
 	pthread_join(wt, NULL);
 	err = p.err;
+	{
+		if (trace)
+			fprintf(stderr,
+				"[mt_pipe] %ld batches in %.3f s | reader: fill %.3f wait %.3f | device: launch %.3f "
+				"complete %.3f wait-for-input %.3f | writer: drain %.3f wait %.3f\n",
+				b, now_s() - t_begin, p.t_fill, p.t_fill_wait, p.t_launch, p.t_complete, p.t_dev_wait,
+				p.t_drain, p.t_drain_wait);
+	}
 	pthread_cond_destroy(&p.cv);
 	pthread_mutex_destroy(&p.mu);
 	return err;

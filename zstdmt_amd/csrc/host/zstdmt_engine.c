@@ -210,8 +210,11 @@ static size_t c_launch(ZSTDCB_CCtx *ctx, struct cslot *s)
 	rc |= gpumt_stream_wait(g, ks, 1);
 	rc |= gpumt_zstd_compress_batch(g, s->in.d, s->n, chunk, s->slots.d, stride, d_len, ks);
 	rc |= gpumt_lz4_compact(g, s->slots.d, stride, d_len, s->nrec, s->stream.d, d_off, ks);
-	rc |= gpumt_stream_wait(g, 2, ks);
-	rc |= gpumt_memcpy_d2h(g, s->meta.h, s->meta.d, ((s->nrec * 4 + 15) & ~(size_t)15) + (s->nrec + 1) * 8, 2);
+	/* sizes, offsets and the packed records go to the pinned mirrors from the slot's own stream, the
+	 * byte count of the records read on the device (d_off[nrec]): no host round trip in between, and
+	 * the batches of the pipeline overlap (gpumt_push_host) */
+	rc |= gpumt_push_host(g, s->meta.h, s->meta.d, ((s->nrec * 4 + 15) & ~(size_t)15) + (s->nrec + 1) * 8, NULL, ks);
+	rc |= gpumt_push_host(g, s->stream.h, s->stream.d, s->stream.cap & ~(size_t)15, d_off + s->nrec, ks);
 	return rc ? ZSTDCB_ERROR(compression_library) : 0;
 }
 
@@ -243,7 +246,7 @@ static size_t cp_launch(void *a, int si)
 {
 	ZSTDCB_CCtx *ctx = (ZSTDCB_CCtx *)a;
 	size_t err = c_launch(ctx, &ctx->s[si]);
-	if (!err && gpumt_mark(ctx->gpu, si, 2))
+	if (!err && gpumt_mark(ctx->gpu, si, 4 + si))
 		err = ZSTDCB_ERROR(compression_library);
 	return err;
 }
@@ -260,8 +263,6 @@ static size_t cp_complete(void *a, int si)
 	total = (size_t)off[s->nrec];
 	if (total > s->stream.cap)
 		return ZSTDCB_ERROR(frame_compress);
-	if (gpumt_memcpy_d2h(g, s->stream.h, s->stream.d, total, 3) || gpumt_stream_sync(g, 3))
-		return ZSTDCB_ERROR(compression_library);
 	return 0;
 }
 

@@ -25,6 +25,7 @@ class DevBuf:
 
     def free(self):
         if self.ptr:
+            lib().gpumt_device_sync(self.eng.h)   # gpumt_free wants an idle buffer (it may be cached and reused)
             lib().gpumt_free(self.eng.h, self.ptr)
             self.ptr = None
 
