@@ -68,6 +68,7 @@ def parse():
                     help="skip the byte-for-byte comparison of the round trip (on by default)")
     ap.add_argument("--only", action="store_true", help="main leg only: no zstd / brotli / api legs under 'configs'")
     ap.add_argument("--extra-gib", type=float, default=2.0, help="size of the extra legs of the default run")
+    ap.add_argument("--api-gib", type=float, default=8.0, help="input size of the drop-in API legs of the default run")
     ap.add_argument("--no-encoder", action="store_true",
                     help="--codec brotli: skip the device-encoder leg (profiling runs of the decoder alone)")
     ap.add_argument("--master-port", type=int, default=0)
@@ -622,18 +623,37 @@ def bench_api(mib):
     exe = os.path.join(ROOT, "zstdmt_amd", "bin", "api_bench")
     lib = os.path.join(ROOT, "zstdmt_amd", "lib", "libzstdmt_amd.so")
     out = {}
-    for codec, chunk in (("lz4", 131072), ("zstd", 1 << 20), ("brotli", 1 << 20)):
+    for key, codec, chunk, level, size in (("lz4", "lz4", 131072, 1, mib << 20), ("zstd", "zstd", 1 << 20, 1, mib << 20),
+                                           ("brotli", "brotli", 1 << 20, 1, mib << 20),
+                                           # the CLI's default level: LZ4HC hash chain on the device
+                                           ("lz4 level 3 (lz4-mt CLI default, LZ4HC)", "lz4", 131072, 3, min(mib, 2048) << 20)):
         try:
             t0 = time.time()
-            txt = subprocess.check_output([exe, codec, str(mib << 20), str(chunk), lib], timeout=300,
+            txt = subprocess.check_output([exe, codec, str(size), str(chunk), lib, str(level)], timeout=300,
                                           stderr=subprocess.DEVNULL)
             r = json.loads(txt.decode().strip().splitlines()[-1])
             r["seconds"] = round(time.time() - t0, 1)
             r["roundtrip_verified"] = True       # api_bench exits non-zero on a mismatch
-            out[codec] = r
+            out[key] = r
         except Exception as e:  # report, never hide
-            out[codec] = {"error": repr(e)}
+            out[key] = {"error": repr(e)}
     return out
+
+
+def cpu_reference_level(level, chunk, cpu_mib):
+    """LZ4MT_* of the reference build at `level` on the host cores (bounded sample)"""
+    exe = os.path.join(ROOT, "oracle", "cpu_bench")
+    ref = os.path.join(ROOT, "oracle", "_ref", "liblz4mt_ref.so")
+    if not (os.path.exists(exe) and os.path.exists(ref)):
+        return None
+    threads = min(os.cpu_count() or 1, 128)
+    try:
+        r = json.loads(subprocess.check_output([exe, "reference", ref, str(cpu_mib << 20), str(chunk), str(threads),
+                                                str(SEED), str(level)], timeout=600))
+        return {"compress_MBps": r["compress_MBps"], "decompress_MBps": r["decompress_MBps"], "threads": threads,
+                "kind": "reference", "sample_MiB": cpu_mib, "ratio": round(r["bytes"] / r["compressed"], 4)}
+    except Exception as e:  # report, never hide
+        return {"error": repr(e)}
 
 
 def rccl_gather(eng, dist, d_buf, sizes, rank, world):
@@ -723,7 +743,10 @@ def main():
         except Exception as e:
             cfgs["brotli-mt decompress (configs[4])"] = {"error": repr(e)}
         eng.close()
-        api = bench_api(int(args.extra_gib * 1024))
+        api = bench_api(int(args.api_gib * 1024))
+        hc = "lz4 level 3 (lz4-mt CLI default, LZ4HC)"
+        if isinstance(api.get(hc), dict) and not args.no_cpu:
+            api[hc]["cpu_reference"] = cpu_reference_level(3, 131072, 1024)
         for codec, leg in (("lz4", res), ("zstd", cfgs["zstd-mt level 1 (configs[3])"]),
                            ("brotli", cfgs["brotli-mt decompress (configs[4])"])):
             cb = (leg or {}).get("cpu_baseline") or {}

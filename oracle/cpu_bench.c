@@ -68,13 +68,14 @@ static double now(void)
 int main(int argc, char **argv)
 {
 	if (argc < 7) {
-		fprintf(stderr, "usage: cpu_bench reference|reference-zstd|reference-brotli|port ref.so bytes chunk threads seed\n");
+		fprintf(stderr, "usage: cpu_bench reference|reference-zstd|reference-brotli|port ref.so bytes chunk threads seed [level]\n");
 		return 2;
 	}
 	const char *kind = argv[1];
 	size_t n = strtoull(argv[3], 0, 10), chunk = strtoull(argv[4], 0, 10);
 	int T = atoi(argv[5]);
 	uint64_t seed = strtoull(argv[6], 0, 10);
+	const int level = argc > 7 ? atoi(argv[7]) : 1; /* reference libraries only */
 	size_t cap = zo_lz4mt_compress_bound(n, chunk) + n / 128 + 4096; /* also covers ZSTD_compressBound */
 	uint8_t *src = malloc(n + 64), *cmp = malloc(cap), *back = malloc(n + 64);
 	double tc, td;
@@ -104,7 +105,7 @@ int main(int argc, char **argv)
 		unsigned (*isErr)(size_t) = dlsym(so, z == 2 ? "BROTLIMT_isError" : z ? "ZSTDCB_isError" : "LZ4MT_isError");
 		struct mem in = { src, n, 0 }, out = { cmp, cap, 0 };
 		RdWr io = { rd, &in, wr, &out };
-		void *c = createC(T, 1, (int)chunk);
+		void *c = createC(T, level, (int)chunk);
 		double t0 = now();
 		size_t rv = compressC(c, &io);
 		tc = now() - t0;
@@ -132,9 +133,9 @@ int main(int argc, char **argv)
 	}
 	if (dsz != n || memcmp(src, back, n))
 		return 7;
-	printf("{\"kind\": \"%s\", \"bytes\": %zu, \"chunk\": %zu, \"threads\": %d, \"compressed\": %zu, "
+	printf("{\"kind\": \"%s\", \"level\": %d, \"bytes\": %zu, \"chunk\": %zu, \"threads\": %d, \"compressed\": %zu, "
 	       "\"compress_s\": %.6f, \"decompress_s\": %.6f, \"compress_MBps\": %.1f, "
 	       "\"decompress_MBps\": %.1f, \"roundtrip_MBps\": %.1f}\n",
-	       kind, n, chunk, T, csz, tc, td, n / 1e6 / tc, n / 1e6 / td, n / 1e6 / (tc + td));
+	       kind, level, n, chunk, T, csz, tc, td, n / 1e6 / tc, n / 1e6 / td, n / 1e6 / (tc + td));
 	return 0;
 }

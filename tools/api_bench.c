@@ -61,6 +61,7 @@ int main(int argc, char **argv)
 	size_t n = argc > 2 ? strtoull(argv[2], 0, 10) : (size_t)1 << 30;
 	int chunk = argc > 3 ? atoi(argv[3]) : 0;
 	void *so = dlopen(argc > 4 ? argv[4] : "libzstdmt_amd.so", RTLD_NOW);
+	const int level = argc > 5 ? atoi(argv[5]) : 1;
 	if (!so) {
 		fprintf(stderr, "dlopen: %s\n", dlerror());
 		return 8;
@@ -82,7 +83,7 @@ int main(int argc, char **argv)
 		struct mem in = { src, n, 0 }, out = { cmp, cap, 0 };
 		RdWr io = { rd, &in, wr, &out };
 		double t0 = now();
-		void *c = createC(4, 1, chunk);
+		void *c = createC(4, level, chunk);
 		if (!c) { fprintf(stderr, "no device\n"); return 2; }
 		double t_create = now() - t0;
 		t0 = now();
@@ -104,8 +105,8 @@ int main(int argc, char **argv)
 		if (isErr(rv)) { fprintf(stderr, "decompress: %s\n", errStr(rv)); return 4; }
 		if (out2.pos != n || memcmp(src, back, n)) { fprintf(stderr, "round trip mismatch\n"); return 5; }
 		if (rep)
-			printf("{\"api\": \"%s*\", \"bytes\": %zu, \"chunk\": %d, \"compressed\": %zu, \"compress_MBps\": %.1f, "
-			       "\"decompress_MBps\": %.1f}\n", pfx, n, chunk, out.pos, n / 1e6 / tc, n / 1e6 / td);
+			printf("{\"api\": \"%s*\", \"level\": %d, \"bytes\": %zu, \"chunk\": %d, \"compressed\": %zu, \"compress_MBps\": %.1f, "
+			       "\"decompress_MBps\": %.1f}\n", pfx, level, n, chunk, out.pos, n / 1e6 / tc, n / 1e6 / td);
 	}
 	return 0;
 }

@@ -177,9 +177,19 @@ zmt_dec_frames_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
  *   - input: each lane parses out of its own 256-byte LDS ring; every 8 steps the wave tops the
  *     rings up in 128-byte pieces, eight lanes fetching one block's piece (8 lines per load
  *     instruction instead of 64);
- *   - output: token positions collect in an LDS tile [lane][64]; all lanes emit exactly one token
- *     per step, so every 64 steps the whole tile leaves as 128-byte lines, again 8 per store.
+ *   - output: token positions collect in an LDS tile [lane][P_TILE]; all lanes emit exactly one
+ *     token per step, so every P_TILE steps the whole tile leaves in 16-byte pieces, P_TILE / 8 lanes
+ *     per block.
  * A parse position outside the ring (after a long literal run) falls back to a direct load.
+ *
+ * Sizing.  A wave's time is fixed by its longest block (about 5 500 steps on the bench text, 3.9 ms
+ * with one wave per SIMD), so the launch takes (rounds of resident waves) x (time of a wave): what
+ * matters is that every wave of the launch is resident at once.  The first version (384-byte rings,
+ * 64-token tile: 34 KiB of LDS, 4 waves per CU) ran the 2 048 waves of the 8 GiB bench in two rounds,
+ * 8.0 ms; at 6 waves per CU (256-byte rings) still two rounds, each slower: 10.3 ms; 256-byte rings
+ * and a 16-token tile are 19.5 KiB = 8 waves per CU, one round of 6.0 ms (a wave takes 1.5 x as long
+ * with two per SIMD: 184 instructions per step, about 57 % of what a SIMD issues for two waves).
+ * Token positions straight to memory (no tile, 9 waves per CU) cost 64 cache lines per store: 7.4 ms.
  */
 #ifndef ZMT_EMU
 #define KT() (prof ? (u64)clock64() : 0ull)
@@ -187,12 +197,16 @@ zmt_dec_frames_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 #define KT() 0ull
 #endif
 #ifndef P_RING
-#define P_RING 384u  /* three 128-byte units per lane */
+#define P_RING 256u  /* two 128-byte units per lane */
 #endif
 #define P_UNIT 128u  /* refill granule: one aligned line of the stream */
 typedef u32 v4u __attribute__((vector_size(16)));
 #define P_RSTRIDE (P_RING + 16u) /* row stride of the input rings: ring + 16-byte mirror */
-#define P_TSTRIDE 136u /* row stride of the token tile (64 x u16 + pad) */
+#ifndef P_TILE
+#define P_TILE 16u   /* token positions a lane collects between two drains of the tile (16, 32 or 64) */
+#endif
+#define P_TSTRIDE (2u * P_TILE + 8u) /* row stride of the token tile (P_TILE x u16 + pad) */
+#define P_TLPR (P_TILE / 8u)         /* lanes that move one row of the tile (16 bytes each) */
 
 /* ring offset of g-coordinate g for a lane whose ring lap starts at rb (0 <= g - rb < 2 * P_RING) */
 static __device__ __forceinline__ u32 ring_off(u32 g, u32 rb)
@@ -273,7 +287,8 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 		pv[i] = (v4u){0, 0, 0, 0};
 	u32 bx_pending = 0;
 	bool ok = true, done = !parse;
-	const int dgrp = lane >> 3, dpiece = lane & 7; /* refill and tile drain: 8 lanes per 128-byte line */
+	const int dgrp = lane >> 3, dpiece = lane & 7; /* refill: 8 lanes per 128-byte line */
+	const int tgrp = lane / (int)P_TLPR, tpiece = lane % (int)P_TLPR; /* tile drain: P_TLPR lanes per row */
 
 	u64 c_refill = 0, c_token = 0, c_drain = 0, c_slow = 0, c_ext = 0, t_begin = KT();
 	u64 c_t1 = 0, c_t2 = 0, c_t3 = 0;
@@ -314,7 +329,7 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 				ghi = greq = rb = gp0 & ~(P_UNIT - 1); /* long jump: restart the ring at the parse position */
 			while (gp0 - rb >= P_RING)
 				rb += P_RING; /* the parse position entered the next lap */
-			/* the slot to be overwritten holds [greq-384, greq-256): already parsed? */
+			/* the slot to be overwritten holds [greq - P_RING, greq - P_RING + 128): already parsed? */
 			const bool need = !done && greq < boff + cs && greq <= gp0 + (P_RING - P_UNIT);
 			pendm = wv_ballot(need);
 			pend_g = greq;
@@ -431,41 +446,42 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 			if ((n & 63) == 0)
 				bidx[((tmin + trel) >> 6) + (n >> 6)] = my_opos;
 #else
-			mytile[n & 63] = (u16)my_pos;
+			mytile[n & (P_TILE - 1)] = (u16)my_pos;
 			if ((n & 63) == 0)
 				bx_pending = my_opos;
 #endif
 			n++;
 		}
 		{ u64 t_ = KT(); c_token += t_ - tk0; tk0 = t_; }
-		/* ---------------- drain the token tile (every 64 steps, and at the end) -------- */
+		/* ---------------- drain the token tile (every P_TILE steps, and at the end) -------- */
 		const bool all_done = !wv_any(!done);
 #ifndef P_DIRECT_TOK
-		if ((step & 63) == 63 || all_done) {
+		if ((step & (P_TILE - 1)) == P_TILE - 1 || all_done) {
 			wv_sync();
 			/* lanes that emitted in this window own tile rows worth writing */
-			const u32 first = step & ~63u;                 /* first step of the window */
+			const u32 first = step & ~(P_TILE - 1);        /* first step of the window */
 			const u32 mine = n > first ? n - first : 0;    /* tokens this lane produced in it */
 			const u64 havem = wv_ballot(mine > 0);
 			ZMT_UNROLL
-			for (int i = 0; i < 8; i++) {
-				const int r = 8 * i + dgrp;
+			for (int i = 0; i < (int)P_TLPR; i++) {
+				const int r = (int)(64u / P_TLPR) * i + tgrp;
 				const u32 r_t = wv_shfl(trel, r);
 				if (((havem >> r) & 1) && !(xflags & 4)) {
-					const u8 *t = tile_lds + (u32)r * P_TSTRIDE + 16u * (u32)dpiece;
+					const u8 *t = tile_lds + (u32)r * P_TSTRIDE + 16u * (u32)tpiece;
 					const u64 x = *(const u64 *)t, y = *(const u64 *)(t + 8);
-					u64 *g = (u64 *)(tok + tmin + r_t + first + 8u * (u32)dpiece);
+					u64 *g = (u64 *)(tok + tmin + r_t + first + 8u * (u32)tpiece);
 					g[0] = x;
 					g[1] = y;
 				}
 			}
-			if (mine > 0)
+			if (mine > 0 && (first & 63) == 0)
 				bidx[((tmin + trel) >> 6) + (first >> 6)] = bx_pending;
 			wv_sync();
 		}
 #else
 		(void)bx_pending;
-		(void)dpiece;
+		(void)tgrp;
+		(void)tpiece;
 #endif
 		{ u64 t_ = KT(); c_drain += t_ - tk0; tk0 = t_; }
 		if (all_done) {
