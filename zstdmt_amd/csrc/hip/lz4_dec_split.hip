@@ -207,6 +207,9 @@ typedef u32 v4u __attribute__((vector_size(16)));
 #endif
 #define P_TSTRIDE (2u * P_TILE + 8u) /* row stride of the token tile (P_TILE x u16 + pad) */
 #define P_TLPR (P_TILE / 8u)         /* lanes that move one row of the tile (16 bytes each) */
+#ifndef P_URGENT
+#define P_URGENT 24u /* top the rings up at once when a lane has fewer bytes than this ahead (0 = never) */
+#endif
 
 /* ring offset of g-coordinate g for a lane whose ring lap starts at rb (0 <= g - rb < 2 * P_RING) */
 static __device__ __forceinline__ u32 ring_off(u32 g, u32 rb)
@@ -299,20 +302,22 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 		 * eight lanes with one 16-byte load each: a load instruction serves 8 blocks and touches
 		 * 8 lines (the texture path costs per line, not per byte).  Software-pipelined: units
 		 * requested in one round land in LDS at the start of the next round. */
-#ifdef P_URGENT
 		/* a lane whose parse position has run past what its ring holds (a long literal run) would
-		 * take the global-memory path for every token until the next scheduled round: top up now */
-		const bool urgent = wv_any(!done && boff + pos + P_URGENT > ghi && ghi < boff + cs);
-#else
-		const bool urgent = false;
-#endif
-		if ((step & 7) == 0 || step < 4 || urgent) { /* start-up: three back-to-back rounds fill the ring */
+		 * take the global-memory path -- a full memory round trip for the whole wave -- for every token
+		 * until the next scheduled round: top up now (slow tokens 1.08 -> 0.04 per step, 6.0 -> 5.1 ms) */
+		const bool urgent = P_URGENT && wv_any(!done && boff + pos + P_URGENT > ghi && ghi < boff + cs);
+		if ((step & 7) == 0 || step < 4 || urgent) { /* start-up: back-to-back rounds fill the ring */
 			if (pendm) {
 				wv_sync();
+				/* the eight cross-lane reads first, then the stores: one wait instead of one per piece */
+				u32 ros[8];
+				ZMT_UNROLL
+				for (int i = 0; i < 8; i++)
+					ros[i] = wv_shfl(pend_off, 8 * i + dgrp);
 				ZMT_UNROLL
 				for (int i = 0; i < 8; i++) {
 					const int r = 8 * i + dgrp;
-					const u32 ro = wv_shfl(pend_off, r);
+					const u32 ro = ros[i];
 					if ((pendm >> r) & 1) {
 						u8 *d = ring_lds + (u32)r * P_RSTRIDE + ro + 16u * (u32)dpiece;
 						*(v4u *)d = pv[i];
@@ -324,6 +329,7 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 				if ((pendm >> lane) & 1)
 					ghi = pend_g + P_UNIT;
 			}
+			{ u64 t_ = KT(); c_ext += t_ - tk0; }
 			const u32 gp0 = boff + pos;
 			if (!done && gp0 >= greq)
 				ghi = greq = rb = gp0 & ~(P_UNIT - 1); /* long jump: restart the ring at the parse position */
@@ -335,10 +341,14 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 			pend_g = greq;
 			pend_off = ring_off(greq, rb);
 			if (pendm) {
+				u32 rgs[8];
+				ZMT_UNROLL
+				for (int i = 0; i < 8; i++)
+					rgs[i] = wv_shfl(greq, 8 * i + dgrp);
 				ZMT_UNROLL
 				for (int i = 0; i < 8; i++) {
 					const int r = 8 * i + dgrp;
-					const u32 r_g = wv_shfl(greq, r);
+					const u32 r_g = rgs[i];
 					v4u v = {0, 0, 0, 0};
 					if (((pendm >> r) & 1) && !(xflags & 2)) {
 						/* 16-byte aligned; may run up to 127 bytes past stream_bytes: the stream
@@ -498,6 +508,7 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 					atomicAdd(prof + 4, (unsigned long long)(step + 1));
 					atomicAdd(prof + 5, (unsigned long long)slow_all);
 					atomicAdd(prof + 6, 1ull);
+					atomicAdd(prof + 7, (unsigned long long)c_ext);
 					atomicAdd(prof + 10, (unsigned long long)c_t1);
 					atomicAdd(prof + 11, (unsigned long long)c_t2);
 					atomicAdd(prof + 12, (unsigned long long)c_t3);
