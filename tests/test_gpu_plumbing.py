@@ -1,0 +1,93 @@
+"""Device plumbing the host engines rely on (include/gpumt.h): the push kernel that carries results to
+pinned host memory, the process-wide buffer caches, and several contexts at work at the same time."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import helpers as H
+from cases import rnd, text
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import zstdmt_amd as z
+    e = z.Engine(0)
+    yield e
+    e.close()
+
+
+def _host(eng, n):
+    eng.L.gpumt_host_alloc.restype = C.c_void_p
+    p = eng.L.gpumt_host_alloc(eng.h, n)
+    assert p
+    return p
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 4096, 1 << 20, (5 << 20) + 7])
+def test_push_host_fixed_and_device_counted(eng, n):
+    """gpumt_push_host: n bytes, or min(n, *d_n) with the count read on the device"""
+    data = rnd(max(n, 1), 3)[:n]
+    d = eng.upload(data + bytes(64))
+    h = _host(eng, n + 64)
+    C.memset(h, 0xEE, n + 64)
+    eng._ck(eng.L.gpumt_push_host(eng.h, C.c_void_p(h), d.ptr, n, None, 5), "push")
+    eng.sync(5)
+    got = C.string_at(h, n + 16)
+    assert got[:n] == data and got[n:] == b"\xEE" * 16
+    if n >= 16:
+        cnt = eng.upload(np.array([n - 9], np.uint64))
+        C.memset(h, 0xEE, n + 64)
+        eng._ck(eng.L.gpumt_push_host(eng.h, C.c_void_p(h), d.ptr, n, cnt.ptr, 6), "push")
+        eng.sync(6)
+        got = C.string_at(h, n)
+        assert got[:n - 9] == data[:n - 9] and got[n - 9:] == b"\xEE" * 9
+        cnt.free()
+    # misaligned addresses are refused, not copied slowly
+    assert eng.L.gpumt_push_host(eng.h, C.c_void_p(h + 4), d.ptr, 16, None, 5) != 0
+    eng.L.gpumt_host_free(eng.h, C.c_void_p(h))
+    d.free()
+
+
+def test_freed_buffers_are_reused(eng):
+    """device and pinned buffers come back from the process-wide caches (same address for the same size)"""
+    a = eng.alloc(37 << 20)
+    pa = a.ptr
+    a.free()
+    b = eng.alloc(37 << 20)
+    assert b.ptr == pa
+    b.free()
+    h1 = _host(eng, 21 << 20)
+    eng.L.gpumt_host_free(eng.h, C.c_void_p(h1))
+    h2 = _host(eng, 21 << 20)
+    assert h2 == h1
+    eng.L.gpumt_host_free(eng.h, C.c_void_p(h2))
+
+
+def test_contexts_on_several_threads():
+    """four callers, each with its own contexts, at the same time: the caches and the pipelines keep
+    them apart (every stream equals the oracle's, every round trip its input)"""
+    from zstdmt_amd._native import lib_path
+    lib = H.bind_lz4mt(C.CDLL(lib_path()))
+    datas = [text(3_000_000 + 70_001 * i, seed=40 + i) + rnd(50_000, i) for i in range(4)]
+    errs = []
+
+    def work(i):
+        try:
+            for rep in range(3):
+                rv, stream, _, _ = H.lz4mt_compress_via(lib, datas[i], 131072, threads=2 + i, level=1)
+                assert rv == 0 and stream == H.oracle_compress(datas[i], 131072)
+                rv, out, _, _ = H.lz4mt_decompress_via(lib, stream, threads=2)
+                assert rv == 0 and out == datas[i]
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errs.append((i, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
