@@ -66,12 +66,39 @@ static void hc_insert(zo_hc *h, uint32_t target)
 	h->next_to_update = target;
 }
 
-/* LZ4HC_InsertAndGetWiderMatch without pattern analysis / chain swap (levels 3..8).
+/* LZ4HC_countPattern / LZ4HC_reverseCountPattern: bytes after p (before p) that continue the
+ * repetition of the 4-byte pattern, phase 0 at p */
+static unsigned hc_count_pattern(const uint8_t *p, const uint8_t *end, uint32_t pattern)
+{
+	const uint8_t *s = p;
+	unsigned k = 0;
+	while (p < end && *p == (uint8_t)(pattern >> (8 * (k & 3)))) {
+		p++;
+		k++;
+	}
+	return (unsigned)(p - s);
+}
+static unsigned hc_reverse_count_pattern(const uint8_t *p, const uint8_t *low, uint32_t pattern)
+{
+	const uint8_t *s = p;
+	unsigned k = 3;
+	while (p > low && p[-1] == (uint8_t)(pattern >> (8 * (k & 3)))) {
+		p--;
+		k--;
+	}
+	return (unsigned)(s - p);
+}
+
+/* LZ4HC_InsertAndGetWiderMatch without chain swap (levels 3..9); `pattern_analysis` is the
+ * repeated-pattern shortcut liblz4 enables for more than 128 attempts (level 9).
  * ip, low, high are positions in the chunk; returns the longest length found (> longest on entry),
  * match position in *mpos and the (possibly moved back) start in *spos. */
 static int hc_wider(zo_hc *h, uint32_t ip, uint32_t low_limit, uint32_t high_limit, int longest,
 		    uint32_t *mpos, uint32_t *spos, int max_attempts)
 {
+	const int pattern_analysis = max_attempts > 128;
+	int repeat = 0; /* 0 untested, 1 not a repetition, 2 confirmed */
+	size_t src_pattern_len = 0;
 	const uint8_t *const s = h->src;
 	const uint32_t ip_index = ip + HC_BASE;
 	const uint32_t lowest = (HC_BASE + HC_DIST_MAX + 1 > ip_index) ? HC_BASE : ip_index - HC_DIST_MAX;
@@ -102,6 +129,53 @@ static int hc_wider(zo_hc *h, uint32_t ip, uint32_t low_limit, uint32_t high_lim
 					longest = ml;
 					*mpos = (uint32_t)((int)m + back);
 					*spos = (uint32_t)((int)ip + back);
+				}
+			}
+		}
+		if (pattern_analysis && h->chain[match_index & (HC_MAXD - 1)] == 1) {
+			/* the candidate sits inside a run of one byte value: jump to where the run can
+			 * match the run at ip in full instead of walking it link by link */
+			const uint32_t cand = match_index - 1;
+			if (repeat == 0) {
+				if (((pattern & 0xFFFF) == (pattern >> 16)) & ((pattern & 0xFF) == (pattern >> 24))) {
+					repeat = 2;
+					src_pattern_len = hc_count_pattern(s + ip + 4, s + high_limit, pattern) + 4;
+				} else {
+					repeat = 1;
+				}
+			}
+			if (repeat == 2 && cand >= lowest) {
+				const uint8_t *mp = s + (cand - HC_BASE);
+				if (rd32(mp) == pattern) {
+					const size_t fwd = hc_count_pattern(mp + 4, s + high_limit, pattern) + 4;
+					size_t back = hc_reverse_count_pattern(mp, s, pattern), cur;
+					{
+						const uint32_t far = cand - (uint32_t)back;
+						back = cand - (far > lowest ? far : lowest);
+					}
+					cur = back + fwd;
+					if (cur >= src_pattern_len && fwd <= src_pattern_len) {
+						match_index = cand + (uint32_t)fwd - (uint32_t)src_pattern_len;
+					} else {
+						match_index = cand - (uint32_t)back;
+						if (look_back == 0) {
+							const size_t max_ml = cur < src_pattern_len ? cur : src_pattern_len;
+							if ((size_t)longest < max_ml) {
+								if (ip_index - match_index > HC_DIST_MAX)
+									break;
+								longest = (int)max_ml;
+								*mpos = match_index - HC_BASE;
+								*spos = ip;
+							}
+							{
+								const uint32_t d = h->chain[match_index & (HC_MAXD - 1)];
+								if (d > match_index)
+									break;
+								match_index -= d;
+							}
+						}
+					}
+					continue;
 				}
 			}
 		}
@@ -312,11 +386,11 @@ last_literals:
 
 static int hc_attempts(int level)
 {
-	static const int a[] = {2, 2, 2, 4, 8, 16, 32, 64, 128};
-	return level >= 0 && level <= 8 ? a[level] : 0;
+	static const int a[] = {2, 2, 2, 4, 8, 16, 32, 64, 128, 256};
+	return level >= 0 && level <= 9 ? a[level] : 0;
 }
 
-int zo_lz4hc_level_supported(int level) { return level >= 3 && level <= 8; }
+int zo_lz4hc_level_supported(int level) { return level >= 3 && level <= 9; }
 
 /* one LZ4 frame as LZ4F_compressFrame writes it for the prefs of lz4-mt at an HC level: same
  * container as zo_lz4f_compress (lz4_oracle.c), blocks from the HC parser with one context per frame

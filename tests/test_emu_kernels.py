@@ -49,10 +49,13 @@ def _hc_inputs():
         "text_rnd_text": (65536, t[:3000] + rnd(1500, 9) + t[:3000]),
         "text_4x2500": (2500, t + t[:1000]),                    # ragged chunks, persistent grid of 2
         "lazy_shapes": (65536, b"".join(t[i * 37:i * 37 + 60 + i % 40] + t[:i % 23] for i in range(120))),
+        # runs of one byte value of many lengths between text: the pattern analysis of level 9
+        "runs": (65536, b"".join(t[i * 11:i * 11 + 9] + bytes([65 + i % 3]) * (3 + (i * 7) % 90) for i in range(90))
+                 + bytes(3000) + t[:50] + bytes(700) + b"x" + bytes(900)),
     }
 
 
-@pytest.mark.parametrize("level", [3, 5, 8])
+@pytest.mark.parametrize("level", [3, 5, 8, 9])
 @pytest.mark.parametrize("name", sorted(_hc_inputs()))
 def test_emu_hc_compress_bit_exact(name, level):
     """lz4_enc_hc.hip on the emulator against the LZ4HC oracle (levels 3..8 = hash chain)."""

@@ -62,13 +62,15 @@ def test_lz4_pipes_chunk_option_and_golden():
     assert r.returncode == 1 and b"lz4-mt" in r.stderr
 
 
-def test_lz4_default_level_is_3_and_levels_above_8_are_reported():
+def test_lz4_default_level_is_3_and_levels_above_9_are_reported():
     data = cases.text(300000)
     # no level option: the reference's default, level 3 = LZ4HC (programs/lz4-mt.c:19), 4 MiB chunks
     p = run([LZ4, "-c"], data)
     assert p.stdout == H.oracle_compress_level(data, 4 << 20, 3)
     assert run([LZ4, "-d", "-c"], p.stdout).stdout == data
-    r = run([LZ4, "-9", "-c"], b"abc" * 1000, check=False)
+    p9 = run([LZ4, "-9", "-c"], data)
+    assert p9.stdout == H.oracle_compress_level(data, 4 << 20, 9)
+    r = run([LZ4, "-10", "-c"], b"abc" * 1000, check=False)
     assert r.returncode == 1 and b"Compression parameter is out of bound" in r.stderr
 
 

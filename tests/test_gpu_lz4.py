@@ -79,9 +79,9 @@ with open(os.path.join(H.GOLDEN_DIR, "lz4hc", "manifest.json")) as _f:
     HCMAN = json.load(_f)
 
 
-@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8, 9])
 def test_hc_compress_golden(eng, level):
-    """LZ4HC levels 3..8 against the digests the reference build wrote (tests/golden/gen_golden_lz4hc.py)."""
+    """LZ4HC levels 3..9 against the digests the reference build wrote (tests/golden/gen_golden_lz4hc.py)."""
     n = 0
     for name, e in HCMAN["cases"].items():
         chunk, thunk = CASES[name]
@@ -101,10 +101,24 @@ def test_hc_fuzz_vs_oracle(eng, seed):
     rng = random.Random(7000 + seed)
     n = rng.randrange(1, 2_000_000)
     chunk = rng.choice([65536, 131072, 100000, 262144, 1 << 20])
-    level = rng.choice([3, 4, 5, 6, 7, 8])
+    level = rng.choice([3, 4, 5, 6, 7, 8, 9])
     data = _mix(rng, n)
     stream, ro, rl = eng.compress_bytes(data, chunk, level=level)
     assert stream == H.oracle_compress_level(data, chunk, level)
+    out, status = eng.decompress_bytes(stream, ro, rl)
+    assert not status.any() and out == data
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hc_level9_runs_vs_oracle(eng, seed):
+    """byte runs of every length: the repeated-pattern shortcut of level 9"""
+    import random
+    from test_oracle_vs_ref import _runs
+    rng = random.Random(9100 + seed)
+    data = _runs(rng, rng.randrange(200_000, 1_500_000))
+    chunk = rng.choice([65536, 131072, 262144])
+    stream, ro, rl = eng.compress_bytes(data, chunk, level=9)
+    assert stream == H.oracle_compress_level(data, chunk, 9)
     out, status = eng.decompress_bytes(stream, ro, rl)
     assert not status.any() and out == data
 
@@ -120,7 +134,7 @@ def test_hc_many_chunks_persistent_grid(eng):
         assert rec == H.oracle_compress_level(data[i * chunk:(i + 1) * chunk], chunk, 3)
     out, status = eng.decompress_bytes(stream, ro, rl)
     assert not status.any() and out == data
-    assert eng.L.gpumt_lz4_level_supported(8) == 1 and eng.L.gpumt_lz4_level_supported(9) == 0
+    assert eng.L.gpumt_lz4_level_supported(9) == 1 and eng.L.gpumt_lz4_level_supported(10) == 0
 
 
 def test_config1_random_64m(eng):

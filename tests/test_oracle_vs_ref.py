@@ -80,10 +80,11 @@ def test_mt_variants_agree():
     assert m == len(data) and back.raw == data
 
 
-@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("seed", range(6))
 def test_fuzz_compress_hc_bit_exact(seed, level):
-    """LZ4 HC levels whose search is a plain hash-chain walk (lz4hc_oracle.c) against the reference
+    """LZ4 HC levels that run the hash-chain parser (lz4hc_oracle.c; level 9 adds the repeated-pattern
+    analysis) against the reference
     library (liblz4 1.9.3 behind lib/lz4-mt_compress.c:281), incl. linked blocks and stored blocks."""
     rng = random.Random(7000 + 31 * seed + level)
     n = rng.choice([0, 1, 12, 13, 14, 65536, 65537, 131072, 131073, rng.randrange(1, 500000),
@@ -96,7 +97,40 @@ def test_fuzz_compress_hc_bit_exact(seed, level):
     assert H.oracle_decompress(s_ref, max(n, 65536)) == data
 
 
-@pytest.mark.parametrize("level", [3, 8])
+def _runs(rng, n):
+    """byte runs of every length next to short repeats and text: what the pattern analysis of level 9 is for"""
+    out = bytearray()
+    while len(out) < n:
+        k = rng.randrange(6)
+        if k == 0:
+            out += bytes([rng.randrange(256)]) * rng.choice([3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 300, 5000, 70000])
+        elif k == 1:
+            out += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 6)))
+        elif k == 2:
+            out += text(rng.randrange(1, 400), rng.randrange(1 << 20))
+        elif k == 3:
+            out += (bytes([rng.randrange(256)]) * rng.randrange(1, 5) + bytes([rng.randrange(256)])) * rng.randrange(1, 40)
+        elif k == 4 and len(out) > 10:
+            a = rng.randrange(len(out))
+            out += out[a:a + rng.randrange(4, 300)]
+        else:
+            out += b"\0" * rng.randrange(1, 2000)
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_level9_runs(seed):
+    rng = random.Random(9900 + seed)
+    n = rng.choice([rng.randrange(1, 400000), 65536, 131072, 200000])
+    chunk = rng.choice([65536, 131072, 100000, 262144])
+    data = _runs(rng, n)
+    for level in (9, rng.choice([3, 5, 8])):
+        rv, s_ref, _, _ = H.lz4mt_compress_via(H.ref(), data, chunk, threads=1, level=level)
+        assert rv == 0
+        assert H.oracle_compress_level(data, chunk, level) == s_ref, (level, n, chunk)
+
+
+@pytest.mark.parametrize("level", [3, 8, 9])
 def test_hc_text_and_runs(level):
     data = text(700000, 21) + bytes(200000) + (text(97, 22) * 3000) + rnd(90000, 23) + text(150000, 24)
     for chunk in (131072, 4 << 20):

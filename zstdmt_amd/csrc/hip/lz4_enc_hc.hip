@@ -1,13 +1,14 @@
 /*
- * lz4_enc_hc.hip -- LZ4 frame encoder for the "HC" levels 3..8 of lz4-mt, bit-exact.
+ * lz4_enc_hc.hip -- LZ4 frame encoder for the "HC" levels 3..9 of lz4-mt, bit-exact.
  *
  * The reference hands levels >= 3 to LZ4F_compressFrame's HC path (prefs.compressionLevel,
  * /root/reference/lib/lz4-mt_compress.c:141-146, call :281; the CLI default is level 3,
- * /root/reference/programs/lz4-mt.c:19).  For levels 3..8 that is liblz4's hash-chain parser: every
+ * /root/reference/programs/lz4-mt.c:19).  For levels 3..9 that is liblz4's hash-chain parser: every
  * position enters a 32 K-entry hash table + 64 K-entry chain of 16-bit deltas, a search walks at
- * most 4 / 8 / 16 / 32 / 64 / 128 chain links, and a lazy evaluation over up to three overlapping
- * matches decides what is emitted (oracle/lz4hc_oracle.c restates it and is pinned against the
- * reference build).  Level 9 (repeated-pattern analysis) and 10..12 (optimal parser) are not here.
+ * most 4 / 8 / 16 / 32 / 64 / 128 / 256 chain links (level 9 also jumps over runs of one byte value:
+ * the "pattern analysis"), and a lazy evaluation over up to three overlapping matches decides what
+ * is emitted (oracle/lz4hc_oracle.c restates it and is pinned against the reference build).  Levels
+ * 10..12 (optimal parser) are not here.
  *
  * The parse is inherently serial per chunk (what is found depends on everything inserted before),
  * so the unit of parallelism is the chunk: one wave per chunk on a persistent grid, tables in a
@@ -123,7 +124,39 @@ static __device__ int hc_count_back(const u8 *s, u32 ip, u32 m, int min, int lan
 	}
 }
 
-/* LZ4HC_InsertAndGetWiderMatch (no pattern analysis, no chain swap: levels 3..8) */
+/* LZ4HC_countPattern: bytes from a[0] on that continue the repetition of the 4-byte pattern (phase 0
+ * at a[0]), at most `limit`; LZ4HC_reverseCountPattern: the same backwards from a[-1], at most `room` */
+static __device__ u32 hc_count_pattern(const u8 *a, u32 limit, u32 pattern, int lane)
+{
+	u32 done = 0;
+	for (;;) {
+		const u32 i = done + (u32)lane;
+		const bool stop = i >= limit || a[i] != (u8)(pattern >> (8 * (i & 3)));
+		const u64 sm = wv_ballot(stop);
+		if (sm) {
+			const u32 r = done + (u32)wv_ffs(sm) - 1;
+			return r < limit ? r : limit;
+		}
+		done += 64;
+	}
+}
+static __device__ u32 hc_reverse_count_pattern(const u8 *a, u32 room, u32 pattern, int lane)
+{
+	u32 done = 0;
+	for (;;) {
+		const u32 i = done + (u32)lane; /* byte a[-1 - i] against pattern byte 3 - (i & 3) */
+		const bool stop = i >= room || a[-1 - (int)i] != (u8)(pattern >> (8 * (3 - (i & 3))));
+		const u64 sm = wv_ballot(stop);
+		if (sm) {
+			const u32 r = done + (u32)wv_ffs(sm) - 1;
+			return r < room ? r : room;
+		}
+		done += 64;
+	}
+}
+
+/* LZ4HC_InsertAndGetWiderMatch (no chain swap: levels 3..9; more than 128 attempts = level 9 turns the
+ * repeated-pattern analysis on, as liblz4 does) */
 static __device__ int hc_wider(HcState &H, u32 ip, u32 low_limit, u32 high_limit, int longest, u32 *mpos,
 			       u32 *spos, int max_attempts, int lane)
 {
@@ -133,6 +166,9 @@ static __device__ int hc_wider(HcState &H, u32 ip, u32 low_limit, u32 high_limit
 	const int look_back = (int)(ip - low_limit);
 	const u32 pattern = uld32(s + ip);
 	int attempts = max_attempts;
+	const bool pattern_analysis = max_attempts > 128;
+	int repeat = 0; /* 0 untested, 1 not a repetition, 2 confirmed */
+	u32 src_pattern_len = 0;
 
 	hc_insert(H, ip_index, lane);
 	u32 match_index = hc_uld_hash(H, hc_hash(pattern));
@@ -153,6 +189,53 @@ static __device__ int hc_wider(HcState &H, u32 ip, u32 low_limit, u32 high_limit
 					longest = ml;
 					*mpos = (u32)((int)m + back);
 					*spos = (u32)((int)ip + back);
+				}
+			}
+		}
+		if (pattern_analysis && hc_uld_chain(H, match_index) == 1) {
+			/* the candidate sits inside a run of one byte value: jump to where that run can match
+			 * the run at ip in full instead of walking it link by link (oracle/lz4hc_oracle.c) */
+			const u32 cand = match_index - 1;
+			if (repeat == 0) {
+				if (((pattern & 0xFFFF) == (pattern >> 16)) & ((pattern & 0xFF) == (pattern >> 24))) {
+					repeat = 2;
+					src_pattern_len = hc_count_pattern(s + ip + 4, high_limit - (ip + 4), pattern, lane) + 4;
+				} else {
+					repeat = 1;
+				}
+			}
+			if (repeat == 2 && cand >= lowest) {
+				const u32 mp = cand - HC_BASE;
+				if (uld32(s + mp) == pattern) {
+					const u32 fwd = hc_count_pattern(s + mp + 4, high_limit - (mp + 4), pattern, lane) + 4;
+					u32 back = hc_reverse_count_pattern(s + mp, mp, pattern, lane);
+					{
+						const u32 far = cand - back;
+						back = cand - (far > lowest ? far : lowest);
+					}
+					const u32 cur = back + fwd;
+					if (cur >= src_pattern_len && fwd <= src_pattern_len) {
+						match_index = cand + fwd - src_pattern_len;
+					} else {
+						match_index = cand - back;
+						if (look_back == 0) {
+							const u32 max_ml = cur < src_pattern_len ? cur : src_pattern_len;
+							if ((u32)longest < max_ml) {
+								if (ip_index - match_index > HC_DIST_MAX)
+									break;
+								longest = (int)max_ml;
+								*mpos = match_index - HC_BASE;
+								*spos = ip;
+							}
+							{
+								const u32 d = hc_uld_chain(H, match_index);
+								if (d > match_index)
+									break;
+								match_index -= d;
+							}
+						}
+					}
+					continue;
 				}
 			}
 		}
