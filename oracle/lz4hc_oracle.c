@@ -93,10 +93,10 @@ static unsigned hc_reverse_count_pattern(const uint8_t *p, const uint8_t *low, u
  * repeated-pattern shortcut liblz4 enables for more than 128 attempts (level 9).
  * ip, low, high are positions in the chunk; returns the longest length found (> longest on entry),
  * match position in *mpos and the (possibly moved back) start in *spos. */
-static int hc_wider(zo_hc *h, uint32_t ip, uint32_t low_limit, uint32_t high_limit, int longest,
-		    uint32_t *mpos, uint32_t *spos, int max_attempts)
+static int hc_wider_core(zo_hc *h, uint32_t ip, uint32_t low_limit, uint32_t high_limit, int longest,
+			 uint32_t *mpos, uint32_t *spos, int max_attempts, int pattern_analysis, int chain_swap)
 {
-	const int pattern_analysis = max_attempts > 128;
+	uint32_t match_chain_pos = 0;
 	int repeat = 0; /* 0 untested, 1 not a repetition, 2 confirmed */
 	size_t src_pattern_len = 0;
 	const uint8_t *const s = h->src;
@@ -111,6 +111,7 @@ static int hc_wider(zo_hc *h, uint32_t ip, uint32_t low_limit, uint32_t high_lim
 	match_index = h->hash[hc_hash(s + ip)];
 	while (match_index >= lowest && attempts > 0) {
 		const uint32_t m = match_index - HC_BASE; /* chunk position of the candidate */
+		int match_len = 0;
 		attempts--;
 		if (rd16(s + low_limit + longest - 1) == rd16(s + m - look_back + longest - 1)) {
 			if (rd32(s + m) == pattern) {
@@ -125,6 +126,7 @@ static int hc_wider(zo_hc *h, uint32_t ip, uint32_t low_limit, uint32_t high_lim
 				}
 				ml = HC_MINMATCH + (int)hc_count(s + ip + HC_MINMATCH, s + m + HC_MINMATCH, s + high_limit);
 				ml -= back;
+				match_len = ml;
 				if (ml > longest) {
 					longest = ml;
 					*mpos = (uint32_t)((int)m + back);
@@ -132,7 +134,32 @@ static int hc_wider(zo_hc *h, uint32_t ip, uint32_t low_limit, uint32_t high_lim
 				}
 			}
 		}
-		if (pattern_analysis && h->chain[match_index & (HC_MAXD - 1)] == 1) {
+		if (chain_swap && match_len == longest) {
+			/* a match as long as the best one: continue on the chain of the position inside it whose
+			 * next candidate is farthest away (the optimal parser only; search forward only) */
+			if (match_index + (uint32_t)longest <= ip_index) {
+				const int k_trigger = 4;
+				uint32_t dist_to_next = 1;
+				const int end = longest - HC_MINMATCH + 1;
+				int step = 1, accel = 1 << k_trigger, pos;
+				for (pos = 0; pos < end; pos += step) {
+					const uint32_t cand_dist = h->chain[(match_index + (uint32_t)pos) & (HC_MAXD - 1)];
+					step = (accel++ >> k_trigger);
+					if (cand_dist > dist_to_next) {
+						dist_to_next = cand_dist;
+						match_chain_pos = (uint32_t)pos;
+						accel = 1 << k_trigger;
+					}
+				}
+				if (dist_to_next > 1) {
+					if (dist_to_next > match_index)
+						break;
+					match_index -= dist_to_next;
+					continue;
+				}
+			}
+		}
+		if (pattern_analysis && match_chain_pos == 0 && h->chain[match_index & (HC_MAXD - 1)] == 1) {
 			/* the candidate sits inside a run of one byte value: jump to where the run can
 			 * match the run at ip in full instead of walking it link by link */
 			const uint32_t cand = match_index - 1;
@@ -179,9 +206,15 @@ static int hc_wider(zo_hc *h, uint32_t ip, uint32_t low_limit, uint32_t high_lim
 				}
 			}
 		}
-		match_index -= h->chain[match_index & (HC_MAXD - 1)];
+		match_index -= h->chain[(match_index + match_chain_pos) & (HC_MAXD - 1)];
 	}
 	return longest;
+}
+/* the hash-chain levels: pattern analysis beyond 128 attempts (level 9), never a chain swap */
+static int hc_wider(zo_hc *h, uint32_t ip, uint32_t low_limit, uint32_t high_limit, int longest,
+		    uint32_t *mpos, uint32_t *spos, int max_attempts)
+{
+	return hc_wider_core(h, ip, low_limit, high_limit, longest, mpos, spos, max_attempts, max_attempts > 128, 0);
 }
 
 /* LZ4HC_encodeSequence; returns 1 when the output limit is hit */
@@ -384,13 +417,236 @@ last_literals:
 	return (size_t)(op - dst);
 }
 
-static int hc_attempts(int level)
+
+/* ---- levels 10..12: LZ4HC_compress_optimal ------------------------------------------------
+ * Prices are bytes of output.  From a position with a match the parser fills a table of the cheapest
+ * way to reach each of the next positions (literals or a match ending there), searching again at
+ * every position where that can pay, then walks the table backwards from the last position reached
+ * and emits the chosen sequences.  nb_searches / sufficient_len / full_update per level:
+ * 96 / 64 / 0, 512 / 128 / 0, 16384 / 4096 / 1. */
+#define HC_OPT_NUM 4096
+#define HC_TRAILING 3
+typedef struct {
+	int price, off, mlen, litlen;
+} hc_opt_t;
+
+static int hc_lit_price(int litlen)
 {
-	static const int a[] = {2, 2, 2, 4, 8, 16, 32, 64, 128, 256};
-	return level >= 0 && level <= 9 ? a[level] : 0;
+	int price = litlen;
+	if (litlen >= 15)
+		price += 1 + (litlen - 15) / 255;
+	return price;
+}
+static int hc_seq_price(int litlen, int mlen)
+{
+	int price = 1 + 2 + hc_lit_price(litlen);
+	if (mlen >= 15 + HC_MINMATCH)
+		price += 1 + (mlen - (15 + HC_MINMATCH)) / 255;
+	return price;
+}
+/* LZ4HC_FindLongerMatch: pattern analysis and chain swap on, forward only */
+static void hc_find_longer(zo_hc *h, uint32_t ip, uint32_t high_limit, int min_len, int nb_searches, int *len, int *off)
+{
+	uint32_t mpos = 0, spos = ip;
+	const int ml = hc_wider_core(h, ip, ip, high_limit, min_len, &mpos, &spos, nb_searches, 1, 1);
+	*len = 0;
+	*off = 0;
+	if (ml <= min_len)
+		return;
+	*len = ml;
+	*off = (int)(ip - mpos);
 }
 
-int zo_lz4hc_level_supported(int level) { return level >= 3 && level <= 9; }
+static size_t hc_opt_block(zo_hc *h, uint32_t start, uint32_t n, uint8_t *dst, size_t cap, int nb_searches,
+			   size_t sufficient_len, int full_update)
+{
+	const uint8_t *const s = h->src;
+	hc_opt_t *const opt = (hc_opt_t *)malloc(sizeof(hc_opt_t) * (HC_OPT_NUM + HC_TRAILING + 8));
+	size_t result = 0;
+	uint32_t ip = start, anchor = start;
+	const uint32_t iend = start + n;
+	const uint32_t mflimit = iend - HC_MFLIMIT, matchlimit = iend - HC_LASTLITERALS;
+	uint8_t *op = dst, *const oend = dst + cap;
+
+	if (!opt)
+		return 0;
+	if (sufficient_len >= HC_OPT_NUM)
+		sufficient_len = HC_OPT_NUM - 1;
+	if (n < HC_MFLIMIT + 1)
+		goto last_literals;
+	while (ip <= mflimit) {
+		const int llen = (int)(ip - anchor);
+		int best_mlen, best_off, cur, last_match_pos = 0, first_len, first_off;
+
+		hc_find_longer(h, ip, matchlimit, HC_MINMATCH - 1, nb_searches, &first_len, &first_off);
+		if (first_len == 0) {
+			ip++;
+			continue;
+		}
+		if ((size_t)first_len > sufficient_len) {
+			/* good enough: immediate encoding */
+			if (hc_encode(s, &ip, &op, &anchor, first_len, ip - (uint32_t)first_off, oend))
+				goto done;
+			continue;
+		}
+		/* prices of the first positions (literals) and of the first match */
+		for (int r = 0; r < HC_MINMATCH; r++) {
+			opt[r].mlen = 1;
+			opt[r].off = 0;
+			opt[r].litlen = llen + r;
+			opt[r].price = hc_lit_price(llen + r);
+		}
+		for (int ml = HC_MINMATCH; ml <= first_len; ml++) {
+			opt[ml].mlen = ml;
+			opt[ml].off = first_off;
+			opt[ml].litlen = llen;
+			opt[ml].price = hc_seq_price(llen, ml);
+		}
+		last_match_pos = first_len;
+		for (int a = 1; a <= HC_TRAILING; a++) {
+			opt[last_match_pos + a].mlen = 1;
+			opt[last_match_pos + a].off = 0;
+			opt[last_match_pos + a].litlen = a;
+			opt[last_match_pos + a].price = opt[last_match_pos].price + hc_lit_price(a);
+		}
+		/* further positions */
+		for (cur = 1; cur < last_match_pos; cur++) {
+			const uint32_t cur_pos = ip + (uint32_t)cur;
+			int new_len, new_off;
+			if (cur_pos > mflimit)
+				break;
+			if (full_update) {
+				if (opt[cur + 1].price <= opt[cur].price && opt[cur + HC_MINMATCH].price < opt[cur].price + 3)
+					continue;
+			} else {
+				if (opt[cur + 1].price <= opt[cur].price)
+					continue;
+			}
+			if (full_update)
+				hc_find_longer(h, cur_pos, matchlimit, HC_MINMATCH - 1, nb_searches, &new_len, &new_off);
+			else
+				hc_find_longer(h, cur_pos, matchlimit, last_match_pos - cur, nb_searches, &new_len, &new_off);
+			if (!new_len)
+				continue;
+			if ((size_t)new_len > sufficient_len || new_len + cur >= HC_OPT_NUM) {
+				best_mlen = new_len;
+				best_off = new_off;
+				last_match_pos = cur + 1;
+				goto encode;
+			}
+			/* before the match: literals */
+			{
+				const int base_litlen = opt[cur].litlen;
+				for (int litlen = 1; litlen < HC_MINMATCH; litlen++) {
+					const int price = opt[cur].price - hc_lit_price(base_litlen) + hc_lit_price(base_litlen + litlen);
+					const int pos = cur + litlen;
+					if (price < opt[pos].price) {
+						opt[pos].mlen = 1;
+						opt[pos].off = 0;
+						opt[pos].litlen = base_litlen + litlen;
+						opt[pos].price = price;
+					}
+				}
+			}
+			/* the match at cur */
+			for (int ml = HC_MINMATCH; ml <= new_len; ml++) {
+				const int pos = cur + ml;
+				int price, ll;
+				if (opt[cur].mlen == 1) {
+					ll = opt[cur].litlen;
+					price = ((cur > ll) ? opt[cur - ll].price : 0) + hc_seq_price(ll, ml);
+				} else {
+					ll = 0;
+					price = opt[cur].price + hc_seq_price(0, ml);
+				}
+				if (pos > last_match_pos + HC_TRAILING || price <= opt[pos].price) {
+					if (ml == new_len && last_match_pos < pos)
+						last_match_pos = pos;
+					opt[pos].mlen = ml;
+					opt[pos].off = new_off;
+					opt[pos].litlen = ll;
+					opt[pos].price = price;
+				}
+			}
+			for (int a = 1; a <= HC_TRAILING; a++) {
+				opt[last_match_pos + a].mlen = 1;
+				opt[last_match_pos + a].off = 0;
+				opt[last_match_pos + a].litlen = a;
+				opt[last_match_pos + a].price = opt[last_match_pos].price + hc_lit_price(a);
+			}
+		}
+		best_mlen = opt[last_match_pos].mlen;
+		best_off = opt[last_match_pos].off;
+		cur = last_match_pos - best_mlen;
+encode:
+		/* reverse traversal: the chosen sequences, first to last */
+		{
+			int candidate_pos = cur, selected_ml = best_mlen, selected_off = best_off;
+			for (;;) {
+				const int next_ml = opt[candidate_pos].mlen, next_off = opt[candidate_pos].off;
+				opt[candidate_pos].mlen = selected_ml;
+				opt[candidate_pos].off = selected_off;
+				selected_ml = next_ml;
+				selected_off = next_off;
+				if (next_ml > candidate_pos)
+					break;
+				candidate_pos -= next_ml;
+			}
+		}
+		{
+			int r = 0;
+			while (r < last_match_pos) {
+				const int ml = opt[r].mlen, offset = opt[r].off;
+				if (ml == 1) {
+					ip++;
+					r++;
+					continue;
+				}
+				r += ml;
+				if (hc_encode(s, &ip, &op, &anchor, ml, ip - (uint32_t)offset, oend))
+					goto done;
+			}
+		}
+	}
+last_literals:
+	{
+		const size_t run = (size_t)(iend - anchor);
+		const size_t lit_len = (run + 255 - 15) / 255;
+		if (op + 1 + lit_len + run > oend)
+			goto done;
+		if (run >= 15) {
+			size_t acc = run - 15;
+			*op++ = 15 << 4;
+			for (; acc >= 255; acc -= 255)
+				*op++ = 255;
+			*op++ = (uint8_t)acc;
+		} else {
+			*op++ = (uint8_t)(run << 4);
+		}
+		memcpy(op, s + anchor, run);
+		op += run;
+	}
+	result = (size_t)(op - dst);
+done:
+	free(opt);
+	return result;
+}
+
+static int hc_attempts(int level)
+{
+	static const int a[] = {2, 2, 2, 4, 8, 16, 32, 64, 128, 256, 96, 512, 16384};
+	return level >= 0 && level <= 12 ? a[level] : 0;
+}
+
+int zo_lz4hc_level_supported(int level) { return level >= 3 && level <= 12; }
+
+static size_t hc_any_block(zo_hc *h, uint32_t start, uint32_t n, uint8_t *dst, size_t cap, int level)
+{
+	if (level >= 10)
+		return hc_opt_block(h, start, n, dst, cap, hc_attempts(level), level == 10 ? 64 : level == 11 ? 128 : HC_OPT_NUM,
+				    level == 12);
+	return hc_block(h, start, n, dst, cap, hc_attempts(level));
+}
 
 /* one LZ4 frame as LZ4F_compressFrame writes it for the prefs of lz4-mt at an HC level: same
  * container as zo_lz4f_compress (lz4_oracle.c), blocks from the HC parser with one context per frame
@@ -423,7 +679,7 @@ size_t zo_lz4f_compress_hc(const uint8_t *src, size_t n, uint8_t *dst, size_t ca
 	op += hdr;
 	for (pos = 0; pos < n; pos += ZO_BLOCK_MAX) {
 		const size_t len = n - pos < ZO_BLOCK_MAX ? n - pos : ZO_BLOCK_MAX;
-		const size_t c = hc_block(h, (uint32_t)pos, (uint32_t)len, op + 4, len - 1, hc_attempts(level));
+		const size_t c = hc_any_block(h, (uint32_t)pos, (uint32_t)len, op + 4, len - 1, level);
 		uint32_t bh;
 		if (c == 0) { /* did not shrink: stored block; the chains keep what the attempt inserted */
 			bh = (uint32_t)len | 0x80000000u;

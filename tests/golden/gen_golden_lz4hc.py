@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 import helpers as H  # noqa: E402
 from cases import CASES  # noqa: E402
 
-LEVELS = (3, 4, 5, 6, 7, 8, 9, 12)
+LEVELS = (3, 4, 5, 6, 7, 8, 9, 10, 11, 12)
 NAMES = ["empty", "hello_5", "abc_12", "abc_13", "text_100", "text_64k", "text_64k_p1", "text_64k_p20", "text_128k",
          "text_3x128k_p100", "text_200k_chunk100000", "text_300k_chunk64k", "text_1m_chunk1m", "zeros_128k",
          "zeros_70000", "A64k_B64k", "period_300", "period_65535", "period_65536", "lcg_128k", "mixed_text_rnd",

@@ -141,7 +141,7 @@ with open(os.path.join(H.GOLDEN_DIR, "lz4hc", "manifest.json")) as _f:
     HCMAN = json.load(_f)["cases"]
 
 
-@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("name", sorted(HCMAN))
 def test_oracle_hc_matches_reference_golden(name, level):
     """LZ4 HC levels 3..9 (lz4hc_oracle.c) against digests of what the reference wrote

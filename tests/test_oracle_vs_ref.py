@@ -80,7 +80,7 @@ def test_mt_variants_agree():
     assert m == len(data) and back.raw == data
 
 
-@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("seed", range(6))
 def test_fuzz_compress_hc_bit_exact(seed, level):
     """LZ4 HC levels that run the hash-chain parser (lz4hc_oracle.c; level 9 adds the repeated-pattern
@@ -124,13 +124,13 @@ def test_fuzz_level9_runs(seed):
     n = rng.choice([rng.randrange(1, 400000), 65536, 131072, 200000])
     chunk = rng.choice([65536, 131072, 100000, 262144])
     data = _runs(rng, n)
-    for level in (9, rng.choice([3, 5, 8])):
+    for level in (9, rng.choice([3, 5, 8]), rng.choice([10, 11, 12])):
         rv, s_ref, _, _ = H.lz4mt_compress_via(H.ref(), data, chunk, threads=1, level=level)
         assert rv == 0
         assert H.oracle_compress_level(data, chunk, level) == s_ref, (level, n, chunk)
 
 
-@pytest.mark.parametrize("level", [3, 8, 9])
+@pytest.mark.parametrize("level", [3, 8, 9, 10, 11, 12])
 def test_hc_text_and_runs(level):
     data = text(700000, 21) + bytes(200000) + (text(97, 22) * 3000) + rnd(90000, 23) + text(150000, 24)
     for chunk in (131072, 4 << 20):
