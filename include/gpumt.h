@@ -124,12 +124,12 @@ int gpumt_lz4_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t ch
 /*
  * The same with lz4-mt's compression level (prefs.compressionLevel, lib/lz4-mt_compress.c:141-146):
  * 1..2 = LZ4 fast (what gpumt_lz4_compress_batch does), 3..9 = LZ4 HC hash-chain parser with
- * 4..256 searches per position (liblz4 1.9.3 lz4hc.c; level 9 with its pattern analysis),
- * byte-identical to the reference at that level.  Levels 10..12 (optimal parser) are not
- * implemented: GPUMT_E_ARG.
- * HC keeps a 256 KiB table set per wave in internal scratch (at most GPUMT_LZ4HC_WAVES of them).
+ * 4..256 searches per position (liblz4 1.9.3 lz4hc.c; level 9 with its pattern analysis), 10..12 =
+ * the LZ4 HC optimal parser (96 / 512 / 16 384 searches): byte-identical to the reference at that
+ * level, and slower with every level (a chain link is a dependent memory access).
+ * HC keeps a 320 KiB table set per wave in internal scratch (at most GPUMT_LZ4HC_WAVES of them).
  */
-#define GPUMT_LZ4HC_SCRATCH 262144u
+#define GPUMT_LZ4HC_SCRATCH 327936u
 #define GPUMT_LZ4HC_WAVES 4096u
 int gpumt_lz4_level_supported(int level);
 int gpumt_lz4_compress_batch_level(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk,

@@ -15,10 +15,8 @@
  *     reference's own contract (lib/lz4-mt_compress.c:256-277 vs :301-303).  With threads == 1
  *     LZ4MT_decompressDCtx runs every callback on the calling thread, as the reference does
  *     (lib/lz4-mt_decompress.c:528-534);
- *   - levels 1-2 (LZ4 "fast") and 3-9 (LZ4HC hash-chain parser) run on the device and are
- *     bit-identical to the reference at the same level; levels 10-12 (the LZ4HC optimal parser)
- *     are not implemented: LZ4MT_compressCCtx returns
- *     LZ4MT_error_compressionParameter_unsupported for such a context;
+ *   - every level runs on the device and is bit-identical to the reference at the same level:
+ *     1-2 (LZ4 "fast"), 3-9 (LZ4HC hash-chain parser), 10-12 (LZ4HC optimal parser; slow);
  *   - plain .lz4 input (no skippable frames; reference: st_decompress, lib/lz4-mt_decompress.c:391-483)
  *     is decoded on the device as well: the frames are split on the host and handed over in batches.
  */

@@ -92,10 +92,10 @@ void emu_lz4hc_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 str
 	const u32 *chkp = chk.data();
 	/* fewer waves than records on purpose: the persistent loop and the table reset are exercised */
 	const u32 grid = nrec > 2 ? (nrec + 1) / 2 : nrec;
-	std::vector<u8> scratch((size_t)grid * 262144, 0xA5);
+	std::vector<u8> scratch((size_t)grid * 327936, 0xA5);
 	u8 *sc = scratch.data();
 	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1},
-		    [=]() { zmt_lz4hc_enc_kernel(in, n, chunk, nrec, slots, stride, rec_len, chkp, sc, 1 << (level - 1)); });
+		    [=]() { zmt_lz4hc_enc_kernel(in, n, chunk, nrec, slots, stride, rec_len, chkp, sc, level); });
 }
 
 void emu_lz4_compact(const u8 *slots, u64 stride, const u32 *rec_len, u32 nrec, u8 *stream, u64 *rec_off)

@@ -64,6 +64,29 @@ def test_emu_hc_compress_bit_exact(name, level):
     assert stream == H.oracle_compress_level(data, chunk, level)
 
 
+def _opt_inputs():
+    t = text(9000)
+    return {
+        "abc_13": (65536, b"abcabcabcabca"),
+        "text_3000": (65536, t[:3000]),
+        "zeros_5000": (65536, bytes(5000)),
+        "period_7": (65536, (b"abcdefg" * 700)[:4000]),
+        "runs": (65536, b"".join(t[i * 11:i * 11 + 9] + bytes([65 + i % 3]) * (3 + (i * 7) % 90) for i in range(40))
+                 + bytes(1500) + t[:50] + bytes(400)),
+        "rnd_1500": (65536, rnd(1500, 5)),
+        "two_chunks": (2500, t[:4200]),
+    }
+
+
+@pytest.mark.parametrize("level", [10, 11, 12])
+@pytest.mark.parametrize("name", sorted(_opt_inputs()))
+def test_emu_hc_optimal_bit_exact(name, level):
+    """levels 10..12 (LZ4HC optimal parser) of lz4_enc_hc.hip on the emulator against the oracle"""
+    chunk, data = _opt_inputs()[name]
+    stream, rec_off, rec_len = E.compress(data, chunk, level)
+    assert stream == H.oracle_compress_level(data, chunk, level)
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("name", SMALL)
 def test_emu_decompress(name, variant):

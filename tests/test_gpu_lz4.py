@@ -79,14 +79,14 @@ with open(os.path.join(H.GOLDEN_DIR, "lz4hc", "manifest.json")) as _f:
     HCMAN = json.load(_f)
 
 
-@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_hc_compress_golden(eng, level):
-    """LZ4HC levels 3..9 against the digests the reference build wrote (tests/golden/gen_golden_lz4hc.py)."""
+    """LZ4HC levels 3..12 against the digests the reference build wrote (tests/golden/gen_golden_lz4hc.py)."""
     n = 0
     for name, e in HCMAN["cases"].items():
         chunk, thunk = CASES[name]
         want = e["levels"].get(str(level))
-        if want is None:
+        if want is None or (level >= 10 and chunk > 131072):   # a 1 MiB chunk is one wave for seconds up there
             continue
         stream, ro, rl = eng.compress_bytes(thunk(), chunk, level=level)
         assert (len(stream), H.sha256(stream)) == (want["out_len"], want["out_sha256"]), name
@@ -101,7 +101,8 @@ def test_hc_fuzz_vs_oracle(eng, seed):
     rng = random.Random(7000 + seed)
     n = rng.randrange(1, 2_000_000)
     chunk = rng.choice([65536, 131072, 100000, 262144, 1 << 20])
-    level = rng.choice([3, 4, 5, 6, 7, 8, 9])
+    level = rng.choice([3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+    chunk = min(chunk, 262144) if level >= 10 else chunk
     data = _mix(rng, n)
     stream, ro, rl = eng.compress_bytes(data, chunk, level=level)
     assert stream == H.oracle_compress_level(data, chunk, level)
@@ -110,15 +111,16 @@ def test_hc_fuzz_vs_oracle(eng, seed):
 
 
 @pytest.mark.parametrize("seed", range(4))
-def test_hc_level9_runs_vs_oracle(eng, seed):
-    """byte runs of every length: the repeated-pattern shortcut of level 9"""
+def test_hc_level9_and_up_runs_vs_oracle(eng, seed):
+    """byte runs of every length: the repeated-pattern shortcut of level 9 and of the optimal parser"""
     import random
     from test_oracle_vs_ref import _runs
     rng = random.Random(9100 + seed)
     data = _runs(rng, rng.randrange(200_000, 1_500_000))
     chunk = rng.choice([65536, 131072, 262144])
-    stream, ro, rl = eng.compress_bytes(data, chunk, level=9)
-    assert stream == H.oracle_compress_level(data, chunk, 9)
+    level = [9, 10, 11, 12][seed]
+    stream, ro, rl = eng.compress_bytes(data, chunk, level=level)
+    assert stream == H.oracle_compress_level(data, chunk, level)
     out, status = eng.decompress_bytes(stream, ro, rl)
     assert not status.any() and out == data
 
@@ -134,7 +136,7 @@ def test_hc_many_chunks_persistent_grid(eng):
         assert rec == H.oracle_compress_level(data[i * chunk:(i + 1) * chunk], chunk, 3)
     out, status = eng.decompress_bytes(stream, ro, rl)
     assert not status.any() and out == data
-    assert eng.L.gpumt_lz4_level_supported(9) == 1 and eng.L.gpumt_lz4_level_supported(10) == 0
+    assert eng.L.gpumt_lz4_level_supported(12) == 1 and eng.L.gpumt_lz4_level_supported(13) == 0
 
 
 def test_config1_random_64m(eng):

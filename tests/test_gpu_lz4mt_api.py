@@ -75,9 +75,9 @@ def test_callback_trace_equals_reference(lib, name):
     assert io_o.reads == io_r.reads and io_o.writes == io_r.writes
 
 
-@pytest.mark.parametrize("level", [3, 4, 6, 8, 9])
+@pytest.mark.parametrize("level", [3, 4, 6, 8, 9, 10, 12])
 def test_hc_levels_match_oracle_and_reference(lib, level):
-    """Levels 3..9 (LZ4HC hash chain, the CLI default is 3): same bytes as the oracle, and as the
+    """Levels 3..12 (LZ4HC hash chain, the CLI default is 3): same bytes as the oracle, and as the
     reference library where it is built; the stream decodes back."""
     data = text(700000) + rnd(70000, 3) + bytes(200000) + text(300000)[::-1]
     chunk = 262144
@@ -123,10 +123,10 @@ def test_create_argument_checks(lib):
     io = H.MemIO(b"x")
     assert lib.LZ4MT_compressCCtx(None, C.byref(io.rdwr)) == ERR(E_PARAM)
     assert lib.LZ4MT_decompressDCtx(None, C.byref(io.rdwr)) == ERR(E_PARAM)
-    # LZ4HC levels 10-12: context is created, compression reports the parameter as unsupported
-    rv, _, _, _ = H.lz4mt_compress_via(lib, b"abc", 131072, threads=1, level=10)
-    assert rv == ERR(E_PARAM) and lib.LZ4MT_isError(rv)
-    assert lib.LZ4MT_getErrorString(rv) == b"Compression parameter is out of bound"
+    # every level the reference accepts is served (12 = LZ4HC optimal parser)
+    rv, s12, _, _ = H.lz4mt_compress_via(lib, b"abc" * 50, 131072, threads=1, level=12)
+    assert rv == 0 and s12 == H.oracle_compress_level(b"abc" * 50, 131072, 12)
+    assert lib.LZ4MT_getErrorString(ERR(E_PARAM)) == b"Compression parameter is out of bound"
     assert not lib.LZ4MT_isError(0)
 
 

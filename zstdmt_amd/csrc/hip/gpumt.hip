@@ -607,7 +607,7 @@ int gpumt_lz4_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t ch
 	return gpumt_lz4_compress_batch_level(h, d_in, n, chunk, d_slots, slot_stride, d_rec_len, 1, s);
 }
 
-int gpumt_lz4_level_supported(int level) { return level >= 1 && level <= 9; }
+int gpumt_lz4_level_supported(int level) { return level >= 1 && level <= 12; }
 
 int gpumt_lz4_compress_batch_level(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk,
 				   void *d_slots, size_t slot_stride, uint32_t *d_rec_len, int level, int s)
@@ -645,11 +645,11 @@ int gpumt_lz4_compress_batch_level(gpumt_ctx *h, const void *d_in, size_t n, siz
 		eprof = h->d_prof;
 	}
 	if (hc) {
-		/* levels 3..9: hash-chain parser, nbSearches = 1 << (level - 1) (liblz4 clTable) */
+		/* levels 3..9: hash-chain parser, 10..12: optimal parser (lz4_enc_hc.hip) */
 		hipLaunchKernelGGL(zmt_lz4hc_enc_kernel, dim3((unsigned)hc_grid), dim3(64), 0, h->st[s],
 				   (const u8 *)d_in, (u64)n, (u32)chunk, (u32)nrec, (u8 *)d_slots,
 				   (u64)slot_stride, d_rec_len, (const u32 *)chk,
-				   (u8 *)h->scratch[0][s] + hc_base, 1 << (level - 1));
+				   (u8 *)h->scratch[0][s] + hc_base, level);
 	} else if (chunk <= 65536) {
 		/* every record is a single independent block: byU16 table */
 		hipLaunchKernelGGL(zmt_lz4_enc3_u16_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],

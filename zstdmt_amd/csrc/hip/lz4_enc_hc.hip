@@ -1,5 +1,5 @@
 /*
- * lz4_enc_hc.hip -- LZ4 frame encoder for the "HC" levels 3..9 of lz4-mt, bit-exact.
+ * lz4_enc_hc.hip -- LZ4 frame encoder for the "HC" levels 3..12 of lz4-mt, bit-exact.
  *
  * The reference hands levels >= 3 to LZ4F_compressFrame's HC path (prefs.compressionLevel,
  * /root/reference/lib/lz4-mt_compress.c:141-146, call :281; the CLI default is level 3,
@@ -8,7 +8,9 @@
  * most 4 / 8 / 16 / 32 / 64 / 128 / 256 chain links (level 9 also jumps over runs of one byte value:
  * the "pattern analysis"), and a lazy evaluation over up to three overlapping matches decides what
  * is emitted (oracle/lz4hc_oracle.c restates it and is pinned against the reference build).  Levels
- * 10..12 (optimal parser) are not here.
+ * 10..12 are liblz4's optimal parser on the same chains (96 / 512 / 16 384 links, chain swap and
+ * pattern analysis on): a table of the cheapest way to reach each of the next <= 4 096 positions, filled
+ * with a search wherever one can pay and read backwards.
  *
  * The parse is inherently serial per chunk (what is found depends on everything inserted before),
  * so the unit of parallelism is the chunk: one wave per chunk on a persistent grid, tables in a
@@ -32,13 +34,20 @@
 #define HC_MFLIMIT 12u
 #define HC_LASTLITERALS 5u
 #define HC_OPTIMAL_ML 18
-#define HC_SCRATCH (32768u * 4u + HC_MAXD * 2u) /* == GPUMT_LZ4HC_SCRATCH */
+#define HC_OPT_NUM 4096
+#define HC_TRAILING 3
+#define HC_OPT_ROWS (HC_OPT_NUM + HC_TRAILING + 5) /* entries of one column of the optimal parser's table */
+#define HC_SCRATCH (32768u * 4u + HC_MAXD * 2u + 4u * HC_OPT_ROWS * 4u + 128u) /* == GPUMT_LZ4HC_SCRATCH */
+
+static_assert(HC_SCRATCH == 327936u, "keep GPUMT_LZ4HC_SCRATCH (include/gpumt.h) in step");
 
 struct HcState {
 	u32 *hash;
 	u16 *chain;
 	const u8 *src;
 	u32 next_to_update;
+	/* levels 10..12: the price table of the optimal parser, one column per field */
+	int *o_price, *o_off, *o_mlen, *o_litlen;
 };
 
 static __device__ __forceinline__ u32 hc_hash(u32 v) { return (v * 2654435761u) >> (32 - HC_HASH_LOG); }
@@ -155,10 +164,10 @@ static __device__ u32 hc_reverse_count_pattern(const u8 *a, u32 room, u32 patter
 	}
 }
 
-/* LZ4HC_InsertAndGetWiderMatch (no chain swap: levels 3..9; more than 128 attempts = level 9 turns the
- * repeated-pattern analysis on, as liblz4 does) */
-static __device__ int hc_wider(HcState &H, u32 ip, u32 low_limit, u32 high_limit, int longest, u32 *mpos,
-			       u32 *spos, int max_attempts, int lane)
+/* LZ4HC_InsertAndGetWiderMatch.  Levels 3..9 never swap chains and analyse patterns beyond 128
+ * attempts (level 9), as liblz4 does; the optimal parser (levels 10..12) turns both on. */
+static __device__ int hc_wider_core(HcState &H, u32 ip, u32 low_limit, u32 high_limit, int longest, u32 *mpos,
+				    u32 *spos, int max_attempts, bool pattern_analysis, bool chain_swap, int lane)
 {
 	const u8 *const s = H.src;
 	const u32 ip_index = ip + HC_BASE;
@@ -166,14 +175,14 @@ static __device__ int hc_wider(HcState &H, u32 ip, u32 low_limit, u32 high_limit
 	const int look_back = (int)(ip - low_limit);
 	const u32 pattern = uld32(s + ip);
 	int attempts = max_attempts;
-	const bool pattern_analysis = max_attempts > 128;
 	int repeat = 0; /* 0 untested, 1 not a repetition, 2 confirmed */
-	u32 src_pattern_len = 0;
+	u32 src_pattern_len = 0, match_chain_pos = 0;
 
 	hc_insert(H, ip_index, lane);
 	u32 match_index = hc_uld_hash(H, hc_hash(pattern));
 	while (match_index >= lowest && attempts > 0) {
 		const u32 m = match_index - HC_BASE;
+		int match_len = 0;
 		attempts--;
 		if (uld16(s + low_limit + (u32)longest - 1) == uld16(s + m - (u32)look_back + (u32)longest - 1)) {
 			if (uld32(s + m) == pattern) {
@@ -185,6 +194,7 @@ static __device__ int hc_wider(HcState &H, u32 ip, u32 low_limit, u32 high_limit
 				int ml = (int)HC_MINMATCH +
 					 (int)hc_count(s + ip + HC_MINMATCH, s + m + HC_MINMATCH, high_limit - (ip + HC_MINMATCH), lane);
 				ml -= back;
+				match_len = ml;
 				if (ml > longest) {
 					longest = ml;
 					*mpos = (u32)((int)m + back);
@@ -192,7 +202,32 @@ static __device__ int hc_wider(HcState &H, u32 ip, u32 low_limit, u32 high_limit
 				}
 			}
 		}
-		if (pattern_analysis && hc_uld_chain(H, match_index) == 1) {
+		if (chain_swap && match_len == longest) {
+			/* a match as long as the best one: go on along the chain of the position inside it whose
+			 * next candidate lies farthest back (forward searches only) */
+			if (match_index + (u32)longest <= ip_index) {
+				const int k_trigger = 4;
+				u32 dist_to_next = 1;
+				const int end = longest - (int)HC_MINMATCH + 1;
+				int step = 1, accel = 1 << k_trigger;
+				for (int pos = 0; pos < end; pos += step) {
+					const u32 cand_dist = hc_uld_chain(H, match_index + (u32)pos);
+					step = (accel++ >> k_trigger);
+					if (cand_dist > dist_to_next) {
+						dist_to_next = cand_dist;
+						match_chain_pos = (u32)pos;
+						accel = 1 << k_trigger;
+					}
+				}
+				if (dist_to_next > 1) {
+					if (dist_to_next > match_index)
+						break;
+					match_index -= dist_to_next;
+					continue;
+				}
+			}
+		}
+		if (pattern_analysis && match_chain_pos == 0 && hc_uld_chain(H, match_index) == 1) {
 			/* the candidate sits inside a run of one byte value: jump to where that run can match
 			 * the run at ip in full instead of walking it link by link (oracle/lz4hc_oracle.c) */
 			const u32 cand = match_index - 1;
@@ -239,9 +274,14 @@ static __device__ int hc_wider(HcState &H, u32 ip, u32 low_limit, u32 high_limit
 				}
 			}
 		}
-		match_index -= hc_uld_chain(H, match_index);
+		match_index -= hc_uld_chain(H, match_index + match_chain_pos);
 	}
 	return longest;
+}
+static __device__ __forceinline__ int hc_wider(HcState &H, u32 ip, u32 low_limit, u32 high_limit, int longest, u32 *mpos,
+					       u32 *spos, int max_attempts, int lane)
+{
+	return hc_wider_core(H, ip, low_limit, high_limit, longest, mpos, spos, max_attempts, max_attempts > 128, false, lane);
 }
 
 /* LZ4HC_encodeSequence: 1 when the output limit is hit.  op / oend are offsets into dst. */
@@ -452,6 +492,240 @@ last_literals:
 	return op;
 }
 
+/* ---- levels 10..12: LZ4HC_compress_optimal (oracle/lz4hc_oracle.c: hc_opt_block) ----------------
+ * The price table lives in the wave's global scratch, one column per field.  The loops over the
+ * lengths of a match (up to 4 095 prices each) run 64 lengths per step; the position loop, the searches
+ * and the reverse traversal are wave-uniform.  Lane 0 owns single-entry stores; wv_sync() between a
+ * phase that stores and one that loads. */
+static __device__ __forceinline__ int hc_lit_price(int litlen)
+{
+	int price = litlen;
+	if (litlen >= 15)
+		price += 1 + (litlen - 15) / 255;
+	return price;
+}
+static __device__ __forceinline__ int hc_seq_price(int litlen, int mlen)
+{
+	int price = 1 + 2 + hc_lit_price(litlen);
+	if (mlen >= 15 + (int)HC_MINMATCH)
+		price += 1 + (mlen - (15 + (int)HC_MINMATCH)) / 255;
+	return price;
+}
+static __device__ __forceinline__ int hc_uld_int(const int *p) { return (int)wv_readfirst((u32)*p); }
+static __device__ __forceinline__ void hc_opt_set(HcState &H, int pos, int price, int off, int mlen, int litlen, int lane)
+{
+	if (lane == 0) {
+		H.o_price[pos] = price;
+		H.o_off[pos] = off;
+		H.o_mlen[pos] = mlen;
+		H.o_litlen[pos] = litlen;
+	}
+}
+static __device__ void hc_opt_trailing(HcState &H, int last_match_pos, int lane)
+{
+	wv_sync();
+	const int base = hc_uld_int(H.o_price + last_match_pos);
+	if (lane >= 1 && lane <= HC_TRAILING) {
+		H.o_mlen[last_match_pos + lane] = 1;
+		H.o_off[last_match_pos + lane] = 0;
+		H.o_litlen[last_match_pos + lane] = lane;
+		H.o_price[last_match_pos + lane] = base + hc_lit_price(lane);
+	}
+	wv_sync();
+}
+static __device__ void hc_find_longer(HcState &H, u32 ip, u32 high_limit, int min_len, int nb_searches, int *len, int *off,
+				      int lane)
+{
+	u32 mpos = 0, spos = ip;
+	const int ml = hc_wider_core(H, ip, ip, high_limit, min_len, &mpos, &spos, nb_searches, true, true, lane);
+	*len = 0;
+	*off = 0;
+	if (ml <= min_len)
+		return;
+	*len = ml;
+	*off = (int)(ip - mpos);
+}
+
+static __device__ u32 hc_opt_block(HcState &H, u32 start, u32 n, u8 *dst, u32 cap, int nb_searches, int sufficient_len,
+				   bool full_update, int lane)
+{
+	const u8 *const s = H.src;
+	u32 ip = start, anchor = start, op = 0;
+	const u32 iend = start + n;
+	const u32 mflimit = iend - HC_MFLIMIT, matchlimit = iend - HC_LASTLITERALS;
+	const u32 oend = cap;
+
+	if (sufficient_len >= HC_OPT_NUM)
+		sufficient_len = HC_OPT_NUM - 1;
+	if (n < HC_MFLIMIT + 1)
+		goto last_literals;
+	while (ip <= mflimit) {
+		const int llen = (int)(ip - anchor);
+		int best_mlen, best_off, cur, last_match_pos = 0, first_len, first_off;
+
+		hc_find_longer(H, ip, matchlimit, (int)HC_MINMATCH - 1, nb_searches, &first_len, &first_off, lane);
+		if (first_len == 0) {
+			ip++;
+			continue;
+		}
+		if (first_len > sufficient_len) {
+			if (hc_encode(s, dst, &ip, &op, &anchor, first_len, ip - (u32)first_off, oend, lane))
+				return 0;
+			continue;
+		}
+		/* prices of the first positions (literals) and of the first match */
+		if (lane < (int)HC_MINMATCH) {
+			H.o_mlen[lane] = 1;
+			H.o_off[lane] = 0;
+			H.o_litlen[lane] = llen + lane;
+			H.o_price[lane] = hc_lit_price(llen + lane);
+		}
+		for (int ml = (int)HC_MINMATCH + lane; ml <= first_len; ml += 64) {
+			H.o_mlen[ml] = ml;
+			H.o_off[ml] = first_off;
+			H.o_litlen[ml] = llen;
+			H.o_price[ml] = hc_seq_price(llen, ml);
+		}
+		last_match_pos = first_len;
+		hc_opt_trailing(H, last_match_pos, lane);
+		/* further positions */
+		for (cur = 1; cur < last_match_pos; cur++) {
+			const u32 cur_pos = ip + (u32)cur;
+			int new_len, new_off;
+			if (cur_pos > mflimit)
+				break;
+			const int p_cur = hc_uld_int(H.o_price + cur), p_next = hc_uld_int(H.o_price + cur + 1);
+			if (full_update) {
+				if (p_next <= p_cur && hc_uld_int(H.o_price + cur + (int)HC_MINMATCH) < p_cur + 3)
+					continue;
+			} else {
+				if (p_next <= p_cur)
+					continue;
+			}
+			hc_find_longer(H, cur_pos, matchlimit, full_update ? (int)HC_MINMATCH - 1 : last_match_pos - cur, nb_searches,
+				       &new_len, &new_off, lane);
+			if (!new_len)
+				continue;
+			if (new_len > sufficient_len || new_len + cur >= HC_OPT_NUM) {
+				best_mlen = new_len;
+				best_off = new_off;
+				last_match_pos = cur + 1;
+				goto encode;
+			}
+			const int cur_mlen = hc_uld_int(H.o_mlen + cur), cur_litlen = hc_uld_int(H.o_litlen + cur);
+			/* before the match: literals (three entries, lanes 1..3) */
+			{
+				const int litlen = lane;
+				if (litlen >= 1 && litlen < (int)HC_MINMATCH) {
+					const int price = p_cur - hc_lit_price(cur_litlen) + hc_lit_price(cur_litlen + litlen);
+					const int pos = cur + litlen;
+					if (price < H.o_price[pos]) {
+						H.o_mlen[pos] = 1;
+						H.o_off[pos] = 0;
+						H.o_litlen[pos] = cur_litlen + litlen;
+						H.o_price[pos] = price;
+					}
+				}
+			}
+			wv_sync();
+			/* the match at cur: one price per length, 64 lengths per step */
+			{
+				int ll, base;
+				if (cur_mlen == 1) {
+					ll = cur_litlen;
+					base = (cur > ll) ? hc_uld_int(H.o_price + cur - ll) : 0;
+				} else {
+					ll = 0;
+					base = p_cur;
+				}
+				bool took_last = false;
+				for (int ml0 = (int)HC_MINMATCH; ml0 <= new_len; ml0 += 64) {
+					const int ml = ml0 + lane;
+					if (ml <= new_len) {
+						const int pos = cur + ml;
+						const int price = base + hc_seq_price(ll, ml);
+						if (pos > last_match_pos + HC_TRAILING || price <= H.o_price[pos]) {
+							if (ml == new_len)
+								took_last = true;
+							H.o_mlen[pos] = ml;
+							H.o_off[pos] = new_off;
+							H.o_litlen[pos] = ll;
+							H.o_price[pos] = price;
+						}
+					}
+				}
+				if (wv_any(took_last) && last_match_pos < cur + new_len)
+					last_match_pos = cur + new_len;
+			}
+			hc_opt_trailing(H, last_match_pos, lane);
+		}
+		wv_sync();
+		best_mlen = hc_uld_int(H.o_mlen + last_match_pos);
+		best_off = hc_uld_int(H.o_off + last_match_pos);
+		cur = last_match_pos - best_mlen;
+encode:
+		/* reverse traversal: the chosen sequences, first to last */
+		wv_sync();
+		{
+			int candidate_pos = cur, selected_ml = best_mlen, selected_off = best_off;
+			for (;;) {
+				const int next_ml = hc_uld_int(H.o_mlen + candidate_pos), next_off = hc_uld_int(H.o_off + candidate_pos);
+				wv_sync();
+				if (lane == 0) {
+					H.o_mlen[candidate_pos] = selected_ml;
+					H.o_off[candidate_pos] = selected_off;
+				}
+				selected_ml = next_ml;
+				selected_off = next_off;
+				if (next_ml > candidate_pos)
+					break;
+				candidate_pos -= next_ml;
+			}
+		}
+		wv_sync();
+		{
+			int r = 0;
+			while (r < last_match_pos) {
+				const int ml = hc_uld_int(H.o_mlen + r), offset = hc_uld_int(H.o_off + r);
+				if (ml == 1) {
+					ip++;
+					r++;
+					continue;
+				}
+				r += ml;
+				if (hc_encode(s, dst, &ip, &op, &anchor, ml, ip - (u32)offset, oend, lane))
+					return 0;
+			}
+		}
+		wv_sync();
+	}
+last_literals:
+	{
+		const u32 run = iend - anchor;
+		const u32 lit_len = (run + 255 - 15) / 255;
+		if (op + 1 + lit_len + run > oend)
+			return 0;
+		if (run >= 15) {
+			const u32 acc = run - 15, n255 = acc / 255;
+			if (lane == 0)
+				dst[op] = 15u << 4;
+			op++;
+			for (u32 i = (u32)lane; i < n255; i += 64)
+				dst[op + i] = 255;
+			if (lane == 0)
+				dst[op + n255] = (u8)(acc - n255 * 255);
+			op += n255 + 1;
+		} else {
+			if (lane == 0)
+				dst[op] = (u8)(run << 4);
+			op++;
+		}
+		wave_copy(dst + op, s + anchor, run, lane);
+		op += run;
+	}
+	return op;
+}
+
 /*
  * Persistent grid: wave w takes records w, w + gridDim.x, ...; scratch + w * HC_SCRATCH holds its
  * hash table and chain.  Record layout as the level-1 encoder writes it (lz4_enc3.hip).
@@ -459,12 +733,19 @@ last_literals:
 extern "C" __global__ void __launch_bounds__(64)
 zmt_lz4hc_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nrec, u8 *__restrict__ slots,
 		     u64 slot_stride, u32 *__restrict__ rec_len, const u32 *__restrict__ chk,
-		     u8 *__restrict__ scratch, int max_attempts)
+		     u8 *__restrict__ scratch, int level)
 {
+	/* liblz4 clTable: searches per position, and for the optimal parser the "good enough" length */
+	const int max_attempts = level <= 9 ? 1 << (level - 1) : level == 10 ? 96 : level == 11 ? 512 : 16384;
+	const int sufficient_len = level == 10 ? 64 : level == 11 ? 128 : HC_OPT_NUM;
 	const int lane = wv_lane();
 	HcState H;
 	H.hash = (u32 *)(scratch + (u64)blockIdx.x * HC_SCRATCH);
 	H.chain = (u16 *)(scratch + (u64)blockIdx.x * HC_SCRATCH + 32768u * 4u);
+	H.o_price = (int *)(scratch + (u64)blockIdx.x * HC_SCRATCH + 32768u * 4u + HC_MAXD * 2u);
+	H.o_off = H.o_price + HC_OPT_ROWS;
+	H.o_mlen = H.o_off + HC_OPT_ROWS;
+	H.o_litlen = H.o_mlen + HC_OPT_ROWS;
 	for (u32 rec = blockIdx.x; rec < nrec; rec += gridDim.x) {
 		const u64 start = (u64)rec * chunk;
 		const u32 len = (u32)((n - start) < (u64)chunk ? (n - start) : (u64)chunk);
@@ -499,7 +780,8 @@ zmt_lz4hc_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nrec, u8 *
 		H.next_to_update = HC_BASE;
 		for (u32 pos = 0; pos < len; pos += ZMT_BLOCK) {
 			const u32 blen = len - pos < ZMT_BLOCK ? len - pos : ZMT_BLOCK;
-			u32 c = hc_block(H, pos, blen, dst + op + 4, blen - 1, max_attempts, lane);
+			u32 c = level >= 10 ? hc_opt_block(H, pos, blen, dst + op + 4, blen - 1, max_attempts, sufficient_len, level == 12, lane)
+					    : hc_block(H, pos, blen, dst + op + 4, blen - 1, max_attempts, lane);
 			u32 bh = c;
 			if (c == 0) { /* did not shrink: stored; the chains keep what the attempt inserted */
 				wave_copy(dst + op + 4, src + pos, blen, lane);

@@ -264,7 +264,7 @@ size_t LZ4MT_compressCCtx(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *rdwr)
 
 	if (!ctx)
 		return ERROR(compressionParameter_unsupported); /* lz4-mt_compress.c:317-318 */
-	if (!gpumt_lz4_level_supported(ctx->level)) /* 10..12: the optimal parser */
+	if (!gpumt_lz4_level_supported(ctx->level)) /* cannot happen for a context createCCtx accepted */
 		return ERROR(compressionParameter_unsupported);
 	ctx->io = rdwr;
 	ctx->maxrec = BATCH_MIN / (size_t)ctx->inputsize;
