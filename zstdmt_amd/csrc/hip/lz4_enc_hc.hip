@@ -184,8 +184,29 @@ static __device__ int hc_wider_core(HcState &H, u32 ip, u32 low_limit, u32 high_
 		const u32 m = match_index - HC_BASE;
 		int match_len = 0;
 		attempts--;
-		if (uld16(s + low_limit + (u32)longest - 1) == uld16(s + m - (u32)look_back + (u32)longest - 1)) {
-			if (uld32(s + m) == pattern) {
+		/* everything this candidate can need in ONE memory round trip: lanes 0..4 each fetch a
+		 * different dword -- the two tails of the quick test, the candidate's first four bytes, the
+		 * chain link that is followed and the link at the candidate itself (pattern analysis) */
+		u32 d_follow, d_here, tail_a, tail_b, cand4;
+		{
+			const u8 *addr = s + low_limit + (u32)longest - 1;
+			if (lane == 1)
+				addr = s + m - (u32)look_back + (u32)longest - 1;
+			else if (lane == 2)
+				addr = s + m;
+			else if (lane == 3)
+				addr = (const u8 *)(H.chain + ((match_index + match_chain_pos) & (HC_MAXD - 1)));
+			else if (lane == 4)
+				addr = (const u8 *)(H.chain + (match_index & (HC_MAXD - 1)));
+			const u32 v = ld32u(addr);
+			tail_a = wv_readlane(v, 0) & 0xFFFFu;
+			tail_b = wv_readlane(v, 1) & 0xFFFFu;
+			cand4 = wv_readlane(v, 2);
+			d_follow = wv_readlane(v, 3) & 0xFFFFu;
+			d_here = wv_readlane(v, 4) & 0xFFFFu;
+		}
+		if (tail_a == tail_b) {
+			if (cand4 == pattern) {
 				int back = 0;
 				if (look_back) {
 					const int min_i = -look_back, min_m = -(int)m;
@@ -225,9 +246,10 @@ static __device__ int hc_wider_core(HcState &H, u32 ip, u32 low_limit, u32 high_
 					match_index -= dist_to_next;
 					continue;
 				}
+				d_follow = hc_uld_chain(H, match_index + match_chain_pos); /* the position may have moved */
 			}
 		}
-		if (pattern_analysis && match_chain_pos == 0 && hc_uld_chain(H, match_index) == 1) {
+		if (pattern_analysis && match_chain_pos == 0 && d_here == 1) {
 			/* the candidate sits inside a run of one byte value: jump to where that run can match
 			 * the run at ip in full instead of walking it link by link (oracle/lz4hc_oracle.c) */
 			const u32 cand = match_index - 1;
@@ -274,7 +296,7 @@ static __device__ int hc_wider_core(HcState &H, u32 ip, u32 low_limit, u32 high_
 				}
 			}
 		}
-		match_index -= hc_uld_chain(H, match_index + match_chain_pos);
+		match_index -= d_follow;
 	}
 	return longest;
 }
