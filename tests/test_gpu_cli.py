@@ -166,3 +166,29 @@ def test_list_mode(tmp_path):
     zb.write_bytes(bytes(bad))
     p = run([LZ4, "-l", str(zb)], check=False)
     assert p.returncode != 0 and p.stdout.decode().splitlines()[1].split()[:3] == ["-", "-", "-"]
+
+
+@pytest.mark.skipif(H.liblz4_frame(b"x") is None, reason="liblz4 not on this box")
+def test_plain_streams_are_decoded_incrementally():
+    """A plain .lz4 / .zst stream (frames of the lz4 / zstd tools, no skippable records) larger than
+    several device batches: the engines read ahead about one batch, decode the complete frames and keep
+    the tail (GPUMT_BATCH_MB=16 makes a 90 MiB stream many rounds; one frame is larger than a batch)."""
+    import subprocess
+    parts = [cases.text(5_000_000 + 300_000 * i, seed=70 + i) for i in range(14)] + [cases.text(40 << 20, seed=99)]
+    parts += [cases.rnd(3_000_000, 5), b"", cases.text(1_234_567, seed=3)]
+    data = b"".join(parts)
+    env = dict(os.environ, GPUMT_BATCH_MB="16")
+    lz = b"".join(H.liblz4_frame(p, content_size=i & 1) for i, p in enumerate(parts))
+    r = subprocess.run([os.path.join(BIN, "lz4cat-mt")], input=lz, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-300:]
+    assert r.stdout == data
+    zs = b"".join(H.libzstd_frame(p, content_size=i & 1, checksum=(i >> 1) & 1) for i, p in enumerate(parts))
+    r = subprocess.run([os.path.join(BIN, "zstdcat-mt")], input=zs, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-300:]
+    assert r.stdout == data
+    # a stream cut inside its last frame is an error, after everything before it was written
+    r = subprocess.run([os.path.join(BIN, "lz4cat-mt")], input=lz[:-3], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=env, timeout=600)
+    assert r.returncode != 0 and data.startswith(r.stdout)

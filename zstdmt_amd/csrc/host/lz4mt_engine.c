@@ -587,23 +587,43 @@ static size_t plain_decompress(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, const uint8_t 
 	const size_t piece = chunk < 65536 ? 65536 : chunk;
 	uint8_t *raw = (uint8_t *)malloc(chunk + 4);
 	size_t cap = chunk + 4, n = 4, err = 0, ip = 0;
+	size_t want_ahead = BATCH_BYTES; /* input buffered before a round of frames is split off */
+	int eof = 0;
 	struct dslot *s = &ctx->s[0];
 	gpumt_ctx *g = ctx->gpu;
 	if (!raw)
 		return ERROR(memory_allocation);
 	memcpy(raw, first, 4);
-	for (;;) { /* read to the end in inputsize requests (:462-476) */
+	ctx->insize = 4;
+	ctx->outsize = 0;
+	/* The input is consumed incrementally: read (in inputsize requests, :462-476) until about one
+	 * batch of input is buffered or the stream ends, decode the complete frames of what is there, keep
+	 * the incomplete tail, repeat -- the host holds about two batches of input plus the largest
+	 * frame, not the whole stream, and output starts before the input ends. */
+	for (;;) {
+	int need_more = 0;
+	while (!eof && n - ip < want_ahead) {
 		LZ4MT_Buffer b;
 		int rv;
+		if (ip && ip == n) {
+			n = 0;
+			ip = 0;
+		}
 		if (n + chunk > cap) {
-			uint8_t *nr;
-			cap = cap * 2 + chunk;
-			nr = (uint8_t *)realloc(raw, cap);
-			if (!nr) {
-				free(raw);
-				return ERROR(memory_allocation);
+			if (ip >= chunk) { /* drop what is decoded instead of growing */
+				memmove(raw, raw + ip, n - ip);
+				n -= ip;
+				ip = 0;
+			} else {
+				uint8_t *nr;
+				cap = cap * 2 + chunk;
+				nr = (uint8_t *)realloc(raw, cap);
+				if (!nr) {
+					free(raw);
+					return ERROR(memory_allocation);
+				}
+				raw = nr;
 			}
-			raw = nr;
 		}
 		b.buf = raw + n;
 		b.size = chunk;
@@ -613,12 +633,13 @@ static size_t plain_decompress(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, const uint8_t 
 			free(raw);
 			return mt_error(rv);
 		}
-		if (b.size == 0)
+		if (b.size == 0) {
+			eof = 1;
 			break;
+		}
 		n += b.size;
+		ctx->insize += b.size;
 	}
-	ctx->insize = n;
-	ctx->outsize = 0;
 	while (ip < n && !err) {
 		size_t in_bytes = 0, out_bytes = 0, nrec = 0, jp = ip;
 		if (dbuf_want(g, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1)) {
@@ -632,11 +653,19 @@ static size_t plain_decompress(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, const uint8_t 
 			if (n - jp >= 8 && (rd32(raw + jp) & 0xFFFFFFF0u) == LZ4FMT_MAGIC_SKIPPABLE) {
 				const size_t sk = 8 + (size_t)rd32(raw + jp + 4);
 				if (sk > n - jp) {
-					err = ERROR(compression_library);
+					if (!eof)
+						need_more = 1; /* the rest of it has not been read yet */
+					else
+						err = ERROR(compression_library);
 					break;
 				}
 				jp += sk;
 				continue;
+			}
+			if (!eof && (n - jp < 8 || (rd32(raw + jp) == LZ4FMT_MAGICNUMBER &&
+						   !lz4_frame_extent(raw + jp, n - jp, &bound, &supported)))) {
+				need_more = 1; /* an incomplete frame (or a damaged one: the end of the input will tell) */
+				break;
 			}
 			if (n - jp < 4 || rd32(raw + jp) != LZ4FMT_MAGICNUMBER ||
 			    !(flen = lz4_frame_extent(raw + jp, n - jp, &bound, &supported)) || !supported ||
@@ -659,6 +688,8 @@ static size_t plain_decompress(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, const uint8_t 
 			break;
 		if (!nrec) {
 			ip = jp;
+			if (need_more)
+				break;
 			continue;
 		}
 		m_out_off(s, 0)[nrec] = out_bytes;
@@ -728,6 +759,13 @@ static size_t plain_decompress(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, const uint8_t 
 			}
 		}
 		ip = jp;
+		if (need_more)
+			break;
+	}
+	if (err || (eof && ip >= n))
+		break;
+	if (need_more && n - ip >= want_ahead)
+		want_ahead = (n - ip) * 2; /* a frame larger than what is buffered: read on */
 	}
 	free(raw);
 	return err;

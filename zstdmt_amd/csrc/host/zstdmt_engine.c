@@ -663,25 +663,43 @@ static size_t plain_decompress(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, const uint8_
 {
 	uint8_t *raw = (uint8_t *)malloc(ZSTD_IN_CHUNK);
 	size_t cap = ZSTD_IN_CHUNK, n = nfirst, err = 0, ip = 0;
+	size_t want_ahead = BATCH_BYTES; /* input buffered before a round of frames is split off */
+	int eof = at_eof, first_read = 1;
 	struct dslot *s = &ctx->s[0];
 	gpumt_ctx *g = ctx->gpu;
 	if (!raw)
 		return ZSTDCB_ERROR(memory_allocation);
 	memcpy(raw, first, nfirst);
-	/* ---- read to the end: first request fills the first buffer behind the sniffed bytes (:590-609) ---- */
-	while (!at_eof) {
+	ctx->insize += nfirst;
+	/* The input is consumed incrementally: read until about one batch of input is buffered or the
+	 * stream ends (first request fills the first buffer behind the sniffed bytes, :590-609), decode
+	 * the complete frames of what is there, keep the incomplete tail, repeat -- the host holds about
+	 * two batches of input plus the largest frame, not the whole stream. */
+	for (;;) {
+	int need_more = 0;
+	while (!eof && n - ip < want_ahead) {
 		ZSTDCB_Buffer b;
 		int rv;
-		const size_t want = n == nfirst ? ZSTD_IN_CHUNK - nfirst : ZSTD_IN_CHUNK;
+		const size_t want = first_read ? ZSTD_IN_CHUNK - nfirst : ZSTD_IN_CHUNK;
+		if (ip && ip == n) {
+			n = 0;
+			ip = 0;
+		}
 		if (n + want > cap) {
-			uint8_t *nr;
-			cap = cap * 2 + want;
-			nr = (uint8_t *)realloc(raw, cap);
-			if (!nr) {
-				free(raw);
-				return ZSTDCB_ERROR(memory_allocation);
+			if (ip >= want) { /* drop what is decoded instead of growing */
+				memmove(raw, raw + ip, n - ip);
+				n -= ip;
+				ip = 0;
+			} else {
+				uint8_t *nr;
+				cap = cap * 2 + want;
+				nr = (uint8_t *)realloc(raw, cap);
+				if (!nr) {
+					free(raw);
+					return ZSTDCB_ERROR(memory_allocation);
+				}
+				raw = nr;
 			}
-			raw = nr;
 		}
 		b.buf = raw + n;
 		b.size = want;
@@ -691,11 +709,14 @@ static size_t plain_decompress(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, const uint8_
 			free(raw);
 			return mt_error(rv);
 		}
-		if (b.size == 0)
+		first_read = 0;
+		if (b.size == 0) {
+			eof = 1;
 			break;
+		}
 		n += b.size;
+		ctx->insize += b.size;
 	}
-	ctx->insize += n;
 	/* ---- frames, in batches the device buffers can hold ---- */
 	while (ip < n && !err) {
 		size_t in_bytes = 0, out_bytes = 0, nrec = 0;
@@ -712,11 +733,19 @@ static size_t plain_decompress(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, const uint8_
 			if (n - jp >= 8 && (rd32(raw + jp) & 0xFFFFFFF0u) == ZSTDCB_MAGIC_SKIPPABLE) {
 				const size_t sk = 8 + (size_t)rd32(raw + jp + 4);
 				if (sk > n - jp) {
-					err = ZSTDCB_ERROR(compression_library);
+					if (!eof)
+						need_more = 1; /* the rest of it has not been read yet */
+					else
+						err = ZSTDCB_ERROR(compression_library);
 					break;
 				}
 				jp += sk;
 				continue;
+			}
+			if (!eof && (n - jp < 8 || (rd32(raw + jp) == ZSTDCB_MAGICNUMBER_MAX &&
+						   !zstd_frame_extent(raw + jp, n - jp, &bound, &sized)))) {
+				need_more = 1; /* an incomplete frame (or a damaged one: the end of the input will tell) */
+				break;
 			}
 			if (n - jp < 4 || rd32(raw + jp) != ZSTDCB_MAGICNUMBER_MAX ||
 			    !(flen = zstd_frame_extent(raw + jp, n - jp, &bound, &sized)) || flen > 0xFFFFFFF0u ||
@@ -740,6 +769,8 @@ static size_t plain_decompress(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, const uint8_
 			break;
 		if (!nrec) { /* only skippable frames were left */
 			ip = jp;
+			if (need_more)
+				break;
 			continue;
 		}
 		m_out_off(s, 0)[nrec] = out_bytes;
@@ -798,6 +829,13 @@ static size_t plain_decompress(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, const uint8_
 			err = plain_write(ctx, io, (const uint8_t *)s->out.h + m_out_off(s, 0)[i], m_out_len(s, 0)[i]);
 		}
 		ip = jp;
+		if (need_more)
+			break;
+	}
+	if (err || (eof && ip >= n))
+		break;
+	if (need_more && n - ip >= want_ahead)
+		want_ahead = (n - ip) * 2; /* a frame larger than what is buffered: read on */
 	}
 	free(raw);
 	return err;
