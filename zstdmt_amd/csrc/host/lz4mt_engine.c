@@ -540,7 +540,7 @@ static size_t dp_drain(void *a, int si)
  * A stream that starts with an LZ4 frame instead of a skippable record is decoded by the reference
  * on one thread with streaming LZ4F_decompress (st_decompress, lz4-mt_decompress.c:391-483): files of
  * the lz4 tool, any number of frames, typically 4 MiB linked blocks and no content size.  Here the
- * input is read to its end, split into frames on the host by walking the block headers (LZ4 frame
+ * input is read about one batch ahead, split into frames on the host by walking the block headers (LZ4 frame
  * format: FLG / BD, optional content size and dictionary id, 4-byte block sizes, end mark, optional
  * content checksum) and decoded by the frame-serial kernel, one wave per frame; a frame that does not
  * state its content size gets blocks x block-maximum as capacity and the decoder reports the size.

@@ -574,7 +574,7 @@ static size_t dp_drain(void *a, int si)
  * The reference hands anything that starts with a zstd frame (and is not the old zstdmt layout) to
  * its single-threaded ZSTD_decompressStream loop (st_decompress, zstd-mt_decompress.c:552-687):
  * frames of the zstd CLI / library, any number of them, possibly without a content size and with
- * skippable frames in between.  Here the input is read to its end (same request sizes as the
+ * skippable frames in between.  Here the input is read about one batch ahead (same request sizes as the
  * reference: ZSTD_DStreamInSize() = 128 KiB + 3), split into frames on the host by walking the
  * block headers (RFC 8878 3.1.1.2), and decoded by the same device kernels, one wave per frame;
  * frames that do not state their content size get the sum of their block bounds as capacity and the
