@@ -3,7 +3,7 @@
  * (reference call site /root/reference/lib/lz4-mt_compress.c:281), rebuilt
  * around what the MI355X measurements say is expensive: dependent global loads and wide gathers.
  *
- *  - The chunk's input is streamed through a 2 KiB LDS ring (1 KiB coalesced refills), so hashing,
+ *  - The chunk's input is streamed through a 1 KiB LDS ring (512-byte coalesced refills), so hashing,
  *    the ip side of catch-up / match counting, the re-match test and literal sources are LDS reads.
  *  - The search evaluates the reference's probe sequence in batches of 16, 16, 32, 64, 64, ...
  *    lanes (lane j = probe kbase + j).  Most matches sit within the first 16 probes, so the one
@@ -12,7 +12,11 @@
  *  - One cooperative fetch of [match-32, match+96) then serves catch-up (backward) and the match
  *    length (forward) for the common case; longer runs continue 64 bytes at a time.
  *  - For chunks <= 128 KiB the 4096-entry table stores 17-bit positions as u16 + one bit
- *    (8.5 KiB instead of 16 KiB), which lets 12 chunk-waves share a CU's LDS instead of 8.
+ *    (8.5 KiB instead of 16 KiB).  A chunk-wave is a latency-bound dependent chain and the encoder's
+ *    time follows 1 / (waves per CU) (14 waves 131.7 ms per 2 GiB, 12: 157, 9: 186, 5: 289), so LDS is
+ *    budgeted for 16 waves per CU = 10 240 B: table 8 704, 1 KiB ring + mirror, 256 B duplicate filter,
+ *    144 B match window.  Larger rings serve more candidates from LDS and lose more in waves than they
+ *    gain (2 KiB at 14 waves: 131.7 ms, 1 KiB at 16 waves: 120.1 ms, 8 KiB at 9 waves: 171 ms).
  *
  * Table modes: T_U16  single block <= 64 KiB (byU16: 8192 x u16, 13-bit hash of 4 bytes)
  *              T_P17  linked blocks, chunk <= 128 KiB (byU32 semantics, 17-bit entries)
@@ -25,9 +29,18 @@
 #define LASTLITERALS 5u
 #define DIST_MAX 65535u
 #ifndef IRING
-#define IRING 2048u /* input ring bytes (power of two): look-ahead + recent history that serves near candidates */
+#define IRING 1024u /* input ring bytes (power of two): look-ahead + recent history that serves near candidates */
+#endif
+#ifndef BM_BITS
+#define BM_BITS 2048u /* bits of the in-batch duplicate filter (a power of two >= 1024): hashes are folded onto
+                       * it, a false "duplicate" only sends the batch through the exact readlane loop */
 #endif
 #define IPIECE 512u /* refill granule: 8 bytes per lane */
+/* bytes ring_want() makes resident ahead of a position: >= 72 (a batch of 64 consecutive probes reads
+ * 8 bytes each) and small enough that IRING - IAHEAD - IPIECE >= 64 bytes of history stay behind it
+ * (catch-up compares 64 bytes backwards, the re-match step reads ip - 2) */
+#define IAHEAD (IRING >= 2048u ? 512u : 256u)
+static_assert(IRING >= IAHEAD + IPIECE + 64u, "the input ring must keep 64 bytes of history");
 #define IMIRROR 16u
 /* uniform branches are what a single wave pays most for: keep the common path falling through */
 #define E_RARE(c) __builtin_expect(!!(c), 0)
@@ -126,10 +139,10 @@ struct InRing {
 #define EPC(R, i) do { } while (0)
 #endif
 
-/* make [pos, pos + IPIECE) (clipped to the input) resident */
+/* make [pos, pos + IAHEAD) (clipped to the input) resident */
 static __device__ __forceinline__ void ring_want(InRing &R, u32 pos, int lane)
 {
-	const u32 want_hi = pos + IPIECE;
+	const u32 want_hi = pos + IAHEAD;
 	if (want_hi > R.rhi + 2 * IRING) {
 		/* far jump (long literal run): restart the ring at the new position */
 		R.rhi = pos & ~(IPIECE - 1);
@@ -273,11 +286,11 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				{
 					bool d = false;
 					if (valid)
-						d = (lds_or(&bitmap[h >> 5], 1u << (h & 31)) >> (h & 31)) & 1;
+						d = (lds_or(&bitmap[(h & (BM_BITS - 1)) >> 5], 1u << (h & 31)) >> (h & 31)) & 1;
 					const bool any_dup = wv_any(d);
 					wv_sync();
 					if (valid)
-						bitmap[h >> 5] = 0;
+						bitmap[(h & (BM_BITS - 1)) >> 5] = 0;
 					if (E_RARE(any_dup)) {
 						for (u32 i = 0; i < bsz; i++) {
 							const u32 hi_ = wv_readlane(h, (int)i);
@@ -561,9 +574,8 @@ static __device__ __forceinline__ void enc3_body(u32 *tlo, u32 *thi, u32 *bitmap
 	for (u32 i = (u32)lane; i < tab_words; i += 64)
 		tlo[i] = 0;
 	for (u32 i = (u32)lane; i < 128; i += 64) {
-		bitmap[i] = 0;
-		if (TM == T_U16)
-			bitmap[i + 128] = 0;
+		if (i < BM_BITS / 32)
+			bitmap[i] = 0;
 		if (TM == T_P17)
 			thi[i] = 0;
 	}
@@ -623,7 +635,7 @@ static __device__ __forceinline__ void enc3_body(u32 *tlo, u32 *thi, u32 *bitmap
 	{                                                                                          \
 		__shared__ __attribute__((aligned(16))) u32 tlo[(TABBYTES) / 4];                   \
 		__shared__ u32 thi[128];                                                           \
-		__shared__ u32 bitmap[(TM) == T_U16 ? 256 : 128];                                  \
+		__shared__ u32 bitmap[BM_BITS / 32];                                               \
 		__shared__ __attribute__((aligned(16))) u8 ring[IRING + IMIRROR];                  \
 		__shared__ __attribute__((aligned(16))) u8 mwin[MWIN + 16];                        \
 		enc3_body<TM>(tlo, thi, bitmap, ring, mwin, in, n, chunk, rec0, nrec, slots,       \
