@@ -11,7 +11,7 @@ for codec in ${1:-lz4 zstd brotli}; do
     rm -rf $O/sq_${codec}_${pass}
     eval "ctr=\$$pass"
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/sq_${codec}_${pass} -- \
-        python bench.py --codec $codec --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/sq_${codec}_${pass}.err
+        python bench.py --only --codec $codec --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/sq_${codec}_${pass}.err
   done
 done
 ls $O | grep sq_
