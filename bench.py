@@ -128,9 +128,20 @@ def cpu_baseline(codec, chunk, cpu_mib):
                 "sample": f"{cpu_mib} MiB of the same synthetic text, {chunk}-byte chunks, level 1: "
                           f"BROTLIMT_decompressDCtx of the stream BROTLIMT_compressCCtx wrote, memcpy "
                           f"callbacks, T={threads}"}
+    # the reference at T = 1 and 4 as well (configs[0] is `-T4`), on a small sample
+    by_threads = {}
+    if kind == "reference" and not zstd:
+        for t, mib in ((1, 128), (4, 256)):
+            try:
+                o = json.loads(subprocess.check_output([exe, kind, ref, str(mib << 20), str(chunk), str(t), str(SEED)],
+                                                       timeout=120))
+                by_threads[str(t)] = {"compress_MBps": o["compress_MBps"], "decompress_MBps": o["decompress_MBps"],
+                                      "sample_MiB": mib}
+            except Exception as e:  # report, never hide
+                by_threads[str(t)] = {"error": repr(e)}
     return {"value": r["roundtrip_MBps"], "unit": "MB/s", "cores": threads, "kind": kind,
             "compress_MBps": r["compress_MBps"], "decompress_MBps": r["decompress_MBps"],
-            "host_cpus": cores,
+            "host_cpus": cores, "by_threads": by_threads,
             "sample": f"{cpu_mib} MiB of the same synthetic text, {chunk}-byte chunks, "
                       f"{'ZSTDCB' if zstd else 'LZ4MT'}_compressCCtx+decompressDCtx (level 1) with memcpy "
                       f"callbacks, T={threads}"}
