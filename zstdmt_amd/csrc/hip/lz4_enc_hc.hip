@@ -59,33 +59,46 @@ static __device__ __forceinline__ u32 hc_uld_chain(const HcState &H, u32 idx)
 	return wv_readfirst((u32)H.chain[idx & (HC_MAXD - 1)]);
 }
 
-/* LZ4HC_Insert: positions [next_to_update, target) enter the chains, 64 at a time */
-static __device__ void hc_insert(HcState &H, u32 target, int lane)
+/*
+ * LZ4HC_Insert + the lookup that follows it in LZ4HC_InsertAndGetWiderMatch: positions
+ * [next_to_update, target) enter the chains, 64 at a time, and the search at `target` gets its four
+ * bytes (*pattern) and the head of its chain (*head = hashTable[hash(pattern)] after the insertions).
+ * The lookup rides on the last batch: a spare lane loads the bytes at `target` with the batch's source
+ * loads and its table entry with the batch's gather; an inserted position with the same hash overrides
+ * the entry exactly as the store the serial code would have read back.  Two memory round trips instead
+ * of four in front of every search.
+ */
+static __device__ void hc_insert_lookup(HcState &H, u32 target, u32 *pattern, u32 *head, int lane)
 {
-	while (H.next_to_update < target) {
+	for (;;) {
 		const u32 base = H.next_to_update;
-		const u32 cnt = target - base < 64u ? target - base : 64u;
+		const u32 left = target > base ? target - base : 0u;
+		const u32 cnt = left < 64u ? left : 64u;
+		const bool fin = left < 64u;                 /* the last batch: lane `cnt` is free for the lookup */
 		const bool act = (u32)lane < cnt;
-		const u32 idx = base + (u32)lane;
-		const u32 hv = act ? hc_hash(ld32u(H.src + (idx - HC_BASE))) : 0x10000u + (u32)lane;
-		const u32 prev = act ? H.hash[hv] : 0u;
-		/* lanes of the batch that share a hash: chained in lane order, the last one owns the table */
+		const bool probe = fin && (u32)lane == cnt;
+		const u32 idx = probe ? target : base + (u32)lane;
+		const u32 w = (act || probe) ? ld32u(H.src + (idx - HC_BASE)) : 0u;
+		const u32 hv = (act || probe) ? hc_hash(w) : 0x10000u + (u32)lane;
+		const u32 prev = (act || probe) ? H.hash[hv] : 0u;
+		/* lanes of the batch that share a hash: chained in lane order, the last inserting one owns the table */
+		const u64 actm = wv_ballot(act);
 		u32 pred = 64;
 		bool last = true;
-		u64 todo = wv_ballot(act);
+		u64 todo = wv_ballot(act || probe);
 		while (todo) {
 			const int f = wv_ffs(todo) - 1;
 			const u32 hvf = wv_readlane(hv, f);
-			const u64 same = wv_ballot(act && hv == hvf);
-			if (act && hv == hvf) {
-				const u64 below = same & ((1ull << lane) - 1ull);
+			const u64 same = wv_ballot((act || probe) && hv == hvf);
+			if ((act || probe) && hv == hvf) {
+				const u64 below = same & actm & ((1ull << lane) - 1ull);
 				pred = below ? 63u - (u32)__builtin_clzll(below) : 64u;
-				last = (lane == 63) || ((same >> (lane + 1)) == 0);
+				last = (lane == 63) || (((same & actm) >> (lane + 1)) == 0);
 			}
 			todo &= ~same;
 		}
+		const u32 from = pred < 64u ? base + pred : prev;
 		if (act) {
-			const u32 from = pred < 64u ? base + pred : prev;
 			u32 delta = idx - from;
 			if (delta > HC_DIST_MAX)
 				delta = HC_DIST_MAX;
@@ -93,8 +106,14 @@ static __device__ void hc_insert(HcState &H, u32 target, int lane)
 			if (last)
 				H.hash[hv] = idx;
 		}
-		H.next_to_update = base + cnt;
+		if (cnt)
+			H.next_to_update = base + cnt;
 		wv_sync(); /* the next batch and the search read what other lanes stored */
+		if (fin) {
+			*pattern = wv_readlane(w, (int)cnt);
+			*head = wv_readlane(from, (int)cnt);
+			return;
+		}
 	}
 }
 
@@ -173,13 +192,12 @@ static __device__ int hc_wider_core(HcState &H, u32 ip, u32 low_limit, u32 high_
 	const u32 ip_index = ip + HC_BASE;
 	const u32 lowest = (HC_BASE + HC_DIST_MAX + 1 > ip_index) ? HC_BASE : ip_index - HC_DIST_MAX;
 	const int look_back = (int)(ip - low_limit);
-	const u32 pattern = uld32(s + ip);
 	int attempts = max_attempts;
 	int repeat = 0; /* 0 untested, 1 not a repetition, 2 confirmed */
 	u32 src_pattern_len = 0, match_chain_pos = 0;
+	u32 pattern, match_index;
 
-	hc_insert(H, ip_index, lane);
-	u32 match_index = hc_uld_hash(H, hc_hash(pattern));
+	hc_insert_lookup(H, ip_index, &pattern, &match_index, lane);
 	while (match_index >= lowest && attempts > 0) {
 		const u32 m = match_index - HC_BASE;
 		int match_len = 0;
