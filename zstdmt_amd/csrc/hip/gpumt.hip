@@ -130,7 +130,9 @@ static int want_scratch(gpumt_ctx *h, int k, int s, size_t bytes)
 	if (bytes <= h->scratch_bytes[k][s])
 		return GPUMT_OK;
 	if (h->scratch[k][s]) {
-		CK(hipDeviceSynchronize());
+		/* only work queued on this stream can be using the old area; a device-wide wait here would
+		 * stall the batches other slots have in flight (130 ms per growing brotli batch, GPUMT_TRACE) */
+		CK(hipStreamSynchronize(h->st[s]));
 		dev_free(h, h->scratch[k][s]);
 		h->scratch[k][s] = NULL;
 		h->scratch_bytes[k][s] = 0;
