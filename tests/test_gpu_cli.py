@@ -192,3 +192,23 @@ def test_plain_streams_are_decoded_incrementally():
     r = subprocess.run([os.path.join(BIN, "lz4cat-mt")], input=lz[:-3], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        env=env, timeout=600)
     assert r.returncode != 0 and data.startswith(r.stdout)
+
+
+@pytest.mark.parametrize("env", [
+    {"GPUMT_SLOTS": "2", "GPUMT_BATCH_MB": "16"},
+    {"GPUMT_SLOTS": "8", "GPUMT_BATCH_MB": "32", "GPU_MAX_HW_QUEUES": "4"},
+    {"GPUMT_PINNED_CACHE_MB": "0", "GPUMT_DEVICE_CACHE_MB": "0", "GPUMT_TRACE": "1"},
+])
+def test_pipeline_knobs_round_trip(env):
+    """the pipeline's environment knobs (slots, batch size, caches off, trace) change timing, never bytes"""
+    import subprocess
+    data = cases.text(70 << 20, seed=17) + cases.rnd(2 << 20, 4)
+    e = dict(os.environ, **env)
+    want = H.oracle_compress(data, 1 << 20)
+    for tool, cat in ((LZ4, "lz4cat-mt"), (ZSTD, "zstdcat-mt"), (os.path.join(BIN, "brotli-mt"), "brotlicat-mt")):
+        c = subprocess.run([tool, "-1", "-b", "1", "-c"], input=data, capture_output=True, env=e, timeout=300)
+        assert c.returncode == 0, c.stderr[-300:]
+        if tool == LZ4:
+            assert c.stdout == want
+        d = subprocess.run([os.path.join(BIN, cat)], input=c.stdout, capture_output=True, env=e, timeout=300)
+        assert d.returncode == 0 and d.stdout == data, (tool, d.stderr[-300:])
