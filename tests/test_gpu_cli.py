@@ -198,9 +198,14 @@ def test_plain_streams_are_decoded_incrementally():
     {"GPUMT_SLOTS": "2", "GPUMT_BATCH_MB": "16"},
     {"GPUMT_SLOTS": "8", "GPUMT_BATCH_MB": "32", "GPU_MAX_HW_QUEUES": "4"},
     {"GPUMT_PINNED_CACHE_MB": "0", "GPUMT_DEVICE_CACHE_MB": "0", "GPUMT_TRACE": "1"},
+    # slots dealt out to several device contexts (here: the same GPU opened twice / three times, and "all")
+    {"GPUMT_DEVICES": "0,0", "GPUMT_BATCH_MB": "16"},
+    {"GPUMT_DEVICES": "0,0,0", "GPUMT_SLOTS": "5", "GPUMT_BATCH_MB": "16"},
+    {"GPUMT_DEVICES": "all"},
 ])
 def test_pipeline_knobs_round_trip(env):
-    """the pipeline's environment knobs (slots, batch size, caches off, trace) change timing, never bytes"""
+    """the pipeline's environment knobs (slots, batch size, caches off, trace, several devices) change
+    timing, never bytes"""
     import subprocess
     data = cases.text(70 << 20, seed=17) + cases.rnd(2 << 20, 4)
     e = dict(os.environ, **env)

@@ -80,7 +80,7 @@ struct cslot {
 struct BROTLIMT_CCtx_s {
 	int level, threads, inputsize;
 	size_t insize, outsize, curframe, frames; /* insize / frames: reader; outsize / curframe: writer */
-	gpumt_ctx *gpu;
+	mt_gpus gpus; /* the devices the batch slots are dealt out to (mt_host.h) */
 	struct cslot s[MT_NSLOT];
 	BROTLIMT_RdWr_t *io;
 	size_t maxrec;
@@ -101,7 +101,7 @@ BROTLIMT_CCtx *BROTLIMT_createCCtx(int threads, int level, int inputsize)
 	ctx->threads = threads;
 	ctx->level = level;
 	ctx->inputsize = inputsize ? inputsize : 1024 * 1024 * (level ? level : 1); /* :105-109 */
-	if (gpumt_open(GPUMT_DEVICE_DEFAULT, &ctx->gpu) != GPUMT_OK) {
+	if (mt_gpus_open(&ctx->gpus)) {
 		free(ctx); /* no device: fail loudly, there is no CPU path */
 		return NULL;
 	}
@@ -113,12 +113,12 @@ void BROTLIMT_freeCCtx(BROTLIMT_CCtx *ctx)
 	if (!ctx)
 		return;
 	for (int i = 0; i < MT_NSLOT; i++) {
-		dbuf_free(ctx->gpu, &ctx->s[i].in);
-		dbuf_free(ctx->gpu, &ctx->s[i].slots);
-		dbuf_free(ctx->gpu, &ctx->s[i].stream);
-		dbuf_free(ctx->gpu, &ctx->s[i].meta);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].in);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].slots);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].stream);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].meta);
 	}
-	gpumt_close(ctx->gpu);
+	mt_gpus_close(&ctx->gpus);
 	free(ctx);
 }
 
@@ -158,8 +158,8 @@ static size_t c_read_batch(BROTLIMT_CCtx *ctx, BROTLIMT_RdWr_t *io, struct cslot
 
 static size_t c_launch(BROTLIMT_CCtx *ctx, struct cslot *s)
 {
-	gpumt_ctx *g = ctx->gpu;
-	const int ks = 4 + (int)(s - ctx->s); /* the slot's own kernel stream: batches overlap on the device */
+	gpumt_ctx *g = mt_gpu_of(&ctx->gpus, (int)(s - ctx->s));
+	const int ks = mt_stream_of(&ctx->gpus, (int)(s - ctx->s)); /* the slot's own kernel stream: batches overlap on the device */
 	const size_t chunk = (size_t)ctx->inputsize;
 	const size_t stride = gpumt_zstd_slot_stride(chunk);
 	uint32_t *d_len = (uint32_t *)s->meta.d;
@@ -190,10 +190,10 @@ static size_t cp_fill(void *a, int si, int *has_data, int *eof)
 		lim = BATCH_MAXREC;
 	if (ctx->maxrec > lim)
 		ctx->maxrec = lim;
-	if (dbuf_want(ctx->gpu, &s->in, ctx->maxrec * chunk + 512, 1, 1) ||
-	    dbuf_want(ctx->gpu, &s->slots, ctx->maxrec * stride, 0, 1) ||
-	    dbuf_want(ctx->gpu, &s->stream, ctx->maxrec * stride + 512, 1, 1) ||
-	    dbuf_want(ctx->gpu, &s->meta, ctx->maxrec * 12 + 64, 1, 1))
+	if (dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->in, ctx->maxrec * chunk + 512, 1, 1) ||
+	    dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->slots, ctx->maxrec * stride, 0, 1) ||
+	    dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->stream, ctx->maxrec * stride + 512, 1, 1) ||
+	    dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->meta, ctx->maxrec * 12 + 64, 1, 1))
 		return BROTLIMT_ERROR(memory_allocation);
 	err = c_read_batch(ctx, ctx->io, s, ctx->maxrec, eof);
 	*has_data = s->nrec > 0;
@@ -205,7 +205,7 @@ static size_t cp_launch(void *a, int si)
 {
 	BROTLIMT_CCtx *ctx = (BROTLIMT_CCtx *)a;
 	size_t err = c_launch(ctx, &ctx->s[si]);
-	if (!err && gpumt_mark(ctx->gpu, si, 4 + si))
+	if (!err && gpumt_mark(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si), mt_stream_of(&ctx->gpus, si)))
 		err = BROTLIMT_ERROR(frame_compress);
 	return err;
 }
@@ -214,10 +214,9 @@ static size_t cp_complete(void *a, int si)
 {
 	BROTLIMT_CCtx *ctx = (BROTLIMT_CCtx *)a;
 	struct cslot *s = &ctx->s[si];
-	gpumt_ctx *g = ctx->gpu;
 	const uint64_t *off = (const uint64_t *)((const uint8_t *)s->meta.h + ((s->nrec * 4 + 15) & ~(size_t)15));
 	size_t total;
-	if (gpumt_mark_sync(g, si))
+	if (gpumt_mark_sync(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si)))
 		return BROTLIMT_ERROR(frame_compress);
 	total = (size_t)off[s->nrec];
 	if (total > s->stream.cap)
@@ -257,8 +256,8 @@ size_t BROTLIMT_compressCCtx(BROTLIMT_CCtx *ctx, BROTLIMT_RdWr_t *rdwr)
 	ctx->maxrec = BATCH_MIN / (size_t)ctx->inputsize;
 	if (ctx->maxrec < 1)
 		ctx->maxrec = 1;
-	err = mt_pipe_run(&ops, ctx);
-	gpumt_device_sync(ctx->gpu);
+	err = mt_pipe_run_n(&ops, ctx, mt_nslot_for(ctx->gpus.n));
+	mt_gpus_sync(&ctx->gpus);
 	return err;
 }
 
@@ -275,7 +274,7 @@ struct BROTLIMT_DCtx_s {
 	int threads, inputsize;
 	size_t budget;
 	size_t insize, outsize, curframe, frames;
-	gpumt_ctx *gpu;
+	mt_gpus gpus; /* the devices the batch slots are dealt out to (mt_host.h) */
 	struct dslot s[MT_NSLOT];
 	BROTLIMT_RdWr_t *io;
 	int have_hdr; /* a record header read ahead of its batch */
@@ -293,7 +292,7 @@ BROTLIMT_DCtx *BROTLIMT_createDCtx(int threads, int inputsize)
 		return NULL;
 	ctx->threads = threads;
 	ctx->inputsize = inputsize ? inputsize : 1024 * 64; /* brotli-mt_decompress.c:110-113 */
-	if (gpumt_open(GPUMT_DEVICE_DEFAULT, &ctx->gpu) != GPUMT_OK) {
+	if (mt_gpus_open(&ctx->gpus)) {
 		free(ctx);
 		return NULL;
 	}
@@ -305,12 +304,12 @@ void BROTLIMT_freeDCtx(BROTLIMT_DCtx *ctx)
 	if (!ctx)
 		return;
 	for (int i = 0; i < MT_NSLOT; i++) {
-		dbuf_free(ctx->gpu, &ctx->s[i].in);
-		dbuf_free(ctx->gpu, &ctx->s[i].meta);
-		dbuf_free(ctx->gpu, &ctx->s[i].res);
-		dbuf_free(ctx->gpu, &ctx->s[i].out);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].in);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].meta);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].res);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].out);
 	}
-	gpumt_close(ctx->gpu);
+	mt_gpus_close(&ctx->gpus);
 	free(ctx);
 }
 
@@ -403,13 +402,13 @@ static size_t d_read_batch(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *io, struct dslot
 			if (want < 2 * old.cap)
 				want = 2 * old.cap;
 			memset(&s->in, 0, sizeof s->in);
-			if (dbuf_want(ctx->gpu, &s->in, want, 1, 1)) {
-				dbuf_free(ctx->gpu, &s->in);
+			if (dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->in, want, 1, 1)) {
+				dbuf_free(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->in);
 				s->in = old; /* keep the slot as it was: freeCtx releases it */
 				return BROTLIMT_ERROR(memory_allocation);
 			}
 			memcpy(s->in.h, old.h, s->in_bytes);
-			dbuf_free(ctx->gpu, &old);
+			dbuf_free(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &old);
 		}
 		b.buf = (uint8_t *)s->in.h + s->in_bytes;
 		b.size = csize;
@@ -435,10 +434,10 @@ static size_t d_read_batch(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *io, struct dslot
 
 static size_t d_launch(BROTLIMT_DCtx *ctx, struct dslot *s)
 {
-	gpumt_ctx *g = ctx->gpu;
+	gpumt_ctx *g = mt_gpu_of(&ctx->gpus, (int)(s - ctx->s));
 	/* each batch slot launches on its own kernel stream (4 + slot): the decoders are bound by the
 	 * latency of a record, so the batches of the pipeline must overlap on the device */
-	const int ks = 4 + (int)(s - ctx->s);
+	const int ks = mt_stream_of(&ctx->gpus, (int)(s - ctx->s));
 	int rc = 0;
 	if (dbuf_want(g, &s->out, s->out_bytes + 64, 1, 1) || dbuf_want(g, &s->res, BATCH_MAXREC * 8 + 64, 1, 1))
 		return BROTLIMT_ERROR(memory_allocation);
@@ -459,8 +458,8 @@ static size_t dp_fill(void *a, int si, int *has_data, int *eof)
 	BROTLIMT_DCtx *ctx = (BROTLIMT_DCtx *)a;
 	struct dslot *s = &ctx->s[si];
 	size_t err;
-	if (dbuf_want(ctx->gpu, &s->in, (ctx->budget >> 1) + 4096, 1, 1) ||
-	    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1))
+	if (dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->in, (ctx->budget >> 1) + 4096, 1, 1) ||
+	    dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1))
 		return BROTLIMT_ERROR(memory_allocation);
 	err = d_read_batch(ctx, ctx->io, s, eof);
 	*has_data = s->nrec > 0;
@@ -473,7 +472,7 @@ static size_t dp_launch(void *a, int si)
 {
 	BROTLIMT_DCtx *ctx = (BROTLIMT_DCtx *)a;
 	size_t err = d_launch(ctx, &ctx->s[si]);
-	if (!err && gpumt_mark(ctx->gpu, si, 2))
+	if (!err && gpumt_mark(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si), 2))
 		err = BROTLIMT_ERROR(frame_decompress);
 	return err;
 }
@@ -481,7 +480,7 @@ static size_t dp_launch(void *a, int si)
 static size_t dp_complete(void *a, int si)
 {
 	BROTLIMT_DCtx *ctx = (BROTLIMT_DCtx *)a;
-	return gpumt_mark_sync(ctx->gpu, si) ? BROTLIMT_ERROR(frame_decompress) : 0;
+	return gpumt_mark_sync(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si)) ? BROTLIMT_ERROR(frame_decompress) : 0;
 }
 
 static size_t dp_drain(void *a, int si)
@@ -532,7 +531,7 @@ size_t BROTLIMT_decompressDCtx(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *rdwr)
 	ctx->budget = BATCH_MIN;
 	ctx->io = rdwr;
 	/* threads == 1: every callback on the calling thread, as the reference (its single-thread path) */
-	err = ctx->threads == 1 ? mt_pipe_run_inline(&ops, ctx) : mt_pipe_run(&ops, ctx);
-	gpumt_device_sync(ctx->gpu);
+	err = ctx->threads == 1 ? mt_pipe_run_inline(&ops, ctx) : mt_pipe_run_n(&ops, ctx, mt_nslot_for(ctx->gpus.n));
+	mt_gpus_sync(&ctx->gpus);
 	return err;
 }

@@ -82,7 +82,7 @@ struct cslot {
 struct LZ4MT_CCtx_s {
 	int level, threads, inputsize;
 	size_t insize, outsize, curframe, frames; /* insize / frames: reader; outsize / curframe: writer */
-	gpumt_ctx *gpu;
+	mt_gpus gpus; /* the devices the batch slots are dealt out to (mt_host.h) */
 	struct cslot s[MT_NSLOT];
 	LZ4MT_RdWr_t *io; /* callbacks of the running call */
 	size_t maxrec;    /* records per device batch, grows (reader) */
@@ -103,7 +103,7 @@ LZ4MT_CCtx *LZ4MT_createCCtx(int threads, int level, int inputsize)
 	ctx->level = level;
 	ctx->threads = threads;
 	ctx->inputsize = inputsize ? inputsize : 1024 * 1024 * 4; /* lz4-mt_compress.c:111-114 */
-	if (gpumt_open(GPUMT_DEVICE_DEFAULT, &ctx->gpu) != GPUMT_OK) {
+	if (mt_gpus_open(&ctx->gpus)) {
 		free(ctx); /* no device: fail loudly, there is no CPU path */
 		return NULL;
 	}
@@ -115,12 +115,12 @@ void LZ4MT_freeCCtx(LZ4MT_CCtx *ctx)
 	if (!ctx)
 		return;
 	for (int i = 0; i < MT_NSLOT; i++) {
-		dbuf_free(ctx->gpu, &ctx->s[i].in);
-		dbuf_free(ctx->gpu, &ctx->s[i].slots);
-		dbuf_free(ctx->gpu, &ctx->s[i].stream);
-		dbuf_free(ctx->gpu, &ctx->s[i].meta);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].in);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].slots);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].stream);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].meta);
 	}
-	gpumt_close(ctx->gpu);
+	mt_gpus_close(&ctx->gpus);
 	free(ctx);
 }
 
@@ -167,8 +167,8 @@ static size_t c_read_batch(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *io, struct cslot *s, s
 
 static size_t c_launch(LZ4MT_CCtx *ctx, struct cslot *s)
 {
-	gpumt_ctx *g = ctx->gpu;
-	const int ks = 4 + (int)(s - ctx->s); /* the slot's own kernel stream: batches overlap on the device */
+	gpumt_ctx *g = mt_gpu_of(&ctx->gpus, (int)(s - ctx->s));
+	const int ks = mt_stream_of(&ctx->gpus, (int)(s - ctx->s)); /* the slot's own kernel stream: batches overlap on the device */
 	const size_t chunk = (size_t)ctx->inputsize;
 	const size_t stride = gpumt_lz4_slot_stride(chunk);
 	uint32_t *d_len = (uint32_t *)s->meta.d;
@@ -201,10 +201,10 @@ static size_t cp_fill(void *a, int si, int *has_data, int *eof)
 	if (ctx->maxrec > lim)
 		ctx->maxrec = lim;
 	/* (re)size this slot for the current batch size; it is free: nothing of it is in flight */
-	if (dbuf_want(ctx->gpu, &s->in, ctx->maxrec * chunk + 512, 1, 1) ||
-	    dbuf_want(ctx->gpu, &s->slots, ctx->maxrec * stride, 0, 1) ||
-	    dbuf_want(ctx->gpu, &s->stream, ctx->maxrec * stride + 512, 1, 1) ||
-	    dbuf_want(ctx->gpu, &s->meta, ctx->maxrec * 12 + 64, 1, 1))
+	if (dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->in, ctx->maxrec * chunk + 512, 1, 1) ||
+	    dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->slots, ctx->maxrec * stride, 0, 1) ||
+	    dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->stream, ctx->maxrec * stride + 512, 1, 1) ||
+	    dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->meta, ctx->maxrec * 12 + 64, 1, 1))
 		return ERROR(memory_allocation);
 	err = c_read_batch(ctx, ctx->io, s, ctx->maxrec, eof);
 	*has_data = s->nrec > 0;
@@ -216,7 +216,7 @@ static size_t cp_launch(void *a, int si)
 {
 	LZ4MT_CCtx *ctx = (LZ4MT_CCtx *)a;
 	size_t err = c_launch(ctx, &ctx->s[si]);
-	if (!err && gpumt_mark(ctx->gpu, si, 4 + si))
+	if (!err && gpumt_mark(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si), mt_stream_of(&ctx->gpus, si)))
 		err = ERROR(compression_library);
 	return err;
 }
@@ -225,10 +225,9 @@ static size_t cp_complete(void *a, int si)
 {
 	LZ4MT_CCtx *ctx = (LZ4MT_CCtx *)a;
 	struct cslot *s = &ctx->s[si];
-	gpumt_ctx *g = ctx->gpu;
 	const uint64_t *off = (const uint64_t *)((const uint8_t *)s->meta.h + ((s->nrec * 4 + 15) & ~(size_t)15));
 	size_t total;
-	if (gpumt_mark_sync(g, si)) /* record sizes and offsets are in host memory */
+	if (gpumt_mark_sync(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si))) /* record sizes and offsets are in host memory */
 		return ERROR(compression_library);
 	total = (size_t)off[s->nrec];
 	if (total > s->stream.cap)
@@ -271,8 +270,8 @@ size_t LZ4MT_compressCCtx(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *rdwr)
 	if (ctx->maxrec < 1)
 		ctx->maxrec = 1;
 	/* the reference keeps its counters across calls; so do we */
-	err = mt_pipe_run(&ops, ctx);
-	gpumt_device_sync(ctx->gpu);
+	err = mt_pipe_run_n(&ops, ctx, mt_nslot_for(ctx->gpus.n));
+	mt_gpus_sync(&ctx->gpus);
 	return err;
 }
 
@@ -289,7 +288,7 @@ struct LZ4MT_DCtx_s {
 	int threads, inputsize;
 	size_t budget; /* output bytes per device batch, grows from BATCH_MIN to BATCH_BYTES */
 	size_t insize, outsize, curframe, frames;
-	gpumt_ctx *gpu;
+	mt_gpus gpus; /* the devices the batch slots are dealt out to (mt_host.h) */
 	struct dslot s[MT_NSLOT];
 	LZ4MT_RdWr_t *io;
 	/* a record header read ahead of its batch */
@@ -307,7 +306,7 @@ LZ4MT_DCtx *LZ4MT_createDCtx(int threads, int inputsize)
 		return NULL;
 	ctx->threads = threads;
 	ctx->inputsize = inputsize ? inputsize : 1024 + 1024 * 4; /* sic, lz4-mt_decompress.c:115 */
-	if (gpumt_open(GPUMT_DEVICE_DEFAULT, &ctx->gpu) != GPUMT_OK) {
+	if (mt_gpus_open(&ctx->gpus)) {
 		free(ctx);
 		return NULL;
 	}
@@ -319,12 +318,12 @@ void LZ4MT_freeDCtx(LZ4MT_DCtx *ctx)
 	if (!ctx)
 		return;
 	for (int i = 0; i < MT_NSLOT; i++) {
-		dbuf_free(ctx->gpu, &ctx->s[i].in);
-		dbuf_free(ctx->gpu, &ctx->s[i].meta);
-		dbuf_free(ctx->gpu, &ctx->s[i].status);
-		dbuf_free(ctx->gpu, &ctx->s[i].out);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].in);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].meta);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].status);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].out);
 	}
-	gpumt_close(ctx->gpu);
+	mt_gpus_close(&ctx->gpus);
 	free(ctx);
 }
 
@@ -410,13 +409,13 @@ static size_t d_read_batch(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, struct dslot *s, i
 			/* a single record larger than the slot: grow (nothing is in flight in this slot) */
 			dbuf old = s->in;
 			memset(&s->in, 0, sizeof s->in);
-			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + 12 + (size_t)csize + 512, 1, 1)) {
-				dbuf_free(ctx->gpu, &s->in);
+			if (dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->in, s->in_bytes + 12 + (size_t)csize + 512, 1, 1)) {
+				dbuf_free(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->in);
 				s->in = old; /* keep the slot as it was: freeCtx releases it */
 				return ERROR(memory_allocation);
 			}
 			memcpy(s->in.h, old.h, s->in_bytes);
-			dbuf_free(ctx->gpu, &old);
+			dbuf_free(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &old);
 		}
 		rec = (uint8_t *)s->in.h + s->in_bytes;
 		/* rebuild the 12-byte header in front of the payload: the device checks it too */
@@ -454,10 +453,10 @@ static size_t d_read_batch(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, struct dslot *s, i
 
 static size_t d_launch(LZ4MT_DCtx *ctx, struct dslot *s)
 {
-	gpumt_ctx *g = ctx->gpu;
+	gpumt_ctx *g = mt_gpu_of(&ctx->gpus, (int)(s - ctx->s));
 	/* each batch slot launches on its own kernel stream (4 + slot): the decoders are bound by the
 	 * latency of a record, so the batches of the pipeline must overlap on the device */
-	const int ks = 4 + (int)(s - ctx->s);
+	const int ks = mt_stream_of(&ctx->gpus, (int)(s - ctx->s));
 	int rc = 0;
 	if (dbuf_want(g, &s->out, s->out_bytes + 64, 1, 1) || dbuf_want(g, &s->status, s->nrec * 4 + 64, 1, 1))
 		return ERROR(memory_allocation);
@@ -481,8 +480,8 @@ static size_t dp_fill(void *a, int si, int *has_data, int *eof)
 	size_t err;
 	/* input slot sized for the batch budget (compressed data is never larger than that plus
 	 * per-record overhead); the slot is free here */
-	if (dbuf_want(ctx->gpu, &s->in, ctx->budget + (ctx->budget >> 3) + 4096, 1, 1) ||
-	    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1))
+	if (dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->in, ctx->budget + (ctx->budget >> 3) + 4096, 1, 1) ||
+	    dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1))
 		return ERROR(memory_allocation);
 	err = d_read_batch(ctx, ctx->io, s, eof);
 	*has_data = s->nrec > 0;
@@ -495,7 +494,7 @@ static size_t dp_launch(void *a, int si)
 {
 	LZ4MT_DCtx *ctx = (LZ4MT_DCtx *)a;
 	size_t err = d_launch(ctx, &ctx->s[si]);
-	if (!err && gpumt_mark(ctx->gpu, si, 2))
+	if (!err && gpumt_mark(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si), 2))
 		err = ERROR(compression_library);
 	return err;
 }
@@ -503,7 +502,7 @@ static size_t dp_launch(void *a, int si)
 static size_t dp_complete(void *a, int si)
 {
 	LZ4MT_DCtx *ctx = (LZ4MT_DCtx *)a;
-	return gpumt_mark_sync(ctx->gpu, si) ? ERROR(compression_library) : 0;
+	return gpumt_mark_sync(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si)) ? ERROR(compression_library) : 0;
 }
 
 static size_t dp_drain(void *a, int si)
@@ -590,7 +589,7 @@ static size_t plain_decompress(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, const uint8_t 
 	size_t want_ahead = BATCH_BYTES; /* input buffered before a round of frames is split off */
 	int eof = 0;
 	struct dslot *s = &ctx->s[0];
-	gpumt_ctx *g = ctx->gpu;
+	gpumt_ctx *g = mt_gpu_of(&ctx->gpus, (int)(s - ctx->s));
 	if (!raw)
 		return ERROR(memory_allocation);
 	memcpy(raw, first, 4);
@@ -800,7 +799,7 @@ size_t LZ4MT_decompressDCtx(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *rdwr)
 	ctx->have_hdr = 0;
 	ctx->budget = BATCH_MIN;
 	/* threads == 1: every callback on the calling thread, as the reference (its single-thread path) */
-	err = ctx->threads == 1 ? mt_pipe_run_inline(&ops, ctx) : mt_pipe_run(&ops, ctx);
-	gpumt_device_sync(ctx->gpu);
+	err = ctx->threads == 1 ? mt_pipe_run_inline(&ops, ctx) : mt_pipe_run_n(&ops, ctx, mt_nslot_for(ctx->gpus.n));
+	mt_gpus_sync(&ctx->gpus);
 	return err;
 }

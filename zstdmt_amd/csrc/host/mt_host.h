@@ -42,6 +42,72 @@ static inline uint64_t rd64(const uint8_t *p)
 	return (uint64_t)rd32(p) | (uint64_t)rd32(p + 4) << 32;
 }
 
+/*
+ * The devices of a context.  By default one: the GPU GPUMT_DEVICE names (0 if unset).  With
+ * GPUMT_DEVICES = "all" or a list ("0,1,2,3") a context opens several and deals its batch slots out
+ * round-robin (slot s -> device s % n): every batch lives on one device from its H2D copy to its
+ * result, batches of different devices run side by side, order is kept by the pipeline as before.
+ * The callback contract bounds what this buys to the reader's / writer's memcpy rate (~15-20 GB/s),
+ * which is why it matters for the device-bound legs: LZ4HC levels, brotli decode.
+ */
+#define MT_NGPU_MAX 16
+typedef struct {
+	gpumt_ctx *g[MT_NGPU_MAX];
+	int n;
+} mt_gpus;
+
+static inline void mt_gpus_close(mt_gpus *m)
+{
+	for (int i = 0; i < m->n; i++)
+		gpumt_close(m->g[i]);
+	m->n = 0;
+}
+/* 0 on success; nothing is left open on failure */
+static inline int mt_gpus_open(mt_gpus *m)
+{
+	const char *e = getenv("GPUMT_DEVICES");
+	m->n = 0;
+	if (!e || !*e) {
+		if (gpumt_open(GPUMT_DEVICE_DEFAULT, &m->g[0]) != GPUMT_OK)
+			return -1;
+		m->n = 1;
+		return 0;
+	}
+	if (!strcmp(e, "all")) {
+		const int nd = gpumt_device_count();
+		for (int d = 0; d < nd && m->n < MT_NGPU_MAX; d++) {
+			if (gpumt_open(d, &m->g[m->n]) != GPUMT_OK) {
+				mt_gpus_close(m);
+				return -1;
+			}
+			m->n++;
+		}
+		return m->n ? 0 : -1;
+	}
+	while (*e && m->n < MT_NGPU_MAX) {
+		char *end;
+		const long d = strtol(e, &end, 10);
+		if (end == e || d < 0 || gpumt_open((int)d, &m->g[m->n]) != GPUMT_OK) {
+			mt_gpus_close(m);
+			return -1;
+		}
+		m->n++;
+		e = *end == ',' ? end + 1 : end;
+		if (*end && *end != ',')
+			break;
+	}
+	return m->n ? 0 : -1;
+}
+static inline gpumt_ctx *mt_gpu_of(const mt_gpus *m, int slot) { return m->g[slot % m->n]; }
+/* the slot's own kernel stream (4..15) and completion mark on its device */
+static inline int mt_stream_of(const mt_gpus *m, int slot) { return 4 + (slot / m->n) % 12; }
+static inline int mt_mark_of(const mt_gpus *m, int slot) { return (slot / m->n) % GPUMT_NMARKS; }
+static inline void mt_gpus_sync(const mt_gpus *m)
+{
+	for (int i = 0; i < m->n; i++)
+		gpumt_device_sync(m->g[i]);
+}
+
 /* a device buffer + pinned mirror that only ever grows */
 typedef struct {
 	void *d;

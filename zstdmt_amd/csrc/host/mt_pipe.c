@@ -13,16 +13,17 @@ static double now_s(void)
 	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-int mt_nslot(void)
+int mt_nslot_for(int ndevices)
 {
-	static int n;
-	if (!n) {
-		const char *e = getenv("GPUMT_SLOTS");
-		int v = e && *e ? atoi(e) : 4;
-		n = v < 2 ? 2 : v > MT_NSLOT ? MT_NSLOT : v;
-	}
-	return n;
+	const char *e = getenv("GPUMT_SLOTS");
+	int v = e && *e ? atoi(e) : (ndevices > 1 ? 2 * ndevices + 2 : 4);
+	if (ndevices < 1)
+		ndevices = 1;
+	if (v > 12 * ndevices) /* a device serves its slots on 12 kernel streams / completion marks */
+		v = 12 * ndevices;
+	return v < 2 ? 2 : v > MT_NSLOT ? MT_NSLOT : v;
 }
+int mt_nslot(void) { return mt_nslot_for(1); }
 
 enum { S_FREE, S_FILLED, S_DONE };
 
@@ -146,7 +147,9 @@ static void mark_done(pipe_t *p, long b)
 	pthread_mutex_unlock(&p->mu);
 }
 
-size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
+size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg) { return mt_pipe_run_n(ops, arg, mt_nslot()); }
+
+size_t mt_pipe_run_n(const mt_pipe_ops *ops, void *arg, int nslot)
 {
 	pipe_t p;
 	pthread_t rt, wt;
@@ -155,7 +158,7 @@ size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg)
 
 	p.ops = ops;
 	p.arg = arg;
-	p.nslot = mt_nslot();
+	p.nslot = nslot < 2 ? 2 : nslot > MT_NSLOT ? MT_NSLOT : nslot;
 	p.err = 0;
 	p.n_filled = p.n_done = 0;
 	p.reader_over = p.device_over = 0;

@@ -21,11 +21,13 @@
 
 #include <stddef.h>
 
-#define MT_NSLOT 8 /* slots a context owns; the pipeline uses the first mt_nslot() of them */
+#define MT_NSLOT 32 /* slots a context owns; the pipeline uses the first mt_nslot_for() of them */
 
-/* slots in use: GPUMT_SLOTS (2..MT_NSLOT), default 4 -- more slots keep more batches on the device at
- * once (the wave-per-record decoders are latency-bound per record) at the price of pinned memory */
+/* slots in use: GPUMT_SLOTS (2..MT_NSLOT); default 4 on one device -- more slots keep more batches on
+ * the device at once (the wave-per-record decoders are latency-bound per record) at the price of pinned
+ * memory -- and 2 per device + 2 when a context spreads its slots over several devices (GPUMT_DEVICES) */
 int mt_nslot(void);
+int mt_nslot_for(int ndevices);
 
 typedef struct {
 	/* fill: *has_data = 0 when the input ended before anything was read into the slot; *eof = 1
@@ -36,7 +38,8 @@ typedef struct {
 	size_t (*drain)(void *arg, int slot);
 } mt_pipe_ops;
 
-size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg);
+size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg);             /* mt_nslot() slots */
+size_t mt_pipe_run_n(const mt_pipe_ops *ops, void *arg, int nslot); /* nslot in 2..MT_NSLOT */
 
 /* The same batches, every role on the calling thread, one batch at a time: what the reference does
  * for a decompress context with threads == 1 (lib/lz4-mt_decompress.c:528-534 calls pt_decompress

@@ -113,7 +113,7 @@ struct cslot {
 struct ZSTDCB_CCtx_s {
 	int level, threads, inputsize;
 	size_t insize, outsize, curframe, frames; /* insize / frames: reader; outsize / curframe: writer */
-	gpumt_ctx *gpu;
+	mt_gpus gpus; /* the devices the batch slots are dealt out to (mt_host.h) */
 	struct cslot s[MT_NSLOT];
 	ZSTDCB_RdWr_t *io;
 	size_t maxrec;
@@ -138,7 +138,7 @@ ZSTDCB_CCtx *ZSTDCB_createCCtx(int threads, int level, int inputsize)
 	ctx->level = level;
 	ctx->threads = threads;
 	ctx->inputsize = inputsize ? inputsize : 1 << (window_log[level] + 1);
-	if (gpumt_open(GPUMT_DEVICE_DEFAULT, &ctx->gpu) != GPUMT_OK) {
+	if (mt_gpus_open(&ctx->gpus)) {
 		free(ctx); /* no device: fail loudly, there is no CPU path */
 		return NULL;
 	}
@@ -150,12 +150,12 @@ void ZSTDCB_freeCCtx(ZSTDCB_CCtx *ctx)
 	if (!ctx)
 		return;
 	for (int i = 0; i < MT_NSLOT; i++) {
-		dbuf_free(ctx->gpu, &ctx->s[i].in);
-		dbuf_free(ctx->gpu, &ctx->s[i].slots);
-		dbuf_free(ctx->gpu, &ctx->s[i].stream);
-		dbuf_free(ctx->gpu, &ctx->s[i].meta);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].in);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].slots);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].stream);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].meta);
 	}
-	gpumt_close(ctx->gpu);
+	mt_gpus_close(&ctx->gpus);
 	free(ctx);
 }
 
@@ -198,8 +198,8 @@ static size_t c_read_batch(ZSTDCB_CCtx *ctx, ZSTDCB_RdWr_t *io, struct cslot *s,
 
 static size_t c_launch(ZSTDCB_CCtx *ctx, struct cslot *s)
 {
-	gpumt_ctx *g = ctx->gpu;
-	const int ks = 4 + (int)(s - ctx->s); /* the slot's own kernel stream: batches overlap on the device */
+	gpumt_ctx *g = mt_gpu_of(&ctx->gpus, (int)(s - ctx->s));
+	const int ks = mt_stream_of(&ctx->gpus, (int)(s - ctx->s)); /* the slot's own kernel stream: batches overlap on the device */
 	const size_t chunk = (size_t)ctx->inputsize;
 	const size_t stride = gpumt_zstd_slot_stride(chunk);
 	uint32_t *d_len = (uint32_t *)s->meta.d;
@@ -231,10 +231,10 @@ static size_t cp_fill(void *a, int si, int *has_data, int *eof)
 		lim = BATCH_MAXREC;
 	if (ctx->maxrec > lim)
 		ctx->maxrec = lim;
-	if (dbuf_want(ctx->gpu, &s->in, ctx->maxrec * chunk + 512, 1, 1) ||
-	    dbuf_want(ctx->gpu, &s->slots, ctx->maxrec * stride, 0, 1) ||
-	    dbuf_want(ctx->gpu, &s->stream, ctx->maxrec * stride + 512, 1, 1) ||
-	    dbuf_want(ctx->gpu, &s->meta, ctx->maxrec * 12 + 64, 1, 1))
+	if (dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->in, ctx->maxrec * chunk + 512, 1, 1) ||
+	    dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->slots, ctx->maxrec * stride, 0, 1) ||
+	    dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->stream, ctx->maxrec * stride + 512, 1, 1) ||
+	    dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->meta, ctx->maxrec * 12 + 64, 1, 1))
 		return ZSTDCB_ERROR(memory_allocation);
 	err = c_read_batch(ctx, ctx->io, s, ctx->maxrec, eof);
 	*has_data = s->nrec > 0;
@@ -246,7 +246,7 @@ static size_t cp_launch(void *a, int si)
 {
 	ZSTDCB_CCtx *ctx = (ZSTDCB_CCtx *)a;
 	size_t err = c_launch(ctx, &ctx->s[si]);
-	if (!err && gpumt_mark(ctx->gpu, si, 4 + si))
+	if (!err && gpumt_mark(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si), mt_stream_of(&ctx->gpus, si)))
 		err = ZSTDCB_ERROR(compression_library);
 	return err;
 }
@@ -255,10 +255,9 @@ static size_t cp_complete(void *a, int si)
 {
 	ZSTDCB_CCtx *ctx = (ZSTDCB_CCtx *)a;
 	struct cslot *s = &ctx->s[si];
-	gpumt_ctx *g = ctx->gpu;
 	const uint64_t *off = (const uint64_t *)((const uint8_t *)s->meta.h + ((s->nrec * 4 + 15) & ~(size_t)15));
 	size_t total;
-	if (gpumt_mark_sync(g, si))
+	if (gpumt_mark_sync(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si)))
 		return ZSTDCB_ERROR(compression_library);
 	total = (size_t)off[s->nrec];
 	if (total > s->stream.cap)
@@ -301,8 +300,8 @@ size_t ZSTDCB_compressCCtx(ZSTDCB_CCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 	ctx->maxrec = BATCH_MIN / (size_t)ctx->inputsize;
 	if (ctx->maxrec < 1)
 		ctx->maxrec = 1;
-	err = mt_pipe_run(&ops, ctx);
-	gpumt_device_sync(ctx->gpu);
+	err = mt_pipe_run_n(&ops, ctx, mt_nslot_for(ctx->gpus.n));
+	mt_gpus_sync(&ctx->gpus);
 	return err;
 }
 
@@ -320,7 +319,7 @@ struct ZSTDCB_DCtx_s {
 	int threads, inputsize;
 	size_t budget;
 	size_t insize, outsize, curframe, frames;
-	gpumt_ctx *gpu;
+	mt_gpus gpus; /* the devices the batch slots are dealt out to (mt_host.h) */
 	struct dslot s[MT_NSLOT];
 	ZSTDCB_RdWr_t *io;
 	int have_hdr; /* a record header read ahead of its batch */
@@ -339,7 +338,7 @@ ZSTDCB_DCtx *ZSTDCB_createDCtx(int threads, int inputsize)
 		return NULL;
 	ctx->threads = threads;
 	ctx->inputsize = inputsize ? inputsize : 1024 * 512; /* zstd-mt_decompress.c:125-128 */
-	if (gpumt_open(GPUMT_DEVICE_DEFAULT, &ctx->gpu) != GPUMT_OK) {
+	if (mt_gpus_open(&ctx->gpus)) {
 		free(ctx);
 		return NULL;
 	}
@@ -351,12 +350,12 @@ void ZSTDCB_freeDCtx(ZSTDCB_DCtx *ctx)
 	if (!ctx)
 		return;
 	for (int i = 0; i < MT_NSLOT; i++) {
-		dbuf_free(ctx->gpu, &ctx->s[i].in);
-		dbuf_free(ctx->gpu, &ctx->s[i].meta);
-		dbuf_free(ctx->gpu, &ctx->s[i].status);
-		dbuf_free(ctx->gpu, &ctx->s[i].out);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].in);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].meta);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].status);
+		dbuf_free(mt_gpu_of(&ctx->gpus, i), &ctx->s[i].out);
 	}
-	gpumt_close(ctx->gpu);
+	mt_gpus_close(&ctx->gpus);
 	free(ctx);
 }
 
@@ -428,13 +427,13 @@ static size_t d_read_batch(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s,
 		if (s->in_bytes + 12 + (size_t)csize + 512 > s->in.cap) {
 			dbuf old = s->in;
 			memset(&s->in, 0, sizeof s->in);
-			if (dbuf_want(ctx->gpu, &s->in, s->in_bytes + 12 + (size_t)csize + 512, 1, 1)) {
-				dbuf_free(ctx->gpu, &s->in);
+			if (dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->in, s->in_bytes + 12 + (size_t)csize + 512, 1, 1)) {
+				dbuf_free(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->in);
 				s->in = old; /* keep the slot as it was: freeCtx releases it */
 				return ZSTDCB_ERROR(memory_allocation);
 			}
 			memcpy(s->in.h, old.h, s->in_bytes);
-			dbuf_free(ctx->gpu, &old);
+			dbuf_free(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &old);
 		}
 		rec = (uint8_t *)s->in.h + s->in_bytes;
 		rec[0] = 0x50; rec[1] = 0x2A; rec[2] = 0x4D; rec[3] = 0x18;
@@ -491,10 +490,10 @@ static size_t d_read_batch(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s,
 
 static size_t d_launch(ZSTDCB_DCtx *ctx, struct dslot *s)
 {
-	gpumt_ctx *g = ctx->gpu;
+	gpumt_ctx *g = mt_gpu_of(&ctx->gpus, (int)(s - ctx->s));
 	/* each batch slot launches on its own kernel stream (4 + slot): the decoders are bound by the
 	 * latency of a record, so the batches of the pipeline must overlap on the device */
-	const int ks = 4 + (int)(s - ctx->s);
+	const int ks = mt_stream_of(&ctx->gpus, (int)(s - ctx->s));
 	int rc = 0;
 	if (dbuf_want(g, &s->out, s->out_bytes + 64, 1, 1) || dbuf_want(g, &s->status, s->nrec * 4 + 64, 1, 1))
 		return ZSTDCB_ERROR(memory_allocation);
@@ -520,8 +519,8 @@ static size_t dp_fill(void *a, int si, int *has_data, int *eof)
 	ZSTDCB_DCtx *ctx = (ZSTDCB_DCtx *)a;
 	struct dslot *s = &ctx->s[si];
 	size_t err;
-	if (dbuf_want(ctx->gpu, &s->in, ctx->budget + (ctx->budget >> 3) + 4096, 1, 1) ||
-	    dbuf_want(ctx->gpu, &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1))
+	if (dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->in, ctx->budget + (ctx->budget >> 3) + 4096, 1, 1) ||
+	    dbuf_want(mt_gpu_of(&ctx->gpus, (int)(s - ctx->s)), &s->meta, D_META_BYTES(BATCH_MAXREC), 1, 1))
 		return ZSTDCB_ERROR(memory_allocation);
 	err = d_read_batch(ctx, ctx->io, s, eof);
 	*has_data = s->nrec > 0;
@@ -534,7 +533,7 @@ static size_t dp_launch(void *a, int si)
 {
 	ZSTDCB_DCtx *ctx = (ZSTDCB_DCtx *)a;
 	size_t err = d_launch(ctx, &ctx->s[si]);
-	if (!err && gpumt_mark(ctx->gpu, si, 2))
+	if (!err && gpumt_mark(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si), 2))
 		err = ZSTDCB_ERROR(compression_library);
 	return err;
 }
@@ -542,7 +541,7 @@ static size_t dp_launch(void *a, int si)
 static size_t dp_complete(void *a, int si)
 {
 	ZSTDCB_DCtx *ctx = (ZSTDCB_DCtx *)a;
-	return gpumt_mark_sync(ctx->gpu, si) ? ZSTDCB_ERROR(compression_library) : 0;
+	return gpumt_mark_sync(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si)) ? ZSTDCB_ERROR(compression_library) : 0;
 }
 
 static size_t dp_drain(void *a, int si)
@@ -666,7 +665,7 @@ static size_t plain_decompress(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, const uint8_
 	size_t want_ahead = BATCH_BYTES; /* input buffered before a round of frames is split off */
 	int eof = at_eof, first_read = 1;
 	struct dslot *s = &ctx->s[0];
-	gpumt_ctx *g = ctx->gpu;
+	gpumt_ctx *g = mt_gpu_of(&ctx->gpus, (int)(s - ctx->s));
 	if (!raw)
 		return ZSTDCB_ERROR(memory_allocation);
 	memcpy(raw, first, nfirst);
@@ -899,8 +898,8 @@ size_t ZSTDCB_decompressDCtx(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 	ctx->budget = BATCH_MIN;
 	ctx->io = rdwr;
 	/* threads == 1: every callback on the calling thread, as the reference (its single-thread path) */
-	err = ctx->threads == 1 ? mt_pipe_run_inline(&ops, ctx) : mt_pipe_run(&ops, ctx);
-	gpumt_device_sync(ctx->gpu);
+	err = ctx->threads == 1 ? mt_pipe_run_inline(&ops, ctx) : mt_pipe_run_n(&ops, ctx, mt_nslot_for(ctx->gpus.n));
+	mt_gpus_sync(&ctx->gpus);
 	return err;
 }
 
