@@ -207,6 +207,9 @@ typedef u32 v4u __attribute__((vector_size(16)));
 #endif
 #define P_TSTRIDE (2u * P_TILE + 8u) /* row stride of the token tile (P_TILE x u16 + pad) */
 #define P_TLPR (P_TILE / 8u)         /* lanes that move one row of the tile (16 bytes each) */
+#ifndef P_CADENCE
+#define P_CADENCE 16u /* scheduled top-ups every P_CADENCE steps (a power of two); lanes that run short in between ask at once (P_URGENT) */
+#endif
 #ifndef P_URGENT
 #define P_URGENT 24u /* top the rings up at once when a lane has fewer bytes than this ahead (0 = never) */
 #endif
@@ -297,7 +300,7 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 	u64 c_t1 = 0, c_t2 = 0, c_t3 = 0;
 	for (u32 step = 0;; step++) {
 		u64 tk0 = KT();
-		/* ---------------- top up the rings (every 8 steps) ----------------
+		/* ---------------- top up the rings (every P_CADENCE steps) ----------------
 		 * Refill unit = one 128-byte line of the stream, aligned in *global* memory, fetched by
 		 * eight lanes with one 16-byte load each: a load instruction serves 8 blocks and touches
 		 * 8 lines (the texture path costs per line, not per byte).  Software-pipelined: units
@@ -306,7 +309,7 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 		 * take the global-memory path -- a full memory round trip for the whole wave -- for every token
 		 * until the next scheduled round: top up now (slow tokens 1.08 -> 0.04 per step, 6.0 -> 5.1 ms) */
 		const bool urgent = P_URGENT && wv_any(!done && boff + pos + P_URGENT > ghi && ghi < boff + cs);
-		if ((step & 7) == 0 || step < 4 || urgent) { /* start-up: back-to-back rounds fill the ring */
+		if ((step & (P_CADENCE - 1)) == 0 || step < 4 || urgent) { /* start-up: back-to-back rounds fill the ring */
 			if (pendm) {
 				wv_sync();
 				/* the eight cross-lane reads first, then the stores: one wait instead of one per piece */
