@@ -11,10 +11,10 @@
  *                     complete(slot)  wait until the slot's results are in pinned memory
  *     writer thread : drain(slot)     fn_write from the slot's pinned output, in order
  *
- * over MT_NSLOT slots: up to MT_NSLOT - 1 batches are launched and not yet completed (the decompress
- * engines give every slot its own kernel stream, so their kernels overlap on the device), the
- * remaining slot is being read into or written out.  Order is positional (batch b lives in slot b % MT_NSLOT); the first error stops
- * all roles and is returned.
+ * over n slots (4 by default, see mt_nslot_for): up to n - 1 batches are launched and not yet completed
+ * (every slot has its own kernel stream, so their kernels overlap on the device -- or on several
+ * devices, mt_host.h), the remaining slot is being read into or written out.  Order is positional
+ * (batch b lives in slot b % n); the first error stops all roles and is returned.
  */
 #ifndef ZMT_MT_PIPE_H
 #define ZMT_MT_PIPE_H
