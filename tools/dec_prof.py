@@ -41,7 +41,7 @@ for v in variants:
             cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
             eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
             L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); w = max(c[6], 1); st_ = max(c[4], 1)
-            print(f"   K2 prof xflags={xf}: parse_ms={eng.timer_ms(14):.3f} waves={c[6]} steps/wave={c[4]/w:.0f} cycles/step total={c[0]/st_:.0f} refill={c[1]/st_:.0f} (landing {c[7]/st_:.0f}) token={c[2]/st_:.0f} drain={c[3]/st_:.0f} slowloads/step={c[5]/st_:.2f} | token split: read={c[10]/st_:.0f} lit={c[11]/st_:.0f} ml+state={c[12]/st_:.0f} emit={c[2]/st_:.0f}")
+            print(f"   K2 prof xflags={xf}: parse_ms={eng.timer_ms(14):.3f} waves={c[6]} steps/wave={c[4]/w:.0f} cycles/step total={c[0]/st_:.0f} refill={c[1]/st_:.0f} (landing {c[7]/st_:.0f}, rounds/step {c[8]/st_:.2f}) token={c[2]/st_:.0f} drain={c[3]/st_:.0f} slowloads/step={c[5]/st_:.2f} | token split: read={c[10]/st_:.0f} lit={c[11]/st_:.0f} ml+state={c[12]/st_:.0f} emit={c[2]/st_:.0f}")
             eng.set_variant("profile", 1); eng.set_variant("k2x", 0)
         if os.environ.get("K3PROF") and v == 0:
             eng.set_variant("profile", 3)

@@ -239,6 +239,7 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 		     unsigned long long *prof, u32 xflags)
 {
 	__shared__ __attribute__((aligned(16))) u8 ring_lds[64 * P_RSTRIDE];
+	__shared__ __attribute__((aligned(16))) u8 dump_lds[128]; /* where the pieces of rows that asked for nothing go */
 #ifndef P_DIRECT_TOK
 	__shared__ __attribute__((aligned(16))) u8 tile_lds[64 * P_TSTRIDE];
 #endif
@@ -297,7 +298,7 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 	const int tgrp = lane / (int)P_TLPR, tpiece = lane % (int)P_TLPR; /* tile drain: P_TLPR lanes per row */
 
 	u64 c_refill = 0, c_token = 0, c_drain = 0, c_slow = 0, c_ext = 0, t_begin = KT();
-	u64 c_t1 = 0, c_t2 = 0, c_t3 = 0;
+	u64 c_t1 = 0, c_t2 = 0, c_t3 = 0, c_rounds = 0;
 	for (u32 step = 0;; step++) {
 		u64 tk0 = KT();
 		/* ---------------- top up the rings (every P_CADENCE steps) ----------------
@@ -310,6 +311,7 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 		 * until the next scheduled round: top up now (slow tokens 1.08 -> 0.04 per step, 6.0 -> 5.1 ms) */
 		const bool urgent = P_URGENT && wv_any(!done && boff + pos + P_URGENT > ghi && ghi < boff + cs);
 		if ((step & (P_CADENCE - 1)) == 0 || step < 4 || urgent) { /* start-up: back-to-back rounds fill the ring */
+			c_rounds++;
 			if (pendm) {
 				wv_sync();
 				/* the eight cross-lane reads first, then the stores: one wait instead of one per piece */
@@ -317,16 +319,21 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 				ZMT_UNROLL
 				for (int i = 0; i < 8; i++)
 					ros[i] = wv_shfl(pend_off, 8 * i + dgrp);
+				/* no branches around the stores: every exec-masked block ends in a wait of its own and
+				 * eight of them in a row cost ~1 400 cycles per round; rows that asked for nothing put
+				 * their (meaningless) piece into a 128-byte dump instead */
 				ZMT_UNROLL
 				for (int i = 0; i < 8; i++) {
 					const int r = 8 * i + dgrp;
 					const u32 ro = ros[i];
-					if ((pendm >> r) & 1) {
-						u8 *d = ring_lds + (u32)r * P_RSTRIDE + ro + 16u * (u32)dpiece;
-						*(v4u *)d = pv[i];
-						if (ro == 0 && dpiece == 0)
-							*(v4u *)(d + P_RING) = pv[i]; /* mirror: dword reads never wrap */
-					}
+					const bool live = (pendm >> r) & 1;
+					u8 *const dump = dump_lds + 16u * (u32)dpiece;
+					u8 *const d = ring_lds + (u32)r * P_RSTRIDE + ro + 16u * (u32)dpiece;
+					u8 *const d1 = live ? d : dump;
+					*(v4u *)d1 = pv[i];
+					/* mirror of the ring's first 16 bytes (dword reads never wrap); every other lane
+					 * stores its piece a second time where it already is */
+					*(v4u *)((live && ro == 0 && dpiece == 0) ? d + P_RING : d1) = pv[i];
 				}
 				wv_sync();
 				if ((pendm >> lane) & 1)
@@ -348,17 +355,15 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 				ZMT_UNROLL
 				for (int i = 0; i < 8; i++)
 					rgs[i] = wv_shfl(greq, 8 * i + dgrp);
+				/* unconditional loads for the same reason: a row that asked for nothing fetches the wave's
+				 * first line again (always inside the stream) and its piece goes to the dump */
 				ZMT_UNROLL
 				for (int i = 0; i < 8; i++) {
 					const int r = 8 * i + dgrp;
-					const u32 r_g = rgs[i];
-					v4u v = {0, 0, 0, 0};
-					if (((pendm >> r) & 1) && !(xflags & 2)) {
-						/* 16-byte aligned; may run up to 127 bytes past stream_bytes: the stream
-						 * allocation carries that slack (include/gpumt.h) */
-						v = *(const v4u *)(stream + abase + r_g + 16u * (u32)dpiece);
-					}
-					pv[i] = v;
+					const u32 r_g = ((pendm >> r) & 1) && !(xflags & 2) ? rgs[i] : 0u;
+					/* 16-byte aligned; may run up to 127 bytes past stream_bytes: the stream allocation
+					 * carries that slack (include/gpumt.h) */
+					pv[i] = *(const v4u *)(stream + abase + r_g + 16u * (u32)dpiece);
 				}
 				if (need)
 					greq += P_UNIT;
@@ -512,6 +517,7 @@ zmt_dec_parse_kernel(const u8 *__restrict__ stream, u64 stream_bytes,
 					atomicAdd(prof + 5, (unsigned long long)slow_all);
 					atomicAdd(prof + 6, 1ull);
 					atomicAdd(prof + 7, (unsigned long long)c_ext);
+					atomicAdd(prof + 8, (unsigned long long)c_rounds);
 					atomicAdd(prof + 10, (unsigned long long)c_t1);
 					atomicAdd(prof + 11, (unsigned long long)c_t2);
 					atomicAdd(prof + 12, (unsigned long long)c_t3);
