@@ -1,0 +1,58 @@
+"""Host-side frame splitting of the plain .lz4 / .zst paths (lz4_frame_extent, zstd_frame_extent in the
+engines) on the CPU: frame lengths equal what liblz4 / libzstd wrote, the capacity bound covers the
+content, and no proper prefix of a frame is mistaken for a complete one (the incremental reader relies
+on that to wait for more input)."""
+import os
+import subprocess
+
+import pytest
+
+import helpers as H
+from cases import rnd, text
+
+HOST = os.path.join(H.ROOT, "tests", "host")
+
+
+def build(kind):
+    exe = os.path.join(HOST, "extent_harness_" + kind)
+    subprocess.check_call(["gcc", "-O1", "-g", "-pthread", "-w", "-I" + os.path.join(H.ROOT, "include"),
+                           "-I" + os.path.join(H.ROOT, "zstdmt_amd", "csrc", "host")]
+                          + (["-DHARNESS_ZSTD"] if kind == "zstd" else [])
+                          + [os.path.join(HOST, "extent_harness.c"),
+                             os.path.join(H.ROOT, "zstdmt_amd", "csrc", "host", "mt_pipe.c"),
+                             "-Wl,--unresolved-symbols=ignore-all", "-o", exe])
+    return exe
+
+
+def frames(kind):
+    parts = [text(300_000, 5), b"", rnd(70_000, 2), text(17, 3), bytes(500_000), text(1_100_000, 9)]
+    out = []
+    for i, p in enumerate(parts):
+        if kind == "lz4":
+            out.append(H.liblz4_frame(p, content_size=i & 1, checksum=(i >> 1) & 1, block_checksum=(i >> 2) & 1,
+                                      block_id=4 + i % 4))
+        else:
+            out.append(H.libzstd_frame(p, content_size=i & 1, checksum=(i >> 1) & 1, level=1 + 3 * (i % 3)))
+    return parts, out
+
+
+@pytest.mark.parametrize("kind", ["lz4", "zstd"])
+def test_frame_extents(kind, tmp_path):
+    if (kind == "lz4" and H.liblz4_frame(b"x") is None) or (kind == "zstd" and H.libzstd_frame(b"x") is None):
+        pytest.skip("codec library not on this box")
+    exe = build(kind)
+    parts, fr = frames(kind)
+    f = tmp_path / "stream.bin"
+    f.write_bytes(b"".join(fr))
+    rows = [tuple(int(x) for x in ln.split()) for ln in subprocess.check_output([exe, str(f)]).decode().splitlines()]
+    assert len(rows) == len(fr)
+    off = 0
+    for (o, ln, bound, flag), frame, part in zip(rows, fr, parts):
+        assert (o, ln) == (off, len(frame))
+        assert bound >= len(part)
+        off += len(frame)
+    # no proper prefix of a frame passes for a whole one
+    for frame in (fr[0], fr[2], fr[3]):
+        f.write_bytes(frame)
+        full, wrong = (int(x) for x in subprocess.check_output([exe, str(f), "cut"]).split())
+        assert (full, wrong) == (len(frame), 0)
