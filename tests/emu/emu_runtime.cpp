@@ -7,13 +7,44 @@ Block *g_blk = nullptr;
 
 static const size_t kStack = 256 * 1024;
 
+#if !defined(__x86_64__)
+#error "the fiber switch below is x86-64 System V only"
+#endif
+/* ucontext's swapcontext makes a signal-mask system call per switch, and the emulator switches at
+ * every cross-lane operation of every lane: this one only moves the callee-saved registers. */
+asm(".text\n"
+    ".globl emu_switch\n"
+    ".type emu_switch,@function\n"
+    "emu_switch:\n"
+    "	pushq %rbp\n"
+    "	pushq %rbx\n"
+    "	pushq %r12\n"
+    "	pushq %r13\n"
+    "	pushq %r14\n"
+    "	pushq %r15\n"
+    "	movq %rsp, (%rdi)\n"
+    "	movq %rsi, %rsp\n"
+    "	popq %r15\n"
+    "	popq %r14\n"
+    "	popq %r13\n"
+    "	popq %r12\n"
+    "	popq %rbx\n"
+    "	popq %rbp\n"
+    "	ret\n"
+    ".size emu_switch,.-emu_switch\n");
+
 static void trampoline()
 {
 	Block *b = g_blk;
 	b->body();
 	b->fib[b->cur].done = true;
-	swapcontext(&b->fib[b->cur].ctx, &b->sched);
+	emu_switch(&b->fib[b->cur].sp, b->sched_sp);
+	abort(); /* a finished fiber is never resumed */
 }
+
+/* fiber stacks live as long as the process: a block of 1024 work-items would otherwise map and unmap
+ * 256 MiB per launch */
+static std::vector<char *> g_stacks;
 
 static void run_block(Block &b)
 {
@@ -26,14 +57,18 @@ static void run_block(Block &b)
 	b.gen.assign(b.nwaves + 1, 0);
 	for (unsigned i = 0; i < n; i++) {
 		Fiber &f = b.fib[i];
-		f.stack = (char *)malloc(kStack);
+		if (g_stacks.size() <= i)
+			g_stacks.push_back((char *)malloc(kStack));
+		f.stack = g_stacks[i];
 		f.done = false;
 		f.tid = i;
-		getcontext(&f.ctx);
-		f.ctx.uc_stack.ss_sp = f.stack;
-		f.ctx.uc_stack.ss_size = kStack;
-		f.ctx.uc_link = nullptr;
-		makecontext(&f.ctx, (void (*)())trampoline, 0);
+		/* first switch "returns" into trampoline with the stack aligned as after a call */
+		void **top = (void **)(((uintptr_t)f.stack + kStack) & ~(uintptr_t)15) - 2;
+		top[0] = (void *)trampoline;
+		top[1] = nullptr;
+		for (int r = 1; r <= 6; r++)
+			top[-r] = nullptr;
+		f.sp = top - 6;
 	}
 	unsigned live = n;
 	unsigned long idle_rounds = 0;
@@ -44,7 +79,7 @@ static void run_block(Block &b)
 				continue;
 			b.cur = i;
 			/* snapshot barrier generations to detect progress */
-			swapcontext(&b.sched, &b.fib[i].ctx);
+			emu_switch(&b.sched_sp, b.fib[i].sp);
 			if (b.fib[i].done) {
 				live--;
 				progressed++;
@@ -66,8 +101,6 @@ static void run_block(Block &b)
 			idle_rounds = 0;
 		}
 	}
-	for (unsigned i = 0; i < n; i++)
-		free(b.fib[i].stack);
 	g_blk = nullptr;
 }
 

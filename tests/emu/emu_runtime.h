@@ -3,7 +3,8 @@
  * can be debugged (gdb/ASan) in a container without a GPU.  Never part of the product: the shipped
  * library is built by hipcc for gfx950 and has no CPU path.
  *
- * Model: one workgroup at a time, every work-item is a ucontext fiber on one OS thread.  Fibers
+ * Model: one workgroup at a time, every work-item is a fiber (its own stack, switched by a few
+ * instructions of x86-64 assembly in emu_runtime.cpp) on one OS thread.  Fibers
  * run to their next synchronisation point (wave-level cross-lane op, wv_sync, __syncthreads) in
  * lane order, i.e. the *opposite* extreme of hardware lockstep: code that forgets a wv_sync()
  * between a store by one lane and a load by another gives wrong answers here, which is the point.
@@ -17,7 +18,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <ucontext.h>
 
 #include <functional>
 #include <vector>
@@ -37,7 +37,7 @@ struct dim3 {
 };
 
 struct Fiber {
-	ucontext_t ctx;
+	void *sp; /* saved stack pointer while the fiber is switched out */
 	char *stack;
 	bool done;
 	unsigned tid;
@@ -46,7 +46,7 @@ struct Fiber {
 struct Block {
 	unsigned nthreads, nwaves;
 	std::vector<Fiber> fib;
-	ucontext_t sched;
+	void *sched_sp;
 	unsigned cur;
 	/* barrier state: index 0..nwaves-1 = wave barriers, nwaves = block barrier */
 	std::vector<unsigned> arrived, gen;
@@ -58,12 +58,15 @@ struct Block {
 
 extern Block *g_blk;
 
+/* save the callee-saved registers and the stack pointer at *save_sp, continue on load_sp */
+extern "C" void emu_switch(void **save_sp, void *load_sp);
+
 inline unsigned tid() { return g_blk->cur; }
 
 inline void yield_to_sched()
 {
 	Block *b = g_blk;
-	swapcontext(&b->fib[b->cur].ctx, &b->sched);
+	emu_switch(&b->fib[b->cur].sp, b->sched_sp);
 }
 
 /* generic barrier over `count` participants identified by barrier index bi */

@@ -372,7 +372,7 @@ static size_t d_read_batch(BROTLIMT_DCtx *ctx, BROTLIMT_RdWr_t *io, struct dslot
 	s->in_bytes = 0;
 	s->out_bytes = 0;
 	while (s->nrec < BATCH_MAXREC) {
-		uint32_t csize, hint;
+		uint32_t csize = 0, hint = 0;
 		BROTLIMT_Buffer b;
 		size_t err, cap;
 		int rv;

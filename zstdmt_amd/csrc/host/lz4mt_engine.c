@@ -294,6 +294,10 @@ struct LZ4MT_DCtx_s {
 	/* a record header read ahead of its batch */
 	int have_hdr;
 	uint32_t hdr_csize;
+	/* the next header is the stream's first: its magic went with the sniff.  (The reference tests
+	 * frames == 0 for this, lz4-mt_decompress.c:200, so its DCtx decodes one stream only -- the
+	 * counters carry over and a second call fails with data_error; here a DCtx can be used again.) */
+	int first_hdr;
 };
 
 LZ4MT_DCtx *LZ4MT_createDCtx(int threads, int inputsize)
@@ -345,7 +349,8 @@ static size_t d_read_header(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, uint32_t *csize, 
 	uint8_t hb[12];
 	LZ4MT_Buffer b;
 	int rv;
-	if (ctx->frames == 0) { /* magic already consumed by the sniff */
+	if (ctx->first_hdr) { /* magic already consumed by the sniff */
+		ctx->first_hdr = 0;
 		b.buf = hb + 4;
 		b.size = 8;
 		b.allocated = 8;
@@ -383,7 +388,7 @@ static size_t d_read_batch(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, struct dslot *s, i
 	s->in_bytes = 0;
 	s->out_bytes = 0;
 	while (s->nrec < BATCH_MAXREC) {
-		uint32_t csize;
+		uint32_t csize = 0;
 		uint64_t osz = 0;
 		uint8_t *rec;
 		LZ4MT_Buffer b;
@@ -797,6 +802,7 @@ size_t LZ4MT_decompressDCtx(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *rdwr)
 	}
 	ctx->io = rdwr;
 	ctx->have_hdr = 0;
+	ctx->first_hdr = 1;
 	ctx->budget = BATCH_MIN;
 	/* threads == 1: every callback on the calling thread, as the reference (its single-thread path) */
 	err = ctx->threads == 1 ? mt_pipe_run_inline(&ops, ctx) : mt_pipe_run_n(&ops, ctx, mt_nslot_for(ctx->gpus.n));

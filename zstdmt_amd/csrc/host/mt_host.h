@@ -19,15 +19,20 @@
  * start at 64 MiB (small inputs stay cheap) and grow to 256 MiB; the buffers live as long as the
  * context, so repeated calls on one context do not pay for them again.
  */
-#define BATCH_MIN ((size_t)64 << 20)
+#define BATCH_MIN (zmt_batch_bytes() < ((size_t)64 << 20) ? zmt_batch_bytes() : (size_t)64 << 20)
 #define BATCH_BYTES (zmt_batch_bytes())
 static inline size_t zmt_batch_bytes(void)
 {
 	static size_t v;
 	if (!v) {
 		const char *e = getenv("GPUMT_BATCH_MB"); /* developer knob: device batch size */
+		const char *k = getenv("GPUMT_BATCH_KB"); /* test knob: batches of a few records (tests/emu) */
 		size_t mb = e && *e ? (size_t)strtoull(e, 0, 10) : 256;
 		v = (mb < 16 ? 16 : mb > 2048 ? 2048 : mb) << 20;
+		if (k && *k) {
+			size_t kb = (size_t)strtoull(k, 0, 10);
+			v = (kb < 16 ? 16 : kb > (2048u << 10) ? (2048u << 10) : kb) << 10;
+		}
 	}
 	return v;
 }

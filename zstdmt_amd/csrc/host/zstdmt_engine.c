@@ -403,7 +403,7 @@ static size_t d_read_batch(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s,
 	s->in_bytes = 0;
 	s->out_bytes = 0;
 	while (s->nrec < BATCH_MAXREC) {
-		uint32_t csize;
+		uint32_t csize = 0;
 		uint64_t osz;
 		uint8_t *rec;
 		ZSTDCB_Buffer b;
