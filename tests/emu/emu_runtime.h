@@ -27,6 +27,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define __noinline__ __attribute__((noinline))
 #define __shared__ static
 #define __restrict__ __restrict
 

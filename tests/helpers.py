@@ -498,3 +498,42 @@ def dense_sequences(n, lits=b"aaaabbcd"):
     while len(out) < n:
         out += rng.choice(words) + bytes([rng.choice(lits) if lits else rng.randrange(256)])
     return bytes(out[:n])
+
+
+def zstd_walk_blocks(frame: bytes):
+    """Blocks of one zstd frame (RFC 8878 3.1.1): list of dicts with type (0 raw, 1 RLE, 2 compressed),
+    size, and for compressed blocks the literals type, the number of sequences and the
+    Symbol_Compression_Modes byte (None without sequences).  Test helper, no validation."""
+    assert frame[:4] == bytes([0x28, 0xB5, 0x2F, 0xFD])
+    fhd = frame[4]
+    ss, fcs_flag, did = (fhd >> 5) & 1, fhd >> 6, fhd & 3
+    at = 5 + (0 if ss else 1) + (0, 1, 2, 4)[did] + ((1 if ss else 0), 2, 4, 8)[fcs_flag]
+    out = []
+    while True:
+        bh = int.from_bytes(frame[at:at + 3], "little")
+        last, typ, size = bh & 1, (bh >> 1) & 3, bh >> 3
+        ent = {"type": typ, "size": size}
+        body = frame[at + 3:at + 3 + (1 if typ == 1 else size)]
+        if typ == 2:
+            b0 = body[0]
+            lt, sf = b0 & 3, (b0 >> 2) & 3
+            if lt < 2:      # raw / RLE literals
+                hl = (1, 2, 1, 3)[sf]
+                regen = int.from_bytes(body[:hl], "little") >> (3 if hl == 1 else 4)
+                lsz = hl + (regen if lt == 0 else 1)
+            else:
+                hl = (3, 3, 4, 5)[sf]
+                v = int.from_bytes(body[:hl], "little")
+                bits = (10, 10, 14, 18)[sf]
+                lsz = hl + ((v >> (4 + bits)) & ((1 << bits) - 1))
+            sq = body[lsz:]
+            n, p = sq[0], 1
+            if n == 255:
+                n, p = int.from_bytes(sq[1:3], "little") + 0x7F00, 3
+            elif n >= 128:
+                n, p = ((n - 128) << 8) + sq[1], 2
+            ent.update(lit_type=lt, nseq=n, modes=sq[p] if n else None)
+        out.append(ent)
+        at += 3 + (1 if typ == 1 else size)
+        if last:
+            return out

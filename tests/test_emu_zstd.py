@@ -110,6 +110,24 @@ def test_emu_encode_decompress_identical(name):
     assert E.zstd_compress(data, chunk, grid=1) == st
 
 
+def test_emu_encoder_fits_sequence_tables_per_unit():
+    """A unit (the blocks of one 128 KiB of input) with enough sequences describes its own FSE tables
+    in its first block (modes 0xA8: three Compressed) and the others repeat them (0xFC); a small unit
+    keeps the predefined tables (0).  The tables keep the predefined sizes (2^6 / 2^5 / 2^6 cells)."""
+    data = cases.text(2 * 131072 + 3000, 11)
+    st = E.zstd_compress(data, 1 << 20)
+    blocks = H.zstd_walk_blocks(st[12:])
+    modes = [b["modes"] for b in blocks if b["type"] == 2]
+    heads = [i for i, m in enumerate(modes) if m == 0xA8]
+    assert len(heads) == 2 and heads[0] == 0                      # two full units
+    assert all(m == 0xFC for m in modes[1:heads[1]]) and heads[1] >= 2
+    assert modes[-1] == 0 and blocks[-1]["nseq"] < 256            # the 3000-byte tail: predefined
+    assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
+    # and it pays: the bench-like text shrinks by more than it did with predefined tables (2.29)
+    big = cases.text(1 << 20, 5)
+    assert len(big) / len(E.zstd_compress(big, 131072, grid=8)) > 2.40
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_emu_fuzz_encode_and_decode(seed):
     """Structured soup through the emulated encoder, the oracle and the emulated decoder; and, where

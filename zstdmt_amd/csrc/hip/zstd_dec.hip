@@ -19,7 +19,8 @@
  *     matches that read this batch's own output resolve in watermark rounds, long copies are
  *     done by the whole wave;
  *   - units: a block with a Huffman tree (or raw literals) followed by blocks with treeless (raw)
- *     literals and predefined sequence tables -- what the device encoder writes per 128 KiB -- is
+ *     literals, all with the predefined sequence tables or all with the tables the first one
+ *     describes (repeat mode) -- what the device encoder writes per 128 KiB -- is
  *     decoded side by side: up to 64 Huffman streams on 64 lanes, then up to 16 sequence
  *     bitstreams on 16 x (LL, OF, ML) lanes into the record's scratch; the blocks then only
  *     execute.  Anything else ends the unit and takes the per-block path above.
@@ -1076,10 +1077,15 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 			}
 			const u32 nseq = L.misc[ZM_D];
 			const u32 sq_hdr = L.misc[ZM_E];
-			/* all three tables predefined (what the device encoder writes) */
+			/* what the device encoder writes at the head of a unit: three predefined tables (the
+			 * blocks behind it say "predefined" again), or three described ones (the blocks behind
+			 * it say "repeat") */
 			const bool all_pre = nseq && (L.misc[ZM_A] & 0xC0000000u) == 0x40000000u &&
 					     (L.misc[ZM_A + 1] & 0xC0000000u) == 0x40000000u &&
 					     (L.misc[ZM_A + 2] & 0xC0000000u) == 0x40000000u;
+			const bool all_fit = nseq && L.misc[ZM_A] < 0x40000000u && L.misc[ZM_A + 1] < 0x40000000u &&
+					     L.misc[ZM_A + 2] < 0x40000000u;
+			const u32 unit_modes = all_fit ? 0xFCu : 0u; /* Symbol_Compression_Modes of the unit's other blocks */
 			u32 lpos = 0; /* literals consumed */
 			if (nseq) {
 				/* ---- build the three tables on lanes 0..2 ---- */
@@ -1137,7 +1143,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 				}
 				long pos = 8 * (long)(bs_len - 1) + hb32(lastb); /* unread bits, wave-uniform */
 				/* ---- unit: the sequences of this block and of the blocks looked at above ----
-				 * Their bitstreams are independent and, with predefined tables everywhere, read
+				 * Their bitstreams are independent and, with one set of tables for the unit, read
 				 * through the same three tables: four lanes per block (LL / OF / ML state + one
 				 * idle) decode up to 16 blocks side by side into the record's scratch, 8 bytes a
 				 * sequence (ll | ml << 18 | offset value << 36); the blocks then only execute.
@@ -1145,7 +1151,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 				if (unit_head) {
 					unit_head = false;
 					sq_left = 0;
-					if (all_pre && unit_n) {
+					if ((all_pre || all_fit) && unit_n) {
 						const u32 *pre = (const u32 *)L.w;
 						const u32 g = (u32)lane >> 2, sl = (u32)lane & 3;
 						bool act = g <= unit_n, gbad = false;
@@ -1164,7 +1170,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 									g_n = ((b0 - 128) << 8) + f[s0 + 1];
 									p = 2;
 								}
-								if (f[s0 + p] != 0)
+								if (f[s0 + p] != unit_modes)
 									g_n = 0; /* a table of its own */
 								g_off = s0 + p + 1;
 								if (g_off >= bend)
@@ -1305,6 +1311,11 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 							}
 							sq_left = ngrp;
 							sq_pos = 0;
+#ifdef ZMT_EMU
+							if (getenv("ZMT_EMU_DEBUG") && lane == 0)
+								fprintf(stderr, "zstd_dec: unit of %u blocks decoded side by side (%s tables)\n", ngrp,
+									all_fit ? "described" : "predefined");
+#endif
 							wv_sync();
 						}
 					}

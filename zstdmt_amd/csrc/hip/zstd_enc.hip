@@ -9,18 +9,21 @@
  * sequential match finder:
  *
  *   zmt_zstd_enc_kernel      one wave per 128 KiB block (persistent waves, blocks round-robin).
- *     match finding          64 positions per step, one per lane: 4-byte hash, 8192-entry u16 LDS
+ *     match finding          64 positions per step, one per lane: hash of 7 bytes, 4096-entry u16 LDS
  *                            table (the newest position of a step wins, deterministically),
- *                            candidates verified with one unaligned 8-byte compare per lane, loads
- *                            software-pipelined two steps ahead, long matches extended 512 bytes
- *                            per step by the whole wave;
- *     parse                  greedy, leftmost match first, resolved with ballots;
+ *                            candidates verified with unaligned 8-byte compares per lane (24 bytes
+ *                            forwards, 4 backwards), loads software-pipelined two steps ahead, long
+ *                            matches extended 512 bytes per step by the whole wave;
+ *     parse                  greedy, leftmost match first, resolved with ballots; a match grows
+ *                            backwards into the literals in front of it;
  *     literals               gathered lane-per-run, one Huffman code per 128 KiB unit (its first block
  *                            carries the tree, the others are treeless), coded in parallel (histogram with LDS
  *                            atomics, repaired ceil(log2) code lengths, canonical codes by ballots,
  *                            bit packing by prefix sum + atomicOr into LDS), raw when that does not pay;
- *     sequences              the list is cut into up to 16 zstd blocks, FSE-coded with the predefined
- *                            tables (RFC 8878 3.1.1.3.2.2) by 16 lanes side by side.
+ *     sequences              the list is cut into up to 16 zstd blocks, FSE-coded by 16 lanes side by
+ *                            side with tables fitted to the unit (described in its first block,
+ *                            repeated by the others; predefined-size tables, see ze_normalize) or,
+ *                            for a unit with few sequences, the predefined ones (RFC 8878 3.1.1.3.2.2).
  *     A block that does not shrink is stored raw.
  *   zmt_zstd_assemble_kernel one workgroup per chunk: skippable header + frame header
  *                            (single segment, content size) + the chunk's blocks moved together.
@@ -40,7 +43,9 @@
 #ifndef ZE_HLOG
 #define ZE_HLOG 12
 #endif
+#ifndef ZE_MINMATCH
 #define ZE_MINMATCH 7u
+#endif
 #define ZE_MAXSEQ (ZE_BLOCK / 4u) /* capacity of the per-wave sequence arrays (>= BLOCK / MINMATCH) */
 #define ZE_CAP 64u
 #define ZE_HUF_MAXLOG 10 /* longest literal code: 10 bits keep the decoder's table at 2 KiB (format max 11) */
@@ -48,8 +53,10 @@
  * Huffman coder plus the other entropy-phase arrays (ZEncLds), ZE_ENT_BYTES of them */
 #define ZE_ENT_BYTES (1024u + 512u + 256u + 136u + 8u + 1536u)
 #define ZE_STAGE_WORDS (((2u << ZE_HLOG) - ZE_ENT_BYTES) / 4u)
+/* bytes hashed: 7 = the shortest match taken; hashing 6 lets strings that differ in the 7th byte evict each
+ * other from the small table (ratio 2.428 vs 2.446 on the bench text with ZE_MINMATCH 7) */
 #ifndef ZE_HBYTES
-#define ZE_HBYTES 6
+#define ZE_HBYTES 7
 #endif
 #if ZE_HBYTES == 4
 #define ZE_HASH(v) (((u32)(v) * 2654435761u) >> (32 - ZE_HLOG))
@@ -69,7 +76,7 @@ struct ZEncLds {
 			u32 stage[16][8][3];          /* 8 staged sequences (ll, ml, offset) per run */
 		};
 	};
-	u16 st_ll[64], st_ml[64], st_of[32]; /* FSE state tables of the predefined distributions */
+	u16 st_ll[64], st_ml[64], st_of[32]; /* FSE state tables: predefined distributions, or fitted to the unit */
 	u32 tt_ll[36][2], tt_ml[53][2], tt_of[29][2]; /* per symbol: deltaNbBits, deltaFindState */
 	u32 llx[36], mlx[53];            /* value base | extra bits << 24 */
 	u8 llcode[64], mlcode[128];      /* code of literal length v / match length v + 3 */
@@ -104,7 +111,7 @@ __device__ static const u8 ZE_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
 
 /* FSE compression table of a normalized distribution (one lane): state table + per-symbol
  * transform, the encoder-side mirror of RFC 8878 4.1.1's decoding table */
-static __device__ void fse_ctable(u16 *state_tab, u32 (*tt)[2], const short *norm, int nsym, int log, u8 *scratch)
+static __device__ __noinline__ void fse_ctable(u16 *state_tab, u32 (*tt)[2], const short *norm, int nsym, int log, u8 *scratch)
 {
 	const u32 size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
 	u32 cumul[54];
@@ -147,6 +154,117 @@ static __device__ void fse_ctable(u16 *state_tab, u32 (*tt)[2], const short *nor
 			total += (u32)c;
 		}
 	}
+}
+
+/* ------------------------------------------------------------------ sequence tables of a unit
+ * The three FSE tables are fitted to the unit's own code statistics (Compressed mode in the unit's
+ * first block, Repeat mode in the others) when the unit has enough sequences to pay for the three
+ * descriptions; the table sizes are those of the predefined tables (2^6 / 2^5 / 2^6 cells), so the
+ * LDS arrays, the final-state widths and the decoder's small tables stay as they are.
+ * [1 MiB of the bench text: code bits 102.3 -> 76.3 KB, ratio 2.29 -> 2.43; 2^9 / 2^8 / 2^9 cells
+ * would give 72.5 KB] */
+#define ZE_ADAPT_MIN 256u /* sequences from which fitted tables pay for their descriptions */
+#define ZE_DESC 192u      /* room in front of run 0's bitstream for the three descriptions */
+
+/* counts -> cells of a 2^log table, every present symbol at least one (one lane).  Returns the
+ * number of present symbols. */
+static __device__ __noinline__ u32 ze_normalize(const u32 *hist, int nsym, u32 total, int log, short *norm)
+{
+	const u32 size = 1u << log;
+	u32 sum = 0, present = 0;
+	for (int s = 0; s < nsym; s++) {
+		const u32 c = hist[s];
+		u32 q = c ? (u32)(((u64)c << log) / total) : 0;
+		if (c && !q)
+			q = 1;
+		norm[s] = (short)q;
+		sum += q;
+		present += c != 0;
+	}
+	/* hand out what the rounding left to the symbols whose cells are fullest (largest count per
+	 * cell), or take cells back from where a cell holds least */
+	while (sum < size) {
+		int best = -1;
+		for (int s = 0; s < nsym; s++)
+			if (hist[s] && (best < 0 || (u64)hist[s] * (u32)norm[best] > (u64)hist[best] * (u32)norm[s]))
+				best = s;
+		norm[best]++;
+		sum++;
+	}
+	while (sum > size) {
+		int best = -1;
+		for (int s = 0; s < nsym; s++)
+			if (norm[s] > 1 &&
+			    (best < 0 || (u64)hist[s] * (u32)(norm[best] - 1) < (u64)hist[best] * (u32)(norm[s] - 1)))
+				best = s;
+		norm[best]--;
+		sum--;
+	}
+	return present;
+}
+
+/* RFC 8878 4.1.1 description of a normalized distribution (no "less than one" entries); nsym =
+ * last present symbol + 1.  One lane, output into LDS; returns its length. */
+static __device__ __noinline__ u32 ze_write_ncount(u8 *out, const short *norm, int nsym, int log)
+{
+	u64 acc = (u64)(log - 5);
+	u32 nb = 4, len = 0;
+	int remaining = (1 << log) + 1, threshold = 1 << log, nbits = log + 1, sym = 0;
+	bool prev0 = false;
+	while (sym < nsym && remaining > 1) {
+		if (prev0) {
+			int start = sym;
+			while (sym < nsym && !norm[sym])
+				sym++;
+			if (sym == nsym)
+				break;
+			while (sym >= start + 24) {
+				start += 24;
+				acc |= 0xFFFFull << nb;
+				nb += 16;
+				while (nb >= 8) {
+					out[len++] = (u8)acc;
+					acc >>= 8;
+					nb -= 8;
+				}
+			}
+			while (sym >= start + 3) {
+				start += 3;
+				acc |= 3ull << nb;
+				nb += 2;
+			}
+			acc |= (u64)(sym - start) << nb;
+			nb += 2;
+			while (nb >= 8) {
+				out[len++] = (u8)acc;
+				acc >>= 8;
+				nb -= 8;
+			}
+		}
+		{
+			int count = norm[sym++];
+			const int max = (2 * threshold - 1) - remaining;
+			remaining -= count;
+			count++;
+			if (count >= threshold)
+				count += max;
+			acc |= (u64)(u32)count << nb;
+			nb += (u32)nbits - (count < max ? 1u : 0u);
+			prev0 = count == 1;
+			while (remaining < threshold) {
+				nbits--;
+				threshold >>= 1;
+			}
+		}
+		while (nb >= 8) {
+			out[len++] = (u8)acc;
+			acc >>= 8;
+			nb -= 8;
+		}
+	}
+	if (nb)
+		out[len++] = (u8)acc;
+	return len;
 }
 
 /* lane-private forward bit writer (LSB first), 4-byte flushes */
@@ -712,6 +830,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			fse_ctable(L.st_of, L.tt_of, ZE_OF_DEF, 29, 5, scr);
 	}
 	wv_sync();
+	bool tabs_pre = true; /* st_* / tt_* hold the predefined distributions */
 
 	for (u32 g = blockIdx.x; g < nblk_total; g += gridDim.x) {
 		const u32 rec = g / blk_per_rec, bi = g % blk_per_rec;
@@ -782,10 +901,16 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			(M).c = ld64u(cp_ + 16);                                                   \
 			(M).d = ld64u(ip_ + 8);                                                    \
 			(M).e = ld64u(ip_ + 16);                                                   \
+			/* and the 4 bytes in front of both: a match grows backwards into the literals   \
+			 * before it (its first bytes often hashed to an entry that was overwritten) */  \
+			const bool b_ = (Cc) != 0xFFFFFFFFu && (Cc) >= 4u;                         \
+			(M).pb = ld32u(src + (b_ ? p_ - 4u : 0u));                                 \
+			(M).cb = ld32u(src + (b_ ? (Cc) - 4u : 0u));                               \
 		}                                                                                  \
 	} while (0)
 		struct Cmp {
 			u64 v, a, b, c, d, e; /* input bytes 0..7, candidate bytes 0..23, input bytes 8..23 */
+			u32 pb, cb;           /* the 4 bytes in front of the position / of the candidate */
 		};
 		/* three register sets rotate by unrolling (copying a set would wait for its loads) */
 		Cmp M[3]; /* compare data of steps t, t+1, t+2 at index step % 3 */
@@ -818,6 +943,10 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 				const bool cand = c0 != 0xFFFFFFFFu && p >= cursor;
 				if (cand && m > bsize - p)
 					m = bsize - p;
+				const u32 xb = m0.pb ^ m0.cb;
+				const u32 back = !(cand && c0 >= 4u) ? 0u
+						 : xb                ? (u32)__builtin_clz(xb) >> 3
+								     : 4u; /* equal bytes right in front */
 				u64 mask = wv_ballot(cand && m >= ZE_MINMATCH);
 				ZEP(7);
 				while (mask) {
@@ -857,9 +986,11 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 					}
 					/* sequences collect in registers (lane = index mod 64) and leave 64 at a time */
 					{
+						u32 bk = wv_readlane(back, j); /* as far back as the literals since the last match reach */
+						bk = bk < pj - anchor ? bk : pj - anchor;
 						const bool me = (u32)lane == (ns & 63);
-						r_ll = me ? pj - anchor : r_ll;
-						r_ml = me ? ml : r_ml;
+						r_ll = me ? pj - bk - anchor : r_ll;
+						r_ml = me ? ml + bk : r_ml;
 						r_of = me ? pj - cj : r_of;
 					}
 					ns++;
@@ -901,10 +1032,74 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 #endif
 
 		ZEP(0);
+		/* ------------------------------------------------ sequence tables of the unit
+		 * (see ze_normalize): histogram of the three codes by all lanes, then lanes 0 / 1 / 2
+		 * fit, build and describe the LL / OF / ML table.  The hash table is idle from here on;
+		 * the bit-packing stage of the literals is not in use yet and lends its first KiB. */
+		bool fitted = false;
+		u32 desc_len = 0;
+		{
+			u32 *shist = L.bitstage;                    /* LL at 0, ML at 36, OF at 89 */
+			short *snorm = (short *)(L.bitstage + 128); /* same layout */
+			u8 *sscr = (u8 *)(L.bitstage + 192);        /* 64 bytes per table: spread scratch, then its description */
+			const int t_off = lane == 0 ? 0 : lane == 1 ? 89 : 36;
+			const int t_alpha = lane == 0 ? 36 : lane == 1 ? 29 : 53, t_log = lane == 1 ? 5 : 6;
+			u16 *t_st = lane == 0 ? L.st_ll : lane == 1 ? L.st_of : L.st_ml;
+			u32(*t_tt)[2] = lane == 0 ? L.tt_ll : lane == 1 ? L.tt_of : L.tt_ml;
+			if (ns >= ZE_ADAPT_MIN) {
+				for (u32 i = (u32)lane; i < 128; i += 64)
+					shist[i] = 0;
+				wv_sync();
+				for (u32 i = (u32)lane; i < ns; i += 64) {
+					const u32 ll = sq_ll[i], mlb = sq_ml[i] - 3, ofv = sq_of[i] + 3;
+					atomicAdd(&shist[ll < 64 ? L.llcode[ll] : (u32)hb32(ll) + 19], 1u);
+					atomicAdd(&shist[36 + (mlb < 128 ? L.mlcode[mlb] : (u32)hb32(mlb) + 36)], 1u);
+					atomicAdd(&shist[89 + (u32)hb32(ofv)], 1u);
+				}
+				wv_sync();
+				u32 present = 2;
+				if (lane < 3)
+					present = ze_normalize(shist + t_off, t_alpha, ns, t_log, snorm + t_off);
+				/* a table with a single symbol would be RLE mode: such a unit keeps the predefined ones */
+				fitted = !wv_any(present < 2);
+			}
+			if (fitted) {
+				u32 dl = 0;
+				if (lane < 3) {
+					int nsym = t_alpha;
+					while (!snorm[t_off + nsym - 1])
+						nsym--;
+					fse_ctable(t_st, t_tt, snorm + t_off, nsym, t_log, sscr + 64 * lane);
+					for (int s2 = nsym; s2 < t_alpha; s2++) { /* symbols behind the last present one */
+						t_tt[s2][0] = ((u32)(t_log + 1) << 16) - (1u << t_log);
+						t_tt[s2][1] = 0;
+					}
+					dl = ze_write_ncount(sscr + 64 * lane, snorm + t_off, nsym, t_log);
+				}
+				wv_sync();
+				const u32 d_ll = wv_readlane(dl, 0), d_of = wv_readlane(dl, 1), d_ml = wv_readlane(dl, 2);
+				desc_len = d_ll + d_of + d_ml;
+				/* LL, OF, ML descriptions end where run 0's bitstream starts */
+				for (u32 i = (u32)lane; i < desc_len; i += 64)
+					bstmp[ZE_DESC - desc_len + i] = i < d_ll          ? sscr[i]
+									: i < d_ll + d_of ? sscr[64 + i - d_ll]
+											  : sscr[128 + i - d_ll - d_of];
+				tabs_pre = false;
+			} else if (!tabs_pre) {
+				if (lane == 0)
+					fse_ctable(L.st_ll, L.tt_ll, ZE_LL_DEF, 36, 6, sscr);
+				else if (lane == 1)
+					fse_ctable(L.st_of, L.tt_of, ZE_OF_DEF, 29, 5, sscr + 64);
+				else if (lane == 2)
+					fse_ctable(L.st_ml, L.tt_ml, ZE_ML_DEF, 53, 6, sscr + 128);
+				tabs_pre = true;
+			}
+			wv_sync();
+		}
 		/* ------------------------------------------------ sequences -> bitstreams
 		 * The sequence list is cut into G runs of equal count; each run becomes its own zstd
 		 * block, so G lanes can FSE-code side by side (an FSE stream is a serial chain; a block
-		 * boundary costs 8 bytes).  Lane s codes run s into bstmp + s * ZE_BSTMP. */
+		 * boundary costs 8 bytes).  Lane s codes run s into bstmp + s * ZE_BSTMP + ZE_DESC. */
 		u32 total = 0; /* bytes written at out; 0 = store the block raw */
 		if (ns) {
 			const u32 G = ns < 512 ? 1u : (ns / 512 < ZE_G ? ns / 512 : ZE_G);
@@ -914,8 +1109,8 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			}
 			wv_sync();
 			BitW w;
-			w.p = bstmp + (u32)lane * ZE_BSTMP;
-			w.limit = w.p + ZE_BSTMP;
+			w.p = bstmp + (u32)lane * ZE_BSTMP + ZE_DESC;
+			w.limit = w.p + ZE_BSTMP - ZE_DESC;
 			w.acc = 0;
 			w.nb = 0;
 			w.ovf = false;
@@ -989,7 +1184,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 						w.p[t] = (u8)(w.acc >> (8 * t));
 				}
 				w.p += tail;
-				L.sb_bits[lane] = w.ovf ? 0xFFFFFFFFu : (u32)(w.p - (bstmp + (u32)lane * ZE_BSTMP));
+				L.sb_bits[lane] = w.ovf ? 0xFFFFFFFFu : (u32)(w.p - (bstmp + (u32)lane * ZE_BSTMP + ZE_DESC));
 			}
 			wave_mem_fence();
 			wv_sync();
@@ -1031,6 +1226,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			for (u32 sb = 0; sb < G && fits; sb++) {
 				const u32 lo = (u32)(((u64)sb * ns) / G), hi = (u32)(((u64)(sb + 1) * ns) / G);
 				const u32 nsq = hi - lo, bits = L.sb_bits[sb];
+				const u32 dsc = fitted && sb == 0 ? desc_len : 0; /* the unit's table descriptions */
 				/* sizes of this run: literal bytes, input bytes */
 				u32 lsum = 0, isum = 0;
 				for (u32 b = lo; b < hi; b += 64) {
@@ -1045,7 +1241,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 				const u32 lh = regen < 32 ? 1u : regen < 4096 ? 2u : 3u;
 				const u32 sh = nsq < 128 ? 1u : nsq < 0x7F00 ? 2u : 3u;
 				/* room check with the literals raw (coding them only shrinks the block) */
-				if (bits == 0xFFFFFFFFu || at + 3 + lh + regen + sh + 1 + bits + 8 > bsize) {
+				if (bits == 0xFFFFFFFFu || at + 3 + lh + regen + sh + 1 + dsc + bits + 8 > bsize) {
 					fits = false;
 					break;
 				}
@@ -1065,7 +1261,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 					lsec = lh + regen;
 				}
 				ZEP(3);
-				const u32 csize = lsec + sh + 1 + bits;
+				const u32 csize = lsec + sh + 1 + dsc + bits;
 				if (lane == 0) {
 					const u32 bh = (fin ? last : 0u) | 2u << 1 | csize << 3;
 					o[0] = (u8)bh;
@@ -1084,9 +1280,11 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 						sp[1] = (u8)(nsq - 0x7F00);
 						sp[2] = (u8)((nsq - 0x7F00) >> 8);
 					}
-					sp[sh] = 0; /* Symbol_Compression_Modes: three predefined tables */
+					/* Symbol_Compression_Modes: three predefined tables, or the unit's own: Compressed
+					 * in its first block, Repeat in the others */
+					sp[sh] = !fitted ? 0 : sb == 0 ? 0xA8 : 0xFC;
 				}
-				wave_copy(sp + sh + 1, bstmp + sb * ZE_BSTMP, bits, lane);
+				wave_copy(sp + sh + 1, bstmp + sb * ZE_BSTMP + ZE_DESC - dsc, dsc + bits, lane);
 				at += 3 + csize;
 				ipos += isum;
 				lbase += regen;
