@@ -11,7 +11,7 @@
  *   zmt_zstd_enc_kernel      one wave per 128 KiB block (persistent waves, blocks round-robin).
  *     match finding          64 positions per step, one per lane: hash of 7 bytes, 4096-entry u16 LDS
  *                            table (the newest position of a step wins, deterministically),
- *                            candidates verified with unaligned 8-byte compares per lane (24 bytes
+ *                            candidates verified with unaligned 8-byte compares per lane (20 bytes
  *                            forwards, 4 backwards), loads software-pipelined two steps ahead, long
  *                            matches extended 512 bytes per step by the whole wave;
  *     parse                  greedy, leftmost match first, resolved with ballots; a match grows
@@ -48,6 +48,7 @@
 #endif
 #define ZE_MAXSEQ (ZE_BLOCK / 4u) /* capacity of the per-wave sequence arrays (>= BLOCK / MINMATCH) */
 #define ZE_CAP 64u
+#define ZE_FWD 20u /* bytes of a match measured by the lane that found it; longer ones by the whole wave */
 #define ZE_HUF_MAXLOG 10 /* longest literal code: 10 bits keep the decoder's table at 2 KiB (format max 11) */
 /* While a block is assembled the hash table is idle: its LDS doubles as the bit-packing stage of the
  * Huffman coder plus the other entropy-phase arrays (ZEncLds), ZE_ENT_BYTES of them */
@@ -86,6 +87,9 @@ struct ZEncLds {
 static_assert(sizeof(((ZEncLds *)0)->table) >= ZE_STAGE_WORDS * 4 + ZE_ENT_BYTES, "entropy-phase arrays must fit the idle hash table");
 static_assert(ZE_STAGE_WORDS >= 1024, "one packing round adds up to 176 words and the stage flushes at 3/4");
 
+#ifndef ZE_COLD
+#define ZE_COLD __noinline__ /* once-per-unit table code: kept out of the kernel's register allocation */
+#endif
 static __device__ __forceinline__ void st64g(u8 *p, u64 v) { __builtin_memcpy(p, &v, 8); }
 static __device__ __forceinline__ int hb32(u32 v) { return 31 - __builtin_clz(v); }
 
@@ -111,7 +115,7 @@ __device__ static const u8 ZE_ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
 
 /* FSE compression table of a normalized distribution (one lane): state table + per-symbol
  * transform, the encoder-side mirror of RFC 8878 4.1.1's decoding table */
-static __device__ __noinline__ void fse_ctable(u16 *state_tab, u32 (*tt)[2], const short *norm, int nsym, int log, u8 *scratch)
+static __device__ ZE_COLD void fse_ctable(u16 *state_tab, u32 (*tt)[2], const short *norm, int nsym, int log, u8 *scratch)
 {
 	const u32 size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
 	u32 cumul[54];
@@ -163,12 +167,14 @@ static __device__ __noinline__ void fse_ctable(u16 *state_tab, u32 (*tt)[2], con
  * LDS arrays, the final-state widths and the decoder's small tables stay as they are.
  * [1 MiB of the bench text: code bits 102.3 -> 76.3 KB, ratio 2.29 -> 2.43; 2^9 / 2^8 / 2^9 cells
  * would give 72.5 KB] */
+#ifndef ZE_ADAPT_MIN
 #define ZE_ADAPT_MIN 256u /* sequences from which fitted tables pay for their descriptions */
+#endif
 #define ZE_DESC 192u      /* room in front of run 0's bitstream for the three descriptions */
 
 /* counts -> cells of a 2^log table, every present symbol at least one (one lane).  Returns the
  * number of present symbols. */
-static __device__ __noinline__ u32 ze_normalize(const u32 *hist, int nsym, u32 total, int log, short *norm)
+static __device__ ZE_COLD u32 ze_normalize(const u32 *hist, int nsym, u32 total, int log, short *norm)
 {
 	const u32 size = 1u << log;
 	u32 sum = 0, present = 0;
@@ -205,7 +211,7 @@ static __device__ __noinline__ u32 ze_normalize(const u32 *hist, int nsym, u32 t
 
 /* RFC 8878 4.1.1 description of a normalized distribution (no "less than one" entries); nsym =
  * last present symbol + 1.  One lane, output into LDS; returns its length. */
-static __device__ __noinline__ u32 ze_write_ncount(u8 *out, const short *norm, int nsym, int log)
+static __device__ ZE_COLD u32 ze_write_ncount(u8 *out, const short *norm, int nsym, int log)
 {
 	u64 acc = (u64)(log - 5);
 	u32 nb = 4, len = 0;
@@ -889,28 +895,34 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		u32 c_ = (p_ & ~0xFFFFu) | e_;                                                     \
 		if (c_ >= p_)                                                                      \
 			c_ -= 65536u;                                                              \
-		(Cc) = (ok_ && c_ < p_) ? c_ : 0xFFFFFFFFu;                                        \
-		/* 24 bytes of the candidate and of the input beyond the hashed 8: most matches are   \
-		 * measured right here, without the wave-wide extension below */                      \
+		/* (the four positions at the very start of a block are no candidates: the window below  \
+		 * starts 4 bytes in front of one) */                                                  \
+		(Cc) = (ok_ && c_ < p_ && c_ >= 4u) ? c_ : 0xFFFFFFFFu;                            \
+		/* 24 bytes around the candidate -- 4 in front of it, 20 from it on -- and the same of    \
+		 * the input: most matches are measured right here, without the wave-wide extension     \
+		 * below, and a match grows backwards into the literals in front of it (its first bytes \
+		 * often hashed to an entry that was overwritten).  One window, so that looking back    \
+		 * costs no gather of its own [MI355X, 8 GiB: 92.2 ms without looking back, 108.1 ms    \
+		 * with a separate 4-byte gather, 91.0 ms this way] */                                  \
 		{                                                                                  \
-			const u8 *cp_ = src + ((Cc) != 0xFFFFFFFFu ? (Cc) : 0u);                   \
-			const u8 *ip_ = src + (ok_ ? p_ : 0u);                                     \
+			const bool v_ = (Cc) != 0xFFFFFFFFu;                                       \
+			const u8 *cp_ = src + (v_ ? (Cc) - 4u : 0u);                               \
+			const u8 *ip_ = src + (v_ ? p_ : 0u);                                      \
 			(M).v = (V);                                                               \
 			(M).a = ld64u(cp_);                                                        \
 			(M).b = ld64u(cp_ + 8);                                                    \
 			(M).c = ld64u(cp_ + 16);                                                   \
 			(M).d = ld64u(ip_ + 8);                                                    \
-			(M).e = ld64u(ip_ + 16);                                                   \
-			/* and the 4 bytes in front of both: a match grows backwards into the literals   \
-			 * before it (its first bytes often hashed to an entry that was overwritten) */  \
-			const bool b_ = (Cc) != 0xFFFFFFFFu && (Cc) >= 4u;                         \
-			(M).pb = ld32u(src + (b_ ? p_ - 4u : 0u));                                 \
-			(M).cb = ld32u(src + (b_ ? (Cc) - 4u : 0u));                               \
+			(M).e = ld32u(ip_ + 16);                                                   \
+			/* the input's own 4 bytes in front: the low half of the word 4 lanes down (a      \
+			 * step's first four positions go without: 94.3 -> 91.0 ms against a load) */     \
+			const u32 n_ = wv_shfl((u32)(V), lane - 4);                                \
+			(M).pb = lane >= 4 ? n_ : ~(u32)(M).a;                                     \
 		}                                                                                  \
 	} while (0)
 		struct Cmp {
-			u64 v, a, b, c, d, e; /* input bytes 0..7, candidate bytes 0..23, input bytes 8..23 */
-			u32 pb, cb;           /* the 4 bytes in front of the position / of the candidate */
+			u64 v, a, b, c, d; /* input bytes 0..7, candidate window (bytes -4..19), input bytes 8..15 */
+			u32 e, pb;         /* input bytes 16..19, input bytes -4..-1 (lanes 4..63) */
 		};
 		/* three register sets rotate by unrolling (copying a set would wait for its loads) */
 		Cmp M[3]; /* compare data of steps t, t+1, t+2 at index step % 3 */
@@ -935,18 +947,17 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			const u64 v0 = m0.v;
 			const u32 p0 = t * 64u, p = p0 + (u32)lane;
 			if (p0 + 64 > cursor) { /* else the whole step lies inside the previous match */
-				const u64 x0 = v0 ^ m0.a, x1 = m0.d ^ m0.b, x2 = m0.e ^ m0.c;
+				const u64 x0 = v0 ^ (m0.a >> 32 | m0.b << 32), x1 = m0.d ^ (m0.b >> 32 | m0.c << 32);
+				const u32 x2 = m0.e ^ (u32)(m0.c >> 32);
 				u32 m = x0   ? (u32)__builtin_ctzll(x0) >> 3
 					: x1 ? 8u + ((u32)__builtin_ctzll(x1) >> 3)
-					: x2 ? 16u + ((u32)__builtin_ctzll(x2) >> 3)
-					     : 24u;
+					: x2 ? 16u + ((u32)__builtin_ctz(x2) >> 3)
+					     : ZE_FWD;
 				const bool cand = c0 != 0xFFFFFFFFu && p >= cursor;
 				if (cand && m > bsize - p)
 					m = bsize - p;
-				const u32 xb = m0.pb ^ m0.cb;
-				const u32 back = !(cand && c0 >= 4u) ? 0u
-						 : xb                ? (u32)__builtin_clz(xb) >> 3
-								     : 4u; /* equal bytes right in front */
+				const u32 xb = m0.pb ^ (u32)m0.a;
+				const u32 back = !cand ? 0u : xb ? (u32)__builtin_clz(xb) >> 3 : 4u; /* equal bytes right in front */
 				u64 mask = wv_ballot(cand && m >= ZE_MINMATCH);
 				ZEP(7);
 				while (mask) {
@@ -957,10 +968,10 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 						continue;
 					const u32 cj = wv_readlane(c0, j);
 					u32 ml = wv_readlane(m, j);
-					if (__builtin_expect(ml == 24, 0)) {
+					if (__builtin_expect(ml == ZE_FWD, 0)) {
 						const u64 tx_ = ZET();
 						/* extend: 64 lanes x 8 bytes per step */
-						for (u32 base = 24;; base += 512) {
+						for (u32 base = ZE_FWD;; base += 512) {
 							const u32 o = base + 8u * (u32)lane;
 							u32 k = 0;
 							bool stop = true;
