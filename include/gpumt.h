@@ -237,6 +237,31 @@ int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint
 				  const uint64_t *d_out_off, const uint32_t *d_out_cap,
 				  uint32_t *d_out_len, uint32_t *d_status, int stream);
 
+/* ---- snappy-mt records (16-byte header + one raw snappy stream, lib/snappy-mt_compress.c:280-300) ----
+ *
+ * gpumt_snappy_compress_batch: chunk i = d_in[i*chunk, ...) -> one record (header with the payload size,
+ * "SP" and the reference's hint, + one raw snappy stream that decodes to the chunk; replaces
+ * snappy_compress at lib/snappy-mt_compress.c:264-276) at d_slots + i*slot_stride, its length to
+ * d_rec_len[i]; slot_stride >= gpumt_snappy_slot_stride(chunk) (16 + snappy_max_compressed_length).
+ * gpumt_lz4_compact packs the records.  The streams are valid raw snappy (copies stay inside 64 KiB
+ * blocks); their bytes are not those of the reference's snappy library, which is not part of its tree
+ * -- the bar is decompress-identical.  d_in must extend 64 readable bytes past n.
+ *
+ * gpumt_snappy_decompress_batch: decode nrec raw snappy streams (replaces snappy_uncompress at
+ * lib/snappy-mt_decompress.c:350).  Stream i is d_stream + d_rec_off[i], d_rec_len[i] bytes (the
+ * payload behind the 16-byte header); its output goes to d_out + d_out_off[i] and may take
+ * d_out_cap[i] bytes -- the caller reads the stream's varint preamble for it, as the reference does
+ * (snappy_uncompressed_length, :262-267).  d_out_len[i] receives the decoded size, d_status[i]
+ * GPUMT_ST_OK, GPUMT_ST_BAD_BLOCK (malformed / truncated stream, or not the size its preamble states)
+ * or GPUMT_ST_SIZE_MISMATCH (the preamble exceeds the capacity).  Same d_stream slack rule as above. */
+size_t gpumt_snappy_slot_stride(size_t chunk);
+int gpumt_snappy_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
+				size_t slot_stride, uint32_t *d_rec_len, int stream);
+int gpumt_snappy_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
+				  const uint32_t *d_rec_len, size_t nrec, void *d_out,
+				  const uint64_t *d_out_off, const uint32_t *d_out_cap,
+				  uint32_t *d_out_len, uint32_t *d_status, int stream);
+
 /* XXH32 (seed 0) of n items: item i = d_base + d_off[i], d_len[i] bytes -> d_hash[i]. */
 int gpumt_xxh32_batch(gpumt_ctx *h, const void *d_base, const uint64_t *d_off,
 		      const uint32_t *d_len, size_t n, uint32_t *d_hash, int stream);

@@ -123,6 +123,12 @@ size_t zo_brotli_transform(const uint8_t *blob, uint8_t *dst, const uint8_t *wor
 /* whole brotli-mt stream of 16-byte-header records (lib/brotli-mt_decompress.c:187-377) */
 size_t zo_brotlimt_decompress(const uint8_t *src, size_t slen, uint8_t *dst, size_t cap, const uint8_t *blob);
 
+/* snappy (snappy_oracle.c): varint preamble, one raw stream, the snappy-mt record walk
+ * (lib/snappy-mt_decompress.c:185-377); (size_t)-1 / 0 on malformed input */
+size_t zo_snappy_uncompressed_length(const uint8_t *src, size_t n, uint32_t *out);
+size_t zo_snappy_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap);
+size_t zo_snappymt_decompress(const uint8_t *src, size_t slen, uint8_t *dst, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,7 +4,7 @@
  * A small gzip-like front end with the option letters, file handling and -B report lines of the
  * reference CLI (/root/reference/programs/main.c:124-165 usage text, :166-170 + :238-243 "-B"
  * statistics line, :970-977 timing line), so that BASELINE.json's configurations can be typed as
- * written ("lz4-mt -1 -T4 FILE").  One source, the codec is chosen at build time (-DZMT_ZSTD, -DZMT_BROTLI) like
+ * written ("lz4-mt -1 -T4 FILE").  One source, the codec is chosen at build time (-DZMT_ZSTD, -DZMT_BROTLI, -DZMT_SNAPPY) like
  * the reference does with programs/lz4-mt.c / programs/zstd-mt.c; the personality (compress /
  * decompress / cat) follows argv[0].  -l lists compressed / uncompressed sizes (and crc32 + mtime with -v, -C
  * switches the crc off) in the reference's layout (programs/main.c:383-418).
@@ -33,6 +33,20 @@
 #define MT(x) BROTLIMT_##x
 typedef BROTLIMT_Buffer MT_Buffer;
 typedef BROTLIMT_RdWr_t MT_RdWr_t;
+#elif defined(ZMT_SNAPPY)
+#include "snappy-mt.h"
+#define PROGNAME "snappy-mt" /* programs/snappy-mt.c:13-22 */
+#define UNZIP "unsnappy-mt"
+#define ZCAT "snappycat-mt"
+#define SUFFIX ".snp"
+#define METHOD "snappy"
+#define LEVEL_DEF 0
+#define LEVEL_MIN 0
+#define LEVEL_MAX 1
+#define THREAD_MAX SNAPPYMT_THREAD_MAX
+#define MT(x) SNAPPYMT_##x
+typedef SNAPPYMT_Buffer MT_Buffer;
+typedef SNAPPYMT_RdWr_t MT_RdWr_t;
 #elif defined(ZMT_ZSTD)
 #include "zstd-mt.h"
 #define PROGNAME "zstd-mt"

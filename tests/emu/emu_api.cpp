@@ -34,6 +34,8 @@ void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u3
 void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
 void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 void zmt_zstd_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
+void zmt_snappy_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *);
+void zmt_snappy_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
 }
 
 using emu::dim3;
@@ -243,6 +245,28 @@ void emu_zstd_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stri
 		    [=]() { zmt_zstd_enc_kernel(in, n, chunk, nblk, bpr, slots, stride, bl, sq); });
 	emu::launch(dim3{nrec, 1, 1}, dim3{256, 1, 1},
 		    [=]() { zmt_zstd_assemble_kernel(n, chunk, nrec, bpr, slots, stride, bl, rec_len); });
+}
+
+/* snappy: `grid` persistent waves over the records */
+size_t emu_snappy_slot_stride(size_t chunk) { return (16 + 32 + chunk + chunk / 6 + 255) & ~(size_t)255; }
+
+void emu_snappy_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid)
+{
+	u32 nrec = n ? (u32)((n + chunk - 1) / chunk) : 1;
+	if (grid > nrec)
+		grid = nrec;
+	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1},
+		    [=]() { zmt_snappy_enc_kernel(in, n, chunk, nrec, slots, stride, rec_len); });
+}
+
+void emu_snappy_decompress_batch(const u8 *stream, const u64 *rec_off, const u32 *rec_len, u32 nrec, u8 *out,
+				 const u64 *out_off, const u32 *out_cap, u32 *out_len, u32 *status, u32 grid)
+{
+	if (grid > nrec)
+		grid = nrec;
+	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1}, [=]() {
+		zmt_snappy_dec_kernel(stream, rec_off, rec_len, nrec, out, out_off, out_cap, out_len, status);
+	});
 }
 
 } /* extern "C" */

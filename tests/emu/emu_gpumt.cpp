@@ -39,6 +39,10 @@ void emu_brotli_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 st
 void emu_brotli_decompress_batch(const u8 *stream, const u64 *rec_off, const u32 *rec_len, u32 nrec, u8 *out,
 				 const u64 *out_off, const u32 *out_cap, u32 *out_len, u32 *status,
 				 const u8 *blob, u32 grid);
+size_t emu_snappy_slot_stride(size_t chunk);
+void emu_snappy_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid);
+void emu_snappy_decompress_batch(const u8 *stream, const u64 *rec_off, const u32 *rec_len, u32 nrec, u8 *out,
+				 const u64 *out_off, const u32 *out_cap, u32 *out_len, u32 *status, u32 grid);
 extern const unsigned char zmt_brotli_static[], zmt_brotli_static_end[];
 }
 
@@ -253,6 +257,32 @@ int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint
 	count(h);
 	emu_brotli_decompress_batch((const u8 *)d_stream, d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off,
 				    d_out_cap, d_out_len, d_status, zmt_brotli_static, GRID);
+	return GPUMT_OK;
+}
+
+size_t gpumt_snappy_slot_stride(size_t chunk) { return emu_snappy_slot_stride(chunk); }
+
+int gpumt_snappy_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
+				size_t slot_stride, uint32_t *d_rec_len, int s)
+{
+	if (!h || !STREAM_OK(s) || chunk == 0 || chunk > 0x40000000u || slot_stride < gpumt_snappy_slot_stride(chunk))
+		return GPUMT_E_ARG;
+	std::lock_guard<std::mutex> lk(g_launch);
+	count(h);
+	emu_snappy_compress_batch((const u8 *)d_in, n, (u32)chunk, (u8 *)d_slots, slot_stride, d_rec_len, GRID);
+	return GPUMT_OK;
+}
+
+int gpumt_snappy_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
+				  const uint32_t *d_rec_len, size_t nrec, void *d_out, const uint64_t *d_out_off,
+				  const uint32_t *d_out_cap, uint32_t *d_out_len, uint32_t *d_status, int s)
+{
+	if (!h || !STREAM_OK(s) || nrec == 0 || nrec > 0x3FFFFFFFu)
+		return GPUMT_E_ARG;
+	std::lock_guard<std::mutex> lk(g_launch);
+	count(h);
+	emu_snappy_decompress_batch((const u8 *)d_stream, d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off,
+				    d_out_cap, d_out_len, d_status, GRID);
 	return GPUMT_OK;
 }
 

@@ -193,3 +193,70 @@ def zstd_compress(data: bytes, chunk: int, grid: int = 3):
     stream = np.full(int(rec_len.sum()) + 16, 0xDD, np.uint8)
     L.emu_lz4_compact(_p(slots), C.c_uint64(stride), _p(rec_len), C.c_uint32(nrec), _p(stream), _p(rec_off))
     return stream[:int(rec_off[nrec])].tobytes()
+
+
+# snappy-mt ------------------------------------------------------------------------------------
+def walk_snappy_records(stream: bytes):
+    """(payload offsets, payload lengths, hints) of a snappy-mt stream, or None (host-side walk)."""
+    ro, rl, hints = [], [], []
+    at = 0
+    while at < len(stream):
+        if len(stream) - at < 16:
+            return None
+        magic, eight, csz, sp, hint = struct.unpack_from("<IIIHH", stream, at)
+        if magic != 0x184D2A50 or eight != 8 or sp != 0x5053 or csz > len(stream) - at - 16:
+            return None
+        ro.append(at + 16)
+        rl.append(csz)
+        hints.append(hint)
+        at += 16 + csz
+    return np.array(ro, np.uint64), np.array(rl, np.uint32), hints
+
+
+def snappy_preamble(payload: bytes):
+    v = 0
+    for i, b in enumerate(payload[:5]):
+        v |= (b & 127) << (7 * i)
+        if b < 128:
+            return v if v < 1 << 32 else None
+    return None
+
+
+def snappy_decompress(stream: bytes, grid: int = 2, rec=None, caps=None):
+    """Emulated gpumt_snappy_decompress_batch over the records of `stream` (capacity of a record = its
+    preamble, as the engine sizes it; `caps` overrides).  -> (bytes of the accepted records, status[])"""
+    L = lib()
+    ro, rl = rec if rec is not None else walk_snappy_records(stream)[:2]
+    n = len(ro)
+    if caps is None:
+        caps = []
+        for o, ln in zip(ro.tolist(), rl.tolist()):
+            v = snappy_preamble(stream[o:o + ln])
+            caps.append(v if v is not None else 0)
+    cap = np.array(caps, np.uint32)
+    out_off = np.zeros(n + 1, np.uint64)
+    out_off[1:] = np.cumsum(cap.astype(np.uint64))
+    buf = np.frombuffer(stream + b"\0" * 256, np.uint8).copy()
+    out = np.full(int(out_off[n]) + 64, 0xCC, np.uint8)
+    out_len = np.zeros(n, np.uint32)
+    status = np.full(n, 0xA5, np.uint32)
+    L.emu_snappy_decompress_batch(_p(buf), _p(ro), _p(rl), C.c_uint32(n), _p(out), _p(out_off), _p(cap),
+                                  _p(out_len), _p(status), C.c_uint32(grid))
+    parts = [out[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() for i in range(n) if status[i] == 0]
+    return b"".join(parts), status
+
+
+def snappy_compress(data: bytes, chunk: int, grid: int = 3):
+    """Emulated gpumt_snappy_compress_batch + compact -> the snappy-mt stream."""
+    L = lib()
+    L.emu_snappy_slot_stride.restype = C.c_size_t
+    L.emu_snappy_slot_stride.argtypes = [C.c_size_t]
+    n = len(data)
+    nrec = max(1, (n + chunk - 1) // chunk)
+    stride = L.emu_snappy_slot_stride(chunk)
+    inp = np.frombuffer(data + b"\0" * 64, np.uint8).copy()
+    slots = np.full(nrec * stride, 0xEE, np.uint8)
+    rec_len = np.full(nrec, 0xA5A5A5A5, np.uint32)
+    L.emu_snappy_compress_batch(_p(inp), C.c_uint64(n), C.c_uint32(chunk), _p(slots), C.c_uint64(stride),
+                                _p(rec_len), C.c_uint32(grid))
+    return b"".join(slots[i * stride:i * stride + int(rec_len[i])].tobytes() for i in range(nrec))

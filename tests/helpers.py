@@ -6,6 +6,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch o
 import ctypes as C
 import hashlib
 import os
+import struct
 import subprocess
 import threading
 
@@ -71,6 +72,12 @@ def oracle():
         lib.zo_brotli_transform.argtypes = [p8, C.c_void_p, p8, C.c_uint32, C.c_uint32]
         lib.zo_brotlimt_decompress.restype = sz
         lib.zo_brotlimt_decompress.argtypes = [p8, sz, C.c_void_p, sz, p8]
+        lib.zo_snappy_decompress.restype = sz
+        lib.zo_snappy_decompress.argtypes = [p8, sz, C.c_void_p, sz]
+        lib.zo_snappymt_decompress.restype = sz
+        lib.zo_snappymt_decompress.argtypes = [p8, sz, C.c_void_p, sz]
+        lib.zo_snappy_uncompressed_length.restype = sz
+        lib.zo_snappy_uncompressed_length.argtypes = [p8, sz, C.POINTER(C.c_uint32)]
         _oracle = lib
     return _oracle
 
@@ -537,3 +544,82 @@ def zstd_walk_blocks(frame: bytes):
         at += 3 + (1 if typ == 1 else size)
         if last:
             return out
+
+
+# snappy-mt ------------------------------------------------------------------------------------
+LIBSNAPPY = "/opt/conda/lib/libsnappy.so.1"
+_snappy = None
+
+
+def have_libsnappy():
+    return os.path.exists(LIBSNAPPY)
+
+
+def libsnappy():
+    """The image's libsnappy 1.1.8 through its C API (snappy-c.h).  Not the reference's library (that
+    is a C port the zstdmt repository vendors outside /root/reference) but an independent
+    implementation of the same format: the pin of oracle/snappy_oracle.c."""
+    global _snappy
+    if _snappy is None:
+        L = C.CDLL(LIBSNAPPY)
+        L.snappy_compress.restype = C.c_int
+        L.snappy_compress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+        L.snappy_uncompress.restype = C.c_int
+        L.snappy_uncompress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+        L.snappy_max_compressed_length.restype = C.c_size_t
+        L.snappy_max_compressed_length.argtypes = [C.c_size_t]
+        _snappy = L
+    return _snappy
+
+
+def libsnappy_compress(data: bytes) -> bytes:
+    L = libsnappy()
+    cap = L.snappy_max_compressed_length(len(data))
+    out = C.create_string_buffer(cap)
+    n = C.c_size_t(cap)
+    assert L.snappy_compress(data, len(data), out, C.byref(n)) == 0
+    return out.raw[:n.value]
+
+
+def libsnappy_decompress(stream: bytes, cap: int):
+    """snappy_uncompress: bytes, or None unless SNAPPY_OK."""
+    out = C.create_string_buffer(max(cap, 1))
+    n = C.c_size_t(cap)
+    rv = libsnappy().snappy_uncompress(stream, len(stream), out, C.byref(n))
+    return out.raw[:n.value] if rv == 0 else None
+
+
+def oracle_snappy_decompress(stream: bytes, cap: int):
+    out = C.create_string_buffer(max(cap, 1))
+    n = oracle().zo_snappy_decompress(stream, len(stream), out, cap)
+    return None if n == SIZE_ERR else out.raw[:n]
+
+
+def oracle_snappymt_decompress(stream: bytes, cap: int):
+    out = C.create_string_buffer(max(cap, 1))
+    n = oracle().zo_snappymt_decompress(stream, len(stream), out, cap)
+    return None if n == SIZE_ERR else out.raw[:n]
+
+
+def snappy_record(payload: bytes, hint: int) -> bytes:
+    """One snappy-mt record (lib/snappy-mt_compress.c:280-300): skippable magic, 8, size, "SP", hint."""
+    return struct.pack("<IIIHH", 0x184D2A50, 8, len(payload), 0x5053, hint) + payload
+
+
+def snappymt_stream(data: bytes, chunk: int) -> bytes:
+    """What SNAPPYMT_compressCCtx writes for `data` (framing of the reference, payloads by libsnappy)."""
+    out = []
+    n = max(1, -(-len(data) // chunk))
+    for i in range(n):
+        part = data[i * chunk:(i + 1) * chunk]
+        hint = (len(part) >> 16) + 1 if len(part) < chunk else chunk >> 16
+        out.append(snappy_record(libsnappy_compress(part), hint))
+    return b"".join(out)
+
+
+def snappymt_compress_via(lib, data, chunk, threads=1, level=1):
+    return lz4mt_compress_via(lib, data, chunk, threads, level, pfx="SNAPPYMT_")
+
+
+def snappymt_decompress_via(lib, stream, threads=2, inputsize=0):
+    return lz4mt_decompress_via(lib, stream, threads, inputsize, pfx="SNAPPYMT_")

@@ -12,7 +12,7 @@ def _declared(header):
     txt = open(os.path.join(H.ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     txt = re.sub(r"^\s*#\s*define[^\n]*$", "", txt, flags=re.M)   # function-like macros are not symbols
-    return sorted(set(re.findall(r"\b((?:gpumt|LZ4MT|ZSTDCB|ZSTDMT|BROTLIMT)_[A-Za-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b((?:gpumt|LZ4MT|ZSTDCB|ZSTDMT|BROTLIMT|SNAPPYMT)_[A-Za-z0-9_]+)\s*\(", txt)))
 
 
 @pytest.fixture(scope="module")
@@ -24,7 +24,7 @@ def native():
     return C.CDLL(lib_path())
 
 
-@pytest.mark.parametrize("header", [h for h in ("gpumt.h", "lz4-mt.h", "zstd-mt.h", "brotli-mt.h")
+@pytest.mark.parametrize("header", [h for h in ("gpumt.h", "lz4-mt.h", "zstd-mt.h", "brotli-mt.h", "snappy-mt.h")
                                     if os.path.exists(os.path.join(H.ROOT, "include", h))])
 def test_exports(native, header):
     names = _declared(header)

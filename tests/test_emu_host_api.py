@@ -1,4 +1,4 @@
-"""The host engines on CPU: LZ4MT_* / ZSTDCB_* / BROTLIMT_* of tests/emu/libzstdmt_emu_host.so -- the
+"""The host engines on CPU: LZ4MT_* / ZSTDCB_* / BROTLIMT_* / SNAPPYMT_* of tests/emu/libzstdmt_emu_host.so -- the
 unchanged engine sources (zstdmt_amd/csrc/host/*.c) linked over an emulated device boundary
 (tests/emu/emu_gpumt.cpp: the kernels compiled as host C++ under the fiber emulator) -- driven through
 the reference's callback protocol like the `-m gpu` API tests, on inputs small enough for the
@@ -32,7 +32,7 @@ def lib():
     old = os.environ.get("GPUMT_BATCH_KB")
     os.environ["GPUMT_BATCH_KB"] = "16"      # read once, at the library's first batch
     L = C.CDLL(os.path.join(EMU_DIR, "libzstdmt_emu_host.so"))
-    for pfx in ("LZ4MT_", "ZSTDCB_", "BROTLIMT_"):
+    for pfx in ("LZ4MT_", "ZSTDCB_", "BROTLIMT_", "SNAPPYMT_"):
         H.bind_lz4mt(L, pfx)
     L.emu_gpumt_launches.restype = C.c_ulonglong
     L.emu_gpumt_launches.argtypes = [C.c_int]
@@ -499,3 +499,108 @@ def test_brotlimt_errors(lib):
     assert lib.BROTLIMT_compressCCtx(ctx, C.byref(io.rdwr)) == ERR(E_MEM)
     lib.BROTLIMT_freeCCtx(ctx)
     assert not lib.BROTLIMT_createCCtx(0, 1, 0) and not lib.BROTLIMT_createCCtx(1, 12, 0)
+
+
+# --------------------------------------------------------------------------------------- snappy-mt
+SCHUNK = 4096
+
+
+@pytest.mark.parametrize("name,chunk,thunk", [("empty", SCHUNK, lambda: b""), ("hello", SCHUNK, lambda: b"hello world, hello!"),
+                                              ("ragged", SCHUNK, lambda: _mixed(30000, 41)),
+                                              ("exact", SCHUNK, lambda: cases.text(8 * SCHUNK, 42)),
+                                              ("default_64k", 0, lambda: cases.text(150000, 43))])
+def test_snappymt_compress_is_decompress_identical(lib, name, chunk, thunk):
+    data = thunk()
+    rv, st, io, stats = H.snappymt_compress_via(lib, data, chunk, threads=3, level=0)
+    assert rv == 0
+    eff = chunk or 65536                     # SNAPPY_IN_ALLOC_SIZE, lib/snappy-mt_compress.c:12,102
+    frames = max(1, -(-len(data) // eff))
+    assert stats == (frames, len(data), len(st))
+    assert all(want == eff for want, _ in io.reads) and len(io.writes) == frames
+    at = 0
+    for i, w in enumerate(io.writes):        # 16-byte record headers (lib/snappy-mt_compress.c:280-300)
+        magic, eight, csz, sp, hint = struct.unpack_from("<IIIHH", st, at)
+        n = min(eff, len(data) - i * eff)
+        assert (magic, eight, csz, sp) == (0x184D2A50, 8, w - 16, 0x5053)
+        assert hint == ((n >> 16) + 1 if n < eff else eff >> 16)
+        at += w
+    assert at == len(st)
+    assert H.oracle_snappymt_decompress(st, len(data) + 64) == data
+    rv, back, io, dstats = H.snappymt_decompress_via(lib, st, threads=3)
+    assert rv == 0 and back == data and dstats == (frames, len(st), len(data))
+    # reads of pt_read: 4-byte sniff, 12 more for the first header, payload, then 16 + payload, EOF
+    wants = [w for w, _ in io.reads]
+    assert wants[0] == 4 and wants[1] == 12 and wants[-1] == 16 and io.reads[-1][1] == 0
+    assert len(io.writes) == frames
+    # the same stream whatever the level argument (unused, lib/snappy-mt_compress.c:80,96)
+    rv, st9, _, _ = H.snappymt_compress_via(lib, data, chunk, threads=1, level=9)
+    assert rv == 0 and st9 == st
+
+
+@pytest.mark.skipif(not H.have_libsnappy(), reason="libsnappy not on this box")
+@pytest.mark.parametrize("threads", [1, 4])
+def test_snappymt_decompress_foreign_streams(lib, threads):
+    """Payloads written by libsnappy 1.1.8, framed as the reference does; a zero hint changes nothing
+    (the output is sized from the stream's preamble, lib/snappy-mt_decompress.c:234-238,262-267)."""
+    data = _mixed(40000, 44)
+    st = H.snappymt_stream(data, SCHUNK)
+    rv, out, io, stats = H.snappymt_decompress_via(lib, st, threads=threads)
+    assert rv == 0 and out == data and stats == (10, len(st), len(data))
+    if threads == 1:
+        me = threading.get_ident()
+        assert io.read_threads == {me} and io.write_threads == {me}
+    nohint = bytearray(st)
+    at = 0
+    while at < len(nohint):
+        nohint[at + 14:at + 16] = b"\0\0"
+        at += 16 + struct.unpack_from("<I", nohint, at + 8)[0]
+    rv, out, _, _ = H.snappymt_decompress_via(lib, bytes(nohint), threads=threads)
+    assert rv == 0 and out == data
+
+
+def test_snappymt_errors(lib):
+    data = cases.text(40000, 45)
+    rv, st, _, _ = H.snappymt_compress_via(lib, data, SCHUNK, threads=2)
+    assert rv == 0
+    rv, _, _, _ = H.snappymt_decompress_via(lib, b"\x00" * 64)
+    assert rv == ERR(E_DATA)
+    rv, _, _, _ = H.snappymt_decompress_via(lib, st[:-7])
+    assert rv == ERR(E_DATA)                 # "needed more bytes"
+    bad = bytearray(st)
+    bad[12] ^= 1                             # the "SP" mark of the first record
+    rv, _, _, _ = H.snappymt_decompress_via(lib, bytes(bad))
+    assert rv == ERR(E_DATA)
+    c0 = struct.unpack_from("<I", st, 8)[0]
+    bad = bytearray(st)
+    bad[16 + c0] ^= 1                        # skippable magic of the second record
+    rv, _, _, _ = H.snappymt_decompress_via(lib, bytes(bad))
+    assert rv == ERR(E_DATA)
+    bad = bytearray(st)
+    bad[16] = 0xFF                           # preamble of the first stream: claims far more than it holds
+    bad[17] = 0xFF
+    rv, _, _, _ = H.snappymt_decompress_via(lib, bytes(bad))
+    assert rv == ERR(E_FD)                   # frame_decompress, as a failing snappy_uncompress (:350-357)
+    bad = bytearray(st)
+    bad[16 + c0 // 2] ^= 0x5A                # inside the first stream
+    rv, out, _, _ = H.snappymt_decompress_via(lib, bytes(bad))
+    want = H.oracle_snappymt_decompress(bytes(bad), len(data) + 64)
+    assert (rv == 0 and out == want) if want is not None else rv == ERR(E_FD)
+    io = H.MemIO(st, fail_read_at=2, read_rv=-2)
+    ctx = lib.SNAPPYMT_createDCtx(2, 0)
+    assert lib.SNAPPYMT_decompressDCtx(ctx, C.byref(io.rdwr)) == ERR(E_CANCEL)
+    lib.SNAPPYMT_freeDCtx(ctx)
+    io = H.MemIO(data, fail_write_at=3, write_rv=-3)
+    ctx = lib.SNAPPYMT_createCCtx(2, 0, SCHUNK)
+    assert lib.SNAPPYMT_compressCCtx(ctx, C.byref(io.rdwr)) == ERR(E_MEM)
+    lib.SNAPPYMT_freeCCtx(ctx)
+    assert not lib.SNAPPYMT_createCCtx(0, 1, 0) and not lib.SNAPPYMT_createCCtx(129, 1, 0)
+    ctx = lib.SNAPPYMT_createCCtx(1, 77, 0)  # any level
+    assert ctx
+    lib.SNAPPYMT_freeCCtx(ctx)
+    assert not lib.SNAPPYMT_createDCtx(0, 0)
+    io = H.MemIO(b"x")
+    assert lib.SNAPPYMT_compressCCtx(None, C.byref(io.rdwr)) == ERR(E_PARAM)
+    assert lib.SNAPPYMT_decompressDCtx(None, C.byref(io.rdwr)) == ERR(E_PARAM)
+    assert lib.SNAPPYMT_getErrorString(ERR(E_DATA)) == b"Malformed input"
+    assert lib.SNAPPYMT_getErrorString(ERR(E_CANCEL)) == b"Unspecified snappy error code"
+    assert lib.BROTLIMT_getErrorString(ERR(E_CANCEL)) == b"Unspecified brotli error code"

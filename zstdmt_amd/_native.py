@@ -55,6 +55,9 @@ GPUMT_SYMBOLS = {
     "gpumt_zstd_decompress_batch": (_i, [_vp, _vp, _sz, _u64p, _u32p, _sz, _vp, _sz, _u64p, _u32p, _u32p, _i]),
     "gpumt_brotli_compress_batch": (_i, [_vp, _vp, _sz, _sz, _vp, _sz, _u32p, _i]),
     "gpumt_brotli_decompress_batch": (_i, [_vp, _vp, _u64p, _u32p, _sz, _vp, _u64p, _u32p, _u32p, _u32p, _i]),
+    "gpumt_snappy_slot_stride": (_sz, [_sz]),
+    "gpumt_snappy_compress_batch": (_i, [_vp, _vp, _sz, _sz, _vp, _sz, _u32p, _i]),
+    "gpumt_snappy_decompress_batch": (_i, [_vp, _vp, _u64p, _u32p, _sz, _vp, _u64p, _u32p, _u32p, _u32p, _i]),
     "gpumt_xxh32_batch": (_i, [_vp, _vp, _u64p, _u32p, _sz, _u32p, _i]),
     "gpumt_set_variant": (_i, [_vp, C.c_char_p, _i]),
     "gpumt_debug_counters": (_i, [_vp, _vp, _i]),

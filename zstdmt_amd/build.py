@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 
-HIP_SRCS = ["xxh32.hip", "lz4_enc3.hip", "lz4_enc_hc.hip", "lz4_dec.hip", "lz4_dec_split.hip", "lz4_dec_copy2.hip", "zstd_dec.hip", "zstd_enc.hip", "brotli_dec.hip", "brotli_enc.hip", "pack.hip", "gpumt.hip"]
+HIP_SRCS = ["xxh32.hip", "snappy.hip", "lz4_enc3.hip", "lz4_enc_hc.hip", "lz4_dec.hip", "lz4_dec_split.hip", "lz4_dec_copy2.hip", "zstd_dec.hip", "zstd_enc.hip", "brotli_dec.hip", "brotli_enc.hip", "pack.hip", "gpumt.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 HIPFLAGS += os.environ.get("ZMT_HIPFLAGS", "").split()   # developer: -D overrides for A/B builds
@@ -56,7 +56,7 @@ def build(force=False, verbose=True):
                 continue
             s = os.path.join(hostdir, src)
             o = os.path.join(OBJDIR, src + ".o")
-            hh = [os.path.join(hostdir, h) for h in os.listdir(hostdir) if h.endswith(".h")]
+            hh = [os.path.join(hostdir, h) for h in os.listdir(hostdir) if h.endswith((".h", ".inc"))]
             datadir = os.path.join(CSRC, "data")
             hh += [os.path.join(datadir, d) for d in os.listdir(datadir)]
             if force or _stale(o, [s] + headers + hh):
@@ -69,13 +69,14 @@ def build(force=False, verbose=True):
     tsrc = os.path.join(CSRC, "tools", "gen_text.c")
     if force or _stale(tools, [tsrc]):
         _run(["gcc", "-O2", "-fPIC", "-shared", "-pthread", tsrc, "-o", tools, "-lm"])
-    # command line front ends (programs/zmt_cli.c): lz4-mt, zstd-mt, brotli-mt + their un* / *cat personalities
+    # command line front ends (programs/zmt_cli.c): lz4-mt, zstd-mt, brotli-mt, snappy-mt + their un* / *cat personalities
     bindir = os.path.join(HERE, "bin")
     os.makedirs(bindir, exist_ok=True)
     cli = os.path.join(ROOT, "programs", "zmt_cli.c")
     for name, flags, links in (("lz4-mt", [], ("unlz4-mt", "lz4cat-mt")),
                                ("zstd-mt", ["-DZMT_ZSTD"], ("unzstd-mt", "zstdcat-mt")),
-                               ("brotli-mt", ["-DZMT_BROTLI"], ("unbrotli-mt", "brotlicat-mt"))):
+                               ("brotli-mt", ["-DZMT_BROTLI"], ("unbrotli-mt", "brotlicat-mt")),
+                               ("snappy-mt", ["-DZMT_SNAPPY"], ("unsnappy-mt", "snappycat-mt"))):
         exe = os.path.join(bindir, name)
         if force or _stale(exe, [cli, lib] + headers):
             _run(["gcc", "-O2", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include")] + flags +

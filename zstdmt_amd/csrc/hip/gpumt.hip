@@ -42,6 +42,8 @@ __global__ void zmt_dec_copy2_kernel_prof(const u8 *, u64, u32, u32, u8 *, const
 					  const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 					  const u32 *, const u32 *, u32 *, unsigned long long *);
 __global__ void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
+__global__ void zmt_snappy_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *);
+__global__ void zmt_snappy_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
 __global__ void zmt_brotli_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 __global__ void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *,
 				      u32 *, u32 *, u8 *, const u8 *);
@@ -87,6 +89,7 @@ struct gpumt_ctx {
 	int zdec_variant; /* 0 = small-table kernel, then general; 1 = general only */
 	int bdec_waves;   /* resident waves of the persistent brotli decoder kernel (whole device) */
 	int benc_waves;   /* ... of the brotli encoder kernel */
+	int senc_waves, sdec_waves; /* ... of the snappy kernels */
 	void *d_brotli_static; /* device copy of the RFC 7932 constant data */
 	char err[256];
 	char name[128];
@@ -1016,6 +1019,60 @@ int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint
 				   d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap, d_out_len,
 				   d_status, (u8 *)h->scratch[1][s], (const u8 *)h->d_brotli_static);
 	PROF1(12);
+	CK(hipGetLastError());
+	return GPUMT_OK;
+}
+
+/* ---- snappy-mt (snappy.hip): persistent waves, one record at a time ---- */
+size_t gpumt_snappy_slot_stride(size_t chunk)
+{
+	return (16 + 32 + chunk + chunk / 6 + 255) & ~(size_t)255; /* header + snappy_max_compressed_length */
+}
+
+static int snappy_waves(gpumt_ctx *h, int *cache, const void *kernel, const char *what)
+{
+	if (!*cache) {
+		int per_cu = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess)
+			per_cu = 0;
+		*cache = (per_cu > 0 ? per_cu : 8) * (h->num_cus > 0 ? h->num_cus : 256);
+		if (getenv("GPUMT_VERBOSE"))
+			fprintf(stderr, "gpumt: snappy %s grid %d waves\n", what, *cache);
+	}
+	return *cache;
+}
+
+int gpumt_snappy_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
+				size_t slot_stride, uint32_t *d_rec_len, int s)
+{
+	if (!h || !STREAM_OK(s) || chunk == 0 || chunk > 0x40000000u || slot_stride < gpumt_snappy_slot_stride(chunk))
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	const size_t nrec = gpumt_lz4_record_count(n, chunk);
+	if (nrec > 0x7FFFFFFFu)
+		return GPUMT_E_ARG;
+	const int waves = snappy_waves(h, &h->senc_waves, (const void *)zmt_snappy_enc_kernel, "encoder");
+	const unsigned grid = (unsigned)(nrec < (size_t)waves ? nrec : (size_t)waves);
+	hipLaunchKernelGGL(zmt_snappy_enc_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
+			   (u32)chunk, (u32)nrec, (u8 *)d_slots, (u64)slot_stride, d_rec_len);
+	CK(hipGetLastError());
+	return GPUMT_OK;
+}
+
+int gpumt_snappy_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
+				  const uint32_t *d_rec_len, size_t nrec, void *d_out,
+				  const uint64_t *d_out_off, const uint32_t *d_out_cap,
+				  uint32_t *d_out_len, uint32_t *d_status, int s)
+{
+	if (!h || !STREAM_OK(s) || nrec == 0 || nrec > 0x3FFFFFFFu)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	const int waves = snappy_waves(h, &h->sdec_waves, (const void *)zmt_snappy_dec_kernel, "decoder");
+	const unsigned grid = (unsigned)(nrec < (size_t)waves ? nrec : (size_t)waves);
+	hipLaunchKernelGGL(zmt_snappy_dec_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_stream, d_rec_off,
+			   d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap, d_out_len, d_status);
 	CK(hipGetLastError());
 	return GPUMT_OK;
 }
