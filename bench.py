@@ -628,7 +628,7 @@ def bench_brotli(ctx, gib_args=None, steps=None, warmup=None, cpu=True, main=Tru
 
 
 def bench_api(mib):
-    """PCIe-inclusive rates of the drop-in APIs (LZ4MT_* / ZSTDCB_* / BROTLIMT_* compressCCtx and
+    """PCIe-inclusive rates of the drop-in APIs (LZ4MT_* / ZSTDCB_* / BROTLIMT_* / SNAPPYMT_* compressCCtx and
     decompressDCtx with memcpy callbacks, round trip checked) -- zstdmt_amd/bin/api_bench, the same
     measurement oracle/cpu_bench makes for the reference libraries."""
     exe = os.path.join(ROOT, "zstdmt_amd", "bin", "api_bench")
@@ -637,7 +637,9 @@ def bench_api(mib):
     for key, codec, chunk, level, size in (("lz4", "lz4", 131072, 1, mib << 20), ("zstd", "zstd", 1 << 20, 1, mib << 20),
                                            ("brotli", "brotli", 1 << 20, 1, mib << 20),
                                            # the CLI's default level: LZ4HC hash chain on the device
-                                           ("lz4 level 3 (lz4-mt CLI default, LZ4HC)", "lz4", 131072, 3, min(mib, 2048) << 20)):
+                                           ("lz4 level 3 (lz4-mt CLI default, LZ4HC)", "lz4", 131072, 3, min(mib, 2048) << 20),
+                                           # snappy-mt at its default 64 KiB chunk (the level is unused)
+                                           ("snappy", "snappy", 0, 0, min(mib, 2048) << 20)):
         try:
             t0 = time.time()
             txt = subprocess.check_output([exe, codec, str(size), str(chunk), lib, str(level)], timeout=300,

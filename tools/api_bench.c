@@ -1,9 +1,9 @@
 /*
  * api_bench.c -- end-to-end (PCIe-inclusive) throughput of the drop-in APIs of libzstdmt_amd.so:
- * LZ4MT_*, ZSTDCB_* or BROTLIMT_* compressCCtx / decompressDCtx with in-memory callbacks, i.e. the same
+ * LZ4MT_*, ZSTDCB_*, BROTLIMT_* or SNAPPYMT_* compressCCtx / decompressDCtx with in-memory callbacks, i.e. the same
  * measurement oracle/cpu_bench.c makes for the reference libraries.  Developer tool (numbers quoted
  * in DESIGN.md).  The two APIs have identical shapes, so they are bound by name at run time.
- *   api_bench <lz4|zstd|brotli> <bytes> <chunk>
+ *   api_bench <lz4|zstd|brotli|snappy> <bytes> <chunk>
  */
 #include <dlfcn.h>
 #include <stdint.h>
@@ -57,7 +57,7 @@ static void *sym(void *so, const char *pfx, const char *name)
 int main(int argc, char **argv)
 {
 	const char *codec = argc > 1 ? argv[1] : "lz4";
-	const char *pfx = !strcmp(codec, "zstd") ? "ZSTDCB_" : !strcmp(codec, "brotli") ? "BROTLIMT_" : "LZ4MT_";
+	const char *pfx = !strcmp(codec, "zstd") ? "ZSTDCB_" : !strcmp(codec, "brotli") ? "BROTLIMT_" : !strcmp(codec, "snappy") ? "SNAPPYMT_" : "LZ4MT_";
 	size_t n = argc > 2 ? strtoull(argv[2], 0, 10) : (size_t)1 << 30;
 	int chunk = argc > 3 ? atoi(argv[3]) : 0;
 	void *so = dlopen(argc > 4 ? argv[4] : "libzstdmt_amd.so", RTLD_NOW);
