@@ -106,7 +106,7 @@ size_t zo_snappy_decompress(const uint8_t *src, size_t n, uint8_t *dst, size_t c
 	return op == want ? op : SERR;
 }
 
-/* snappy-mt record walk (lib/snappy-mt_decompress.c:185-268 pt_read, :286-377 pt_decompress): 16-byte
+/* snappy-mt record walk (lib/snappy-mt_decompress.c:185-290 pt_read, :292-377 pt_decompress): 16-byte
  * headers -- skippable magic, 8, compressed size, "SP", a hint the decoder ignores -- each followed by
  * one raw snappy stream whose preamble sizes the output.  Returns total decoded bytes or SERR. */
 size_t zo_snappymt_decompress(const uint8_t *src, size_t slen, uint8_t *dst, size_t cap)
