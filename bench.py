@@ -53,9 +53,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gib", type=float, default=8.0,
                     help="uncompressed GiB: of the whole job (--scaling strong) or per GPU (weak)")
-    ap.add_argument("--codec", choices=("lz4", "zstd", "brotli"), default="lz4",
+    ap.add_argument("--codec", choices=("lz4", "zstd", "brotli", "snappy"), default="lz4",
                     help="lz4 = BASELINE configs[1] (the metric's config); zstd = configs[3], zstd-mt level 1; "
-                         "brotli = configs[4], brotli-mt decompress of level-1 streams at 1 MiB chunks")
+                         "brotli = configs[4], brotli-mt decompress of level-1 streams at 1 MiB chunks; "
+                         "snappy = snappy-mt round trip at its default 64 KiB chunks (no BASELINE config, one GPU)")
     ap.add_argument("--mode", choices=("roundtrip", "decompress"), default="roundtrip",
                     help="decompress = BASELINE configs[2]: only the decompress leg is timed")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
@@ -627,6 +628,90 @@ def bench_brotli(ctx, gib_args=None, steps=None, warmup=None, cpu=True, main=Tru
     return res
 
 
+def bench_snappy(ctx):
+    """snappy-mt (not a BASELINE config): device-resident round trip at the reference's default
+    64 KiB chunk, one GPU.  compress = zmt_snappy_enc_kernel + compact, decompress = zmt_snappy_dec_kernel
+    (one kernel each, so the HIP-event times of the legs are the kernels'); verified byte for byte."""
+    args, eng = ctx.args, ctx.eng
+    if ctx.world != 1:
+        raise SystemExit("--codec snappy runs on one GPU")
+    chunk = args.chunk or 65536
+    n = int(args.gib * (1 << 30)) // chunk * chunk
+    nrec = n // chunk
+    stride = eng.snappy_slot_stride(chunk)
+    d_in, gen_s = generate(ctx, n, 0)
+    d_slots, d_rl, d_ro = eng.alloc(nrec * stride), eng.alloc(nrec * 4), eng.alloc((nrec + 1) * 8)
+    d_stream = eng.alloc(nrec * stride + 512)
+    d_ol, d_st, d_out = eng.alloc(nrec * 4), eng.alloc(nrec * 4), eng.alloc(n + 64)
+    d_oo = eng.upload(np.arange(nrec + 1, dtype=np.uint64) * np.uint64(chunk))
+    d_oc = eng.upload(np.full(nrec, chunk, np.uint32))
+    bufs = [d_in, d_slots, d_rl, d_ro, d_stream, d_ol, d_st, d_out, d_oo, d_oc]
+
+    def compress():
+        eng.timer_start(1)
+        eng.snappy_compress(d_in, n, chunk, d_slots, stride, d_rl)
+        eng.timer_stop(1)
+        eng.timer_start(2)
+        eng.lz4_compact(d_slots, stride, d_rl, nrec, d_stream, d_ro)
+        eng.timer_stop(2)
+
+    compress()
+    eng.sync(0)
+    # payload table (the 16-byte headers are the host engine's to parse): offsets + 16, lengths - 16
+    d_po = eng.upload(eng.download(d_ro, nrec * 8, np.uint64) + np.uint64(16))
+    d_pl = eng.upload((eng.download(d_rl, nrec * 4, np.uint32) - 16).astype(np.uint32))
+    bufs += [d_po, d_pl]
+
+    def decompress():
+        eng.timer_start(3)
+        eng.snappy_decompress(d_stream, d_po, d_pl, nrec, d_out, d_oo, d_oc, d_ol, d_st)
+        eng.timer_stop(3)
+
+    for _ in range(args.warmup):
+        compress()
+        decompress()
+    ctx.barrier()
+    acc = {"compress": 0.0, "compact": 0.0, "decompress": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        compress()
+        decompress()
+        eng.sync(0)
+        for k, slot in (("compress", 1), ("compact", 2), ("decompress", 3)):
+            acc[k] += eng.timer_ms(slot)
+    wall = time.perf_counter() - t0
+    ms = {k: v / args.steps for k, v in acc.items()}
+    total_c = int(eng.download(d_ro, 8, np.uint64, offset=nrec * 8)[0])
+    bad = int((eng.download(d_st, nrec * 4, np.uint32) != 0).sum())
+    ok = bool(eng.equal(d_in, d_out, n)) if args.verify else None
+    for b in bufs:
+        b.free()
+    U, Cb = float(n), float(total_c)
+    alg = U + Cb
+    step_s = wall / args.steps
+
+    def roof(kernel, t_ms):
+        a = alg / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+        return {"kernel": kernel, "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(a * 1e9 / HBM_PEAK, 5), "alg_bytes_per_launch": alg, "avg_launch_ms": round(t_ms, 4),
+                "traffic": None}
+    return {
+        "metric": "MB/s compress+decompress, synthetic text, snappy-mt; % HBM roofline",
+        "value": round(U / 1e6 / step_s, 1), "unit": "MB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"snappy-mt, {U / (1 << 30):g} GiB enwik-style synthetic, {chunk // 1024} KiB chunks, "
+                               "device-resident", "chunk": chunk, "records_per_gpu": nrec, "ratio": round(U / Cb, 4),
+                   "parity": "decompress-identical (no reference build: its snappy library is outside the tree)"},
+        "compress_MBps": round(U / 1e6 / ((ms["compress"] + ms["compact"]) * 1e-3), 1),
+        "decompress_MBps": round(U / 1e6 / (ms["decompress"] * 1e-3), 1),
+        "roofline": roof("zmt_snappy_enc_kernel", ms["compress"]),
+        "roofline_decompress": roof("zmt_snappy_dec_kernel", ms["decompress"]),
+        "kernels": {k: {"ms": round(v, 4)} for k, v in ms.items()},
+        "decode_errors": bad, "roundtrip_verified": ok, "gen_s": round(gen_s, 2), "device": eng.name,
+    }
+
+
 def bench_api(mib):
     """PCIe-inclusive rates of the drop-in APIs (LZ4MT_* / ZSTDCB_* / BROTLIMT_* / SNAPPYMT_* compressCCtx and
     decompressDCtx with memcpy callbacks, round trip checked) -- zstdmt_amd/bin/api_bench, the same
@@ -738,6 +823,8 @@ def main():
 
     if args.codec == "brotli":
         res = bench_brotli(ctx)
+    elif args.codec == "snappy":
+        res = bench_snappy(ctx)
     else:
         res = bench_lz4_zstd(ctx, args.codec)
 

@@ -183,6 +183,20 @@ class Engine:
                                                       d_out.ptr, d_out_off.ptr, d_out_cap.ptr, d_out_len.ptr,
                                                       d_status.ptr, stream), "brotli_decompress_batch")
 
+    # snappy-mt (include/gpumt.h gpumt_snappy_*): same call shapes as brotli
+    def snappy_slot_stride(self, chunk):
+        return int(self.L.gpumt_snappy_slot_stride(int(chunk)))
+
+    def snappy_compress(self, d_in, n, chunk, d_slots, stride, d_rec_len, stream=0):
+        self._ck(self.L.gpumt_snappy_compress_batch(self.h, d_in.ptr, int(n), int(chunk), d_slots.ptr,
+                                                    int(stride), d_rec_len.ptr, stream), "snappy_compress_batch")
+
+    def snappy_decompress(self, d_stream, d_rec_off, d_rec_len, nrec, d_out, d_out_off, d_out_cap, d_out_len,
+                          d_status, stream=0):
+        self._ck(self.L.gpumt_snappy_decompress_batch(self.h, d_stream.ptr, d_rec_off.ptr, d_rec_len.ptr, nrec,
+                                                      d_out.ptr, d_out_off.ptr, d_out_cap.ptr, d_out_len.ptr,
+                                                      d_status.ptr, stream), "snappy_decompress_batch")
+
     def brotli_decompress_bytes(self, stream: bytes, rec_off, rec_len, cap):
         """Records of a brotli-mt stream (payload offsets / sizes / capacities as the host engine
         parses them) -> (list of decoded records, status[n])"""
