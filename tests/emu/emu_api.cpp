@@ -36,6 +36,7 @@ void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *)
 void zmt_zstd_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 void zmt_snappy_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *);
 void zmt_snappy_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
+void zmt_snappy_dec2_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
 }
 
 using emu::dim3;
@@ -259,14 +260,21 @@ void emu_snappy_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 st
 		    [=]() { zmt_snappy_enc_kernel(in, n, chunk, nrec, slots, stride, rec_len); });
 }
 
+/* EMU_SNAPPY_DEC=1 in the environment selects the batched decoder (gpumt_set_variant("snappy_dec", 1)) */
 void emu_snappy_decompress_batch(const u8 *stream, const u64 *rec_off, const u32 *rec_len, u32 nrec, u8 *out,
 				 const u64 *out_off, const u32 *out_cap, u32 *out_len, u32 *status, u32 grid)
 {
 	if (grid > nrec)
 		grid = nrec;
-	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1}, [=]() {
-		zmt_snappy_dec_kernel(stream, rec_off, rec_len, nrec, out, out_off, out_cap, out_len, status);
-	});
+	const char *e = getenv("EMU_SNAPPY_DEC");
+	if (e && *e == '1')
+		emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1}, [=]() {
+			zmt_snappy_dec2_kernel(stream, rec_off, rec_len, nrec, out, out_off, out_cap, out_len, status);
+		});
+	else
+		emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1}, [=]() {
+			zmt_snappy_dec_kernel(stream, rec_off, rec_len, nrec, out, out_off, out_cap, out_len, status);
+		});
 }
 
 } /* extern "C" */

@@ -295,6 +295,7 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 		h->lz4_dec_variant = variant;
 		return prev;
 	}
+	/* ("snappy_dec": the emulated launch reads EMU_SNAPPY_DEC from the environment, see emu_api.cpp) */
 	return 0;
 }
 

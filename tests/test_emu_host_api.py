@@ -558,6 +558,21 @@ def test_snappymt_decompress_foreign_streams(lib, threads):
     assert rv == 0 and out == data
 
 
+def test_snappymt_batched_decoder(lib, monkeypatch):
+    """The second decoder of snappy.hip (64 elements per batch) behind the same API."""
+    monkeypatch.setenv("EMU_SNAPPY_DEC", "1")
+    data = _mixed(60000, 46) + bytes(9000) + b"abc" * 3000
+    rv, st, _, _ = H.snappymt_compress_via(lib, data, 16384, threads=2)
+    assert rv == 0
+    rv, out, _, stats = H.snappymt_decompress_via(lib, st, threads=3)
+    assert rv == 0 and out == data and stats[0] == -(-len(data) // 16384)
+    bad = bytearray(st)
+    bad[40] ^= 0x10
+    want = H.oracle_snappymt_decompress(bytes(bad), len(data) + 64)
+    rv, out, _, _ = H.snappymt_decompress_via(lib, bytes(bad), threads=3)
+    assert (rv == 0 and out == want) if want is not None else rv == ERR(E_FD)
+
+
 def test_snappymt_errors(lib):
     data = cases.text(40000, 45)
     rv, st, _, _ = H.snappymt_compress_via(lib, data, SCHUNK, threads=2)

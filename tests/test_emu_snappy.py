@@ -13,6 +13,13 @@ import helpers as H
 from golden import cases
 from test_snappy_oracle import BAD, HAND, MAN, SDIR
 
+@pytest.fixture(params=["element", "batched"], autouse=True)
+def decoder_variant(request, monkeypatch):
+    """Every test runs with both decoders of snappy.hip: zmt_snappy_dec_kernel (one element at a time, the
+    default) and zmt_snappy_dec2_kernel (64 elements per batch, gpumt_set_variant("snappy_dec", 1))."""
+    monkeypatch.setenv("EMU_SNAPPY_DEC", "1" if request.param == "batched" else "0")
+
+
 ENC_CASES = {
     "empty": (65536, lambda: b""),
     "one": (65536, lambda: b"x"),

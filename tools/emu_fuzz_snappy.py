@@ -15,6 +15,8 @@ n1 = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 bad = 0
 for seed in range(n0, n1):
     rng = random.Random(seed * 3571 + 17)
+    import os
+    os.environ["EMU_SNAPPY_DEC"] = str(seed & 1)   # both decoders of snappy.hip
     n = rng.choice([rng.randrange(1, 250000), 65536, 65537, 131072, rng.randrange(1, 600), 0])
     kind = rng.random()
     data = b"" if n == 0 else text(n, seed=rng.randrange(1 << 30)) if kind < 0.5 else H.soup(rng, n) if kind < 0.8 else \

@@ -44,6 +44,7 @@ __global__ void zmt_dec_copy2_kernel_prof(const u8 *, u64, u32, u32, u8 *, const
 __global__ void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 __global__ void zmt_snappy_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *);
 __global__ void zmt_snappy_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
+__global__ void zmt_snappy_dec2_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
 __global__ void zmt_brotli_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 __global__ void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *,
 				      u32 *, u32 *, u8 *, const u8 *);
@@ -87,9 +88,10 @@ struct gpumt_ctx {
 	int zenc_waves; /* resident waves of the persistent zstd encoder kernel (whole device) */
 	int hc_waves;     /* developer: grid of the LZ4HC encoder (0 = GPUMT_LZ4HC_WAVES) */
 	int zdec_variant; /* 0 = small-table kernel, then general; 1 = general only */
+	int sdec_variant; /* snappy decoder: 0 = element by element, 1 = 64 elements per batch (snappy.hip) */
 	int bdec_waves;   /* resident waves of the persistent brotli decoder kernel (whole device) */
 	int benc_waves;   /* ... of the brotli encoder kernel */
-	int senc_waves, sdec_waves; /* ... of the snappy kernels */
+	int senc_waves, sdec_waves, sdec2_waves; /* ... of the snappy kernels */
 	void *d_brotli_static; /* device copy of the RFC 7932 constant data */
 	char err[256];
 	char name[128];
@@ -216,6 +218,12 @@ int gpumt_open(int device, gpumt_ctx **out)
 	(void)hipEventCreateWithFlags(&h->xev, hipEventDisableTiming);
 	for (int i = 0; i < GPUMT_NMARKS; i++)
 		(void)hipEventCreateWithFlags(&h->mark[i], hipEventDisableTiming);
+	{
+		/* developer knob for A/B runs through the drop-in API / the CLI, which have no handle to call
+		 * gpumt_set_variant on: GPUMT_SNAPPY_DEC=1 selects the batched snappy decoder */
+		const char *e = getenv("GPUMT_SNAPPY_DEC");
+		h->sdec_variant = e && *e ? atoi(e) : 0;
+	}
 	*out = h;
 	return GPUMT_OK;
 }
@@ -1069,6 +1077,14 @@ int gpumt_snappy_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint
 		return GPUMT_E_ARG;
 	if (use(h))
 		return GPUMT_E_HIP;
+	if (h->sdec_variant == 1) {
+		const int waves = snappy_waves(h, &h->sdec2_waves, (const void *)zmt_snappy_dec2_kernel, "decoder (batched)");
+		const unsigned grid = (unsigned)(nrec < (size_t)waves ? nrec : (size_t)waves);
+		hipLaunchKernelGGL(zmt_snappy_dec2_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_stream, d_rec_off,
+				   d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap, d_out_len, d_status);
+		CK(hipGetLastError());
+		return GPUMT_OK;
+	}
 	const int waves = snappy_waves(h, &h->sdec_waves, (const void *)zmt_snappy_dec_kernel, "decoder");
 	const unsigned grid = (unsigned)(nrec < (size_t)waves ? nrec : (size_t)waves);
 	hipLaunchKernelGGL(zmt_snappy_dec_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_stream, d_rec_off,
@@ -1111,6 +1127,9 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	} else if (!strcmp(what, "zstd_dec")) {
 		prev = h->zdec_variant;
 		h->zdec_variant = variant;
+	} else if (!strcmp(what, "snappy_dec")) {
+		prev = h->sdec_variant;
+		h->sdec_variant = variant;
 	} else if (!strcmp(what, "profile")) {
 		prev = h->profile;
 		h->profile = variant;

@@ -397,3 +397,171 @@ zmt_snappy_dec_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec
 		wave_mem_fence();
 	}
 }
+
+/* ------------------------------------------------------------------ decoder, batched variant
+ * (gpumt_set_variant("snappy_dec", 1); written on the emulator after the round's GPU budget was spent, so
+ * it is not the default until it has been timed against the kernel above.)
+ * zmt_snappy_dec_kernel pays a dependent load -> store round trip per element.  Here 64 elements are parsed
+ * at a time -- one lane walks the tags in a 1 KiB LDS window of the stream and leaves kind, length, offset
+ * and positions in LDS -- and then executed by 64 lanes, one element each: literals at once; copies in
+ * watermark rounds (a copy runs when everything it reads is in front of the first element still pending,
+ * so the first pending one always runs), as the zstd decoder executes its sequences.  Same checks, same
+ * verdicts. */
+#define SN_WIN 1024u
+
+struct SnDecLds {
+	u8 win[SN_WIN + 16];
+	u32 e_len[64], e_off[64], e_src[64], e_out[64];
+	u32 cnt, next_ip, next_op, err;
+};
+
+extern "C" __global__ void __launch_bounds__(64)
+zmt_snappy_dec2_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec_off, const u32 *__restrict__ rec_len,
+		       u32 nrec, u8 *__restrict__ out, const u64 *__restrict__ out_off, const u32 *__restrict__ out_cap,
+		       u32 *__restrict__ out_len, u32 *__restrict__ status)
+{
+	__shared__ SnDecLds L;
+	const int lane = wv_lane();
+	for (u32 r = blockIdx.x; r < nrec; r += gridDim.x) {
+		const u8 *src = stream + rec_off[r];
+		const u32 n = rec_len[r], cap = out_cap[r];
+		u8 *dst = out + out_off[r];
+		u32 st = SN_ST_OK, ip = 0, op = 0, want = 0;
+		{ /* varint preamble, at most 5 bytes and 32 bits */
+			u32 sh = 0;
+			for (;;) {
+				if (ip >= n || ip >= 5) {
+					st = SN_ST_BAD_BLOCK;
+					break;
+				}
+				const u32 b = uld8(src + ip);
+				if (ip == 4 && b > 15) {
+					st = SN_ST_BAD_BLOCK;
+					break;
+				}
+				want |= (b & 127u) << sh;
+				sh += 7;
+				ip++;
+				if (b < 128)
+					break;
+			}
+			if (st == SN_ST_OK && want > cap)
+				st = SN_ST_SIZE_MISMATCH;
+		}
+		while (st == SN_ST_OK && ip < n) {
+			/* window: the next 1 KiB of the stream (16 bytes per lane; nothing is read from beyond the
+			 * 16 bytes behind the record) */
+			const u32 wlen = n - ip < SN_WIN ? n - ip : SN_WIN;
+			wv_sync();
+			{
+				const u32 o = 16u * (u32)lane;
+				u64 a = 0, b = 0;
+				if (o < wlen) {
+					a = ld64u(src + ip + o);
+					b = ld64u(src + ip + o + 8);
+				}
+				__builtin_memcpy(L.win + o, &a, 8);
+				__builtin_memcpy(L.win + o + 8, &b, 8);
+			}
+			wv_sync();
+			if (lane == 0) {
+				u32 cnt = 0, p = 0, o = op, err = 0;
+				while (cnt < 64 && p < wlen) {
+					const u32 tag = L.win[p], kind = tag & 3u;
+					u32 used = kind == 0 ? ((tag >> 2) >= 60 ? 1 + ((tag >> 2) - 59) : 1) : kind == 1 ? 2 : kind == 2 ? 3 : 5;
+					if (p + used > wlen) {
+						if (wlen == n - ip)
+							err = 1; /* the stream ends inside the element */
+						break;       /* else: the window does; it restarts at this element */
+					}
+					u32 f = 0; /* the field bytes behind the tag */
+					for (u32 k = 1; k < used; k++)
+						f |= (u32)L.win[p + k] << (8 * (k - 1));
+					u32 len, off;
+					if (kind == 0) {
+						len = (tag >> 2) >= 60 ? f : tag >> 2;
+						if (len == 0xFFFFFFFFu || len + 1 > n - (ip + p + used) || len + 1 > want - o) {
+							err = 1;
+							break;
+						}
+						len += 1;
+						off = 0;
+						L.e_src[cnt] = ip + p + used;
+						p += used + len;
+					} else {
+						if (kind == 1) {
+							len = 4 + ((tag >> 2) & 7u);
+							off = (tag >> 5) << 8 | (f & 255u);
+						} else {
+							len = 1 + (tag >> 2);
+							off = kind == 2 ? f & 0xFFFFu : f;
+						}
+						if (off == 0 || off > o || len > want - o) {
+							err = 1;
+							break;
+						}
+						p += used;
+					}
+					L.e_len[cnt] = len;
+					L.e_off[cnt] = off;
+					L.e_out[cnt] = o;
+					o += len;
+					cnt++;
+				}
+				L.cnt = cnt;
+				L.next_ip = ip + p;
+				L.next_op = o;
+				L.err = err;
+			}
+			wv_sync();
+			const u32 cnt = L.cnt;
+			if (L.err) {
+				st = SN_ST_BAD_BLOCK;
+				break;
+			}
+			const bool mine = (u32)lane < cnt;
+			const u32 len = mine ? L.e_len[lane] : 0u, off = mine ? L.e_off[lane] : 0u;
+			const u32 eo = mine ? L.e_out[lane] : 0u, es = mine ? L.e_src[lane] : 0u;
+			/* literals: straight from the stream */
+			if (mine && off == 0 && len <= SN_CAP)
+				g_copy(dst + eo, src + es, len);
+			u64 lm = wv_ballot(mine && off == 0 && len > SN_CAP);
+			while (lm) {
+				const int j = wv_ffs(lm) - 1;
+				lm &= lm - 1;
+				wave_copy(dst + wv_readlane(eo, j), src + wv_readlane(es, j), wv_readlane(len, j), lane);
+			}
+			/* copies: everything in front of the first pending element is written */
+			bool pending = mine && off != 0;
+			while (wv_any(pending)) {
+				wave_mem_fence();
+				const int first = wv_ffs(wv_ballot(pending)) - 1;
+				const u32 w = wv_readlane(eo, first);
+				const u32 src_end = off >= len ? eo - off + len : eo;
+				if (pending && src_end <= w) {
+					if (off >= len) {
+						g_copy(dst + eo, dst + eo - off, len);
+					} else {
+						u32 j = 0;
+						for (u32 k = 0; k < len; k++) { /* the bytes repeat with period off */
+							dst[eo + k] = dst[eo - off + j];
+							if (++j == off)
+								j = 0;
+						}
+					}
+					pending = false;
+				}
+			}
+			wave_mem_fence();
+			ip = L.next_ip;
+			op = L.next_op;
+		}
+		if (st == SN_ST_OK && op != want)
+			st = SN_ST_BAD_BLOCK;
+		if (lane == 0) {
+			out_len[r] = st == SN_ST_OK ? op : 0u;
+			status[r] = st;
+		}
+		wave_mem_fence();
+	}
+}
