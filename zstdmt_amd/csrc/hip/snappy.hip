@@ -35,13 +35,18 @@
 
 #define SN_BLOCK 65536u
 #define SN_HLOG 12
+#ifndef SN_MINMATCH
 #define SN_MINMATCH 6u
+#endif
+#ifndef SN_HBYTES
+#define SN_HBYTES 6
+#endif
 #define SN_FWD 20u /* bytes of a match measured by the lane that found it; longer ones by the whole wave */
 #define SN_CAP 64u /* longer literal runs are copied by the whole wave */
 #define SN_HDR 16u /* record header: skippable magic, 8, payload size, "SP", hint */
 #define SN_MAGIC_SKIPPABLE 0x184D2A50u
 #define SN_MAGICNUMBER 0x5053u /* lib/snappy-mt.h:16 */
-#define SN_HASH(v) ((u32)((((v) << 16) * 0x9E3779B185EBCA87ull) >> (64 - SN_HLOG)))
+#define SN_HASH(v) ((u32)((((v) << (64 - 8 * SN_HBYTES)) * 0x9E3779B185EBCA87ull) >> (64 - SN_HLOG)))
 
 /* status codes of include/gpumt.h */
 #define SN_ST_OK 0u
