@@ -1,0 +1,28 @@
+"""The kernels once more under the emulator's strict build (-DZMT_EMU_STRICT): wv_readfirst exchanges for
+real there, so a value claimed wave-uniform that is not, or a cross-lane operation under a divergent
+branch -- both silent on the fast build, the second one a hang on hardware at best -- aborts the run.
+A representative subset of the emulator tests of every kernel family, in a process of its own (the
+emulator library is chosen at load time)."""
+import os
+import subprocess
+import sys
+
+import helpers as H
+
+SUBSET = [
+    ("tests/test_emu_kernels.py", "golden or hc_compress"),
+    ("tests/test_emu_zstd.py", "identical or checksummed or unit"),
+    ("tests/test_emu_brotli.py", "golden or identical"),
+    ("tests/test_emu_snappy.py", "identical or golden or hand_built or rejects"),
+]
+
+
+def test_kernels_under_the_strict_emulator():
+    env = dict(os.environ, EMU_STRICT="1")
+    for path, expr in SUBSET:
+        cmd = [sys.executable, "-m", "pytest", os.path.join(H.ROOT, path), "-q", "-x", "-p", "no:cacheprovider"]
+        if expr:
+            cmd += ["-k", expr]
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=H.ROOT)
+        tail = (p.stdout + p.stderr)[-1500:]
+        assert p.returncode == 0, f"{path} under EMU_STRICT=1:\n{tail}"

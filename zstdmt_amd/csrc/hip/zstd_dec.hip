@@ -1564,7 +1564,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 			stc = ST_BAD_FRAME;
 		} else {
 			if (lane == 0) {
-				chk_expect[rec] = uld32(f + ip);
+				chk_expect[rec] = ld32u(f + ip);
 				chk_valid[rec] = 1;
 			}
 			ip += 4;
