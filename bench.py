@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--chunk", type=int, default=0, help="0 = 128 KiB for lz4 (configs[1]), 1 MiB for zstd / brotli")
     ap.add_argument("--dec-variant", type=int, default=0)
+    ap.add_argument("--snappy-dec", type=int, default=0,
+                    help="--codec snappy: 1 = the batched decoder (zmt_snappy_dec2_kernel), 0 = element by element")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-mib", type=int, default=2048, help="cpu_baseline sample size")
     ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of segments to rank 0")
@@ -702,11 +704,13 @@ def bench_snappy(ctx):
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": f"snappy-mt, {U / (1 << 30):g} GiB enwik-style synthetic, {chunk // 1024} KiB chunks, "
                                "device-resident", "chunk": chunk, "records_per_gpu": nrec, "ratio": round(U / Cb, 4),
+                   "dec_variant": args.snappy_dec,
                    "parity": "decompress-identical (no reference build: its snappy library is outside the tree)"},
         "compress_MBps": round(U / 1e6 / ((ms["compress"] + ms["compact"]) * 1e-3), 1),
         "decompress_MBps": round(U / 1e6 / (ms["decompress"] * 1e-3), 1),
         "roofline": roof("zmt_snappy_enc_kernel", ms["compress"]),
-        "roofline_decompress": roof("zmt_snappy_dec_kernel", ms["decompress"]),
+        "roofline_decompress": roof("zmt_snappy_dec2_kernel" if args.snappy_dec == 1 else "zmt_snappy_dec_kernel",
+                                    ms["decompress"]),
         "kernels": {k: {"ms": round(v, 4)} for k, v in ms.items()},
         "decode_errors": bad, "roundtrip_verified": ok, "gen_s": round(gen_s, 2), "device": eng.name,
     }
@@ -818,6 +822,7 @@ def main():
     import zstdmt_amd as z
     eng = z.Engine(local)
     eng.set_variant("lz4_dec", args.dec_variant)
+    eng.set_variant("snappy_dec", args.snappy_dec)
     eng.set_variant("profile", 1)
     ctx = Ctx(args, eng, rank, world, dist)
 
