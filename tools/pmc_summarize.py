@@ -49,6 +49,17 @@ if zstats:
                     part[k] = v
     zl = open(os.path.join(go, "bench_zstd.json")).read().strip().splitlines()[-1]
     json.dump(json.loads(zl), open(os.path.join(root, "profiles", f"{rnd}_bench_zstd_8gib_1gpu.json"), "w"), indent=1)
+sstats = biggest("prof_snappy_stats/**/*_kernel_stats.csv")
+if sstats:
+    shutil.copy(sstats, os.path.join(root, "profiles", f"{rnd}_snappy_kernel_stats.csv"))
+    for part, name in ((fetch, "prof_snappy_fetch"), (write, "prof_snappy_write")):
+        f = biggest(name + "/**/*_counter_collection.csv")
+        if f:
+            for k, v in counter_avg(f).items():
+                if "snappy" in k:
+                    part[k] = v
+    sl = open(os.path.join(go, "bench_snappy.json")).read().strip().splitlines()[-1]
+    json.dump(json.loads(sl), open(os.path.join(root, "profiles", f"{rnd}_bench_snappy_8gib_1gpu.json"), "w"), indent=1)
 bstats = biggest("prof_brotli_stats/**/*_kernel_stats.csv")
 if bstats:
     shutil.copy(bstats, os.path.join(root, "profiles", f"{rnd}_brotli_kernel_stats.csv"))

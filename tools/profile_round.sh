@@ -3,7 +3,8 @@
 # same command, and the two separate PMC passes (FETCH_SIZE, WRITE_SIZE).  Everything lands under
 # gpurun_out/; tools/pmc_summarize.py turns it into the files committed under profiles/.
 #   gpurun --timeout 900 -- 'bash tools/profile_round.sh'            (all three codecs)
-#   gpurun --timeout 400 -- 'bash tools/profile_round.sh zstd'       (one of lz4 | zstd | brotli)
+#   gpurun --timeout 400 -- 'bash tools/profile_round.sh zstd'       (one of lz4 | zstd | brotli | snappy;
+#                                                                     snappy is not part of "all")
 ONLY=${1:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
@@ -46,4 +47,18 @@ rm -rf $O/prof_brotli_enc_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_brotli_enc_stats -- \
     python bench.py --only --codec brotli --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_brotli_enc_stats.err
 cat $O/bench_brotli.json
+fi
+if [ $ONLY = snappy ]; then
+# snappy-mt round trip at the default 64 KiB chunk (not a BASELINE config).  SNAPPY_DEC=1 selects
+# the batched decoder
+rm -rf $O/prof_snappy_stats $O/prof_snappy_fetch $O/prof_snappy_write
+SD=${SNAPPY_DEC:-0}
+python bench.py --codec snappy --snappy-dec $SD > $O/bench_snappy.json 2> $O/bench_snappy.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_snappy_stats -- \
+    python bench.py --codec snappy --snappy-dec $SD --steps 2 --warmup 1 > $O/bench_snappy_prof.json 2> $O/prof_snappy_stats.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_snappy_fetch -- \
+    python bench.py --codec snappy --snappy-dec $SD --steps 1 --warmup 0 > /dev/null 2> $O/prof_snappy_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_snappy_write -- \
+    python bench.py --codec snappy --snappy-dec $SD --steps 1 --warmup 0 > /dev/null 2> $O/prof_snappy_write.err
+cat $O/bench_snappy.json
 fi
