@@ -692,11 +692,15 @@ def bench_snappy(ctx):
     alg = U + Cb
     step_s = wall / args.steps
 
+    traffic = traffic_table(args.gib, chunk, 65536)
+
     def roof(kernel, t_ms):
         a = alg / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
+        tr = traffic.get(kernel)
         return {"kernel": kernel, "bound": "hbm", "achieved": round(a, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(a * 1e9 / HBM_PEAK, 5), "alg_bytes_per_launch": alg, "avg_launch_ms": round(t_ms, 4),
-                "traffic": None}
+                "traffic": tr,
+                "traffic_source": (TRAFFIC_FILE + " (separate rocprofv3 --pmc passes, not this run)") if tr else None}
     return {
         "metric": "MB/s compress+decompress, synthetic text, snappy-mt; % HBM roofline",
         "value": round(U / 1e6 / step_s, 1), "unit": "MB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
