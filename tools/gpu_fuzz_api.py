@@ -1,4 +1,4 @@
-"""GPU fuzz of the three drop-in APIs (developer tool, run through gpurun): random inputs, chunk sizes,
+"""GPU fuzz of the four drop-in APIs (developer tool, run through gpurun): random inputs, chunk sizes,
 thread counts (1 = the inline decompress path) and levels; every stream must decode back through this
 library and, where oracle/_ref is present, through the reference library.
     python tools/gpu_fuzz_api.py [seconds] [first seed]"""
@@ -14,6 +14,7 @@ lib = C.CDLL(lib_path())
 lz = H.bind_lz4mt(lib)
 zs = H.bind_lz4mt(lib, "ZSTDCB_")
 br = H.bind_lz4mt(lib, "BROTLIMT_")
+sn = H.bind_lz4mt(lib, "SNAPPYMT_")
 ref_l = H.ref() if H.have_ref() else None
 ref_z = H.zref() if H.have_zref() else None
 ref_b = H.bref() if H.have_bref() else None
@@ -23,7 +24,7 @@ while time.time() - t0 < budget:
     n = rng.choice([0, 1, rng.randrange(1, 100_000), rng.randrange(1, 6_000_000), 1 << 20, (1 << 20) + 1])
     data = _mix(rng, n) if rng.random() < 0.7 else _runs(rng, n)
     th = rng.choice([1, 2, 5])
-    codec = rng.choice(["lz4", "zstd", "brotli"])
+    codec = rng.choice(["lz4", "zstd", "brotli", "snappy"])
     if codec == "lz4":
         chunk = rng.choice([65536, 131072, 100000, 1 << 20, 0]); level = rng.choice([1, 1, 3, 5, 9])
         rv, s, _, _ = H.lz4mt_compress_via(lz, data, chunk, threads=th, level=level)
@@ -41,6 +42,16 @@ while time.time() - t0 < budget:
         if ref_z is not None:
             rv, out, _, _ = H.lz4mt_decompress_via(ref_z, s, threads=2, pfx="ZSTDCB_")
             assert rv == 0 and out == data, (seed, "zstd reference decompress")
+    elif codec == "snappy":
+        chunk = rng.choice([65536, 4096, 1 << 20, 100000, 0])
+        rv, s, _, _ = H.lz4mt_compress_via(sn, data, chunk, threads=th, level=0, pfx="SNAPPYMT_")
+        assert rv == 0, (seed, "snappy compress", rv)
+        assert H.oracle_snappymt_decompress(s, len(data) + 64) == data, (seed, "snappy oracle decompress")
+        rv, out, _, _ = H.lz4mt_decompress_via(sn, s, threads=th, pfx="SNAPPYMT_")
+        assert rv == 0 and out == data, (seed, "snappy decompress")
+        if H.have_libsnappy() and len(data) < 2_000_000:      # and what libsnappy writes decodes here
+            rv, out, _, _ = H.lz4mt_decompress_via(sn, H.snappymt_stream(data, chunk or 65536), threads=th, pfx="SNAPPYMT_")
+            assert rv == 0 and out == data, (seed, "snappy foreign decompress")
     else:
         chunk = rng.choice([65536, 1 << 20, 100000, 0]); level = rng.choice([0, 1, 5, 11])
         rv, s, _, _ = H.lz4mt_compress_via(br, data, chunk, threads=th, level=level, pfx="BROTLIMT_")
