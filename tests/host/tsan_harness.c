@@ -4,7 +4,8 @@
  * (stored-literal snappy streams out, the oracle's snappy decoder in), synchronous, so what is checked is
  * the engine's own threading: reader, caller and writer threads over the slots, counters and callbacks.
  * (The fiber emulator cannot run under TSan: it switches stacks behind its back.)
- *   tsan_harness <bytes> <chunk> <threads> <slots>   -> "rv_c rv_d frames ok"
+ * The lz4-mt engine (lz4mt_engine.c) runs the same way over the oracle's LZ4 frame coder.
+ *   tsan_harness <bytes> <chunk> <threads> <slots> [snappy|lz4]   -> "rv_c rv_d frames ok"
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -13,6 +14,7 @@
 
 #include "gpumt.h"
 #include "snappy-mt.h"
+#include "lz4-mt.h"
 #include "../../oracle/zmt_oracle.h"
 
 struct gpumt_ctx { int device; };
@@ -112,6 +114,38 @@ int gpumt_snappy_decompress_batch(gpumt_ctx *h, const void *stream, const uint64
 	return 0;
 }
 
+/* lz4-mt: records = 12-byte skippable header + one LZ4 frame, coded by the oracle's frame functions */
+size_t gpumt_lz4_slot_stride(size_t chunk) { return (12 + zo_lz4f_bound(chunk) + 255) & ~(size_t)255; }
+int gpumt_lz4_level_supported(int level) { return level >= 1 && level <= 12; }
+int gpumt_set_variant(gpumt_ctx *h, const char *what, int v) { (void)h; (void)what; (void)v; return 0; }
+int gpumt_lz4_compress_batch_level(gpumt_ctx *h, const void *in, size_t n, size_t chunk, void *slots, size_t stride,
+				   uint32_t *rec_len, int level, int st)
+{
+	(void)h; (void)st; (void)level;
+	const size_t nrec = gpumt_lz4_record_count(n, chunk);
+	for (size_t r = 0; r < nrec; r++) {
+		const size_t clen = n - r * chunk < chunk ? n - r * chunk : chunk;
+		uint8_t *o = (uint8_t *)slots + r * stride;
+		const size_t f = zo_lz4f_compress((const uint8_t *)in + r * chunk, clen, o + 12, stride - 12);
+		const uint32_t hdr[3] = {0x184D2A50u, 4u, (uint32_t)f};
+		memcpy(o, hdr, 12);
+		rec_len[r] = (uint32_t)(12 + f);
+	}
+	return 0;
+}
+int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *stream, size_t stream_bytes, const uint64_t *rec_off,
+			       const uint32_t *rec_len, size_t nrec, void *out, size_t out_bytes, const uint64_t *out_off,
+			       uint32_t *out_len, uint32_t *status, int st)
+{
+	(void)h; (void)st; (void)stream_bytes; (void)out_bytes;
+	for (size_t r = 0; r < nrec; r++) {
+		const size_t got = zo_lz4f_decompress((const uint8_t *)stream + rec_off[r] + 12, rec_len[r] - 12,
+						      (uint8_t *)out + out_off[r], out_len[r]);
+		status[r] = got == out_len[r] ? GPUMT_ST_OK : GPUMT_ST_BAD_BLOCK;
+	}
+	return 0;
+}
+
 struct mem { uint8_t *p; size_t n, pos; };
 static int rd(void *a, SNAPPYMT_Buffer *b)
 {
@@ -142,16 +176,31 @@ int main(int argc, char **argv)
 	for (size_t i = 0; i < n; i++)
 		src[i] = (uint8_t)(i * 2654435761u >> 13);
 	struct mem in = {src, n, 0}, out = {cmp, n + n / 8 + 65536, 0};
-	SNAPPYMT_RdWr_t io = {rd, &in, wr, &out};
-	SNAPPYMT_CCtx *c = SNAPPYMT_createCCtx(threads, 0, chunk);
-	const size_t rv_c = SNAPPYMT_compressCCtx(c, &io);
-	const size_t frames = SNAPPYMT_GetFramesCCtx(c);
-	SNAPPYMT_freeCCtx(c);
-	struct mem in2 = {cmp, out.pos, 0}, out2 = {back, n, 0};
-	SNAPPYMT_RdWr_t io2 = {rd, &in2, wr, &out2};
-	SNAPPYMT_DCtx *d = SNAPPYMT_createDCtx(threads, 0);
-	const size_t rv_d = SNAPPYMT_decompressDCtx(d, &io2);
-	SNAPPYMT_freeDCtx(d);
+	struct mem in2 = {cmp, 0, 0}, out2 = {back, n, 0};
+	size_t rv_c, rv_d, frames;
+	if (argc > 5 && !strcmp(argv[5], "lz4")) { /* LZ4MT_Buffer has the layout of SNAPPYMT_Buffer */
+		LZ4MT_RdWr_t io = {(int (*)(void *, LZ4MT_Buffer *))rd, &in, (int (*)(void *, LZ4MT_Buffer *))wr, &out};
+		LZ4MT_CCtx *c = LZ4MT_createCCtx(threads, 1, chunk);
+		rv_c = LZ4MT_compressCCtx(c, &io);
+		frames = LZ4MT_GetFramesCCtx(c);
+		LZ4MT_freeCCtx(c);
+		in2.n = out.pos;
+		LZ4MT_RdWr_t io2 = {(int (*)(void *, LZ4MT_Buffer *))rd, &in2, (int (*)(void *, LZ4MT_Buffer *))wr, &out2};
+		LZ4MT_DCtx *d = LZ4MT_createDCtx(threads, 0);
+		rv_d = LZ4MT_decompressDCtx(d, &io2);
+		LZ4MT_freeDCtx(d);
+	} else {
+		SNAPPYMT_RdWr_t io = {rd, &in, wr, &out};
+		SNAPPYMT_CCtx *c = SNAPPYMT_createCCtx(threads, 0, chunk);
+		rv_c = SNAPPYMT_compressCCtx(c, &io);
+		frames = SNAPPYMT_GetFramesCCtx(c);
+		SNAPPYMT_freeCCtx(c);
+		in2.n = out.pos;
+		SNAPPYMT_RdWr_t io2 = {rd, &in2, wr, &out2};
+		SNAPPYMT_DCtx *d = SNAPPYMT_createDCtx(threads, 0);
+		rv_d = SNAPPYMT_decompressDCtx(d, &io2);
+		SNAPPYMT_freeDCtx(d);
+	}
 	printf("%zd %zd %zu %d\n", (ssize_t)rv_c, (ssize_t)rv_d, frames, out2.pos == n && !memcmp(src, back, n));
 	return 0;
 }
