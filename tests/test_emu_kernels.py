@@ -159,3 +159,28 @@ def test_emu_block_checksum_and_dictid_frames(variant):
             bad[12 + 40] ^= 0x01
             _, status = E.decompress(bytes(bad), variant, rec=E.walk_records(rec))
             assert status.tolist() == [5], (name, status)   # GPUMT_ST_BAD_CHECKSUM
+
+
+def test_emu_hc_stored_block_after_an_attempt_that_wrote_matches():
+    """A last chunk of 45 bytes whose HC attempt emits a sequence and then fails to shrink: the block is
+    stored raw over the bytes the attempt wrote.  (tools/emu_fuzz_hc.py seed 166: without a wave sync in
+    front of the raw copy the emulator let late stores of the attempt land on top of it.)"""
+    import random
+    rng = random.Random(166 * 4099 + 5)
+    level = rng.choice([3, 4, 5, 6, 7, 8, 9, 9, 10, 11, 12])
+    n = rng.choice([rng.randrange(1, 40000), rng.randrange(1, 3000), 65536 + rng.randrange(0, 50), rng.randrange(60000, 140000)])
+    assert rng.randrange(5) == 3 and (level, n) == (7, 65581)
+    t = bytearray(text(n, seed=rng.randrange(1 << 30)))
+    for _ in range(rng.randrange(1, 15)):
+        a = rng.randrange(0, n - 50)
+        ln = rng.randrange(1, min(3000, n - a))
+        b = rng.randrange(0, n - ln)
+        t[b:b + ln] = t[a:a + ln] if rng.random() < 0.7 else bytes([rng.randrange(256)]) * ln
+    data = bytes(t)
+    tail = data[65536:]
+    assert len(tail) == 45
+    for lv in (3, 7, 9, 10, 12):
+        got = E.compress(tail, 65536, lv)[0]
+        assert got == H.oracle_compress_level(tail, 65536, lv), lv
+        assert got[12 + 15:12 + 19] == (45 | 0x80000000).to_bytes(4, "little")     # stored block
+    assert E.compress(data, 65536, 7)[0] == H.oracle_compress_level(data, 65536, 7)

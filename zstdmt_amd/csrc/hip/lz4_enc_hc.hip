@@ -824,6 +824,7 @@ zmt_lz4hc_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nrec, u8 *
 					    : hc_block(H, pos, blen, dst + op + 4, blen - 1, max_attempts, lane);
 			u32 bh = c;
 			if (c == 0) { /* did not shrink: stored; the chains keep what the attempt inserted */
+				wv_sync(); /* every lane's stores of the attempt lie behind it before the same bytes are rewritten */
 				wave_copy(dst + op + 4, src + pos, blen, lane);
 				c = blen;
 				bh = blen | 0x80000000u;
