@@ -184,3 +184,11 @@ def test_emu_hc_stored_block_after_an_attempt_that_wrote_matches():
         assert got == H.oracle_compress_level(tail, 65536, lv), lv
         assert got[12 + 15:12 + 19] == (45 | 0x80000000).to_bytes(4, "little")     # stored block
     assert E.compress(data, 65536, 7)[0] == H.oracle_compress_level(data, 65536, 7)
+
+
+def test_emu_fast_encoder_stored_block_after_an_attempt_that_wrote_matches():
+    """The same for the level-1 encoder (tools/emu_fuzz_small.py seeds 1 and 280): 18 bytes with a 4-byte repeat
+    -- the attempt emits a sequence, does not shrink, and the block is stored."""
+    for data in (b"Tie sie sspfr mdot", b"abcdabcd-abcdabcd", text(4096, 1) + b"Tie sie sspfr mdot, sie sspfr"):
+        for chunk in (65536, 4096):
+            assert E.compress(data, chunk, 1)[0] == H.oracle_compress(data, chunk), (data[-20:], chunk)

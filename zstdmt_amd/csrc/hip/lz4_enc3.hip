@@ -603,6 +603,7 @@ static __device__ __forceinline__ void enc3_body(u32 *tlo, u32 *thi, u32 *bitmap
 		u32 c = encode_block3<TM>(tlo, thi, bitmap, R, pos, blen, dst + op + 4, blen - 1, lane);
 		u32 bh = c;
 		if (c == 0) {
+			wv_sync(); /* every lane's stores of the attempt lie behind it before the same bytes are rewritten */
 			wave_copy(dst + op + 4, src + pos, blen, lane);
 			c = blen;
 			bh = blen | 0x80000000u;
