@@ -72,9 +72,14 @@ static void run_block(Block &b)
 	}
 	unsigned live = n;
 	unsigned long idle_rounds = 0;
+	/* EMU_REVERSE=1: lanes take their turns from the highest down.  Between two synchronisation points a lane
+	 * then sees the stores of the lanes *above* it instead of those below: code that passes both ways does not
+	 * depend on which neighbour happened to run first. */
+	static const bool reverse = getenv("EMU_REVERSE") && getenv("EMU_REVERSE")[0] == '1';
 	while (live) {
 		unsigned progressed = 0;
-		for (unsigned i = 0; i < n; i++) {
+		for (unsigned k = 0; k < n; k++) {
+			const unsigned i = reverse ? n - 1 - k : k;
 			if (b.fib[i].done)
 				continue;
 			b.cur = i;
