@@ -75,11 +75,24 @@ static void run_block(Block &b)
 	/* EMU_REVERSE=1: lanes take their turns from the highest down.  Between two synchronisation points a lane
 	 * then sees the stores of the lanes *above* it instead of those below: code that passes both ways does not
 	 * depend on which neighbour happened to run first. */
-	static const bool reverse = getenv("EMU_REVERSE") && getenv("EMU_REVERSE")[0] == '1';
+	static const int order = getenv("EMU_REVERSE") ? atoi(getenv("EMU_REVERSE")) : 0;
+	/* EMU_REVERSE=2: a fresh pseudo-random order every round (deterministic: the seed is the launch's shape) */
+	std::vector<unsigned> perm(n);
+	for (unsigned k = 0; k < n; k++)
+		perm[k] = order == 1 ? n - 1 - k : k;
+	unsigned long long rng = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)b.block_idx.x << 20) ^ n;
 	while (live) {
 		unsigned progressed = 0;
+		if (order == 2)
+			for (unsigned k = n - 1; k > 0; k--) {
+				rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+				const unsigned j = (unsigned)((rng >> 33) % (k + 1));
+				const unsigned t = perm[k];
+				perm[k] = perm[j];
+				perm[j] = t;
+			}
 		for (unsigned k = 0; k < n; k++) {
-			const unsigned i = reverse ? n - 1 - k : k;
+			const unsigned i = perm[k];
 			if (b.fib[i].done)
 				continue;
 			b.cur = i;

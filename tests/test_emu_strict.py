@@ -17,17 +17,22 @@ SUBSET = [
 ]
 
 
-def test_kernels_with_lanes_in_reverse_order():
+import pytest
+
+
+@pytest.mark.parametrize("order", ["1", "2"])
+def test_kernels_with_lanes_in_another_order(order):
     """EMU_REVERSE=1: between two synchronisation points the lanes run from the highest down, so a lane sees
-    the stores of the lanes above it instead of those below.  Code that is right both ways does not depend on
-    which neighbour happened to run first (on hardware: on what the memory system happens to have done)."""
-    env = dict(os.environ, EMU_REVERSE="1")
+    the stores of the lanes above it instead of those below; EMU_REVERSE=2: in a fresh pseudo-random order
+    every round.  Code that is right every way does not depend on which neighbour happened to run first (on
+    hardware: on what the memory system happens to have done)."""
+    env = dict(os.environ, EMU_REVERSE=order)
     for path, expr in SUBSET:
         cmd = [sys.executable, "-m", "pytest", os.path.join(H.ROOT, path), "-q", "-x", "-p", "no:cacheprovider"]
         if expr:
             cmd += ["-k", expr]
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=H.ROOT)
-        assert p.returncode == 0, f"{path} under EMU_REVERSE=1:\n{(p.stdout + p.stderr)[-1500:]}"
+        assert p.returncode == 0, f"{path} under EMU_REVERSE={order}:\n{(p.stdout + p.stderr)[-1500:]}"
 
 
 def test_kernels_under_the_strict_emulator():
