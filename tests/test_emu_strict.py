@@ -20,7 +20,7 @@ SUBSET = [
 import pytest
 
 
-@pytest.mark.parametrize("order", ["1", "2"])
+@pytest.mark.parametrize("order", ["2"])   # "1" (plain reverse) passes too; one of the two keeps the suite short
 def test_kernels_with_lanes_in_another_order(order):
     """EMU_REVERSE=1: between two synchronisation points the lanes run from the highest down, so a lane sees
     the stores of the lanes above it instead of those below; EMU_REVERSE=2: in a fresh pseudo-random order
