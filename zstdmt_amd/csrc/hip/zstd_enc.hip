@@ -1308,6 +1308,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			if (lane == 0)
 				blk_len[g] = total;
 		} else {
+			wv_sync(); /* every lane's stores of the attempt lie behind it before the same bytes are rewritten */
 			if (lane == 0) {
 				const u32 bh = last | 0u << 1 | bsize << 3;
 				out[0] = (u8)bh;
