@@ -18,6 +18,8 @@ for seed in range(n0, n1):
     level = rng.choice([3, 4, 5, 6, 7, 8, 9, 9, 10, 11, 12])
     n = rng.choice([rng.randrange(1, 40000), rng.randrange(1, 3000), 65536 + rng.randrange(0, 50), rng.randrange(60000, 140000) if level < 10 else rng.randrange(1, 30000)])
     kind = rng.randrange(5)
+    if level >= 10 and n > 30000:
+        n = 30000   # the optimal parser on 64 KiB of low-entropy bytes runs for many minutes on the emulator
     if kind == 0:
         data = H.soup(rng, n)
     elif kind == 1:
