@@ -99,8 +99,12 @@ size_t ZSTDCB_GetInsizeDCtx(ZSTDCB_DCtx *ctx);
 size_t ZSTDCB_GetOutsizeDCtx(ZSTDCB_DCtx *ctx);
 void ZSTDCB_freeDCtx(ZSTDCB_DCtx *ctx);
 
-/* ---- the names /root/reference/lib/README.md:36-76 documents (ZSTDMT_*): exported aliases of the ZSTDCB_* entry
- * points above, same signatures, for callers written against that README ---------------------------- */
+/* ---- the names /root/reference/lib/README.md:36-76 documents (ZSTDMT_*).  libzstd itself exports ZSTDMT_createCCtx /
+ * ZSTDMT_compressCCtx / ZSTDMT_freeCCtx with other signatures (its multithreading API), which is why upstream renamed
+ * the prefix to ZSTDCB_ and why this library does NOT export ZSTDMT_* symbols: a process that links both would bind one
+ * library's calls to the other's functions.  A caller written against the old README opts in to header-only names, as
+ * the reference's own front end does with macros (/root/reference/programs/zstd-mt.c:13-43): */
+#ifdef ZSTDCB_LEGACY_ZSTDMT_NAMES
 typedef ZSTDCB_Buffer ZSTDMT_Buffer;
 typedef ZSTDCB_RdWr_t ZSTDMT_RdWr_t;
 typedef ZSTDCB_CCtx ZSTDMT_CCtx;
@@ -108,20 +112,21 @@ typedef ZSTDCB_DCtx ZSTDMT_DCtx;
 #define ZSTDMT_THREAD_MAX ZSTDCB_THREAD_MAX
 #define ZSTDMT_LEVEL_MIN ZSTDCB_LEVEL_MIN
 #define ZSTDMT_LEVEL_MAX ZSTDCB_LEVEL_MAX
-extern unsigned ZSTDMT_isError(size_t code);
-extern const char *ZSTDMT_getErrorString(size_t code);
-ZSTDMT_CCtx *ZSTDMT_createCCtx(int threads, int level, int inputsize);
-size_t ZSTDMT_compressCCtx(ZSTDMT_CCtx *ctx, ZSTDMT_RdWr_t *rdwr);
-size_t ZSTDMT_GetFramesCCtx(ZSTDMT_CCtx *ctx);
-size_t ZSTDMT_GetInsizeCCtx(ZSTDMT_CCtx *ctx);
-size_t ZSTDMT_GetOutsizeCCtx(ZSTDMT_CCtx *ctx);
-void ZSTDMT_freeCCtx(ZSTDMT_CCtx *ctx);
-ZSTDMT_DCtx *ZSTDMT_createDCtx(int threads, int inputsize);
-size_t ZSTDMT_decompressDCtx(ZSTDMT_DCtx *ctx, ZSTDMT_RdWr_t *rdwr);
-size_t ZSTDMT_GetFramesDCtx(ZSTDMT_DCtx *ctx);
-size_t ZSTDMT_GetInsizeDCtx(ZSTDMT_DCtx *ctx);
-size_t ZSTDMT_GetOutsizeDCtx(ZSTDMT_DCtx *ctx);
-void ZSTDMT_freeDCtx(ZSTDMT_DCtx *ctx);
+#define ZSTDMT_isError ZSTDCB_isError
+#define ZSTDMT_getErrorString ZSTDCB_getErrorString
+#define ZSTDMT_createCCtx ZSTDCB_createCCtx
+#define ZSTDMT_compressCCtx ZSTDCB_compressCCtx
+#define ZSTDMT_GetFramesCCtx ZSTDCB_GetFramesCCtx
+#define ZSTDMT_GetInsizeCCtx ZSTDCB_GetInsizeCCtx
+#define ZSTDMT_GetOutsizeCCtx ZSTDCB_GetOutsizeCCtx
+#define ZSTDMT_freeCCtx ZSTDCB_freeCCtx
+#define ZSTDMT_createDCtx ZSTDCB_createDCtx
+#define ZSTDMT_decompressDCtx ZSTDCB_decompressDCtx
+#define ZSTDMT_GetFramesDCtx ZSTDCB_GetFramesDCtx
+#define ZSTDMT_GetInsizeDCtx ZSTDCB_GetInsizeDCtx
+#define ZSTDMT_GetOutsizeDCtx ZSTDCB_GetOutsizeDCtx
+#define ZSTDMT_freeDCtx ZSTDCB_freeDCtx
+#endif
 
 #ifdef __cplusplus
 }

@@ -6,9 +6,9 @@
  *
  * The algorithm lives in liblz4's lz4hc.c, a third-party dependency that is NOT in /root/reference
  * (programs/Makefile:9 pins v1.9.4; this image carries the binary of v1.9.3 only).  What follows
- * restates the published hash-chain parser of that file for the levels whose search is a plain chain
- * walk -- 3..8: 4, 8, 16, 32, 64, 128 attempts; level 9 adds the repeated-pattern analysis and
- * 10..12 the optimal parser, not restated -- and is pinned byte for byte against the reference build
+ * restates that file's published parsers for every HC level: 3..8 the hash-chain walk (4, 8, 16, 32, 64,
+ * 128 attempts), 9 the same with the repeated-pattern analysis (256 attempts), 10..12 the optimal
+ * parser (price table, chain swap; below) -- and is pinned byte for byte against the reference build
  * (oracle/_ref/liblz4mt_ref.so, tests/test_oracle_vs_ref.py) and the committed fixtures
  * (tests/golden/lz4hc).  Frame container: lz4_oracle.c.
  */

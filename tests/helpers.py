@@ -95,7 +95,7 @@ def oracle_compress(data: bytes, chunk: int) -> bytes:
 
 
 def oracle_compress_level(data: bytes, chunk: int, level: int) -> bytes:
-    """lz4-mt stream at `level`: 1-2 = LZ4 fast (lz4_oracle.c), 3-8 = LZ4 HC hash chain (lz4hc_oracle.c)"""
+    """lz4-mt stream at `level`: 1-2 = LZ4 fast (lz4_oracle.c), 3-9 = LZ4 HC hash chain, 10-12 = its optimal parser (lz4hc_oracle.c)"""
     lib = oracle()
     cap = len(data) + len(data) // 64 + (len(data) // max(chunk, 1) + 2) * 64 + 1024
     out = C.create_string_buffer(cap)

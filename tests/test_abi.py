@@ -12,7 +12,7 @@ def _declared(header):
     txt = open(os.path.join(H.ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     txt = re.sub(r"^\s*#\s*define[^\n]*$", "", txt, flags=re.M)   # function-like macros are not symbols
-    return sorted(set(re.findall(r"\b((?:gpumt|LZ4MT|ZSTDCB|ZSTDMT|BROTLIMT|SNAPPYMT)_[A-Za-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b((?:gpumt|LZ4MT|ZSTDCB|BROTLIMT|SNAPPYMT)_[A-Za-z0-9_]+)\s*\(", txt)))
 
 
 @pytest.fixture(scope="module")
@@ -31,6 +31,16 @@ def test_exports(native, header):
     assert len(names) >= 10
     missing = [n for n in names if not hasattr(native, n)]
     assert not missing, missing
+
+
+def test_no_libzstd_symbol_collision(native):
+    """libzstd exports ZSTDMT_* itself (its own multithreading API): this library must not."""
+    out = __import__("subprocess").check_output(["nm", "-D", "--defined-only", native._name], text=True)
+    assert not re.findall(r"\bZSTDMT_\w+", out)
+    # the opt-in header names are macros over the exported ZSTDCB_* entry points
+    txt = open(os.path.join(H.ROOT, "include", "zstd-mt.h")).read()
+    for m in re.findall(r"#define (ZSTDMT_[A-Za-z]+) (ZSTDCB_[A-Za-z]+)", txt):
+        assert m[0][7:] == m[1][7:] and (m[1].endswith("_MAX") or m[1].endswith("_MIN") or hasattr(native, m[1])), m
 
 
 def test_binding_table_matches_header(native):

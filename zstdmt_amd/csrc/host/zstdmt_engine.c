@@ -902,20 +902,3 @@ size_t ZSTDCB_decompressDCtx(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 	mt_gpus_sync(&ctx->gpus);
 	return err;
 }
-
-/* ---- ZSTDMT_* : the names of /root/reference/lib/README.md:36-76, aliases of the entry points above ---- */
-#define ZMT_ALIAS(ret, name, args) ret ZSTDMT_##name args __attribute__((alias("ZSTDCB_" #name)))
-ZMT_ALIAS(unsigned, isError, (size_t));
-ZMT_ALIAS(const char *, getErrorString, (size_t));
-ZMT_ALIAS(ZSTDCB_CCtx *, createCCtx, (int, int, int));
-ZMT_ALIAS(size_t, compressCCtx, (ZSTDCB_CCtx *, ZSTDCB_RdWr_t *));
-ZMT_ALIAS(size_t, GetFramesCCtx, (ZSTDCB_CCtx *));
-ZMT_ALIAS(size_t, GetInsizeCCtx, (ZSTDCB_CCtx *));
-ZMT_ALIAS(size_t, GetOutsizeCCtx, (ZSTDCB_CCtx *));
-ZMT_ALIAS(void, freeCCtx, (ZSTDCB_CCtx *));
-ZMT_ALIAS(ZSTDCB_DCtx *, createDCtx, (int, int));
-ZMT_ALIAS(size_t, decompressDCtx, (ZSTDCB_DCtx *, ZSTDCB_RdWr_t *));
-ZMT_ALIAS(size_t, GetFramesDCtx, (ZSTDCB_DCtx *));
-ZMT_ALIAS(size_t, GetInsizeDCtx, (ZSTDCB_DCtx *));
-ZMT_ALIAS(size_t, GetOutsizeDCtx, (ZSTDCB_DCtx *));
-ZMT_ALIAS(void, freeDCtx, (ZSTDCB_DCtx *));
