@@ -70,7 +70,8 @@ def parse():
     ap.add_argument("--no-verify", dest="verify", action="store_false",
                     help="skip the byte-for-byte comparison of the round trip (on by default)")
     ap.add_argument("--only", action="store_true", help="main leg only: no zstd / brotli / api legs under 'configs'")
-    ap.add_argument("--extra-gib", type=float, default=2.0, help="size of the extra legs of the default run")
+    ap.add_argument("--extra-gib", type=float, default=8.0,
+                    help="size of the extra legs (zstd / brotli / snappy) of the default run: BASELINE's 8 GiB")
     ap.add_argument("--api-gib", type=float, default=8.0, help="input size of the drop-in API legs of the default run")
     ap.add_argument("--no-encoder", action="store_true",
                     help="--codec brotli: skip the device-encoder leg (profiling runs of the decoder alone)")
@@ -364,8 +365,8 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
                      ("zmt_dec_frames_kernel", "zmt_dec_parse_kernel", "zmt_dec_copy2_kernel") if split else ())
     dom = r_dec if (dec_only or ms["k_lz4_dec"] >= ms.get("k_lz4_enc", 0.0)) else r_enc
     res = {
-        "metric": (f"MB/s decompress, 8 GiB synthetic, {name}; % HBM roofline" if dec_only else
-                   f"MB/s compress+decompress, 8 GiB synthetic, {name}; % HBM roofline"),
+        "metric": (f"MB/s decompress, {U_all / (1 << 30):g} GiB synthetic, {name}; % HBM roofline" if dec_only else
+                   f"MB/s compress+decompress, {U_all / (1 << 30):g} GiB synthetic, {name}; % HBM roofline"),
         "value": round(U_all / 1e6 / step_s, 1),
         "unit": "MB/s",
         "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -600,7 +601,7 @@ def bench_brotli(ctx, gib_args=None, steps=None, warmup=None, cpu=True, main=Tru
     a = alg / t_k / 1e9
     traffic = traffic_table(gib if world == 1 else -1, chunk, 1 << 20).get("zmt_brotli_dec_kernel")
     res = {
-        "metric": "MB/s decompress, 8 GiB synthetic, brotli-mt (level-1 streams); % HBM roofline",
+        "metric": f"MB/s decompress, {U_all / (1 << 30):g} GiB synthetic, brotli-mt (level-1 streams); % HBM roofline",
         "value": round(U_all / 1e6 / step_s, 1), "unit": "MB/s",
         "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(step_s * 1e3, 3),
@@ -630,14 +631,19 @@ def bench_brotli(ctx, gib_args=None, steps=None, warmup=None, cpu=True, main=Tru
     return res
 
 
-def bench_snappy(ctx):
+def bench_snappy(ctx, gib_args=None, steps=None, warmup=None, main=True):
     """snappy-mt (not a BASELINE config): device-resident round trip at the reference's default
     64 KiB chunk, one GPU.  compress = zmt_snappy_enc_kernel + compact, decompress = zmt_snappy_dec_kernel
     (one kernel each, so the HIP-event times of the legs are the kernels'); verified byte for byte."""
-    args, eng = ctx.args, ctx.eng
+    import copy
+    args, eng = copy.copy(ctx.args), ctx.eng
     if ctx.world != 1:
         raise SystemExit("--codec snappy runs on one GPU")
-    chunk = args.chunk or 65536
+    if gib_args is not None:
+        args.gib = gib_args
+    args.steps = steps or args.steps
+    args.warmup = args.warmup if warmup is None else warmup
+    chunk = (args.chunk if main else 0) or 65536
     n = int(args.gib * (1 << 30)) // chunk * chunk
     nrec = n // chunk
     stride = eng.snappy_slot_stride(chunk)
@@ -702,7 +708,7 @@ def bench_snappy(ctx):
                 "traffic": tr,
                 "traffic_source": (TRAFFIC_FILE + " (separate rocprofv3 --pmc passes, not this run)") if tr else None}
     return {
-        "metric": "MB/s compress+decompress, synthetic text, snappy-mt; % HBM roofline",
+        "metric": f"MB/s compress+decompress, {U / (1 << 30):g} GiB synthetic, snappy-mt; % HBM roofline",
         "value": round(U / 1e6 / step_s, 1), "unit": "MB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
@@ -851,6 +857,11 @@ def main():
                                                                      warmup=1, main=False)
         except Exception as e:
             cfgs["brotli-mt decompress (configs[4])"] = {"error": repr(e)}
+        try:
+            cfgs["snappy-mt, 64 KiB chunks (SURVEY 8f-4, not a BASELINE config)"] = bench_snappy(
+                ctx, gib_args=args.extra_gib, steps=2, warmup=1, main=False)
+        except Exception as e:
+            cfgs["snappy-mt, 64 KiB chunks (SURVEY 8f-4, not a BASELINE config)"] = {"error": repr(e)}
         eng.close()
         api = bench_api(int(args.api_gib * 1024))
         hc = "lz4 level 3 (lz4-mt CLI default, LZ4HC)"

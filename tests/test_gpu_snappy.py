@@ -27,8 +27,19 @@ def lib():
     return H.bind_lz4mt(C.CDLL(lib_path()), "SNAPPYMT_")
 
 
+# every shipped decoder kernel: 0 = zmt_snappy_dec_kernel (element by element), 1 = zmt_snappy_dec2_kernel
+# (batched).  gpumt_open reads GPUMT_SNAPPY_DEC when a context is created, i.e. per SNAPPYMT_createDCtx.
+VARIANTS = (0, 1)
+
+
+@pytest.fixture(params=VARIANTS, ids=lambda v: "dec%d" % v)
+def dec(request, monkeypatch):
+    monkeypatch.setenv("GPUMT_SNAPPY_DEC", str(request.param))
+    return request.param
+
+
 @pytest.mark.parametrize("name", sorted(MAN))
-def test_decompress_golden(lib, name):
+def test_decompress_golden(lib, dec, name):
     ent = MAN[name]
     if "out_file" in ent:
         st = open(os.path.join(SDIR, ent["out_file"]), "rb").read()
@@ -64,7 +75,7 @@ def test_compress_is_decompress_identical(lib, name):
     assert rv == 0 and back == data and dstats == (frames, len(st), len(data))
 
 
-def test_large_default_chunks_many_batches(lib):
+def test_large_default_chunks_many_batches(lib, dec):
     """200 MiB at the default 64 KiB chunk: 3 200 records, several device batches each way."""
     data = cases.text(200 << 20, 61)
     rv, st, io, stats = H.snappymt_compress_via(lib, data, 0, threads=8)
@@ -90,21 +101,21 @@ def test_large_chunks(lib):
 
 
 @pytest.mark.parametrize("name", sorted(HAND))
-def test_hand_built_elements(lib, name):
+def test_hand_built_elements(lib, dec, name):
     payload, want = HAND[name]
     rv, out, _, _ = H.snappymt_decompress_via(lib, H.snappy_record(payload, 1) * 3, threads=2)
     assert rv == 0 and out == want * 3
 
 
 @pytest.mark.parametrize("name", sorted(n for n in BAD if BAD[n]))
-def test_rejects(lib, name):
+def test_rejects(lib, dec, name):
     good = H.snappy_record(HAND["copy4"][0], 1)
     rv, out, _, _ = H.snappymt_decompress_via(lib, good + H.snappy_record(BAD[name], 1) + good, threads=2)
     assert rv == ERR(E_FD)
 
 
 @pytest.mark.parametrize("seed", range(10))
-def test_damaged_streams_get_the_oracles_verdict(lib, seed):
+def test_damaged_streams_get_the_oracles_verdict(lib, dec, seed):
     rng = random.Random(9100 + seed)
     data = H.soup(rng, rng.randrange(1, 400000)) if seed % 3 == 0 else cases.text(rng.randrange(1, 400000), seed)
     own = seed % 2 == 0 or not H.have_libsnappy()
