@@ -22,6 +22,11 @@ void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
 void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *, u32 *, unsigned long long *, u32);
 void zmt_dec_copy2_kernel(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, u32 *);
+void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *, u32 *, u32 *, u32);
+#define C3_DECL(NAME) void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, const u32 *, const u32 *, u32 *);
+C3_DECL(zmt_dec_copy3_w4_kernel)
+C3_DECL(zmt_dec_copy3_w8_kernel)
+C3_DECL(zmt_dec_copy3_w16_kernel)
 void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 void zmt_scan_kernel(const u32 *, u32, u64 *);
 void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
@@ -122,6 +127,10 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 {
 	std::vector<u32> ce(nrec), cv(nrec);
 	u32 *cep = ce.data(), *cvp = cv.data();
+	/* variant: low 4 bits = pipeline (0 frames + parse + copy2, 1 frame-serial, 2 frames + parse3 + copy3),
+	 * bits 4.. = log2 of copy3's ring (0 = 13) */
+	const int ring = (variant >> 4) ? (variant >> 4) : 13;
+	variant &= 15;
 	if (variant == 1) {
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
 			zmt_lz4_dec_serial(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp, 0xFFFFFFFFu);
@@ -141,6 +150,15 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 		emu::launch(dim3{(nrec + 255) / 256, 1, 1}, dim3{256, 1, 1}, [=]() {
 			zmt_dec_frames_kernel(stream, rec_off, rec_len, nrec, out_len, blk0p, bcop, bcsp, rnbp, rflp, status, cep, cvp);
 		});
+		std::vector<u32> nbat(nblk_max, 0xA5A5A5A5u);
+		std::vector<u32> blv(ntok_max / 2 + 64, 0xA5A5A5A5u);
+		u32 *nbatp = nbat.data();
+		u32 *blp = blv.data();
+		if (variant == 2)
+			emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
+				zmt_dec_parse3_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, blp, bntp, nbatp, bolp, (u32)ring);
+			});
+		else
 		emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
 			zmt_dec_parse_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bixp, bntp, bolp, nullptr, 0);
 		});
@@ -150,6 +168,19 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 			for (u32 r = 0; r < nrec; r++)
 				fprintf(stderr, "rec %u status=%u nblk=%u\n", r, status[r], rnb[r]);
 		}
+		if (getenv("ZMT_EMU_DEBUG") && variant == 2)
+			for (size_t b = 0; b < blk0[nrec]; b++)
+				fprintf(stderr, "blk %zu nbat=%u\n", b, nbat[b]);
+		if (variant == 2)
+			emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
+				if (ring == 12)
+					zmt_dec_copy3_w4_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, blp, bntp, nbatp, bolp, status);
+				else if (ring == 13)
+					zmt_dec_copy3_w8_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, blp, bntp, nbatp, bolp, status);
+				else
+					zmt_dec_copy3_w16_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, blp, bntp, nbatp, bolp, status);
+			});
+		else
 		emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{256, 1, 1}, [=]() {
 			zmt_dec_copy2_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
 		});

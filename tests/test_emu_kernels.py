@@ -92,7 +92,12 @@ def test_emu_hc_optimal_bit_exact(name, level):
     assert stream == H.oracle_compress_level(data, chunk, level)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+# decoder variants of the emulator API: 0 = frames + parse + copy2 (round 2), 1 = frame-serial,
+# 2 | ring << 4 = frames + parse3 + copy3 with a 4 / 8 / 16 KiB ring
+DEC_VARIANTS = [0, 1, 2 | 12 << 4, 2 | 13 << 4, 2 | 14 << 4]
+
+
+@pytest.mark.parametrize("variant", DEC_VARIANTS)
 @pytest.mark.parametrize("name", SMALL)
 def test_emu_decompress(name, variant):
     chunk, thunk = CASES[name]
@@ -103,7 +108,7 @@ def test_emu_decompress(name, variant):
     assert out == data
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", DEC_VARIANTS)
 @pytest.mark.parametrize("mutate,code", [("magic", 2), ("hc", 2), ("blocksize", 3), ("checksum", 5),
                                          ("skipmagic", 1), ("skiplen", 1), ("offset0", 3)])
 def test_emu_corrupt_streams(mutate, code, variant):
@@ -143,7 +148,7 @@ def test_emu_corrupt_streams(mutate, code, variant):
     assert out[131072:] == data[131072:]   # the healthy record still decodes
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", DEC_VARIANTS)
 def test_emu_block_checksum_and_dictid_frames(variant):
     """frames with block checksums / a dictionary id (liblz4-written fixtures): the pipeline hands them
     to the wave-per-record decoder, which verifies every block's XXH32"""

@@ -12,7 +12,15 @@ from cases import CASES, KNOWN_HEX, rnd, text
 pytestmark = pytest.mark.gpu
 
 # decoder kernel variants under test (include/gpumt.h gpumt_set_variant "lz4_dec")
-VARIANTS = [0, 1]   # 0 = frames + parse + copy2 pipeline (default), 1 = serial wave-per-record decoder
+# 0 = frames + parse + copy2 pipeline (round 2), 1 = serial wave-per-record decoder,
+# 2 | ring << 4 = frames + parse3 + copy3 with a 4 / 8 / 16 KiB LDS ring per wave ("lz4_ring" = 12 / 13 / 14)
+VARIANTS = [0, 1, 2 | 12 << 4, 2 | 13 << 4, 2 | 14 << 4]
+
+
+def set_dec(eng, v):
+    eng.set_variant("lz4_dec", v & 15)
+    if v >> 4:
+        eng.set_variant("lz4_ring", v >> 4)
 
 with open(os.path.join(H.GOLDEN_DIR, "manifest.json")) as _f:
     MAN = json.load(_f)["cases"]
@@ -48,7 +56,7 @@ def test_decompress_golden(eng, name, variant):
     assert H.sha256(stream) == MAN[name]["out_sha256"]
     import emu_driver as E
     ro, rl = E.walk_records(stream)
-    eng.set_variant("lz4_dec", variant)
+    set_dec(eng, variant)
     try:
         out, status = eng.decompress_bytes(stream, ro, rl)
     finally:
@@ -69,7 +77,7 @@ def test_fuzz_vs_oracle(eng, seed):
     stream, ro, rl = eng.compress_bytes(data, chunk)
     assert stream == want
     for variant in VARIANTS:
-        eng.set_variant("lz4_dec", variant)
+        set_dec(eng, variant)
         out, status = eng.decompress_bytes(stream, ro, rl)
         eng.set_variant("lz4_dec", 0)
         assert not status.any() and out == data
@@ -204,7 +212,7 @@ def test_corrupt_streams_rejected(eng, mutate, code):
         s[12 + 6] = (s[12 + 6] - 1) & 0xFF
         s[12 + 14] = (xxhash.xxh32(bytes(s[12 + 4:12 + 14]), seed=0).intdigest() >> 8) & 0xFF
     for variant in VARIANTS:
-        eng.set_variant("lz4_dec", variant)
+        set_dec(eng, variant)
         out, status = eng.decompress_bytes(bytes(s), ro, rl)
         eng.set_variant("lz4_dec", 0)
         assert status.tolist() == [code], (variant, status)
@@ -235,7 +243,7 @@ def test_block_checksum_and_dictid_frames(eng, variant):
     import emu_driver as E
     d = os.path.join(H.GOLDEN_DIR, "lz4f_flags")
     man = json.load(open(os.path.join(d, "manifest.json")))["cases"]
-    eng.set_variant("lz4_dec", variant)
+    set_dec(eng, variant)
     try:
         for name, e in man.items():
             rec = open(os.path.join(d, name + ".rec"), "rb").read()

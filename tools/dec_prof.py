@@ -23,7 +23,9 @@ eng.lz4_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo)
 eng.sync()
 names = ["stage", "spec", "walk", "decode+scan+classify", "literals", "fence+far", "rounds", "flush", "slowpath", "batches", "seqs", "total"]
 for v in variants:
-    eng.set_variant("lz4_dec", v)
+    eng.set_variant("lz4_dec", v & 15)
+    if v >> 4:
+        eng.set_variant("lz4_ring", v >> 4)
     eng.set_variant("profile", 1)
     for rep in range(2):
         cnt = (C.c_ulonglong * 16)()
@@ -43,7 +45,7 @@ for v in variants:
             L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); w = max(c[6], 1); st_ = max(c[4], 1)
             print(f"   K2 prof xflags={xf}: parse_ms={eng.timer_ms(14):.3f} waves={c[6]} steps/wave={c[4]/w:.0f} cycles/step total={c[0]/st_:.0f} refill={c[1]/st_:.0f} (landing {c[7]/st_:.0f}, rounds/step {c[8]/st_:.2f}) token={c[2]/st_:.0f} drain={c[3]/st_:.0f} slowloads/step={c[5]/st_:.2f} | token split: read={c[10]/st_:.0f} lit={c[11]/st_:.0f} ml+state={c[12]/st_:.0f} emit={c[2]/st_:.0f}")
             eng.set_variant("profile", 1); eng.set_variant("k2x", 0)
-        if os.environ.get("K3PROF") and v == 0:
+        if os.environ.get("K3PROF"):
             eng.set_variant("profile", 3)
             cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
             eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
@@ -51,4 +53,13 @@ for v in variants:
             nm = ["land", "fields", "scan+check", "cuts+reserve+classify", "far-issue", "literals", "slot+sync", "match-r1", "rounds", "flush", "loop/prefetch"]
             print("   copy2 prof (cycles per batch): " + ", ".join(f"{nm[i]}={c[i]/nbat:.0f}" for i in range(11)) + f" total={c[11]/nbat:.0f} batches={c[12]}")
             eng.set_variant("profile", 1)
+    if (v & 15) == 2 and os.environ.get("K3PROF"):
+        eng.set_variant("profile", 8)
+        cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
+        eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
+        L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); nbat = max(c[12], 1)
+        nm = ["wait(stage,tokens,stores)", "prefetch+loop", "fields", "scan+check+classify", "far-issue", "literals", "far-land", "match-r1", "rounds", "flush", "singles"]
+        print(f"   copy3 prof ring {v >> 4} (cycles per batch): " + ", ".join(f"{nm[i]}={c[i]/nbat:.0f}" for i in range(11)) + f" total={c[11]/nbat:.0f} batches={c[12]} rounds/batch={c[13]/nbat:.2f}")
+        eng.set_variant("profile", 1)
+    if (v & 15) in (0, 2):
         print("   split: frames %.3f ms, parse %.3f ms, copy %.3f ms, xxh %.3f ms" % (eng.timer_ms(13), eng.timer_ms(14), eng.timer_ms(15), eng.timer_ms(12)))

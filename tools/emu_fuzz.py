@@ -24,8 +24,11 @@ for seed in range(n0,n1):
             t[b:b+l]=t[a:a+l] if rng.random()<0.7 else bytes([rng.randrange(256)])*l
         data=bytes(t)
     s=H.oracle_compress(data,chunk)
-    out,st=E.decompress(s,0)
-    ok = (not st.any()) and out==data
+    ok=True
+    for v in (0, 2|12<<4, 2|13<<4, 2|14<<4):   # round-2 pipeline, parse3 + copy3 at 4 / 8 / 16 KiB rings
+        out,st=E.decompress(s,v)
+        ok = ok and (not st.any()) and out==data
+        if not ok: print("variant",v); break
     print(seed,kind,n,chunk,"OK" if ok else "FAIL",st.tolist()[:5],flush=True)
     if not ok:
         a=np.frombuffer(out,np.uint8); b=np.frombuffer(data,np.uint8)

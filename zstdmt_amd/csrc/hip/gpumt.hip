@@ -41,6 +41,22 @@ __global__ void zmt_dec_copy2_kernel(const u8 *, u64, u32, u32, u8 *, const u64 
 __global__ void zmt_dec_copy2_kernel_prof(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *,
 					  const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
 					  const u32 *, const u32 *, u32 *, unsigned long long *);
+__global__ void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *, u32 *, u32 *,
+				      u32 *, u32 *, u32);
+#define C3_DECL(NAME)                                                                                              \
+	__global__ void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *,  \
+			     const u32 *, const u32 *, const u32 *, const u16 *, const u32 *, const u32 *, const u32 *, \
+			     const u32 *, u32 *);
+C3_DECL(zmt_dec_copy3_w4_kernel)
+C3_DECL(zmt_dec_copy3_w8_kernel)
+C3_DECL(zmt_dec_copy3_w16_kernel)
+#define C3_DECLP(NAME)                                                                                             \
+	__global__ void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *,  \
+			     const u32 *, const u32 *, const u32 *, const u16 *, const u32 *, const u32 *, const u32 *, \
+			     const u32 *, u32 *, unsigned long long *);
+C3_DECLP(zmt_dec_copy3_w4_kernel_prof)
+C3_DECLP(zmt_dec_copy3_w8_kernel_prof)
+C3_DECLP(zmt_dec_copy3_w16_kernel_prof)
 __global__ void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 __global__ void zmt_snappy_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *);
 __global__ void zmt_snappy_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
@@ -83,6 +99,7 @@ struct gpumt_ctx {
 	int dec_variant;
 	unsigned long long *d_prof; /* 16 phase counters of the profiling decoder */
 	int xflags;  /* experiment switches of the parse kernel (developer) */
+	int lz4_ring; /* copy3: log2 of the LDS ring per wave (12, 13 or 14) */
 	int profile; /* record events in timer slots 8.. around individual kernels */
 	int num_cus;
 	int zenc_waves; /* resident waves of the persistent zstd encoder kernel (whole device) */
@@ -223,6 +240,12 @@ int gpumt_open(int device, gpumt_ctx **out)
 		 * gpumt_set_variant on: GPUMT_SNAPPY_DEC=1 selects the batched snappy decoder */
 		const char *e = getenv("GPUMT_SNAPPY_DEC");
 		h->sdec_variant = e && *e ? atoi(e) : 0;
+		/* GPUMT_LZ4_DEC: 0 = frames + parse + copy2 (round 2), 1 = frame-serial, 2 = frames + parse3 + copy3;
+		 * GPUMT_LZ4_RING: log2 of copy3's LDS ring per wave */
+		e = getenv("GPUMT_LZ4_DEC");
+		h->dec_variant = e && *e ? atoi(e) : 0;
+		e = getenv("GPUMT_LZ4_RING");
+		h->lz4_ring = e && *e ? atoi(e) : 13;
 	}
 	*out = h;
 	return GPUMT_OK;
@@ -755,8 +778,11 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 	CARVE(bol, u32, nblk_max)
 	CARVE(bix, u32, ntok_max / 64 + 2)
 	CARVE(tok, u16, ntok_max)
+	CARVE(nbat, u32, nblk_max)
+	CARVE(bl, u32, ntok_max / 2 + 64)
 #undef CARVE
-	const bool split = (h->dec_variant == 0);
+	const bool split = (h->dec_variant == 0 || h->dec_variant == 2);
+	const bool v3 = h->dec_variant == 2;
 	if (h->profile >= 2 && !h->d_prof) {
 		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
@@ -779,13 +805,46 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 				   (const u8 *)d_stream, d_rec_off, d_rec_len, n, d_out_len,
 				   (const u64 *)blk0, bco, bcs, rnb, rfl, d_status, ce, cv);
 		PROF1(13);
+		u32 *nbat = (u32 *)(sc + nbat_o);
+		u32 *bl = (u32 *)(sc + bl_o);
+		const int ring = h->lz4_ring < 12 ? 12 : h->lz4_ring > 14 ? 14 : h->lz4_ring;
 		PROF0(14);
-		hipLaunchKernelGGL(zmt_dec_parse_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
-				   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
-				   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bix, bnt, bol,
-				   h->profile == 2 ? h->d_prof : (unsigned long long *)NULL, (u32)h->xflags);
+		if (v3)
+			hipLaunchKernelGGL(zmt_dec_parse3_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
+					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
+					   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bl, bnt, nbat, bol, (u32)ring);
+		else
+			hipLaunchKernelGGL(zmt_dec_parse_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
+					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
+					   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bix, bnt, bol,
+					   h->profile == 2 ? h->d_prof : (unsigned long long *)NULL, (u32)h->xflags);
 		PROF1(14);
 		PROF0(15);
+#define C3_LAUNCH(NAME)                                                                                            \
+	hipLaunchKernelGGL(NAME, dim3((unsigned)nrec), dim3(64), 0, h->st[s], (const u8 *)d_stream,               \
+			   (u64)stream_bytes, 0u, n, (u8 *)d_out, d_out_off, d_out_len, (const u64 *)blk0,         \
+			   (const u64 *)bco, (const u32 *)bcs, (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, \
+			   (const u32 *)bl, (const u32 *)bnt, (const u32 *)nbat, (const u32 *)bol, d_status)
+#define C3_LAUNCHP(NAME)                                                                                           \
+	hipLaunchKernelGGL(NAME, dim3((unsigned)nrec), dim3(64), 0, h->st[s], (const u8 *)d_stream,               \
+			   (u64)stream_bytes, 0u, n, (u8 *)d_out, d_out_off, d_out_len, (const u64 *)blk0,         \
+			   (const u64 *)bco, (const u32 *)bcs, (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, \
+			   (const u32 *)bl, (const u32 *)bnt, (const u32 *)nbat, (const u32 *)bol, d_status, h->d_prof)
+		if (v3 && h->profile == 8) {
+			if (ring == 12)
+				C3_LAUNCHP(zmt_dec_copy3_w4_kernel_prof);
+			else if (ring == 13)
+				C3_LAUNCHP(zmt_dec_copy3_w8_kernel_prof);
+			else
+				C3_LAUNCHP(zmt_dec_copy3_w16_kernel_prof);
+		} else if (v3) {
+			if (ring == 12)
+				C3_LAUNCH(zmt_dec_copy3_w4_kernel);
+			else if (ring == 13)
+				C3_LAUNCH(zmt_dec_copy3_w8_kernel);
+			else
+				C3_LAUNCH(zmt_dec_copy3_w16_kernel);
+		} else
 		/* (running the XXH32 verification of record slices on a second stream while the next slice
 		 * is copied was measured: the partial last round of every slice costs more than the overlap
 		 * gains, 12.2 vs 10.5 + 1.5 ms per 8 GiB) */
@@ -1118,6 +1177,9 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	if (!strcmp(what, "lz4_dec")) {
 		prev = h->dec_variant;
 		h->dec_variant = variant;
+	} else if (!strcmp(what, "lz4_ring")) {
+		prev = h->lz4_ring;
+		h->lz4_ring = variant;
 	} else if (!strcmp(what, "k2x")) {
 		prev = h->xflags;
 		h->xflags = variant;

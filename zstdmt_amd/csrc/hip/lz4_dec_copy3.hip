@@ -1,0 +1,569 @@
+/*
+ * lz4_dec_copy3.hip -- copy stage of the LZ4 frame decoder, round 3 ("copy3").
+ *
+ * Same contract as zmt_dec_copy2_kernel (wave per record; replaces LZ4F_decompress at
+ * /root/reference/lib/lz4-mt_decompress.c:349-362 together with the frames / parse3 kernels).
+ *
+ * What the round-3 counters said about copy2 (profiles/r03_tcc_requests.json): it fetched 45.0 GB per
+ * 8 GiB in 351.6 M requests, every one of them a full 128-byte line from memory -- one per match whose
+ * source lay before its 2-4 KiB LDS window (37 % of the matches at a 4 KiB window) -- i.e. 5.2 TB/s for
+ * 13.4 GB of useful bytes: bandwidth-bound on far-match lines as much as on instruction issue.
+ *
+ * So this kernel is built around (1) a big power-of-two LDS RING of the record's output (8 or 16 KiB per
+ * wave: 19 % / 6 % of the matches are sourced before it), addressed modulo, never slid; one wave per
+ * workgroup so that the LDS of a CU divides into as many waves as fit; (2) batches that the parse
+ * kernel has already cut (lz4_dec_parse3.hip: <= 64 small sequences, inside one lap of the ring, inside
+ * the 1 KiB stage), so the batch loop has no cut / classify / reserve code; (3) the compressed bytes of
+ * a batch staged by ONE LDS-DMA instruction (global_load_lds_dwordx4, 1 KiB per wave-instruction, no
+ * VGPRs), a batch ahead, into one of two stage buffers; (4) everything unusual -- long runs, the block's
+ * last sequence, lap-crossing sequences -- executed generically byte by byte THROUGH the ring, so the
+ * ring history is never lost; (5) one vector-memory schedule per batch: gfx9 has ONE in-order counter
+ * for loads and stores, so a wait for a load is a wait for every store before it.  The batch's loads of
+ * sources before the ring go out right after the scan, are waited for after the literal copies, and only
+ * then does everything else leave -- the ring-to-memory stores of what the PREVIOUS batches produced,
+ * the next token positions, the next stage -- so the one full drain per batch (at its top) finds
+ * operations that are most of a batch old.
+ *
+ * Measured on MI355X (tools/ubench/store_cost.hip): a misaligned ds_write costs one LDS cycle per ACTIVE
+ * lane whatever its width (b64: 64 / 32 / 16 / 8.3 cycles at 64 / 32 / 16 / 8 lanes), an aligned one 7-13.
+ * Hence: literal stores are issued only by lanes that have literals, the second match piece only by
+ * matches longer than 8 bytes.
+ */
+#include "lz4_common.h"
+#include "lz4_frame.h"
+
+#define C3_CSTAGE 1024u
+#define C3_CSLACK 32u
+#define C3_CBUF (C3_CSTAGE + C3_CSLACK) /* two of them: the next batch's bytes arrive while this one runs; once a
+					  * batch's literals are copied its buffer holds the 64 x 16 bytes fetched for
+					  * matches sourced before the ring */
+#define C3_BLK_STORED 0x80000000u
+#define C3_SINGLE 0x80u
+#define C3_NEEDS_SERIAL 100u
+
+#ifndef ZMT_EMU
+#define C3KT() (PROF ? (u64)clock64() : 0ull)
+#else
+#define C3KT() 0ull
+#endif
+#define C3PC(i)                                                                                    \
+	do {                                                                                       \
+		if (PROF) {                                                                        \
+			const u64 t_ = C3KT();                                                     \
+			pc[PROF ? (i) : 0] += t_ - tq;                                             \
+			tq = t_;                                                                   \
+		}                                                                                  \
+	} while (0)
+
+static __device__ __forceinline__ void c3_st64(u8 *p, u64 v) { __builtin_memcpy(p, &v, 8); }
+static __device__ __forceinline__ u64 c3_tok_base(u64 coff, u32 gb) { return ((coff / 3) & ~63ull) + 128ull * gb; }
+
+/* 1 KiB of the stream into LDS, lane l moving bytes [16 l, 16 l + 16) of it; `g` is 16-byte aligned */
+static __device__ __forceinline__ void c3_stage(u8 *cb, const u8 *g, u32 nbytes, int lane)
+{
+	if (16u * (u32)lane < nbytes) {
+#ifdef ZMT_EMU
+		__builtin_memcpy(cb + 16 * lane, g + 16 * lane, 16);
+#else
+		__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g + 16 * lane),
+						 (__attribute__((address_space(3))) void *)cb, 16, 0, 0);
+#endif
+	}
+}
+static __device__ __forceinline__ void c3_wait_vm()
+{
+#ifndef ZMT_EMU
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+	wv_sync();
+}
+
+/* eight staged bytes at offset o (any alignment): three aligned dword reads + two funnel shifts */
+static __device__ __forceinline__ u64 c3_ld64s(const u8 *base, u32 o)
+{
+	const u32 *w = (const u32 *)(base + (o & ~3u));
+	const u32 a0 = w[0], a1 = w[1], a2 = w[2];
+	return (u64)wv_alignbyte(a1, a0, o) | ((u64)wv_alignbyte(a2, a1, o) << 32);
+}
+
+template <u32 WIN, bool PROF = false> struct C3 {
+	static constexpr u32 MASK = WIN - 1u;
+
+	/* eight bytes at offset o (any alignment) of an LDS region addressed modulo m + 1 from `base` (the ring: m =
+	 * MASK; a stage buffer: m = ~0): the three dwords wrap individually */
+	static __device__ __forceinline__ u64 ld64m(const u8 *base, u32 o, u32 m)
+	{
+		const u32 a = o & ~3u;
+		const u32 a0 = *(const u32 *)(base + (a & m));
+		const u32 a1 = *(const u32 *)(base + ((a + 4u) & m));
+		const u32 a2 = *(const u32 *)(base + ((a + 8u) & m));
+		return (u64)wv_alignbyte(a1, a0, o) | ((u64)wv_alignbyte(a2, a1, o) << 32);
+	}
+
+	struct St {
+		u32 opos, flushed, valid_from, fenced;
+	};
+
+	/* ring -> memory for output positions [st.flushed, upto); the body in aligned 16-byte pieces */
+	static __device__ __forceinline__ void flush_to(St &st, const u8 *ring, u8 *out, u32 upto, int lane)
+	{
+		u32 f = st.flushed;
+		if (upto <= f)
+			return;
+		if (f & 15u) {
+			u32 head = 16u - (f & 15u);
+			if (head > upto - f)
+				head = upto - f;
+			if ((u32)lane < head)
+				out[f + lane] = ring[(f + lane) & MASK];
+			f += head;
+		}
+		const u32 body_end = f + ((upto - f) & ~15u);
+		for (u32 pos = f + 16u * (u32)lane; pos < body_end; pos += 1024u) {
+			const u8 *r = ring + (pos & MASK);
+			const u64 a = *(const u64 *)r, b = *(const u64 *)(r + 8);
+			c3_st64(out + pos, a);
+			c3_st64(out + pos + 8, b);
+		}
+		if (body_end != upto && (u32)lane < upto - body_end)
+			out[body_end + lane] = ring[(body_end + lane) & MASK];
+		st.flushed = upto;
+	}
+
+	/* the same for the batch loop, where both ends are multiples of 16 unless a stored block or the record's start
+	 * left `flushed` odd (then the general routine realigns it) */
+	static __device__ __forceinline__ void flush_aligned(St &st, const u8 *ring, u8 *out, u32 upto, int lane)
+	{
+		if (st.flushed & 15u) {
+			flush_to(st, ring, out, upto, lane);
+			return;
+		}
+		for (u32 pos = st.flushed + 16u * (u32)lane; pos < upto; pos += 1024u) {
+			const u8 *r = ring + (pos & MASK);
+			const u64 a = *(const u64 *)r, b = *(const u64 *)(r + 8);
+			c3_st64(out + pos, a);
+			c3_st64(out + pos + 8, b);
+		}
+		if (upto > st.flushed)
+			st.flushed = upto;
+	}
+
+	/* one sequence of any shape, by the whole wave, byte by byte THROUGH the ring (fields are wave-uniform).
+	 * Source bytes older than the ring come from the output in memory. */
+	static __device__ __forceinline__ void generic(const u8 *lsrc, u32 lit, u32 off, u32 ml, u8 *ring, u8 *out, St &st, int lane)
+	{
+		while (lit) {
+			const u32 c = lit < 512u ? lit : 512u;
+			for (u32 i = (u32)lane; i < c; i += 64)
+				ring[(st.opos + i) & MASK] = lsrc[i];
+			wv_sync();
+			st.opos += c;
+			lsrc += c;
+			lit -= c;
+			flush_to(st, ring, out, st.opos & ~15u, lane);
+		}
+		u32 done = 0;
+		while (done < ml) {
+			/* a chunk never reads what it writes: at most `off` bytes unless the period is short, in which
+			 * case every byte comes from the `off` bytes in front of the match */
+			u32 c = ml - done < 512u ? ml - done : 512u;
+			if (off >= 64u && c > off)
+				c = off;
+			const u32 mpos = st.opos;
+			const u32 hist = mpos + c + 16u > WIN ? mpos + c + 16u - WIN : 0u; /* ring holds [hist, mpos) */
+			const u32 lo = hist > st.valid_from ? hist : st.valid_from;
+			const u32 first_src = off < 64u ? mpos - done - off : mpos - off;
+			if (first_src < lo && st.fenced < st.flushed) {
+				wave_mem_fence(); /* bytes this wave stored are about to be loaded back */
+				st.fenced = st.flushed;
+			}
+			for (u32 i = (u32)lane; i < c; i += 64) {
+				const u32 p = off < 64u ? mpos - done - off + (done + i) % off : mpos - off + i;
+				const u8 b = p >= lo ? ring[p & MASK] : out[p];
+				ring[(mpos + i) & MASK] = b;
+			}
+			wv_sync();
+			st.opos += c;
+			done += c;
+			flush_to(st, ring, out, st.opos & ~15u, lane);
+		}
+	}
+
+	/* overlapping match (offset < length) of one lane inside the ring: strictly forward */
+	static __device__ __forceinline__ void match_ovl(u8 *ring, u32 mpos, u32 off, u32 ml)
+	{
+		u32 j = 0;
+		for (u32 i = 0; i < ml; i++) {
+			ring[(mpos + i) & MASK] = ring[(mpos - off + j) & MASK];
+			if (++j == off)
+				j = 0;
+		}
+	}
+
+	/* match of 4..64 bytes at output position mpos whose source -- offset so of the region (sb, sm), see ld64m -- is
+	 * complete and does not overlap it: first and last 8 (or 4) bytes, the middle of the rare long one in 8-byte steps */
+	static __device__ __forceinline__ void match(u8 *ring, u32 mpos, u32 ml, const u8 *sb, u32 so, u32 sm)
+	{
+		u8 *const d = ring + (mpos & MASK); /* a batch lies inside one lap: no wrap on the destination side */
+		const bool wide = ml >= 8u;
+		const u32 tl = wide ? ml - 8u : ml - 4u;
+		const u64 a = ld64m(sb, so, sm), b = ld64m(sb, so + tl, sm);
+		if (ml > 16u) {
+			for (u32 i = 8; i + 8 < ml; i += 8)
+				c3_st64(d + i, ld64m(sb, so + i, sm));
+		}
+		if (wide) {
+			c3_st64(d, a);
+			if (ml > 8u)
+				c3_st64(d + tl, b);
+		} else {
+			st32u(d, (u32)a);
+			if (ml > 4u)
+				st32u(d + tl, (u32)b);
+		}
+	}
+
+	static __device__ __forceinline__ void
+	body(const u8 *__restrict__ stream, u64 stream_bytes, u32 rec0, u32 nrec, u8 *out_base,
+	     const u64 *__restrict__ out_off, const u32 *__restrict__ out_len, const u64 *__restrict__ blk0,
+	     const u64 *__restrict__ blk_coff, const u32 *__restrict__ blk_csize, const u32 *__restrict__ rec_nblk,
+	     const u32 *__restrict__ rec_flags, const u16 *__restrict__ tok, const u32 *__restrict__ bl,
+	     const u32 *__restrict__ blk_ntok, const u32 *__restrict__ blk_nbat, const u32 *__restrict__ blk_olen,
+	     u32 *__restrict__ status, u8 *ring, u8 *cbuf, unsigned long long *prof)
+	{
+		const int lane = wv_lane();
+		/* per-phase cycle counters of the profiling build (developer tool, tools/dec_prof.py) */
+		u64 pc[PROF ? 14 : 1] = {0}, tq = C3KT();
+		const u64 t_begin = tq;
+		const u32 rec = rec0 + blockIdx.x;
+		if (rec >= nrec)
+			return;
+		if (wv_readfirst(status[rec]) != ST_OK)
+			return;
+		u8 *const out = out_base + out_off[rec];
+		const u32 cap = out_len[rec];
+		const u64 b0 = blk0[rec];
+		const u32 nb = wv_readfirst(rec_nblk[rec]);
+		const bool indep = wv_readfirst(rec_flags[rec]) & 1;
+		u32 stc = ST_OK;
+		St st;
+		st.opos = st.flushed = st.valid_from = st.fenced = 0;
+
+		for (u32 bi = 0; bi < nb && stc == ST_OK; bi++) {
+			const u32 gb = (u32)(b0 + bi);
+			const u32 cs = wv_readfirst(blk_csize[gb]);
+			const u64 coff = blk_coff[gb];
+			const u8 *const src = stream + coff;
+			const u32 olen = wv_readfirst(blk_olen[gb]);
+			const u32 bstart = st.opos;
+			if (olen == 0xFFFFFFFFu || cap - bstart < olen) {
+				stc = ST_BAD_BLOCK;
+				break;
+			}
+			if (cs & C3_BLK_STORED) {
+				const u32 bsz = cs & 0x7FFFFFFFu;
+				flush_to(st, ring, out, st.opos, lane);
+				wave_copy(out + st.opos, src, bsz, lane);
+				st.opos += bsz;
+				st.flushed = st.opos;
+				st.valid_from = st.opos; /* the ring does not hold a stored block: sources in it come from memory */
+				continue;
+			}
+			if (st.opos & MASK) {
+				/* the parse kernel cut its batches for a block that starts on a lap boundary; LZ4F allows short
+				 * blocks in front (lz4-mt never writes them): the frame-serial kernel decodes this record */
+				stc = C3_NEEDS_SERIAL;
+				break;
+			}
+			const u32 ntok = wv_readfirst(blk_ntok[gb]);
+			const u32 nbat = wv_readfirst(blk_nbat[gb]);
+			const u64 tbase = c3_tok_base(coff, gb);
+			const u16 *const tk = tok + tbase;
+			const u32 *const bd = bl + (tbase >> 1);
+			const u32 low = indep ? bstart : 0;
+			/* ---- batch list three entries ahead, token positions two, compressed bytes one ----
+			 * entry = n | single << 7 | c0 << 16: n small sequences from block position c0 on, then (single) one
+			 * sequence of any shape; its token positions are n + single consecutive entries of the token list */
+#define C3_DESC(J) ((J) < nbat ? bd[(J)] : 0u)
+#define C3_NTOK(D) (((D) & 127u) + (((D) >> 7) & 1u))
+#define C3_TOK(T0, N) (((u32)lane < (N)) ? (u32)tk[(T0) + (u32)lane] : 0u)
+#define C3_STAGE(D, BUF)                                                                                           \
+	do {                                                                                                       \
+		const u32 c_ = (D) >> 16;                                                                          \
+		const u8 *g_ = src + c_;                                                                           \
+		const u32 a_ = (u32)((size_t)g_ & 15u);                                                            \
+		c3_stage(cbuf + (BUF) * C3_CBUF, g_ - a_, cs - c_ + a_ + 16u, lane);                               \
+	} while (0)
+			u32 d_cur = wv_readfirst(C3_DESC(0)), d_nxt = wv_readfirst(C3_DESC(1));
+			u32 d_nn_v = C3_DESC(2); /* lands while the current entry runs */
+			u32 t0 = 0;
+			u32 q_cur = C3_TOK(0, C3_NTOK(d_cur));
+			u32 q_nxt = C3_TOK(C3_NTOK(d_cur), C3_NTOK(d_nxt));
+			u32 cbi = 0; /* stage buffer of the first batch at or after the current entry */
+			if (d_cur & 127u)
+				C3_STAGE(d_cur, cbi);
+			for (u32 j = 0; j < nbat && stc == ST_OK; j++) {
+				const u32 d = d_cur;
+				const u32 n = d & 127u;
+				const u32 ntk = C3_NTOK(d);
+				if (t0 + ntk > ntok || ntk == 0) {
+					stc = ST_BAD_BLOCK; /* cannot happen: the lists come from the parse kernel */
+					break;
+				}
+				C3PC(1);
+				c3_wait_vm(); /* the stage of this batch, the token positions of this and the next entry */
+				C3PC(0);
+				const u32 q = q_cur;
+				const u32 d_nn = wv_readfirst(d_nn_v);
+				const u32 t2 = t0 + ntk + C3_NTOK(d_nxt);
+				/* what leaves for memory this batch (issued together, below): the ring up to the batch's start, the
+				 * token positions two entries ahead, the batch-list entry three ahead, the next stage */
+#define C3_ISSUE()                                                                                                 \
+	do {                                                                                                       \
+		flush_aligned(st, ring, out, st.opos & ~15u, lane);                                                \
+		q_cur = q_nxt;                                                                                     \
+		q_nxt = C3_TOK(t2, C3_NTOK(d_nn));                                                                 \
+		d_nn_v = C3_DESC(j + 3);                                                                           \
+		d_cur = d_nxt;                                                                                     \
+		d_nxt = d_nn;                                                                                      \
+		if (d_cur & 127u)                                                                                  \
+			C3_STAGE(d_cur, cbi); /* (a batch has flipped cbi to the free buffer already) */             \
+	} while (0)
+				if (n == 0) {
+					C3_ISSUE();
+				} else {
+					/* ---------- a batch of n small sequences, lane = sequence ---------- */
+					if (PROF)
+						pc[PROF ? 12 : 0]++;
+					const bool act = (u32)lane < n;
+					u8 *const cb = cbuf + cbi * C3_CBUF;
+					cbi ^= 1u;
+					const u32 c0 = d >> 16;
+					const u32 al = (u32)((size_t)(src + c0) & 15u);
+					const u32 qr = q - c0 + al; /* this lane's token in the stage */
+					u32 lit = 0, ml = 0, off = 1, lsrc = 0;
+					{
+						const u64 w = c3_ld64s(cb, act ? qr : 0u);
+						const u32 wl = (u32)w;
+						const u32 tokb = wl & 255u;
+						const bool lx = (tokb >> 4) == 15u, mx = (tokb & 15u) == 15u;
+						const u32 l_ = (tokb >> 4) + (lx ? (wl >> 8) & 255u : 0u);
+						const u32 h = qr + 1u + (lx ? 1u : 0u);
+						const u32 w2 = (u32)c3_ld64s(cb, act ? h + l_ : 0u);
+						if (act) {
+							lit = l_;
+							lsrc = h;
+							off = w2 & 0xFFFFu;
+							ml = (tokb & 15u) + 4u + (mx ? (w2 >> 16) & 255u : 0u);
+						}
+					}
+					C3PC(2);
+					const u32 len = lit + ml;
+					const u32 incl = wv_scan_incl(len);
+					const u32 o0 = st.opos;
+					const u32 op = o0 + incl - len;
+					const u32 mpos = op + lit;
+					const u32 src_pos = mpos - off;
+					const u32 eff = ml < off ? ml : off;
+					const u32 total = wv_readlane(incl, 63);
+					const u32 o_end = o0 + total;
+					if (wv_any(act & ((off == 0) | (off > mpos - low))) | (total > cap - o0)) {
+						stc = ST_BAD_BLOCK;
+						break;
+					}
+					/* the ring holds [near_lo, o0): what this batch will overwrite (plus store slack) is gone */
+					const u32 hist = o_end + 16u > WIN ? o_end + 16u - WIN : 0u;
+					const u32 near_lo = hist > st.valid_from ? hist : st.valid_from;
+					const bool is_far = act & (src_pos < near_lo);
+					const bool anyfar = wv_any(is_far);
+					/* a source that straddles the start of the ring or of what memory holds, or an overlapping match
+					 * sourced before the ring: possible only right after a stored block or when memory lags far behind;
+					 * then this batch goes one sequence at a time */
+					if ((st.valid_from > hist || near_lo + 128u > st.flushed) && anyfar &&
+					    wv_any(is_far && (src_pos + eff > near_lo || src_pos + eff > st.flushed || off < ml))) {
+						for (u32 i = 0; i < n; i++) {
+							const u32 l1 = wv_readlane(lit, (int)i), m1 = wv_readlane(ml, (int)i);
+							generic(cb + wv_readlane(lsrc, (int)i), l1, wv_readlane(off, (int)i), m1, ring, out, st, lane);
+						}
+						C3_ISSUE();
+					} else {
+						C3PC(3);
+						/* ---- sources before the ring: 16 bytes of the output in memory, loads first ---- */
+						u64 f0 = 0, f1 = 0;
+						if (anyfar) {
+							if (wv_any(is_far & (src_pos + eff > st.fenced))) {
+								wave_mem_fence();
+								st.fenced = st.flushed;
+							}
+							if (is_far) {
+								f0 = ld64u(out + src_pos);
+								if (ml > 8u)
+									f1 = ld64u(out + src_pos + 8);
+							}
+						}
+						C3PC(4);
+						/* ---- literals: only lanes that have some; 4-byte piece for 1..4, 8-byte pieces above ---- */
+						if (act & (lit != 0)) {
+							u8 *const dl = ring + (op & MASK);
+							const u64 a = c3_ld64s(cb, lsrc);
+							if (lit <= 4u) {
+								st32u(dl, (u32)a); /* may spill <= 3 bytes into the lane's own match, written below */
+							} else {
+								c3_st64(dl, a);
+								if (lit > 8u) {
+									c3_st64(dl + lit - 8u, c3_ld64s(cb, lsrc + lit - 8u));
+									for (u32 i = 8; i + 8 < lit; i += 8)
+										c3_st64(dl + i, c3_ld64s(cb, lsrc + i));
+								}
+							}
+						}
+						wv_sync();
+						C3PC(5);
+						if (anyfar) {
+							/* the literals are out of the stage: it now holds the fetched sources, 16 bytes per lane */
+							if (is_far) {
+								*(u64 *)(cb + 16u * (u32)lane) = f0;
+								*(u64 *)(cb + 16u * (u32)lane + 8) = f1;
+								/* the rare long one: the rest straight from memory into the ring (complete, unordered) */
+								for (u32 i = 16; i < ml; i += 8) {
+									const u32 o = i + 8 <= ml ? i : ml - 8;
+									c3_st64(ring + ((mpos + o) & MASK), ld64u(out + src_pos + o));
+								}
+							}
+							wv_sync();
+						}
+						C3PC(6);
+						/* every load of this batch has landed: now the stores and the prefetches leave */
+						C3_ISSUE();
+						C3PC(9);
+						/* ---- matches: complete sources first (one path: ring or fetched slot), then watermark rounds ---- */
+						const bool ovl = off < ml;
+						bool fin = !(act & (ml != 0));
+						{
+							const bool r1 = !fin & (is_far | (src_pos + eff <= o0)) & !ovl;
+							if (r1) {
+								const u8 *const sb = is_far ? cb + 16u * (u32)lane : ring;
+								match(ring, mpos, (is_far && ml > 16u) ? 16u : ml, sb, is_far ? 0u : src_pos, is_far ? ~0u : MASK);
+								fin = true;
+							}
+						}
+						wv_sync();
+						C3PC(7);
+						for (;;) {
+							const u64 unf = wv_ballot(!fin);
+							if (!unf)
+								break;
+							if (PROF)
+								pc[PROF ? 13 : 0]++;
+							const u32 first = (u32)wv_ffs(unf) - 1;
+							const u32 W = wv_readlane(mpos, (int)first);
+							if (!fin & (src_pos + eff <= W)) {
+								if (ovl)
+									match_ovl(ring, mpos, off, ml);
+								else
+									match(ring, mpos, ml, ring, src_pos, MASK);
+								fin = true;
+							}
+							wv_sync();
+						}
+						C3PC(8);
+						st.opos = o_end;
+					}
+				}
+				if (d & C3_SINGLE) {
+					/* ---------- one sequence of any shape (fields from memory, wave-uniform) ---------- */
+					/* (a full batch of 64 plus this one: its position did not fit the 64 lanes) */
+					const u32 qq = n < 64u ? wv_readlane(q, (int)n) : uld16((const u8 *)(tk + t0 + 64u));
+					const bool is_last = t0 + ntk == ntok;
+					u32 t = uld8(src + qq), l2 = t >> 4, h = qq + 1;
+					if (l2 == 15) {
+						u32 b;
+						do {
+							b = uld8(src + h++);
+							l2 += b;
+						} while (b == 255);
+					}
+					u32 off = 1, m2 = 0;
+					if (!is_last) {
+						u32 m = h + l2;
+						off = uld16(src + m);
+						m += 2;
+						m2 = t & 15;
+						if (m2 == 15) {
+							u32 b;
+							do {
+								b = uld8(src + m++);
+								m2 += b;
+							} while (b == 255);
+						}
+						m2 += 4;
+						if (off == 0 || off > st.opos + l2 - low) {
+							stc = ST_BAD_BLOCK;
+							break;
+						}
+					}
+					if (l2 + m2 > cap - st.opos) {
+						stc = ST_BAD_BLOCK;
+						break;
+					}
+					generic(src + h, l2, off, m2, ring, out, st, lane);
+					C3PC(10);
+				}
+				t0 += ntk;
+			}
+#undef C3_DESC
+#undef C3_NTOK
+#undef C3_TOK
+#undef C3_STAGE
+#undef C3_ISSUE
+			if (stc == ST_OK && (t0 != ntok || st.opos != bstart + olen))
+				stc = ST_BAD_BLOCK;
+		}
+		if (stc == ST_OK || stc == ST_SIZE_MISMATCH)
+			flush_to(st, ring, out, st.opos, lane);
+		if (stc == ST_OK && st.opos != cap)
+			stc = ST_SIZE_MISMATCH;
+		if (lane == 0 && stc != ST_OK)
+			status[rec] = stc;
+#ifndef ZMT_EMU
+		if (PROF && prof && lane == 0) {
+			for (int i = 0; i < 11; i++)
+				atomicAdd(prof + i, (unsigned long long)pc[PROF ? i : 0]);
+			atomicAdd(prof + 11, (unsigned long long)(C3KT() - t_begin));
+			atomicAdd(prof + 12, (unsigned long long)pc[PROF ? 12 : 0]);
+			atomicAdd(prof + 13, (unsigned long long)pc[PROF ? 13 : 0]);
+		}
+#endif
+		(void)t_begin;
+		(void)prof;
+	}
+};
+
+#define C3_KERNEL(NAME, WINSZ) C3_KERNEL_(NAME, WINSZ, false, , nullptr)
+#ifndef ZMT_EMU
+#define C3_KERNEL_PROF(NAME, WINSZ) C3_KERNEL_(NAME, WINSZ, true, C3_PROF_ARG, prof)
+#define C3_PROF_ARG , unsigned long long *prof
+#else
+#define C3_KERNEL_PROF(NAME, WINSZ)
+#endif
+#define C3_KERNEL_(NAME, WINSZ, PROFILE, EXTRA, PROFP)                                                             \
+	extern "C" __global__ void __launch_bounds__(64)                                                           \
+	NAME(const u8 *__restrict__ stream, u64 stream_bytes, u32 rec0, u32 nrec, u8 *out_base,                    \
+	     const u64 *__restrict__ out_off, const u32 *__restrict__ out_len, const u64 *__restrict__ blk0,       \
+	     const u64 *__restrict__ blk_coff, const u32 *__restrict__ blk_csize, const u32 *__restrict__ rec_nblk, \
+	     const u32 *__restrict__ rec_flags, const u16 *__restrict__ tok, const u32 *__restrict__ bl,           \
+	     const u32 *__restrict__ blk_ntok, const u32 *__restrict__ blk_nbat, const u32 *__restrict__ blk_olen, \
+	     u32 *__restrict__ status EXTRA)                                                                        \
+	{                                                                                                          \
+		__shared__ __attribute__((aligned(16))) u8 lds[WINSZ + 16u + 2u * C3_CBUF];                        \
+		C3<WINSZ, PROFILE>::body(stream, stream_bytes, rec0, nrec, out_base, out_off, out_len, blk0,       \
+					 blk_coff, blk_csize, rec_nblk, rec_flags, tok, bl, blk_ntok, blk_nbat,    \
+					 blk_olen, status, lds, lds + WINSZ + 16u, PROFP);                         \
+	}
+
+C3_KERNEL(zmt_dec_copy3_w4_kernel, 4096u)
+C3_KERNEL(zmt_dec_copy3_w8_kernel, 8192u)
+C3_KERNEL(zmt_dec_copy3_w16_kernel, 16384u)
+C3_KERNEL_PROF(zmt_dec_copy3_w4_kernel_prof, 4096u)
+C3_KERNEL_PROF(zmt_dec_copy3_w8_kernel_prof, 8192u)
+C3_KERNEL_PROF(zmt_dec_copy3_w16_kernel_prof, 16384u)

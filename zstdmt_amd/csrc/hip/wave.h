@@ -95,7 +95,8 @@ static __device__ __forceinline__ u32 wv_readfirst(u32 v)
 {
 	return (u32)__builtin_amdgcn_readfirstlane((int)v);
 }
-static __device__ __forceinline__ u64 wv_ballot(bool p) { return __ballot(p); }
+/* (the i1 builtin: __ballot(int) would first widen the predicate to 0 / 1 and compare it again) */
+static __device__ __forceinline__ u64 wv_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 static __device__ __forceinline__ int wv_popc(u64 m) { return __popcll(m); }
 static __device__ __forceinline__ int wv_ffs(u64 m) { return __ffsll((unsigned long long)m); }
 static __device__ __forceinline__ u32 wv_mbcnt(u64 m)
@@ -125,14 +126,15 @@ static inline u32 wv_scan_incl(u32 v)
 	return v;
 }
 #else
-/* DPP row shifts inside each 16-lane row, then row broadcasts (gfx9 row_bcast15 / row_bcast31);
- * lanes a shift has no source for keep the `old` operand, 0 */
+/* DPP row shifts inside each 16-lane row, then row broadcasts (gfx9 row_bcast15 / row_bcast31).  bound_ctrl on
+ * the shifts (a lane without a source reads 0) lets the compiler fold each step into ONE v_add_u32_dpp; with
+ * bound_ctrl off it emitted v_mov old + v_mov_dpp + v_add per step (18 instructions instead of 6) */
 static __device__ __forceinline__ u32 wv_scan_incl(u32 v)
 {
-	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
-	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
-	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
-	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); /* row_shr:1 */
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); /* row_shr:2 */
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); /* row_shr:4 */
+	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); /* row_shr:8 */
 	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); /* row_bcast:15 -> rows 1,3 */
 	v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); /* row_bcast:31 -> rows 2,3 */
 	return v;
@@ -163,10 +165,10 @@ static inline u32 wv_alignbyte(u32 hi, u32 lo, u32 sh) { return (u32)((((u64)hi 
 static __device__ __forceinline__ u32 wv_umax(u32 a, u32 b) { return a > b ? a : b; }
 static __device__ __forceinline__ u32 wv_scan_max_incl(u32 v)
 {
-	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false)); /* row_shr:1 */
-	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false)); /* row_shr:2 */
-	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false)); /* row_shr:4 */
-	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false)); /* row_shr:8 */
+	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true)); /* row_shr:1 */
+	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true)); /* row_shr:2 */
+	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true)); /* row_shr:4 */
+	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true)); /* row_shr:8 */
 	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false)); /* row_bcast:15 */
 	v = wv_umax(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false)); /* row_bcast:31 */
 	return v;
