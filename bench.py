@@ -62,8 +62,8 @@ def parse():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--chunk", type=int, default=0, help="0 = 128 KiB for lz4 (configs[1]), 1 MiB for zstd / brotli")
     ap.add_argument("--dec-variant", type=int, default=0,
-                    help="lz4 decoder: 0 = frames + parse + copy2 (round 2), 1 = frame-serial, 2 = frames + parse3 + copy3")
-    ap.add_argument("--lz4-ring", type=int, default=13, help="--dec-variant 2: log2 of copy3's LDS ring per wave (12..14)")
+                    help="lz4 decoder: 0 = frames + parse3 + copy3 (default), 1 = frame-serial")
+    ap.add_argument("--lz4-ring", type=int, default=12, help="log2 of copy3's LDS ring per wave (12..14)")
     ap.add_argument("--snappy-dec", type=int, default=0,
                     help="--codec snappy: 1 = the batched decoder (zmt_snappy_dec2_kernel), 0 = element by element")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -338,8 +338,7 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
     t_c = (ms["compress"] + ms["compact"]) * 1e-3 if not dec_only else None
     want_chunk = (1 << 20) if zstd else 131072
     traffic = traffic_table(gib if world == 1 else -1, chunk, want_chunk)
-    split = args.dec_variant in (0, 2)
-    v3 = args.dec_variant == 2
+    split = args.dec_variant == 0
 
     def roof(kname, t_ms, alg_bytes, pmc_names):
         t = t_ms * 1e-3
@@ -364,8 +363,8 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
         ek = ("zmt_lz4_enc3_p17_kernel" if 65536 < chunk <= 131072 else
               ("zmt_lz4_enc3_u16_kernel" if chunk <= 65536 else "zmt_lz4_enc3_u32_kernel"))
         r_enc = None if dec_only else roof(ek, ms["k_lz4_enc"], alg, (ek,))
-        k_parse = "zmt_dec_parse3_kernel" if v3 else "zmt_dec_parse_kernel"
-        k_copy = ("zmt_dec_copy3_w%d_kernel" % (1 << (args.lz4_ring - 10))) if v3 else "zmt_dec_copy2_kernel"
+        k_parse = "zmt_dec_parse3_kernel"
+        k_copy = "zmt_dec_copy3_w%d_kernel" % (1 << (args.lz4_ring - 10))
         r_dec = roof(f"zmt_dec_frames_kernel + {k_parse} + {k_copy}" if split else "zmt_lz4_dec_serial", ms["k_lz4_dec"], alg,
                      ("zmt_dec_frames_kernel", k_parse, k_copy) if split else ())
     dom = r_dec if (dec_only or ms["k_lz4_dec"] >= ms.get("k_lz4_enc", 0.0)) else r_enc
@@ -383,7 +382,7 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
                                f"{chunk // 1024} KiB chunks, device-resident",
                    "chunk": chunk, "records_per_gpu": nrec, "records": int(total_n // chunk), "level": 1,
                    "ratio": round(ctx_ratio(U_all, Cb_all), 4), "dec_variant": args.dec_variant,
-                   "lz4_ring": args.lz4_ring if args.dec_variant == 2 else None,
+                   "lz4_ring": args.lz4_ring if args.dec_variant == 0 else None,
                    "parallelism": f"chunk-sharded x{world}"},
         "decompress_MBps": round(U / 1e6 / t_d * world, 1),
         "roofline": dom,

@@ -20,8 +20,6 @@ void zmt_lz4hc_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32
 void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u32 *, u32 *, u32 *, u32);
 void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
-void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *, u32 *, unsigned long long *, u32);
-void zmt_dec_copy2_kernel(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, u32 *);
 void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *, u32 *, u32 *, u32);
 #define C3_DECL(NAME) void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, const u32 *, const u32 *, u32 *);
 C3_DECL(zmt_dec_copy3_w4_kernel)
@@ -127,9 +125,9 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 {
 	std::vector<u32> ce(nrec), cv(nrec);
 	u32 *cep = ce.data(), *cvp = cv.data();
-	/* variant: low 4 bits = pipeline (0 frames + parse + copy2, 1 frame-serial, 2 frames + parse3 + copy3),
-	 * bits 4.. = log2 of copy3's ring (0 = 13) */
-	const int ring = (variant >> 4) ? (variant >> 4) : 13;
+	/* variant: low 4 bits = pipeline (0 frames + parse3 + copy3, 1 frame-serial), bits 4.. = log2 of copy3's
+	 * ring (0 = 12, the default of the product) */
+	const int ring = (variant >> 4) ? (variant >> 4) : 12;
 	variant &= 15;
 	if (variant == 1) {
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
@@ -139,10 +137,10 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 		size_t nblk_max = out_bytes / 65536 + nrec + 1;
 		size_t ntok_max = stream_bytes / 3 + 128 * nblk_max + 256;
 		/* scratch starts as garbage, like device memory */
-		std::vector<u32> est(nrec, 0xA5A5A5A5u), rnb(nrec, 0xA5A5A5A5u), rfl(nrec, 0xA5A5A5A5u), bcs(nblk_max, 0x00A5A5A5u), bnt(nblk_max, 0xA5A5A5A5u), bol(nblk_max, 0xA5A5A5A5u), bix(ntok_max / 64 + 2, 0xA5A5A5A5u);
+		std::vector<u32> est(nrec, 0xA5A5A5A5u), rnb(nrec, 0xA5A5A5A5u), rfl(nrec, 0xA5A5A5A5u), bcs(nblk_max, 0x00A5A5A5u), bnt(nblk_max, 0xA5A5A5A5u), bol(nblk_max, 0xA5A5A5A5u);
 		std::vector<u64> blk0(nrec + 1, 0xA5A5A5A5A5A5A5A5ull), bco(nblk_max, 0x00A5A5A5A5A5A5A5ull);
 		std::vector<uint16_t> tok(ntok_max, 0xA5A5);
-		u32 *estp = est.data(), *rnbp = rnb.data(), *rflp = rfl.data(), *bcsp = bcs.data(), *bntp = bnt.data(), *bolp = bol.data(), *bixp = bix.data();
+		u32 *estp = est.data(), *rnbp = rnb.data(), *rflp = rfl.data(), *bcsp = bcs.data(), *bntp = bnt.data(), *bolp = bol.data();
 		u64 *blk0p = blk0.data(), *bcop = bco.data();
 		uint16_t *tokp = tok.data();
 		emu::launch(dim3{(nrec + 255) / 256, 1, 1}, dim3{256, 1, 1}, [=]() { zmt_dec_nblk_kernel(out_len, nrec, estp); });
@@ -154,13 +152,8 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 		std::vector<u32> blv(ntok_max / 2 + 64, 0xA5A5A5A5u);
 		u32 *nbatp = nbat.data();
 		u32 *blp = blv.data();
-		if (variant == 2)
-			emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
-				zmt_dec_parse3_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, blp, bntp, nbatp, bolp, (u32)ring);
-			});
-		else
 		emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
-			zmt_dec_parse_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bixp, bntp, bolp, nullptr, 0);
+			zmt_dec_parse3_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, blp, bntp, nbatp, bolp, (u32)ring);
 		});
 		if (getenv("ZMT_EMU_DEBUG")) {
 			for (size_t b = 0; b < blk0[nrec]; b++)
@@ -168,21 +161,16 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 			for (u32 r = 0; r < nrec; r++)
 				fprintf(stderr, "rec %u status=%u nblk=%u\n", r, status[r], rnb[r]);
 		}
-		if (getenv("ZMT_EMU_DEBUG") && variant == 2)
+		if (getenv("ZMT_EMU_DEBUG"))
 			for (size_t b = 0; b < blk0[nrec]; b++)
 				fprintf(stderr, "blk %zu nbat=%u\n", b, nbat[b]);
-		if (variant == 2)
-			emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
+		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
 				if (ring == 12)
 					zmt_dec_copy3_w4_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, blp, bntp, nbatp, bolp, status);
 				else if (ring == 13)
 					zmt_dec_copy3_w8_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, blp, bntp, nbatp, bolp, status);
 				else
 					zmt_dec_copy3_w16_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, blp, bntp, nbatp, bolp, status);
-			});
-		else
-		emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{256, 1, 1}, [=]() {
-			zmt_dec_copy2_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
 		});
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
 			zmt_lz4_dec_serial(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp, 100u);

@@ -92,9 +92,9 @@ def test_emu_hc_optimal_bit_exact(name, level):
     assert stream == H.oracle_compress_level(data, chunk, level)
 
 
-# decoder variants of the emulator API: 0 = frames + parse + copy2 (round 2), 1 = frame-serial,
-# 2 | ring << 4 = frames + parse3 + copy3 with a 4 / 8 / 16 KiB ring
-DEC_VARIANTS = [0, 1, 2 | 12 << 4, 2 | 13 << 4, 2 | 14 << 4]
+# decoder variants of the emulator API: 0 | ring << 4 = frames + parse3 + copy3 with a 4 / 8 / 16 KiB ring
+# (plain 0 = the product's default, 4 KiB), 1 = frame-serial
+DEC_VARIANTS = [0, 1, 0 | 13 << 4, 0 | 14 << 4]
 
 
 @pytest.mark.parametrize("variant", DEC_VARIANTS)

@@ -12,15 +12,14 @@ from cases import CASES, KNOWN_HEX, rnd, text
 pytestmark = pytest.mark.gpu
 
 # decoder kernel variants under test (include/gpumt.h gpumt_set_variant "lz4_dec")
-# 0 = frames + parse + copy2 pipeline (round 2), 1 = serial wave-per-record decoder,
-# 2 | ring << 4 = frames + parse3 + copy3 with a 4 / 8 / 16 KiB LDS ring per wave ("lz4_ring" = 12 / 13 / 14)
-VARIANTS = [0, 1, 2 | 12 << 4, 2 | 13 << 4, 2 | 14 << 4]
+# 0 | ring << 4 = frames + parse3 + copy3 pipeline with a 4 / 8 / 16 KiB LDS ring per wave ("lz4_ring" = 12 / 13 / 14;
+# the default is 12), 1 = serial wave-per-record decoder
+VARIANTS = [0 | 12 << 4, 1, 0 | 13 << 4, 0 | 14 << 4]
 
 
 def set_dec(eng, v):
     eng.set_variant("lz4_dec", v & 15)
-    if v >> 4:
-        eng.set_variant("lz4_ring", v >> 4)
+    eng.set_variant("lz4_ring", (v >> 4) or 12)
 
 with open(os.path.join(H.GOLDEN_DIR, "manifest.json")) as _f:
     MAN = json.load(_f)["cases"]
@@ -60,7 +59,7 @@ def test_decompress_golden(eng, name, variant):
     try:
         out, status = eng.decompress_bytes(stream, ro, rl)
     finally:
-        eng.set_variant("lz4_dec", 0)
+        set_dec(eng, 0)
     assert status.tolist() == [0] * len(status)
     assert out == data
 
@@ -79,7 +78,7 @@ def test_fuzz_vs_oracle(eng, seed):
     for variant in VARIANTS:
         set_dec(eng, variant)
         out, status = eng.decompress_bytes(stream, ro, rl)
-        eng.set_variant("lz4_dec", 0)
+        set_dec(eng, 0)
         assert not status.any() and out == data
 
 
@@ -214,7 +213,7 @@ def test_corrupt_streams_rejected(eng, mutate, code):
     for variant in VARIANTS:
         set_dec(eng, variant)
         out, status = eng.decompress_bytes(bytes(s), ro, rl)
-        eng.set_variant("lz4_dec", 0)
+        set_dec(eng, 0)
         assert status.tolist() == [code], (variant, status)
     assert H.oracle_decompress(bytes(s), 131072) is None   # the oracle rejects it too
 
@@ -257,4 +256,4 @@ def test_block_checksum_and_dictid_frames(eng, variant):
                 _, status = eng.decompress_bytes(bytes(bad), ro, rl)
                 assert status.tolist() == [5], (name, status)
     finally:
-        eng.set_variant("lz4_dec", 0)
+        set_dec(eng, 0)

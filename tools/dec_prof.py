@@ -5,6 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import zstdmt_amd as z
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+# variants: 0 | ring << 4 = frames + parse3 + copy3 (ring 12 if omitted), 1 = frame-serial
 variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "1"])]
 eng = z.Engine(0); L, h = eng.L, eng.h
 T = C.CDLL(os.path.join(ROOT, "zstdmt_amd", "lib", "libzmt_tools.so"))
@@ -24,8 +25,7 @@ eng.sync()
 names = ["stage", "spec", "walk", "decode+scan+classify", "literals", "fence+far", "rounds", "flush", "slowpath", "batches", "seqs", "total"]
 for v in variants:
     eng.set_variant("lz4_dec", v & 15)
-    if v >> 4:
-        eng.set_variant("lz4_ring", v >> 4)
+    eng.set_variant("lz4_ring", (v >> 4) or 12)
     eng.set_variant("profile", 1)
     for rep in range(2):
         cnt = (C.c_ulonglong * 16)()
@@ -36,24 +36,7 @@ for v in variants:
     st = eng.download(d_st, nrec * 4, np.uint32)
     ok = bool((eng.download(d_out, n) == hb).all())
     print(f"variant {v}: kernel {ms:.3f} ms  ({n/1e6/ms:.1f} GB/s out)  errors={int((st!=0).sum())} data_ok={ok}")
-    if v == 0:
-        for xf in ([int(x) for x in os.environ.get("K2X", "0").split(",")] if os.environ.get("K2PROF") else []):
-            eng.set_variant("k2x", xf)
-            eng.set_variant("profile", 2)
-            cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
-            eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
-            L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); w = max(c[6], 1); st_ = max(c[4], 1)
-            print(f"   K2 prof xflags={xf}: parse_ms={eng.timer_ms(14):.3f} waves={c[6]} steps/wave={c[4]/w:.0f} cycles/step total={c[0]/st_:.0f} refill={c[1]/st_:.0f} (landing {c[7]/st_:.0f}, rounds/step {c[8]/st_:.2f}) token={c[2]/st_:.0f} drain={c[3]/st_:.0f} slowloads/step={c[5]/st_:.2f} | token split: read={c[10]/st_:.0f} lit={c[11]/st_:.0f} ml+state={c[12]/st_:.0f} emit={c[2]/st_:.0f}")
-            eng.set_variant("profile", 1); eng.set_variant("k2x", 0)
-        if os.environ.get("K3PROF"):
-            eng.set_variant("profile", 3)
-            cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
-            eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
-            L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); nbat = max(c[12], 1)
-            nm = ["land", "fields", "scan+check", "cuts+reserve+classify", "far-issue", "literals", "slot+sync", "match-r1", "rounds", "flush", "loop/prefetch"]
-            print("   copy2 prof (cycles per batch): " + ", ".join(f"{nm[i]}={c[i]/nbat:.0f}" for i in range(11)) + f" total={c[11]/nbat:.0f} batches={c[12]}")
-            eng.set_variant("profile", 1)
-    if (v & 15) == 2 and os.environ.get("K3PROF"):
+    if (v & 15) == 0 and os.environ.get("K3PROF"):
         eng.set_variant("profile", 8)
         cnt = (C.c_ulonglong * 16)(); L.gpumt_debug_counters(h, cnt, 16)
         eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
@@ -61,5 +44,5 @@ for v in variants:
         nm = ["wait(stage,tokens,stores)", "prefetch+loop", "fields", "scan+check+classify", "far-issue", "literals", "far-land", "match-r1", "rounds", "flush", "singles"]
         print(f"   copy3 prof ring {v >> 4} (cycles per batch): " + ", ".join(f"{nm[i]}={c[i]/nbat:.0f}" for i in range(11)) + f" total={c[11]/nbat:.0f} batches={c[12]} rounds/batch={c[13]/nbat:.2f}")
         eng.set_variant("profile", 1)
-    if (v & 15) in (0, 2):
+    if (v & 15) == 0:
         print("   split: frames %.3f ms, parse %.3f ms, copy %.3f ms, xxh %.3f ms" % (eng.timer_ms(13), eng.timer_ms(14), eng.timer_ms(15), eng.timer_ms(12)))

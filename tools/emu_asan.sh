@@ -14,7 +14,7 @@ if [ "$1" = kernels ]; then
   make -s libzmt_emu.so > /dev/null
   A=/tmp/zmt_kasan; mkdir -p $A
   SAN="-fsanitize=address -fno-omit-frame-pointer"
-  for k in xxh32 lz4_enc3 lz4_enc_hc lz4_dec lz4_dec_split lz4_dec_copy2 pack zstd_dec zstd_enc brotli_dec brotli_enc snappy; do
+  for k in xxh32 lz4_enc3 lz4_enc_hc lz4_dec lz4_dec_split lz4_dec_parse3 lz4_dec_copy3 pack zstd_dec zstd_enc brotli_dec brotli_enc snappy; do
     g++ -O1 -g -std=c++17 -fPIC -DZMT_EMU $SAN -I. -I../../zstdmt_amd/csrc/hip -w -x c++ -c ../../zstdmt_amd/csrc/hip/$k.hip -o $A/$k.o &
   done
   wait

@@ -33,14 +33,6 @@ __global__ void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8
 __global__ void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 __global__ void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *,
 				      const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
-__global__ void zmt_dec_parse_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *,
-				     u32 *, u32 *, u32 *, unsigned long long *, u32);
-__global__ void zmt_dec_copy2_kernel(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *,
-				     const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
-				     const u32 *, const u32 *, u32 *);
-__global__ void zmt_dec_copy2_kernel_prof(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *,
-					  const u64 *, const u32 *, const u32 *, const u32 *, const u16 *,
-					  const u32 *, const u32 *, u32 *, unsigned long long *);
 __global__ void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *, u32 *, u32 *,
 				      u32 *, u32 *, u32);
 #define C3_DECL(NAME)                                                                                              \
@@ -240,12 +232,12 @@ int gpumt_open(int device, gpumt_ctx **out)
 		 * gpumt_set_variant on: GPUMT_SNAPPY_DEC=1 selects the batched snappy decoder */
 		const char *e = getenv("GPUMT_SNAPPY_DEC");
 		h->sdec_variant = e && *e ? atoi(e) : 0;
-		/* GPUMT_LZ4_DEC: 0 = frames + parse + copy2 (round 2), 1 = frame-serial, 2 = frames + parse3 + copy3;
-		 * GPUMT_LZ4_RING: log2 of copy3's LDS ring per wave */
+		/* GPUMT_LZ4_DEC: 0 = frames + parse3 + copy3 (default), 1 = frame-serial;
+		 * GPUMT_LZ4_RING: log2 of copy3's LDS ring per wave (12 = 4 KiB, the default; 13; 14) */
 		e = getenv("GPUMT_LZ4_DEC");
 		h->dec_variant = e && *e ? atoi(e) : 0;
 		e = getenv("GPUMT_LZ4_RING");
-		h->lz4_ring = e && *e ? atoi(e) : 13;
+		h->lz4_ring = e && *e ? atoi(e) : 12;
 	}
 	*out = h;
 	return GPUMT_OK;
@@ -776,13 +768,11 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 	CARVE(bcs, u32, nblk_max)
 	CARVE(bnt, u32, nblk_max)
 	CARVE(bol, u32, nblk_max)
-	CARVE(bix, u32, ntok_max / 64 + 2)
 	CARVE(tok, u16, ntok_max)
 	CARVE(nbat, u32, nblk_max)
 	CARVE(bl, u32, ntok_max / 2 + 64)
 #undef CARVE
-	const bool split = (h->dec_variant == 0 || h->dec_variant == 2);
-	const bool v3 = h->dec_variant == 2;
+	const bool split = h->dec_variant == 0;
 	if (h->profile >= 2 && !h->d_prof) {
 		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
@@ -796,7 +786,6 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 		u32 *est = (u32 *)(sc + est_o), *rnb = (u32 *)(sc + rnb_o), *rfl = (u32 *)(sc + rfl_o);
 		u64 *blk0 = (u64 *)(sc + blk0_o), *bco = (u64 *)(sc + bco_o);
 		u32 *bcs = (u32 *)(sc + bcs_o), *bnt = (u32 *)(sc + bnt_o), *bol = (u32 *)(sc + bol_o);
-		u32 *bix = (u32 *)(sc + bix_o);
 		u16 *tok = (u16 *)(sc + tok_o);
 		PROF0(13);
 		hipLaunchKernelGGL(zmt_dec_nblk_kernel, dim3(g256), dim3(256), 0, h->st[s], d_out_len, n, est);
@@ -809,15 +798,9 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 		u32 *bl = (u32 *)(sc + bl_o);
 		const int ring = h->lz4_ring < 12 ? 12 : h->lz4_ring > 14 ? 14 : h->lz4_ring;
 		PROF0(14);
-		if (v3)
-			hipLaunchKernelGGL(zmt_dec_parse3_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
-					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
-					   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bl, bnt, nbat, bol, (u32)ring);
-		else
-			hipLaunchKernelGGL(zmt_dec_parse_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
-					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
-					   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bix, bnt, bol,
-					   h->profile == 2 ? h->d_prof : (unsigned long long *)NULL, (u32)h->xflags);
+		hipLaunchKernelGGL(zmt_dec_parse3_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
+				   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
+				   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bl, bnt, nbat, bol, (u32)ring);
 		PROF1(14);
 		PROF0(15);
 #define C3_LAUNCH(NAME)                                                                                            \
@@ -830,36 +813,23 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 			   (u64)stream_bytes, 0u, n, (u8 *)d_out, d_out_off, d_out_len, (const u64 *)blk0,         \
 			   (const u64 *)bco, (const u32 *)bcs, (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, \
 			   (const u32 *)bl, (const u32 *)bnt, (const u32 *)nbat, (const u32 *)bol, d_status, h->d_prof)
-		if (v3 && h->profile == 8) {
+		/* (running the XXH32 verification of record slices on a second stream while the next slice is copied was
+		 * measured in round 2: the partial last round of every slice costs more than the overlap gains) */
+		if (h->profile == 8) {
 			if (ring == 12)
 				C3_LAUNCHP(zmt_dec_copy3_w4_kernel_prof);
 			else if (ring == 13)
 				C3_LAUNCHP(zmt_dec_copy3_w8_kernel_prof);
 			else
 				C3_LAUNCHP(zmt_dec_copy3_w16_kernel_prof);
-		} else if (v3) {
+		} else {
 			if (ring == 12)
 				C3_LAUNCH(zmt_dec_copy3_w4_kernel);
 			else if (ring == 13)
 				C3_LAUNCH(zmt_dec_copy3_w8_kernel);
 			else
 				C3_LAUNCH(zmt_dec_copy3_w16_kernel);
-		} else
-		/* (running the XXH32 verification of record slices on a second stream while the next slice
-		 * is copied was measured: the partial last round of every slice costs more than the overlap
-		 * gains, 12.2 vs 10.5 + 1.5 ms per 8 GiB) */
-		if (h->profile == 3)
-			hipLaunchKernelGGL(zmt_dec_copy2_kernel_prof, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0, h->st[s],
-					   (const u8 *)d_stream, (u64)stream_bytes, 0u, n, (u8 *)d_out, d_out_off,
-					   d_out_len, (const u64 *)blk0, (const u64 *)bco, (const u32 *)bcs,
-					   (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, (const u32 *)bnt,
-					   (const u32 *)bol, d_status, h->d_prof);
-		else
-			hipLaunchKernelGGL(zmt_dec_copy2_kernel, dim3((unsigned)((nrec + 3) / 4)), dim3(256), 0, h->st[s],
-					   (const u8 *)d_stream, (u64)stream_bytes, 0u, n, (u8 *)d_out, d_out_off,
-					   d_out_len, (const u64 *)blk0, (const u64 *)bco, (const u32 *)bcs,
-					   (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, (const u32 *)bnt,
-					   (const u32 *)bol, d_status);
+		}
 		PROF1(15);
 		/* records the fast path does not cover (block size > 64 KiB, odd block counts) */
 		hipLaunchKernelGGL(zmt_lz4_dec_serial, dim3(n), dim3(64), 0, h->st[s], (const u8 *)d_stream,

@@ -1,10 +1,10 @@
 /*
  * lz4_dec_copy3.hip -- copy stage of the LZ4 frame decoder, round 3 ("copy3").
  *
- * Same contract as zmt_dec_copy2_kernel (wave per record; replaces LZ4F_decompress at
+ * Wave per record, the token and batch lists of the parse kernel in, the content out (replaces LZ4F_decompress at
  * /root/reference/lib/lz4-mt_decompress.c:349-362 together with the frames / parse3 kernels).
  *
- * What the round-3 counters said about copy2 (profiles/r03_tcc_requests.json): it fetched 45.0 GB per
+ * What the round-3 counters said about its predecessor, round 2's copy2 (profiles/r03_tcc_requests.json): it fetched 45.0 GB per
  * 8 GiB in 351.6 M requests, every one of them a full 128-byte line from memory -- one per match whose
  * source lay before its 2-4 KiB LDS window (37 % of the matches at a 4 KiB window) -- i.e. 5.2 TB/s for
  * 13.4 GB of useful bytes: bandwidth-bound on far-match lines as much as on instruction issue.

@@ -1,7 +1,7 @@
 /*
  * lz4_dec_parse3.hip -- LZ4 frame decoder, parse stage of the round-3 pipeline ("parse3").
  *
- * Same place in the path as zmt_dec_parse_kernel of lz4_dec_split.hip (replaces, together with the
+ * Second kernel of the pipeline described in lz4_dec_split.hip (replaces, together with the
  * frames and copy kernels, LZ4F_decompress at /root/reference/lib/lz4-mt_decompress.c:349-362):
  * lane per 64 KiB block, serial token walk, u16 token positions to the token list.  The kernel is
  * bound by instruction issue (two waves per SIMD is all the blocks of an 8 GiB batch give, and a wave
@@ -110,11 +110,6 @@ zmt_dec_parse3_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 		pv[i] = (p3v4){0, 0, 0, 0};
 	bool ok = true, done = !parse;
 	const int rgrp = lane >> 2, rpiece = lane & 3; /* refill: 4 lanes per 64-byte unit */
-#ifdef ZMT_EMU
-	static unsigned long long e_steps, e_stall, e_gen, e_need2, e_waves;
-	if (lane == 0)
-		e_waves++;
-#endif
 
 	for (u32 step = 0;; step++) {
 		/* ---------------- refill round: every P3_CADENCE steps, back to back at the start ---------------- */
@@ -207,18 +202,6 @@ zmt_dec_parse3_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 		const bool gen = in12 & odd;
 		u32 e_lit = lit, e_ml = ml, e_nxt = nxt;
 		bool emit = fast, last = fast & is_last;
-#ifdef ZMT_EMU
-		{
-			const bool a_ = wv_any(gen), b_ = wv_any(need2);
-			if (lane == 0) {
-				e_steps++;
-				e_gen += a_;
-				e_need2 += b_;
-			}
-			if (!done && !in12)
-				e_stall++;
-		}
-#endif
 		if (wv_any(gen)) {
 			if (gen) {
 				const u32 pos = g - boff;
@@ -308,11 +291,6 @@ zmt_dec_parse3_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 		if (!wv_any(!done))
 			break;
 	}
-#ifdef ZMT_EMU
-	if (lane == 0 && getenv("ZMT_EMU_P3STAT"))
-		fprintf(stderr, "parse3: waves %llu steps %llu lane-stalls %llu steps-with-gen %llu steps-with-need2 %llu\n", e_waves,
-			e_steps, e_stall, e_gen, e_need2);
-#endif
 	if (exists) {
 		if (parse) {
 			if (b_n != 0 && ok)
