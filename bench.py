@@ -22,8 +22,9 @@ starts it).  Chunks are independent, so rank r takes the contiguous chunk range 
 ONE `--gib` buffer (`--scaling strong`, the default: BASELINE's metric is one 8 GiB job at 1/2/4/8
 GPUs) or its own `--gib` buffer (`--scaling weak`).  The only exchange on the path is the all-gather
 of the per-rank segment sizes (-> byte offsets of the segments in the final stream, included in the
-timed region); `--gather` additionally times the RCCL gather of the segments to rank 0 and reports
-it as gather_ms / value_with_gather, never as `value`.
+timed region); `--gather rccl|d2h` additionally times the reassembly of the
+segments (grouped send/recv gatherv to rank 0, or every GPU's own copy into one shared pinned host buffer) and reports
+it as gather_ms / value_with_gather, never as `value`; `per_rank_ms` carries every rank's kernel times.
 `--mode decompress` = configs[2] (decompress only: the records are written untimed, then timed).
 """
 import argparse
@@ -68,7 +69,10 @@ def parse():
                     help="--codec snappy: 1 = the batched decoder (zmt_snappy_dec2_kernel), 0 = element by element")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-mib", type=int, default=2048, help="cpu_baseline sample size")
-    ap.add_argument("--gather", action="store_true", help="also time the RCCL gather of segments to rank 0")
+    ap.add_argument("--gather", nargs="?", const="rccl", default="none", choices=("none", "rccl", "d2h"),
+                    help="also time the reassembly of the per-rank segments (never part of `value`): rccl = grouped "
+                         "send/recv gatherv to rank 0 over xGMI; d2h = every GPU copies its segment to its offset of ONE "
+                         "pinned host buffer shared by the ranks, no inter-GPU traffic (SURVEY 8e)")
     ap.add_argument("--no-verify", dest="verify", action="store_false",
                     help="skip the byte-for-byte comparison of the round trip (on by default)")
     ap.add_argument("--only", action="store_true", help="main leg only: no zstd / brotli / api legs under 'configs'")
@@ -180,6 +184,16 @@ class Ctx:
         t = torch.tensor([x], device="cuda", dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
+
+    def gather_floats(self, vals):
+        """-> one list of floats per rank (on every rank)"""
+        if self.dist is None:
+            return [list(vals)]
+        import torch
+        mine = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        out = torch.zeros(self.world * len(vals), dtype=torch.float64, device="cuda")
+        self.dist.all_gather_into_tensor(out, mine)
+        return out.view(self.world, len(vals)).tolist()
 
     def all_true(self, ok):
         return self.sum_over_ranks(0.0 if ok else 1.0) == 0.0
@@ -319,11 +333,15 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
         ok = ctx.all_true(eng.equal(d_in, d_out, n))
 
     gather_ms = None
-    if dist is not None and args.gather and main:
+    if dist is not None and args.gather != "none" and main:
         from zstdmt_amd.shard import exchange_segment_sizes
         sizes, _ = exchange_segment_sizes(n if dec_only else total_c, device="cuda")
-        gather_ms = rccl_gather(eng, dist, d_out if dec_only else d_stream, sizes, rank, world)
+        fn = rccl_gather if args.gather == "rccl" else d2h_gather
+        gather_ms = fn(eng, dist, d_out if dec_only else d_stream, sizes, rank, world)
     Cb_all = ctx.sum_over_ranks(float(total_c))
+    # per-rank kernel times (ms per step): what each GPU spent, next to the max-over-ranks wall clock
+    by_rank = ctx.gather_floats([ms.get("k_lz4_enc", 0.0), ms.get("k_lz4_dec", 0.0), ms.get("compress", 0.0) +
+                                 ms.get("compact", 0.0), ms.get("decompress", 0.0)])
     for b in bufs:
         b.free()
     if rank != 0:
@@ -393,7 +411,9 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
         "kernels": kern,
         "decode_errors": bad, "roundtrip_verified": ok,
         "gen_s": round(gen_s, 2), "device": eng.name,
-        "segment_offset_rank0": seg_off[0], "gather_ms": gather_ms,
+        "segment_offset_rank0": seg_off[0], "gather": args.gather, "gather_ms": gather_ms,
+        "per_rank_ms": [{"rank": r, "k_enc": round(v[0], 3), "k_dec": round(v[1], 3), "compress_leg": round(v[2], 3),
+                         "decompress_leg": round(v[3], 3)} for r, v in enumerate(by_rank)],
     }
     if not dec_only:
         res["compress_MBps"] = round(U / 1e6 / t_c * world, 1)
@@ -791,6 +811,34 @@ def rccl_gather(eng, dist, d_buf, sizes, rank, world):
     return round((time.perf_counter() - t0) * 1e3, 3)
 
 
+def d2h_gather(eng, dist, d_buf, sizes, rank, world):
+    """the no-collective reassembly: ONE pinned host buffer mapped by every rank (zstdmt_amd.shard.SharedHostStream),
+    each GPU copies its segment to its own offset over its own PCIe link; timed like rccl_gather"""
+    import torch
+    from zstdmt_amd.shard import SharedHostStream
+    total, off, mine = int(sum(sizes)), int(sum(sizes[:rank])), int(sizes[rank])
+    name = "zstdmt_amd_bench_%s" % os.environ.get("MASTER_PORT", "0")
+    if rank == 0:
+        shm = SharedHostStream(name, total, owner=True)
+    dist.barrier()
+    if rank != 0:
+        shm = SharedHostStream(name, total, owner=False)
+    base = shm.address()
+    eng._ck(eng.L.gpumt_host_register(eng.h, base, shm.total), "host_register")
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if mine:
+        eng._ck(eng.L.gpumt_memcpy_d2h(eng.h, base + off, d_buf.ptr, mine, 0), "d2h")
+    eng.sync(0)
+    dist.barrier()
+    ms = round((time.perf_counter() - t0) * 1e3, 3)
+    eng._ck(eng.L.gpumt_host_unregister(eng.h, base), "host_unregister")
+    dist.barrier()
+    shm.close()
+    return ms
+
+
 def dry_run(args, rank, local, world, dist):
     """ranks report where they would run; no GPU is touched (CPU test of the launch path)"""
     from zstdmt_amd.shard import shard_range
@@ -804,8 +852,12 @@ def dry_run(args, rank, local, world, dist):
     else:
         ranks = [me]
     if rank == 0:
+        # the keys a real multi-GPU line carries beside the contract's: reassembly mode + time, per-rank kernel times
         print(json.dumps({"dry_run": True, "n_gpus": world, "scaling": args.scaling, "codec": args.codec,
-                          "mode": args.mode, "ranks": ranks}), flush=True)
+                          "mode": args.mode, "gather": args.gather, "gather_ms": None,
+                          "per_rank_ms": [{"rank": r["rank"], "k_enc": None, "k_dec": None, "compress_leg": None,
+                                           "decompress_leg": None} for r in sorted(ranks, key=lambda x: x["rank"])],
+                          "ranks": ranks}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

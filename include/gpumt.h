@@ -76,6 +76,13 @@ void *gpumt_malloc(gpumt_ctx *h, size_t bytes);
 void  gpumt_free(gpumt_ctx *h, void *dptr);
 void *gpumt_host_alloc(gpumt_ctx *h, size_t bytes);          /* pinned */
 void  gpumt_host_free(gpumt_ctx *h, void *hptr);
+/* Pin / unpin memory the caller owns (hipHostRegister): an application buffer, or one mapping shared by the ranks
+ * of a multi-GPU job into which every GPU copies its segment at its offset (bench.py --gather d2h). */
+int gpumt_host_register(gpumt_ctx *h, void *p, size_t bytes);
+int gpumt_host_unregister(gpumt_ctx *h, void *p);
+/* Freed device and pinned buffers stay in process-wide caches (GPUMT_DEVICE_CACHE_MB / GPUMT_PINNED_CACHE_MB, 16 GiB
+ * each by default) for the next context; this releases whatever is idle and returns the bytes given back. */
+size_t gpumt_trim_caches(gpumt_ctx *h);
 int   gpumt_memcpy_h2d(gpumt_ctx *h, void *dst, const void *src, size_t n, int stream);
 int   gpumt_memcpy_d2h(gpumt_ctx *h, void *dst, const void *src, size_t n, int stream);
 int   gpumt_memcpy_d2d(gpumt_ctx *h, void *dst, const void *src, size_t n, int stream);

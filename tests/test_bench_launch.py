@@ -27,6 +27,17 @@ def test_two_ranks_distinct_devices_and_tiled_chunks():
     assert len({x["pid"] for x in ranks}) == 2
     # one 8 GiB job of 65 536 chunks, split in two contiguous halves
     assert ranks[0]["chunks"] == [0, 32768] and ranks[1]["chunks"] == [32768, 65536]
+    # the multi-GPU line's extra keys: reassembly mode / time and one entry of kernel times per rank
+    assert r["gather"] == "none" and "gather_ms" in r
+    assert [x["rank"] for x in r["per_rank_ms"]] == [0, 1]
+    assert set(r["per_rank_ms"][0]) == {"rank", "k_enc", "k_dec", "compress_leg", "decompress_leg"}
+
+
+def test_gather_modes_are_accepted():
+    for mode in ("rccl", "d2h"):
+        r = _run("--gpus", "2", "--gather", mode)
+        assert r["gather"] == mode and r["n_gpus"] == 2
+    assert _run("--gpus", "2", "--gather")["gather"] == "rccl"   # bare flag = round 2's behaviour
 
 
 def test_three_ranks_weak_and_decompress_mode():

@@ -28,7 +28,20 @@ def _worker(rank, world, port, n, chunk, q):
         sizes, my_off = exchange_segment_sizes(len(seg))
         full = gather_segments(torch.frombuffer(bytearray(seg), dtype=torch.uint8) if seg
                                else torch.empty(0, dtype=torch.uint8), sizes, dst=0)
-        q.put((rank, lo, hi, my_off, sizes, bytes(full.numpy().tobytes()) if rank == 0 else None))
+        # the no-collective variant: every rank writes its segment at its offset of ONE shared host buffer
+        from zstdmt_amd.shard import SharedHostStream
+        name = "zstdmt_amd_test_%d" % port
+        if rank == 0:
+            shm = SharedHostStream(name, sum(sizes), owner=True)
+        dist.barrier()
+        if rank != 0:
+            shm = SharedHostStream(name, sum(sizes), owner=False)
+        shm.write_at(my_off, seg)
+        dist.barrier()
+        placed = bytes(shm.map[:sum(sizes)]) if rank == 0 else None
+        dist.barrier()
+        shm.close()
+        q.put((rank, lo, hi, my_off, sizes, bytes(full.numpy().tobytes()) if rank == 0 else None, placed))
     finally:
         dist.destroy_process_group()
 
@@ -47,7 +60,8 @@ def test_sharded_stream_equals_single_stream(world, n):
         p.join(timeout=60)
         assert p.exitcode == 0
     whole = H.oracle_compress(text(n), chunk)
-    assert res[0][5] == whole
+    assert res[0][5] == whole      # grouped send/recv gatherv
+    assert res[0][6] == whole      # every rank's own copy into the shared host buffer
     # ranges tile the chunk list, offsets are the exclusive scan of the sizes
     assert res[0][1] == 0 and all(res[i][2] == res[i + 1][1] for i in range(world - 1))
     assert [r[3] for r in res] == [sum(res[0][4][:i]) for i in range(world)]

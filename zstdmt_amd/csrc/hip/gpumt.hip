@@ -455,6 +455,56 @@ void gpumt_host_free(gpumt_ctx *h, void *p)
 		(void)hipHostFree(hd);
 }
 
+/* pin memory the caller owns (a mapping shared by the ranks of a multi-GPU job, an application buffer) so that
+ * gpumt_memcpy_d2h / _h2d move it at copy-engine speed without a staging pass */
+int gpumt_host_register(gpumt_ctx *h, void *p, size_t bytes)
+{
+	if (!h || !p || !bytes)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipHostRegister(p, bytes, hipHostRegisterPortable));
+	return GPUMT_OK;
+}
+int gpumt_host_unregister(gpumt_ctx *h, void *p)
+{
+	if (!h || !p)
+		return GPUMT_E_ARG;
+	if (use(h))
+		return GPUMT_E_HIP;
+	CK(hipHostUnregister(p));
+	return GPUMT_OK;
+}
+
+/* give the idle buffers of the process-wide caches (device memory of this context's device, pinned host memory)
+ * back to the system: a long-running host that compressed once does not have to keep up to 2 x 16 GiB alive.
+ * Returns the number of bytes released. */
+size_t gpumt_trim_caches(gpumt_ctx *h)
+{
+	size_t freed = 0;
+	if (!h || use(h))
+		return 0;
+	pthread_mutex_lock(&g_dev.mu);
+	for (int i = 0; i < DEV_CACHE_SLOTS; i++)
+		if (g_dev.p[i] && !g_dev.used[i] && g_dev.dev[i] == h->device) {
+			(void)hipFree(g_dev.p[i]);
+			g_dev.idle -= g_dev.cap[i];
+			freed += g_dev.cap[i];
+			g_dev.p[i] = NULL;
+		}
+	pthread_mutex_unlock(&g_dev.mu);
+	pthread_mutex_lock(&g_pin.mu);
+	for (int i = 0; i < PIN_CACHE_SLOTS; i++)
+		if (g_pin.p[i]) {
+			(void)hipHostFree((u8 *)g_pin.p[i] - sizeof(struct pin_hdr));
+			g_pin.total -= g_pin.cap[i];
+			freed += g_pin.cap[i];
+			g_pin.p[i] = NULL;
+		}
+	pthread_mutex_unlock(&g_pin.mu);
+	return freed;
+}
+
 #define STREAM_OK(s) ((s) >= 0 && (s) < GPUMT_NSTREAMS)
 
 int gpumt_memcpy_h2d(gpumt_ctx *h, void *dst, const void *src, size_t n, int s)

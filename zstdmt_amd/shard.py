@@ -30,23 +30,68 @@ def exchange_segment_sizes(my_bytes: int, device="cpu"):
 
 
 def gather_segments(segment: torch.Tensor, sizes, dst: int = 0):
-    """gatherv of variable-length uint8 segments to rank `dst` (grouped send/recv).
-    Returns the concatenated stream on dst, None elsewhere."""
+    """gatherv of variable-length uint8 segments to rank `dst` as ONE group of point-to-point operations
+    (`dist.batch_isend_irecv` = ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd under RCCL): the root's
+    receives are posted together, so the W - 1 transfers run side by side over the root's W - 1 xGMI links
+    instead of one after the other on one stream.  Returns the concatenated stream on dst,
+    None elsewhere."""
     world, rank = dist.get_world_size(), dist.get_rank()
     assert segment.dtype == torch.uint8 and segment.numel() == sizes[rank]
     if rank != dst:
         if sizes[rank]:
-            dist.send(segment, dst=dst)
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, segment, dst)]):
+                q.wait()
         return None
     full = torch.empty(sum(sizes), dtype=torch.uint8, device=segment.device)
-    off, reqs = 0, []
+    off, ops = 0, []
     for r in range(world):
         view = full[off:off + sizes[r]]
         if r == dst:
             view.copy_(segment)
         elif sizes[r]:
-            reqs.append(dist.irecv(view, src=r))
+            ops.append(dist.P2POp(dist.irecv, view, r))
         off += sizes[r]
-    for q in reqs:
-        q.wait()
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
     return full
+
+
+class SharedHostStream:
+    """The no-collective reassembly: ONE host buffer of the whole stream, mapped by every rank of the
+    node (POSIX shared memory), into which each rank copies its own segment at its own offset -- W device-to-host
+    copies over W PCIe links in parallel, no inter-GPU traffic at all.  `name` must be the same on every rank;
+    rank `owner` creates and finally unlinks it."""
+
+    def __init__(self, name: str, total_bytes: int, owner: bool):
+        import mmap
+        import os
+        self.path = "/dev/shm/" + name
+        self.total = max(1, int(total_bytes))
+        self.owner = owner
+        if owner:
+            fd = os.open(self.path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+            os.ftruncate(fd, self.total)
+        else:
+            fd = os.open(self.path, os.O_RDWR)
+        try:
+            self.map = mmap.mmap(fd, self.total)
+        finally:
+            os.close(fd)
+
+    def address(self) -> int:
+        import ctypes
+        return ctypes.addressof(ctypes.c_char.from_buffer(self.map))
+
+    def write_at(self, off: int, data: bytes):
+        """CPU path of the same placement (tests; the GPU path copies device -> self.address() + off)"""
+        self.map[off:off + len(data)] = data
+
+    def close(self):
+        import os
+        self.map.close()
+        if self.owner:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
