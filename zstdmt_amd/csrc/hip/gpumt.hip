@@ -171,6 +171,14 @@ int gpumt_device_count(void)
 	return n;
 }
 
+/* The host engines keep several batches in flight on streams of their own; with the runtime's default of 4
+ * hardware queues those streams share queues and wait for each other's kernels (measured:
+ * tools/ubench/pipe_overlap.hip).  Set once, when the library is loaded -- before any thread of the host can be
+ * inside getenv / setenv on our account and before the first HIP call of a process that reaches HIP through
+ * this library (the CLI, the drop-in APIs); a host that exports its own value, or initialised HIP earlier, keeps
+ * what it has (overwrite = 0). */
+__attribute__((constructor)) static void gpumt_library_init(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 int gpumt_open(int device, gpumt_ctx **out)
 {
 	int n = 0;
@@ -178,11 +186,6 @@ int gpumt_open(int device, gpumt_ctx **out)
 	if (!out)
 		return GPUMT_E_ARG;
 	*out = NULL;
-	/* The host engines keep several batches in flight on streams of their own; with the runtime's
-	 * default of 4 hardware queues those streams share queues and wait for each other's kernels
-	 * (measured: tools/ubench/pipe_overlap.hip).  Effective when this is the first HIP call of the
-	 * process (the CLI, the drop-in APIs); a process that initialises HIP earlier exports it itself. */
-	setenv("GPU_MAX_HW_QUEUES", "16", 0);
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
 		return GPUMT_E_NODEVICE;
 	if (device == GPUMT_DEVICE_DEFAULT) {
