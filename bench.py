@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--lz4-ring", type=int, default=12, help="log2 of copy3's LDS ring per wave (12..14)")
     ap.add_argument("--snappy-dec", type=int, default=0,
                     help="--codec snappy: 1 = the batched decoder (zmt_snappy_dec2_kernel), 0 = element by element")
+    ap.add_argument("--zstd-level", type=int, default=1,
+                    help="--codec zstd: level handed to the device encoder (tiers 1-2 / 3-9 / 10-22); BASELINE configs[3] is 1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-mib", type=int, default=2048, help="cpu_baseline sample size")
     ap.add_argument("--gather", nargs="?", const="rccl", default="none", choices=("none", "rccl", "d2h"),
@@ -269,7 +271,7 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
     def compress():
         eng.timer_start(1)
         if zstd:
-            eng.zstd_compress(d_in, n, chunk, d_slots, stride, d_rl)
+            eng.zstd_compress(d_in, n, chunk, d_slots, stride, d_rl, level=args.zstd_level if main else 1)
         else:
             eng.lz4_compress(d_in, n, chunk, d_slots, stride, d_rl)
         eng.timer_stop(1)
@@ -371,7 +373,8 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
 
     kern = {k: {"ms": round(v, 4)} for k, v in ms.items() if k.startswith("k_")}
     if zstd:
-        name, what = "zstd-mt level 1", "zstd-mt -1"
+        zl = args.zstd_level if main else 1
+        name, what = f"zstd-mt level {zl}", f"zstd-mt -{zl}"
         r_enc = None if dec_only else roof("zmt_zstd_enc_kernel(+assemble)", ms["k_lz4_enc"], alg,
                                            ("zmt_zstd_enc_kernel", "zmt_zstd_assemble_kernel"))
         r_dec = roof("zmt_zstd_dec_small_kernel(+zmt_zstd_dec_kernel for frames with full-size tables)",

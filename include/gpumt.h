@@ -206,6 +206,12 @@ size_t gpumt_zstd_slot_stride(size_t chunk);
  */
 int gpumt_zstd_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk,
 			      void *d_slots, size_t slot_stride, uint32_t *d_rec_len, int stream);
+/* The same at `level` 1..22 (what the reference hands to ZSTD_compress, lib/zstd-mt_compress.c:285): the device encoder
+ * has three tiers -- levels 1-2, 3-9, 10-22 (gpumt_zstd_level_tier = 0, 1, 2) -- that trade speed for ratio through
+ * the size of the hash table and the number of bytes hashed; gpumt_zstd_compress_batch is level 1. */
+int gpumt_zstd_level_tier(int level);
+int gpumt_zstd_compress_batch_level(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
+				    size_t slot_stride, uint32_t *d_rec_len, int level, int stream);
 
 int gpumt_zstd_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,
 			   const uint32_t *d_rec_len, size_t nrec, uint32_t *d_out_len,

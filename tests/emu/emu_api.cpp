@@ -36,6 +36,8 @@ void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u
 void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *, u32 *);
 void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
 void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
+void zmt_zstd_enc_t2_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
+void zmt_zstd_enc_t3_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 void zmt_zstd_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 void zmt_snappy_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *);
 void zmt_snappy_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
@@ -250,7 +252,13 @@ size_t emu_zstd_slot_stride(size_t chunk)
 }
 
 /* zstd compress: block encoder on `grid` persistent waves (scratch starts as garbage), then assemble */
+void emu_zstd_compress_batch_level(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid, int level);
 void emu_zstd_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid)
+{
+	emu_zstd_compress_batch_level(in, n, chunk, slots, stride, rec_len, grid, 1);
+}
+/* level -> tier as gpumt_zstd_level_tier: 1-2, 3-9, 10-22 */
+void emu_zstd_compress_batch_level(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid, int level)
 {
 	u32 nrec = n ? (u32)((n + chunk - 1) / chunk) : 1;
 	u32 bpr = (chunk + 131071) / 131072;
@@ -261,8 +269,14 @@ void emu_zstd_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stri
 	std::vector<u8> seq((size_t)grid * (3 * 32768 * 4 + 16 * 20544 + 131072 + 64), 0xA5);
 	u32 *bl = blk_len.data();
 	u8 *sq = seq.data();
-	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1},
-		    [=]() { zmt_zstd_enc_kernel(in, n, chunk, nblk, bpr, slots, stride, bl, sq); });
+	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1}, [=]() {
+		if (level <= 2)
+			zmt_zstd_enc_kernel(in, n, chunk, nblk, bpr, slots, stride, bl, sq);
+		else if (level <= 9)
+			zmt_zstd_enc_t2_kernel(in, n, chunk, nblk, bpr, slots, stride, bl, sq);
+		else
+			zmt_zstd_enc_t3_kernel(in, n, chunk, nblk, bpr, slots, stride, bl, sq);
+	});
 	emu::launch(dim3{nrec, 1, 1}, dim3{256, 1, 1},
 		    [=]() { zmt_zstd_assemble_kernel(n, chunk, nrec, bpr, slots, stride, bl, rec_len); });
 }

@@ -329,6 +329,18 @@ def test_zstdmt_compress_is_decompress_identical(lib, name, thunk):
         assert rv == 0 and back == data
 
 
+def test_zstdmt_level_reaches_the_encoder(lib):
+    """ZSTDCB_createCCtx(level) is not just a chunk size: levels 1-2 / 3-9 / 10-22 select the encoder's tiers
+    (the reference hands level to ZSTD_compress, lib/zstd-mt_compress.c:285)"""
+    data = cases.text(300000, 23)
+    sizes = {}
+    for level in (1, 3, 19):
+        rv, st, _, _ = H.zstdmt_compress_via(lib, data, 131072, threads=2, level=level)
+        assert rv == 0 and H.oracle_zstdmt_decompress(st, len(data) + 64) == data
+        sizes[level] = len(st)
+    assert sizes[1] > sizes[3] > sizes[19]
+
+
 def _strip_eof(reads):
     r = list(reads)
     while r and r[-1][1] == 0:

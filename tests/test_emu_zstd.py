@@ -128,6 +128,31 @@ def test_emu_encoder_fits_sequence_tables_per_unit():
     assert len(big) / len(E.zstd_compress(big, 131072, grid=8)) > 2.40
 
 
+@pytest.mark.parametrize("level", [3, 10])
+@pytest.mark.parametrize("name", ["text_2x128k_p5", "text_300k_chunk1m", "mixed", "period_300", "dense_sequences", "empty"])
+def test_emu_encode_level_tiers_decompress_identical(name, level):
+    """levels 3-9 and 10-22 run the encoder's larger-table tiers (gpumt_zstd_level_tier): the same bar"""
+    chunk, thunk = ENC_CASES[name]
+    data = thunk()
+    st = E.zstd_compress(data, chunk, level=level)
+    assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
+    out, status = E.zstd_decompress(st)
+    assert (status == 0).all() and out == data
+    assert E.zstd_compress(data, chunk, grid=1, level=level) == st
+
+
+def test_emu_ratio_is_monotone_in_level():
+    """the reference hands `level` to ZSTD_compress (lib/zstd-mt_compress.c:285): a higher level must not
+    compress worse, and the tiers must be worth having on text"""
+    data = cases.text(1 << 20, 5)
+    sizes = [len(E.zstd_compress(data, 1 << 20, grid=8, level=lv)) for lv in (1, 3, 10)]
+    assert sizes[0] > sizes[1] > sizes[2]
+    assert sizes[0] / sizes[2] > 1.04
+    # same tier, same bytes
+    assert len(E.zstd_compress(data, 1 << 20, grid=8, level=9)) == sizes[1]
+    assert len(E.zstd_compress(data, 1 << 20, grid=8, level=22)) == sizes[2]
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_emu_fuzz_encode_and_decode(seed):
     """Structured soup through the emulated encoder, the oracle and the emulated decoder; and, where
@@ -136,7 +161,7 @@ def test_emu_fuzz_encode_and_decode(seed):
     rng = random.Random(3000 + seed)
     data = H.soup(rng, rng.choice([7, 300, 70000, 140000, rng.randrange(1, 260000)]))
     chunk = rng.choice([65536, 131072, 1 << 20])
-    st = E.zstd_compress(data, chunk)
+    st = E.zstd_compress(data, chunk, level=rng.choice([1, 1, 5, 19]))
     assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
     out, status = E.zstd_decompress(st)
     assert (status == 0).all() and out == data

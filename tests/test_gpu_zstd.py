@@ -139,13 +139,27 @@ def test_fuzz_encode_is_decompress_identical(eng, seed):
                     200000, rng.randrange(1, 600000), rng.randrange(1, 3000000)])
     chunk = rng.choice([65536, 131072, 131072, 100000, 262144, 1 << 20])
     data = H.soup(rng, n)
-    st, ro, rl = eng.compress_bytes(data, chunk, codec="zstd")
+    st, ro, rl = eng.compress_bytes(data, chunk, codec="zstd", level=rng.choice([1, 1, 4, 12]))
     assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
     out, status = eng.decompress_bytes(st, ro, rl, codec="zstd")
     assert (status == 0).all() and out == data
     if H.have_zref():
         rv, back, _, _ = H.zstdmt_decompress_via(H.zref(), st, threads=2)
         assert rv == 0 and back == data
+
+
+def test_level_tiers_ratio_monotone_and_decompress_identical(eng):
+    """level reaches the encoder (the reference hands it to ZSTD_compress, lib/zstd-mt_compress.c:285): three tiers,
+    each decompress-identical, ratio monotone in level"""
+    data = cases.text(4 << 20, 77)
+    sizes = []
+    for lv in (1, 3, 10, 22):
+        st, ro, rl = eng.compress_bytes(data, 1 << 20, codec="zstd", level=lv)
+        assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
+        out, status = eng.decompress_bytes(st, ro, rl, codec="zstd")
+        assert (status == 0).all() and out == data
+        sizes.append(len(st))
+    assert sizes[0] > sizes[1] > sizes[2] == sizes[3]
 
 
 @pytest.mark.skipif(not H.have_zref(), reason="reference build not on this box")

@@ -67,6 +67,8 @@ __global__ void zmt_zstd_dec_kernel_prof(const u8 *, u64, const u64 *, const u32
 __global__ void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *,
 					u32 *);
 __global__ void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
+__global__ void zmt_zstd_enc_t2_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
+__global__ void zmt_zstd_enc_t3_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 __global__ void zmt_zstd_enc_kernel_prof(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *, unsigned long long *);
 __global__ void zmt_zstd_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 __global__ void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
@@ -94,7 +96,7 @@ struct gpumt_ctx {
 	int lz4_ring; /* copy3: log2 of the LDS ring per wave (12, 13 or 14) */
 	int profile; /* record events in timer slots 8.. around individual kernels */
 	int num_cus;
-	int zenc_waves; /* resident waves of the persistent zstd encoder kernel (whole device) */
+	int zenc_waves[3]; /* resident waves of the persistent zstd encoder kernels (whole device), per level tier */
 	int hc_waves;     /* developer: grid of the LZ4HC encoder (0 = GPUMT_LZ4HC_WAVES) */
 	int zdec_variant; /* 0 = small-table kernel, then general; 1 = general only */
 	int sdec_variant; /* snappy decoder: 0 = element by element, 1 = 64 elements per batch (snappy.hip) */
@@ -915,11 +917,23 @@ size_t gpumt_zstd_slot_stride(size_t chunk)
 	return (ZE_HDR + nb * ZE_BSTRIDE + 255) & ~(size_t)255;
 }
 
+/* level -> encoder tier (zstd_enc.hip): 1-2 the fast parse (4 Ki-entry table, 16 waves per CU), 3-9 and 10-22
+ * larger tables and a 6-byte hash (8 / 4 waves per CU) */
+int gpumt_zstd_level_tier(int level) { return level <= 2 ? 0 : level <= 9 ? 1 : 2; }
+
 int gpumt_zstd_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
 			      size_t slot_stride, uint32_t *d_rec_len, int s)
 {
-	if (!h || !STREAM_OK(s) || chunk == 0 || chunk > 0x40000000u || slot_stride < gpumt_zstd_slot_stride(chunk))
+	return gpumt_zstd_compress_batch_level(h, d_in, n, chunk, d_slots, slot_stride, d_rec_len, 1, s);
+}
+
+int gpumt_zstd_compress_batch_level(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
+				    size_t slot_stride, uint32_t *d_rec_len, int level, int s)
+{
+	if (!h || !STREAM_OK(s) || chunk == 0 || chunk > 0x40000000u || slot_stride < gpumt_zstd_slot_stride(chunk) ||
+	    level < 1 || level > 22)
 		return GPUMT_E_ARG;
+	const int tier = h->profile == 6 ? 0 : gpumt_zstd_level_tier(level);
 	if (use(h))
 		return GPUMT_E_HIP;
 	const size_t nrec = gpumt_lz4_record_count(n, chunk);
@@ -928,12 +942,17 @@ int gpumt_zstd_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t c
 	if (nblk > 0x7FFFFFFFu)
 		return GPUMT_E_ARG;
 	/* persistent waves, exactly as many as stay resident (LDS-limited), blocks taken round-robin */
-	if (!h->zenc_waves) {
+	if (!h->zenc_waves[tier]) {
 		int per_cu = 0;
-		CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zmt_zstd_enc_kernel, 64, 0));
-		h->zenc_waves = (per_cu > 0 ? per_cu : 4) * (h->num_cus > 0 ? h->num_cus : 256);
+		if (tier == 0)
+			CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zmt_zstd_enc_kernel, 64, 0));
+		else if (tier == 1)
+			CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zmt_zstd_enc_t2_kernel, 64, 0));
+		else
+			CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zmt_zstd_enc_t3_kernel, 64, 0));
+		h->zenc_waves[tier] = (per_cu > 0 ? per_cu : 4) * (h->num_cus > 0 ? h->num_cus : 256);
 	}
-	const unsigned grid = (unsigned)(nblk < (size_t)h->zenc_waves ? nblk : (size_t)h->zenc_waves);
+	const unsigned grid = (unsigned)(nblk < (size_t)h->zenc_waves[tier] ? nblk : (size_t)h->zenc_waves[tier]);
 	const size_t seq_bytes = (size_t)grid * (3 * ZE_MAXSEQ * 4 + 16 * 20544 + ZE_BLOCK + 64);
 	if (h->profile == 6)
 		fprintf(stderr, "gpumt: zstd encoder grid %u waves\n", grid);
@@ -950,8 +969,14 @@ int gpumt_zstd_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t c
 		hipLaunchKernelGGL(zmt_zstd_enc_kernel_prof, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in,
 				   (u64)n, (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len,
 				   seqbuf, h->d_prof);
-	else
+	else if (tier == 0)
 		hipLaunchKernelGGL(zmt_zstd_enc_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
+				   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);
+	else if (tier == 1)
+		hipLaunchKernelGGL(zmt_zstd_enc_t2_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
+				   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);
+	else
+		hipLaunchKernelGGL(zmt_zstd_enc_t3_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
 				   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);
 	hipLaunchKernelGGL(zmt_zstd_assemble_kernel, dim3((unsigned)nrec), dim3(256), 0, h->st[s], (u64)n,
 			   (u32)chunk, (u32)nrec, bpr, (u8 *)d_slots, (u64)slot_stride, (const u32 *)blk_len,

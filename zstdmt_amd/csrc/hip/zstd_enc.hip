@@ -59,13 +59,27 @@
 #ifndef ZE_HBYTES
 #define ZE_HBYTES 7
 #endif
-#if ZE_HBYTES == 4
-#define ZE_HASH(v) (((u32)(v) * 2654435761u) >> (32 - ZE_HLOG))
-#else
-#define ZE_HASH(v) ((u32)((((v) << (64 - 8 * ZE_HBYTES)) * 0x9E3779B185EBCA87ull) >> (64 - ZE_HLOG)))
-#endif
+template <int HB, int HLOG> static __device__ __forceinline__ u32 ze_hash(u64 v)
+{
+	if (HB == 4)
+		return ((u32)v * 2654435761u) >> (32 - HLOG);
+	return (u32)(((v << (64 - 8 * HB)) * 0x9E3779B185EBCA87ull) >> (64 - HLOG));
+}
+/* Level tiers (the reference hands `level` to ZSTD_compress, /root/reference/lib/zstd-mt_compress.c:285): what the
+ * wave-parallel match finder can trade is table size (LDS, i.e. waves per CU) and hash width against ratio.
+ * Bench text, 1 MiB chunks (emulator, deterministic): tier 1 = 7 bytes hashed / minimum match 7 / 4 Ki entries:
+ * 2.503; tier 2 = 6 / 6 / 8 Ki: 2.610; tier 3 = 6 / 6 / 16 Ki: 2.672 (6 / 6 / 4 Ki: 2.517; 32 Ki: 2.704;
+ * libzstd level 1: 2.84) */
 
 struct ZEncLds {
+	u16 st_ll[64], st_ml[64], st_of[32]; /* FSE state tables: predefined distributions, or fitted to the unit */
+	u32 tt_ll[36][2], tt_ml[53][2], tt_of[29][2]; /* per symbol: deltaNbBits, deltaFindState */
+	u32 llx[36], mlx[53];            /* value base | extra bits << 24 */
+	u8 llcode[64], mlcode[128];      /* code of literal length v / match length v + 3 */
+	u32 sb_lo[16], sb_hi[16], sb_bits[16]; /* runs: sequence range left to code, bitstream bytes */
+	u32 misc[8];
+	/* LAST member: the kernels of the higher level tiers declare the rest of a larger hash table right behind
+	 * the struct (ZEncLdsExt), the table simply runs on */
 	union {
 		u16 table[1u << ZE_HLOG]; /* match finding: low 16 bits of the newest position of a hash */
 		struct {                  /* block assembly (the table is rebuilt for the next block) */
@@ -77,12 +91,10 @@ struct ZEncLds {
 			u32 stage[16][8][3];          /* 8 staged sequences (ll, ml, offset) per run */
 		};
 	};
-	u16 st_ll[64], st_ml[64], st_of[32]; /* FSE state tables: predefined distributions, or fitted to the unit */
-	u32 tt_ll[36][2], tt_ml[53][2], tt_of[29][2]; /* per symbol: deltaNbBits, deltaFindState */
-	u32 llx[36], mlx[53];            /* value base | extra bits << 24 */
-	u8 llcode[64], mlcode[128];      /* code of literal length v / match length v + 3 */
-	u32 sb_lo[16], sb_hi[16], sb_bits[16]; /* runs: sequence range left to code, bitstream bytes */
-	u32 misc[8];
+};
+template <int HLOG> struct ZEncLdsExt {
+	ZEncLds L;
+	u16 more[(1u << HLOG) - (1u << ZE_HLOG) + 8]; /* entries ZE_HLOG.. of a 2^HLOG-entry table */
 };
 static_assert(sizeof(((ZEncLds *)0)->table) >= ZE_STAGE_WORDS * 4 + ZE_ENT_BYTES, "entropy-phase arrays must fit the idle hash table");
 static_assert(ZE_STAGE_WORDS >= 1024, "one packing round adds up to 176 words and the stage flushes at 3/4");
@@ -793,7 +805,7 @@ static __device__ u32 ze_huf_encode(ZEncLds &L, u32 *stage, const ZHuf hf, const
 		}                                                                                  \
 	} while (0)
 
-template <bool PROF>
+template <bool PROF, int HB, u32 MM, int HLOG>
 static __device__ __forceinline__ void
 zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
 	      u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch,
@@ -861,12 +873,13 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		 * Table entries are positions mod 64 Ki; a candidate is rebuilt as the newest position
 		 * below p with those low bits and then verified, so stale or aliased entries only cost a
 		 * missed match. */
-		for (u32 i = (u32)lane; i < (1u << ZE_HLOG); i += 64)
-			L.table[i] = 0;
+		u16 *const tab = L.table; /* (2^HLOG entries: runs on behind the struct for the larger tiers) */
+		for (u32 i = (u32)lane; i < (1u << HLOG); i += 64)
+			tab[i] = 0;
 		wv_sync();
 		u32 ns = 0, anchor = 0, cursor = 0;
 		u32 r_ll = 0, r_ml = 0, r_of = 0;
-		const u32 steps = bsize >= ZE_MINMATCH ? (bsize - ZE_MINMATCH) / 64 + 1 : 0;
+		const u32 steps = bsize >= MM ? (bsize - MM) / 64 + 1 : 0;
 /* All loads of the pipeline are unconditional (addresses clamped, results of invalid lanes ignored):
  * a load under an exec mask needs its destination initialised first, and that write would have to
  * wait for every load still in flight. */
@@ -878,18 +891,18 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 #define ZE_LOOKUP(t, V, Cc, M)                                                                     \
 	do {                                                                                       \
 		const u32 p_ = (t) * 64u + (u32)lane;                                              \
-		const bool ok_ = (t) < steps && p_ + ZE_MINMATCH <= bsize;                         \
-		const u32 h_ = ZE_HASH(V);                                                         \
-		const u32 e_ = ok_ ? L.table[h_] : 0;                                              \
+		const bool ok_ = (t) < steps && p_ + MM <= bsize;                                  \
+		const u32 h_ = ze_hash<HB, HLOG>(V);                                               \
+		const u32 e_ = ok_ ? tab[h_] : 0;                                                  \
 		wv_sync();                                                                         \
 		if (ok_)                                                                           \
-			L.table[h_] = (u16)p_;                                                     \
+			tab[h_] = (u16)p_;                                                         \
 		wv_sync();                                                                         \
 		/* equal hashes inside one step: the highest position must stay, whatever order the   \
 		 * LDS served the conflicting lanes in (a step never straddles a 64 Ki boundary) */    \
-		while (wv_any(ok_ && L.table[h_] < (u16)p_)) {                                     \
-			if (ok_ && L.table[h_] < (u16)p_)                                          \
-				L.table[h_] = (u16)p_;                                             \
+		while (wv_any(ok_ && tab[h_] < (u16)p_)) {                                         \
+			if (ok_ && tab[h_] < (u16)p_)                                              \
+				tab[h_] = (u16)p_;                                                 \
 			wv_sync();                                                                 \
 		}                                                                                  \
 		u32 c_ = (p_ & ~0xFFFFu) | e_;                                                     \
@@ -958,7 +971,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 					m = bsize - p;
 				const u32 xb = m0.pb ^ (u32)m0.a;
 				const u32 back = !cand ? 0u : xb ? (u32)__builtin_clz(xb) >> 3 : 4u; /* equal bytes right in front */
-				u64 mask = wv_ballot(cand && m >= ZE_MINMATCH);
+				u64 mask = wv_ballot(cand && m >= MM);
 				ZEP(7);
 				while (mask) {
 					const int j = wv_ffs(mask) - 1;
@@ -1336,7 +1349,23 @@ zmt_zstd_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total,
 		    u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch)
 {
 	__shared__ __attribute__((aligned(16))) ZEncLds L;
-	zstd_enc_body<false>(L, in, n, chunk, nblk_total, blk_per_rec, slots, stride, blk_len, scratch, nullptr);
+	zstd_enc_body<false, ZE_HBYTES, ZE_MINMATCH, ZE_HLOG>(L, in, n, chunk, nblk_total, blk_per_rec, slots, stride, blk_len,
+							       scratch, nullptr);
+}
+/* tiers 2 and 3 (levels 3..9 and 10..22): 6 bytes hashed, minimum match 6, 8 Ki / 16 Ki table entries */
+extern "C" __global__ void __launch_bounds__(64)
+zmt_zstd_enc_t2_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
+		       u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch)
+{
+	__shared__ __attribute__((aligned(16))) ZEncLdsExt<13> S;
+	zstd_enc_body<false, 6, 6u, 13>(S.L, in, n, chunk, nblk_total, blk_per_rec, slots, stride, blk_len, scratch, nullptr);
+}
+extern "C" __global__ void __launch_bounds__(64)
+zmt_zstd_enc_t3_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
+		       u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch)
+{
+	__shared__ __attribute__((aligned(16))) ZEncLdsExt<14> S;
+	zstd_enc_body<false, 6, 6u, 14>(S.L, in, n, chunk, nblk_total, blk_per_rec, slots, stride, blk_len, scratch, nullptr);
 }
 
 #ifndef ZMT_EMU
@@ -1347,7 +1376,8 @@ zmt_zstd_enc_kernel_prof(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_t
 			 unsigned long long *prof)
 {
 	__shared__ __attribute__((aligned(16))) ZEncLds L;
-	zstd_enc_body<true>(L, in, n, chunk, nblk_total, blk_per_rec, slots, stride, blk_len, scratch, prof);
+	zstd_enc_body<true, ZE_HBYTES, ZE_MINMATCH, ZE_HLOG>(L, in, n, chunk, nblk_total, blk_per_rec, slots, stride, blk_len,
+							      scratch, prof);
 }
 #endif
 

@@ -208,7 +208,9 @@ static size_t c_launch(ZSTDCB_CCtx *ctx, struct cslot *s)
 	if (s->n)
 		rc |= gpumt_memcpy_h2d(g, s->in.d, s->in.h, s->n, 1);
 	rc |= gpumt_stream_wait(g, ks, 1);
-	rc |= gpumt_zstd_compress_batch(g, s->in.d, s->n, chunk, s->slots.d, stride, d_len, ks);
+	/* the level the caller asked for reaches the encoder as the reference hands it to ZSTD_compress
+	 * (/root/reference/lib/zstd-mt_compress.c:285): three device tiers, gpumt_zstd_level_tier */
+	rc |= gpumt_zstd_compress_batch_level(g, s->in.d, s->n, chunk, s->slots.d, stride, d_len, ctx->level, ks);
 	rc |= gpumt_lz4_compact(g, s->slots.d, stride, d_len, s->nrec, s->stream.d, d_off, ks);
 	/* sizes, offsets and the packed records go to the pinned mirrors from the slot's own stream, the
 	 * byte count of the records read on the device (d_off[nrec]): no host round trip in between, and

@@ -157,9 +157,10 @@ class Engine:
     def zstd_slot_stride(self, chunk):
         return int(self.L.gpumt_zstd_slot_stride(chunk))
 
-    def zstd_compress(self, d_in, n, chunk, d_slots, stride, d_rec_len, stream=0):
-        self._ck(self.L.gpumt_zstd_compress_batch(self.h, d_in.ptr, int(n), int(chunk), d_slots.ptr,
-                                                  int(stride), d_rec_len.ptr, stream), "zstd_compress_batch")
+    def zstd_compress(self, d_in, n, chunk, d_slots, stride, d_rec_len, stream=0, level=1):
+        self._ck(self.L.gpumt_zstd_compress_batch_level(self.h, d_in.ptr, int(n), int(chunk), d_slots.ptr,
+                                                        int(stride), d_rec_len.ptr, int(level), stream),
+                 "zstd_compress_batch_level")
 
     def zstd_probe(self, d_stream, d_rec_off, d_rec_len, nrec, d_out_len, d_out_off, d_status, stream=0):
         self._ck(self.L.gpumt_zstd_probe_sizes(self.h, d_stream.ptr, d_rec_off.ptr, d_rec_len.ptr, nrec,
@@ -239,7 +240,7 @@ class Engine:
         d_off = self.alloc((nrec + 1) * 8)
         try:
             if codec == "zstd":
-                self.zstd_compress(d_in, n, chunk, d_slots, stride, d_len)
+                self.zstd_compress(d_in, n, chunk, d_slots, stride, d_len, level=level)
             elif codec == "brotli":
                 self.brotli_compress(d_in, n, chunk, d_slots, stride, d_len)
             else:
