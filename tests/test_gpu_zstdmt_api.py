@@ -170,9 +170,15 @@ def test_compress_is_decompress_identical(lib, name):
 def test_compress_is_deterministic_and_bounded(lib):
     data = cases.text(3 << 20, 19) + cases.rnd(1 << 20, 2)
     rv, a, _, _ = H.zstdmt_compress_via(lib, data, 1 << 20, threads=2, level=1)
-    rv2, b, _, _ = H.zstdmt_compress_via(lib, data, 1 << 20, threads=9, level=7)
-    assert rv == 0 and rv2 == 0 and a == b        # one device setting, independent of threads / level
+    rv2, b, _, _ = H.zstdmt_compress_via(lib, data, 1 << 20, threads=9, level=2)
+    assert rv == 0 and rv2 == 0 and a == b        # same encoder tier: independent of threads and of the level inside it
     assert len(a) < 0.62 * (3 << 20) + (1 << 20) + 200   # text shrinks, noise is stored raw
+    # the level reaches the encoder (lib/zstd-mt_compress.c:285): tiers 3-9 and 10-22 compress better
+    rv3, c, _, _ = H.zstdmt_compress_via(lib, data, 1 << 20, threads=4, level=7)
+    rv4, d, _, _ = H.zstdmt_compress_via(lib, data, 1 << 20, threads=4, level=19)
+    assert rv3 == 0 and rv4 == 0 and len(a) > len(c) > len(d)
+    for st in (c, d):
+        assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
 
 
 def test_compress_argument_and_callback_errors(lib):
