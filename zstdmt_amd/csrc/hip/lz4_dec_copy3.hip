@@ -56,6 +56,7 @@
 	} while (0)
 
 static __device__ __forceinline__ void c3_st64(u8 *p, u64 v) { __builtin_memcpy(p, &v, 8); }
+static __device__ __forceinline__ u64 c3_tok_base(u64 coff, u32 gb) { return ((coff / 3) & ~63ull) + 128ull * gb; }
 /* (the 8-byte loads of sources before the ring fetch a whole 128-byte line each; nt / sc0 / sc1 policy bits on
  * the load do not change the request size -- profiles/r03_sweeps/far_load_cache_policy.txt -- so they are plain) */
 
