@@ -241,6 +241,11 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
  * brotli is decompress-identical. */
 int gpumt_brotli_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
 				size_t slot_stride, uint32_t *d_rec_len, int stream);
+/* The same at quality `level` 0..11 (what the reference hands to BrotliEncoderCompress, lib/brotli-mt_compress.c:269-272):
+ * three device tiers -- 0-3, 4-8, 9-11 (gpumt_brotli_level_tier = 0, 1, 2); gpumt_brotli_compress_batch is quality 1. */
+int gpumt_brotli_level_tier(int level);
+int gpumt_brotli_compress_batch_level(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
+				      size_t slot_stride, uint32_t *d_rec_len, int level, int stream);
 
 #define GPUMT_BROTLI_SCRATCH 825856u
 /* zstd decode: scratch per record (literals of one 128 KiB unit + 24576 sequences decoded ahead) */

@@ -30,6 +30,8 @@ void zmt_scan_kernel(const u32 *, u32, u64 *);
 void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
 void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *, u32);
 void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
+void zmt_brotli_enc_t2_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
+void zmt_brotli_enc_t3_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 void zmt_brotli_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u8 *, const u8 *);
 void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *);
@@ -214,7 +216,13 @@ void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *re
 
 /* brotli compress: block encoder on `grid` persistent waves (scratch starts as garbage), then assemble;
  * slot geometry is the zstd one */
+void emu_brotli_compress_batch_level(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid, int level);
 void emu_brotli_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid)
+{
+	emu_brotli_compress_batch_level(in, n, chunk, slots, stride, rec_len, grid, 1);
+}
+/* quality -> tier as gpumt_brotli_level_tier: 0-3, 4-8, 9-11 */
+void emu_brotli_compress_batch_level(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid, int level)
 {
 	u32 nrec = n ? (u32)((n + chunk - 1) / chunk) : 1;
 	u32 bpr = (chunk + 131071) / 131072;
@@ -225,8 +233,14 @@ void emu_brotli_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 st
 	std::vector<u8> seq((size_t)grid * (3 * 32768 * 4), 0xA5);
 	u32 *bl = blk_len.data();
 	u8 *sq = seq.data();
-	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1},
-		    [=]() { zmt_brotli_enc_kernel(in, n, chunk, nblk, bpr, slots, stride, bl, sq); });
+	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1}, [=]() {
+		if (level <= 3)
+			zmt_brotli_enc_kernel(in, n, chunk, nblk, bpr, slots, stride, bl, sq);
+		else if (level <= 8)
+			zmt_brotli_enc_t2_kernel(in, n, chunk, nblk, bpr, slots, stride, bl, sq);
+		else
+			zmt_brotli_enc_t3_kernel(in, n, chunk, nblk, bpr, slots, stride, bl, sq);
+	});
 	emu::launch(dim3{nrec, 1, 1}, dim3{256, 1, 1},
 		    [=]() { zmt_brotli_assemble_kernel(n, chunk, nrec, bpr, slots, stride, bl, rec_len); });
 }

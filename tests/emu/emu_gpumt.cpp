@@ -37,6 +37,7 @@ void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *re
 void emu_zstd_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid);
 void emu_zstd_compress_batch_level(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid, int level);
 void emu_brotli_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid);
+void emu_brotli_compress_batch_level(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 stride, u32 *rec_len, u32 grid, int level);
 void emu_brotli_decompress_batch(const u8 *stream, const u64 *rec_off, const u32 *rec_len, u32 nrec, u8 *out,
 				 const u64 *out_off, const u32 *out_cap, u32 *out_len, u32 *status,
 				 const u8 *blob, u32 grid);
@@ -247,15 +248,22 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 	return GPUMT_OK;
 }
 
-int gpumt_brotli_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
-				size_t slot_stride, uint32_t *d_rec_len, int s)
+int gpumt_brotli_level_tier(int level) { return level <= 3 ? 0 : level <= 8 ? 1 : 2; }
+int gpumt_brotli_compress_batch_level(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
+				      size_t slot_stride, uint32_t *d_rec_len, int level, int s)
 {
-	if (!h || !STREAM_OK(s) || chunk == 0 || chunk > 0x40000000u || slot_stride < gpumt_zstd_slot_stride(chunk))
+	if (!h || !STREAM_OK(s) || chunk == 0 || chunk > 0x40000000u || slot_stride < gpumt_zstd_slot_stride(chunk) ||
+	    level < 0 || level > 11)
 		return GPUMT_E_ARG;
 	std::lock_guard<std::mutex> lk(g_launch);
 	count(h);
-	emu_brotli_compress_batch((const u8 *)d_in, n, (u32)chunk, (u8 *)d_slots, slot_stride, d_rec_len, GRID);
+	emu_brotli_compress_batch_level((const u8 *)d_in, n, (u32)chunk, (u8 *)d_slots, slot_stride, d_rec_len, GRID, level);
 	return GPUMT_OK;
+}
+int gpumt_brotli_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
+				size_t slot_stride, uint32_t *d_rec_len, int s)
+{
+	return gpumt_brotli_compress_batch_level(h, d_in, n, chunk, d_slots, slot_stride, d_rec_len, 1, s);
 }
 
 int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint64_t *d_rec_off,

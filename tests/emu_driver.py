@@ -159,8 +159,8 @@ def brotli_decompress(stream: bytes, grid: int = 2, rec=None):
     return recs, status
 
 
-def brotli_compress(data: bytes, chunk: int, grid: int = 3):
-    """-> brotli-mt stream bytes through the emulated block encoder + assemble + compact kernels"""
+def brotli_compress(data: bytes, chunk: int, grid: int = 3, level: int = 1):
+    """-> brotli-mt stream bytes through the emulated block encoder (tier of quality `level`) + assemble + compact"""
     L = lib()
     L.emu_zstd_slot_stride.restype = C.c_size_t
     L.emu_zstd_slot_stride.argtypes = [C.c_size_t]
@@ -170,8 +170,8 @@ def brotli_compress(data: bytes, chunk: int, grid: int = 3):
     inp = np.frombuffer(data + b"\xEE" * 64, np.uint8).copy()
     slots = np.full(nrec * stride, 0xEE, np.uint8)
     rec_len = np.zeros(nrec, np.uint32)
-    L.emu_brotli_compress_batch(_p(inp), C.c_uint64(n), C.c_uint32(chunk), _p(slots), C.c_uint64(stride),
-                                _p(rec_len), C.c_uint32(grid))
+    L.emu_brotli_compress_batch_level(_p(inp), C.c_uint64(n), C.c_uint32(chunk), _p(slots), C.c_uint64(stride),
+                                      _p(rec_len), C.c_uint32(grid), C.c_int(level))
     rec_off = np.zeros(nrec + 1, np.uint64)
     stream = np.full(int(rec_len.sum()) + 16, 0xDD, np.uint8)
     L.emu_lz4_compact(_p(slots), C.c_uint64(stride), _p(rec_len), C.c_uint32(nrec), _p(stream), _p(rec_off))

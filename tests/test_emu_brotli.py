@@ -120,6 +120,27 @@ def test_encoder_round_trip(name):
     assert (status == 0).all() and b"".join(recs) == data
 
 
+@pytest.mark.parametrize("level", [5, 11])
+@pytest.mark.parametrize("name", ["two_blocks_two_chunks", "zeros", "random", "single_command"])
+def test_encoder_quality_tiers_round_trip(name, level):
+    """qualities 4-8 and 9-11 run the encoder's larger-table tiers (gpumt_brotli_level_tier): the same bar"""
+    data, chunk = ENC[name]
+    st = E.brotli_compress(data, chunk, grid=2, level=level)
+    assert H.oracle_brotlimt_decompress(st, len(data) + 65536) == data
+    recs, status = E.brotli_decompress(st, grid=2)
+    assert (status == 0).all() and b"".join(recs) == data
+    assert E.brotli_compress(data, chunk, grid=1, level=level) == st
+
+
+def test_encoder_ratio_is_monotone_in_quality():
+    """the reference hands the level to BrotliEncoderCompress (lib/brotli-mt_compress.c:269-272)"""
+    data = cases.text(1 << 20, 5)
+    sizes = [len(E.brotli_compress(data, 1 << 20, grid=8, level=q)) for q in (1, 5, 11)]
+    assert sizes[0] > sizes[1] > sizes[2] and sizes[0] / sizes[2] > 1.04
+    assert len(E.brotli_compress(data, 1 << 20, grid=8, level=3)) == sizes[0]
+    assert len(E.brotli_compress(data, 1 << 20, grid=8, level=8)) == sizes[1]
+
+
 def test_encoder_is_deterministic_across_grids():
     data = cases.text(140000, 17)
     assert E.brotli_compress(data, 65536, grid=1) == E.brotli_compress(data, 65536, grid=3)

@@ -212,6 +212,20 @@ def test_compress_many_batches_and_determinism(lib):
     assert rv == 0 and out == data
 
 
+def test_quality_reaches_the_encoder(lib):
+    """BROTLIMT_createCCtx(level) selects the device encoder's tier (0-3 / 4-8 / 9-11), as the reference hands the
+    level to BrotliEncoderCompress (lib/brotli-mt_compress.c:269-272): decompress-identical, ratio monotone"""
+    data = cases.text(6 << 20, 33)
+    sizes = []
+    for q in (1, 5, 11):
+        rv, st, _, _ = H.brotlimt_compress_via(lib, data, 1 << 20, threads=4, level=q)
+        assert rv == 0 and H.oracle_brotlimt_decompress(st, len(data) + 65536) == data
+        rv, out, _, _ = H.brotlimt_decompress_via(lib, st, threads=4)
+        assert rv == 0 and out == data
+        sizes.append(len(st))
+    assert sizes[0] > sizes[1] > sizes[2]
+
+
 def test_compress_callback_errors(lib):
     data = cases.text(400000, 41)
     for fail_at, code, want in ((0, -1, E_READ), (1, -2, E_CANCEL), (2, -3, E_MEM)):

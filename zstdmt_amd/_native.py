@@ -59,6 +59,8 @@ GPUMT_SYMBOLS = {
     "gpumt_zstd_probe_sizes": (_i, [_vp, _vp, _u64p, _u32p, _sz, _u32p, _u64p, _u32p, _i]),
     "gpumt_zstd_decompress_batch": (_i, [_vp, _vp, _sz, _u64p, _u32p, _sz, _vp, _sz, _u64p, _u32p, _u32p, _i]),
     "gpumt_brotli_compress_batch": (_i, [_vp, _vp, _sz, _sz, _vp, _sz, _u32p, _i]),
+    "gpumt_brotli_compress_batch_level": (_i, [_vp, _vp, _sz, _sz, _vp, _sz, _u32p, _i, _i]),
+    "gpumt_brotli_level_tier": (_i, [_i]),
     "gpumt_brotli_decompress_batch": (_i, [_vp, _vp, _u64p, _u32p, _sz, _vp, _u64p, _u32p, _u32p, _u32p, _i]),
     "gpumt_snappy_slot_stride": (_sz, [_sz]),
     "gpumt_snappy_compress_batch": (_i, [_vp, _vp, _sz, _sz, _vp, _sz, _u32p, _i]),

@@ -31,11 +31,22 @@
 #define BE_BLOCK 131072u
 #define BE_BSTRIDE (BE_BLOCK + 16u) /* area of one block inside a record slot (same as zstd's) */
 #define BE_HDR 32u
+#ifndef BE_HLOG
 #define BE_HLOG 12
+#endif
+#ifndef BE_MINMATCH
 #define BE_MINMATCH 7u
+#endif
 #define BE_MAXSEQ (BE_BLOCK / 4u)
 #define BE_WSCRATCH (3u * BE_MAXSEQ * 4u) /* per persistent wave: the three sequence arrays */
-#define BE_HASH(v) ((u32)((((v) << 16) * 0x9E3779B185EBCA87ull) >> (64 - BE_HLOG)))
+/* 6 bytes hashed; quality tiers (the reference hands `level` to BrotliEncoderCompress, /root/reference/lib/brotli-mt_compress.c:269-272):
+ * as in zstd_enc.hip what the wave-parallel match finder can trade is table size (LDS, waves per CU) and minimum
+ * match against ratio -- bench text, 1 MiB chunks (emulator): 4 Ki entries / minimum match 7: 2.450; 8 Ki / 6:
+ * 2.584; 16 Ki / 6: 2.659 (libbrotli quality 1: 2.81) */
+template <int HLOG> static __device__ __forceinline__ u32 be_hash(u64 v)
+{
+	return (u32)(((v << 16) * 0x9E3779B185EBCA87ull) >> (64 - HLOG));
+}
 #ifndef BE_WAVES_PER_EU
 #define BE_WAVES_PER_EU 4
 #endif
@@ -47,6 +58,10 @@
 #define BE_NSYM 1024u
 
 struct BEncLds {
+	u32 kins[24], kcopy[24]; /* insert / copy length codes: base | extra bits << 24 */
+	u32 misc[8];
+	/* LAST member: the kernels of the higher quality tiers declare the rest of a larger hash table right behind
+	 * the struct (BEncLdsExt), the table simply runs on */
 	union {
 		u16 table[1u << BE_HLOG]; /* match finding */
 		struct {                  /* block assembly (the table is rebuilt for the next block) */
@@ -55,8 +70,10 @@ struct BEncLds {
 			u8 len[BE_NSYM];
 		};
 	};
-	u32 kins[24], kcopy[24]; /* insert / copy length codes: base | extra bits << 24 */
-	u32 misc[8];
+};
+template <int HLOG> struct BEncLdsExt {
+	BEncLds L;
+	u16 more[(1u << HLOG) - (1u << BE_HLOG) + 8];
 };
 static_assert(sizeof(((BEncLds *)0)->table) >= BE_NSYM * 7, "entropy-phase arrays must fit the idle hash table");
 
@@ -332,12 +349,13 @@ static __device__ __forceinline__ BeCmd be_command(const BEncLds &L, u32 ins, u3
 	return c;
 }
 
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BE_WAVES_PER_EU, BE_WAVES_PER_EU)))
-zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
-		      u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch)
+template <int HLOG, u32 MM>
+static __device__ __forceinline__ void
+brotli_enc_body(BEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
+		u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch)
 {
-	__shared__ __attribute__((aligned(16))) BEncLds L;
 	const int lane = wv_lane();
+	u16 *const tab = L.table; /* 2^HLOG entries: runs on behind the struct for the larger tiers */
 	u8 *const wscr = scratch + (u64)blockIdx.x * BE_WSCRATCH;
 	u32 *const sq_ll = (u32 *)wscr;
 	u32 *const sq_ml = sq_ll + BE_MAXSEQ, *const sq_of = sq_ml + BE_MAXSEQ;
@@ -362,12 +380,12 @@ zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_tota
 		u8 *out = slots + (u64)rec * stride + BE_HDR + (u64)bi * BE_BSTRIDE;
 
 		/* ------------------------------------------------ match finding + greedy parse (zstd_enc.hip) */
-		for (u32 i = (u32)lane; i < (1u << BE_HLOG); i += 64)
-			L.table[i] = 0;
+		for (u32 i = (u32)lane; i < (1u << HLOG); i += 64)
+			tab[i] = 0;
 		wv_sync();
 		u32 ns = 0, anchor = 0, cursor = 0;
 		u32 r_ll = 0, r_ml = 0, r_of = 0;
-		const u32 steps = bsize >= BE_MINMATCH ? (bsize - BE_MINMATCH) / 64 + 1 : 0;
+		const u32 steps = bsize >= MM ? (bsize - MM) / 64 + 1 : 0;
 /* All loads of the pipeline are unconditional (addresses clamped, results of invalid lanes ignored):
  * a load under an exec mask needs its destination initialised first, and that write would have to
  * wait for every load still in flight. */
@@ -379,18 +397,18 @@ zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_tota
 #define BE_LOOKUP(t, V, Cc, M)                                                                     \
 	do {                                                                                       \
 		const u32 p_ = (t) * 64u + (u32)lane;                                              \
-		const bool ok_ = (t) < steps && p_ + BE_MINMATCH <= bsize;                         \
-		const u32 h_ = BE_HASH(V);                                                         \
-		const u32 e_ = ok_ ? L.table[h_] : 0;                                              \
+		const bool ok_ = (t) < steps && p_ + MM <= bsize;                                  \
+		const u32 h_ = be_hash<HLOG>(V);                                                   \
+		const u32 e_ = ok_ ? tab[h_] : 0;                                                  \
 		wv_sync();                                                                         \
 		if (ok_)                                                                           \
-			L.table[h_] = (u16)p_;                                                     \
+			tab[h_] = (u16)p_;                                                         \
 		wv_sync();                                                                         \
 		/* equal hashes inside one step: the highest position must stay, whatever order the   \
 		 * LDS served the conflicting lanes in (a step never straddles a 64 Ki boundary) */    \
-		while (wv_any(ok_ && L.table[h_] < (u16)p_)) {                                     \
-			if (ok_ && L.table[h_] < (u16)p_)                                          \
-				L.table[h_] = (u16)p_;                                             \
+		while (wv_any(ok_ && tab[h_] < (u16)p_)) {                                         \
+			if (ok_ && tab[h_] < (u16)p_)                                              \
+				tab[h_] = (u16)p_;                                                 \
 			wv_sync();                                                                 \
 		}                                                                                  \
 		u32 c_ = (p_ & ~0xFFFFu) | e_;                                                     \
@@ -443,7 +461,7 @@ zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_tota
 				const bool cand = c0 != 0xFFFFFFFFu && p >= cursor;
 				if (cand && m > bsize - p)
 					m = bsize - p;
-				u64 mask = wv_ballot(cand && m >= BE_MINMATCH);
+				u64 mask = wv_ballot(cand && m >= MM);
 				while (mask) {
 					const int j = wv_ffs(mask) - 1;
 					mask &= mask - 1;
@@ -776,6 +794,28 @@ zmt_brotli_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_tota
 		if (lane == 0)
 			blk_len[g] = total;
 	}
+}
+
+#define BE_KERNEL_ARGS                                                                                             \
+	const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec, u8 *__restrict__ slots,      \
+		u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch
+/* qualities 0..3 */
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BE_WAVES_PER_EU, BE_WAVES_PER_EU)))
+zmt_brotli_enc_kernel(BE_KERNEL_ARGS)
+{
+	__shared__ __attribute__((aligned(16))) BEncLds L;
+	brotli_enc_body<BE_HLOG, BE_MINMATCH>(L, in, n, chunk, nblk_total, blk_per_rec, slots, stride, blk_len, scratch);
+}
+/* qualities 4..8 and 9..11: 8 Ki / 16 Ki table entries, minimum match 6 */
+extern "C" __global__ void __launch_bounds__(64) zmt_brotli_enc_t2_kernel(BE_KERNEL_ARGS)
+{
+	__shared__ __attribute__((aligned(16))) BEncLdsExt<13> S;
+	brotli_enc_body<13, 6u>(S.L, in, n, chunk, nblk_total, blk_per_rec, slots, stride, blk_len, scratch);
+}
+extern "C" __global__ void __launch_bounds__(64) zmt_brotli_enc_t3_kernel(BE_KERNEL_ARGS)
+{
+	__shared__ __attribute__((aligned(16))) BEncLdsExt<14> S;
+	brotli_enc_body<14, 6u>(S.L, in, n, chunk, nblk_total, blk_per_rec, slots, stride, blk_len, scratch);
 }
 
 /* ---------------------------------------------------------------------------------------------

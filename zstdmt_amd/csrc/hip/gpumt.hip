@@ -50,6 +50,8 @@ C3_DECLP(zmt_dec_copy3_w4_kernel_prof)
 C3_DECLP(zmt_dec_copy3_w8_kernel_prof)
 C3_DECLP(zmt_dec_copy3_w16_kernel_prof)
 __global__ void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
+__global__ void zmt_brotli_enc_t2_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
+__global__ void zmt_brotli_enc_t3_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 __global__ void zmt_snappy_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *);
 __global__ void zmt_snappy_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
 __global__ void zmt_snappy_dec2_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
@@ -101,7 +103,7 @@ struct gpumt_ctx {
 	int zdec_variant; /* 0 = small-table kernel, then general; 1 = general only */
 	int sdec_variant; /* snappy decoder: 0 = element by element, 1 = 64 elements per batch (snappy.hip) */
 	int bdec_waves;   /* resident waves of the persistent brotli decoder kernel (whole device) */
-	int benc_waves;   /* ... of the brotli encoder kernel */
+	int benc_waves[3]; /* resident waves of the persistent brotli encoder kernels (whole device), per quality tier */
 	int senc_waves, sdec_waves, sdec2_waves; /* ... of the snappy kernels */
 	void *d_brotli_static; /* device copy of the RFC 7932 constant data */
 	char err[256];
@@ -1058,11 +1060,23 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 }
 
 /* brotli-mt compress: same slot geometry as zstd (gpumt_zstd_slot_stride), 16-byte record headers */
+/* quality -> encoder tier (brotli_enc.hip): 0-3 the fast parse (4 Ki-entry table), 4-8 and 9-11 larger tables and
+ * minimum match 6 */
+int gpumt_brotli_level_tier(int level) { return level <= 3 ? 0 : level <= 8 ? 1 : 2; }
+
 int gpumt_brotli_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
 				size_t slot_stride, uint32_t *d_rec_len, int s)
 {
-	if (!h || !STREAM_OK(s) || chunk == 0 || chunk > 0x40000000u || slot_stride < gpumt_zstd_slot_stride(chunk))
+	return gpumt_brotli_compress_batch_level(h, d_in, n, chunk, d_slots, slot_stride, d_rec_len, 1, s);
+}
+
+int gpumt_brotli_compress_batch_level(gpumt_ctx *h, const void *d_in, size_t n, size_t chunk, void *d_slots,
+				      size_t slot_stride, uint32_t *d_rec_len, int level, int s)
+{
+	if (!h || !STREAM_OK(s) || chunk == 0 || chunk > 0x40000000u || slot_stride < gpumt_zstd_slot_stride(chunk) ||
+	    level < 0 || level > 11)
 		return GPUMT_E_ARG;
+	const int tier = gpumt_brotli_level_tier(level);
 	if (use(h))
 		return GPUMT_E_HIP;
 	const size_t nrec = gpumt_lz4_record_count(n, chunk);
@@ -1070,22 +1084,34 @@ int gpumt_brotli_compress_batch(gpumt_ctx *h, const void *d_in, size_t n, size_t
 	const size_t nblk = nrec * bpr;
 	if (nblk > 0x7FFFFFFFu)
 		return GPUMT_E_ARG;
-	if (!h->benc_waves) {
+	if (!h->benc_waves[tier]) {
 		int per_cu = 0;
-		CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zmt_brotli_enc_kernel, 64, 0));
-		h->benc_waves = (per_cu > 0 ? per_cu : 4) * (h->num_cus > 0 ? h->num_cus : 256);
+		if (tier == 0)
+			CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zmt_brotli_enc_kernel, 64, 0));
+		else if (tier == 1)
+			CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zmt_brotli_enc_t2_kernel, 64, 0));
+		else
+			CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, zmt_brotli_enc_t3_kernel, 64, 0));
+		h->benc_waves[tier] = (per_cu > 0 ? per_cu : 4) * (h->num_cus > 0 ? h->num_cus : 256);
 		if (getenv("GPUMT_VERBOSE"))
-			fprintf(stderr, "gpumt: brotli encoder grid %d waves\n", h->benc_waves);
+			fprintf(stderr, "gpumt: brotli encoder tier %d grid %d waves\n", tier, h->benc_waves[tier]);
 	}
-	const unsigned grid = (unsigned)(nblk < (size_t)h->benc_waves ? nblk : (size_t)h->benc_waves);
+	const unsigned grid = (unsigned)(nblk < (size_t)h->benc_waves[tier] ? nblk : (size_t)h->benc_waves[tier]);
 	const size_t seq_bytes = (size_t)grid * (3 * ZE_MAXSEQ * 4);
 	if (want_scratch(h, 0, s, nblk * 4 + 64 + seq_bytes))
 		return GPUMT_E_HIP;
 	u32 *blk_len = (u32 *)h->scratch[0][s];
 	u8 *seqbuf = (u8 *)h->scratch[0][s] + ((nblk * 4 + 63) & ~(size_t)63);
 	PROF0(9);
-	hipLaunchKernelGGL(zmt_brotli_enc_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
-			   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);
+	if (tier == 0)
+		hipLaunchKernelGGL(zmt_brotli_enc_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
+				   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);
+	else if (tier == 1)
+		hipLaunchKernelGGL(zmt_brotli_enc_t2_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
+				   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);
+	else
+		hipLaunchKernelGGL(zmt_brotli_enc_t3_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
+				   (u32)chunk, (u32)nblk, bpr, (u8 *)d_slots, (u64)slot_stride, blk_len, seqbuf);
 	hipLaunchKernelGGL(zmt_brotli_assemble_kernel, dim3((unsigned)nrec), dim3(256), 0, h->st[s], (u64)n,
 			   (u32)chunk, (u32)nrec, bpr, (u8 *)d_slots, (u64)slot_stride, (const u32 *)blk_len,
 			   d_rec_len);

@@ -174,9 +174,10 @@ class Engine:
                                                     int(out_bytes), d_out_off.ptr, d_out_len.ptr,
                                                     d_status.ptr, stream), "zstd_decompress_batch")
 
-    def brotli_compress(self, d_in, n, chunk, d_slots, stride, d_rec_len, stream=0):
-        self._ck(self.L.gpumt_brotli_compress_batch(self.h, d_in.ptr, int(n), int(chunk), d_slots.ptr,
-                                                    int(stride), d_rec_len.ptr, stream), "brotli_compress_batch")
+    def brotli_compress(self, d_in, n, chunk, d_slots, stride, d_rec_len, stream=0, level=1):
+        self._ck(self.L.gpumt_brotli_compress_batch_level(self.h, d_in.ptr, int(n), int(chunk), d_slots.ptr,
+                                                          int(stride), d_rec_len.ptr, int(level), stream),
+                 "brotli_compress_batch_level")
 
     def brotli_decompress(self, d_stream, d_rec_off, d_rec_len, nrec, d_out, d_out_off, d_out_cap, d_out_len,
                           d_status, stream=0):
@@ -242,7 +243,7 @@ class Engine:
             if codec == "zstd":
                 self.zstd_compress(d_in, n, chunk, d_slots, stride, d_len, level=level)
             elif codec == "brotli":
-                self.brotli_compress(d_in, n, chunk, d_slots, stride, d_len)
+                self.brotli_compress(d_in, n, chunk, d_slots, stride, d_len, level=level)
             else:
                 self.lz4_compress(d_in, n, chunk, d_slots, stride, d_len, level=level)
             rec_len = self.download(d_len, nrec * 4, np.uint32)
