@@ -20,8 +20,8 @@ void zmt_lz4hc_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32
 void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u32 *, u32 *, u32 *, u32);
 void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
-void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *, u32 *, u32 *, u32);
-#define C3_DECL(NAME) void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, const u32 *, const u32 *, u32 *);
+void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *);
+#define C3_DECL(NAME) void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, u32 *);
 C3_DECL(zmt_dec_copy3_w4_kernel)
 C3_DECL(zmt_dec_copy3_w8_kernel)
 C3_DECL(zmt_dec_copy3_w16_kernel)
@@ -152,12 +152,8 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 		emu::launch(dim3{(nrec + 255) / 256, 1, 1}, dim3{256, 1, 1}, [=]() {
 			zmt_dec_frames_kernel(stream, rec_off, rec_len, nrec, out_len, blk0p, bcop, bcsp, rnbp, rflp, status, cep, cvp);
 		});
-		std::vector<u32> nbat(nblk_max, 0xA5A5A5A5u);
-		std::vector<u32> blv(ntok_max / 2 + 64, 0xA5A5A5A5u);
-		u32 *nbatp = nbat.data();
-		u32 *blp = blv.data();
 		emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
-			zmt_dec_parse3_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, blp, bntp, nbatp, bolp, (u32)ring);
+			zmt_dec_parse3_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bntp, bolp);
 		});
 		if (getenv("ZMT_EMU_DEBUG")) {
 			for (size_t b = 0; b < blk0[nrec]; b++)
@@ -165,16 +161,13 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 			for (u32 r = 0; r < nrec; r++)
 				fprintf(stderr, "rec %u status=%u nblk=%u\n", r, status[r], rnb[r]);
 		}
-		if (getenv("ZMT_EMU_DEBUG"))
-			for (size_t b = 0; b < blk0[nrec]; b++)
-				fprintf(stderr, "blk %zu nbat=%u\n", b, nbat[b]);
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
 				if (ring == 12)
-					zmt_dec_copy3_w4_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, blp, bntp, nbatp, bolp, status);
+					zmt_dec_copy3_w4_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
 				else if (ring == 13)
-					zmt_dec_copy3_w8_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, blp, bntp, nbatp, bolp, status);
+					zmt_dec_copy3_w8_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
 				else
-					zmt_dec_copy3_w16_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, blp, bntp, nbatp, bolp, status);
+					zmt_dec_copy3_w16_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
 		});
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
 			zmt_lz4_dec_serial(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp, 100u);

@@ -6,12 +6,12 @@ timeout 900 python -m pytest tests/test_gpu_lz4.py -x -q -m gpu > $O/pytest_lz4.
 tail -3 $O/pytest_lz4.txt
 B="python bench.py --only --mode decompress --steps 5 --warmup 1 --no-cpu"
 for r in 12 13 14; do
-  timeout 300 $B --dec-variant 2 --lz4-ring $r > $O/dec_v2_r$r.json 2> $O/dec_v2_r$r.err
+  timeout 300 $B --lz4-ring $r > $O/dec_v2_r$r.json 2> $O/dec_v2_r$r.err
 done
-K3PROF=1 timeout 300 python tools/dec_prof.py 2 210,226 > $O/dec_prof.txt 2>&1
+K3PROF=1 timeout 300 python tools/dec_prof.py 2 0,208 > $O/dec_prof.txt 2>&1
 A="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH"
 timeout 300 rocprofv3 --pmc $A --kernel-trace --output-format csv -d $O/sq_A -- \
-   python bench.py --only --mode decompress --dec-variant 2 --lz4-ring 13 --steps 1 --warmup 0 --no-cpu --no-verify > /dev/null 2> $O/sq_A.err
+   python bench.py --only --mode decompress --lz4-ring 12 --steps 1 --warmup 0 --no-cpu --no-verify > /dev/null 2> $O/sq_A.err
 python - <<'PY'
 import json,glob,csv,os
 from collections import defaultdict

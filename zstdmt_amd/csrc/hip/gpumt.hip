@@ -33,19 +33,17 @@ __global__ void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8
 __global__ void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 __global__ void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *,
 				      const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
-__global__ void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *, u32 *, u32 *,
-				      u32 *, u32 *, u32);
+__global__ void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *, u32 *, u32 *);
 #define C3_DECL(NAME)                                                                                              \
 	__global__ void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *,  \
-			     const u32 *, const u32 *, const u32 *, const u16 *, const u32 *, const u32 *, const u32 *, \
-			     const u32 *, u32 *);
+			     const u32 *, const u32 *, const u32 *, const u16 *, const u32 *, const u32 *, u32 *);
 C3_DECL(zmt_dec_copy3_w4_kernel)
 C3_DECL(zmt_dec_copy3_w8_kernel)
 C3_DECL(zmt_dec_copy3_w16_kernel)
 #define C3_DECLP(NAME)                                                                                             \
 	__global__ void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *,  \
-			     const u32 *, const u32 *, const u32 *, const u16 *, const u32 *, const u32 *, const u32 *, \
-			     const u32 *, u32 *, unsigned long long *);
+			     const u32 *, const u32 *, const u32 *, const u16 *, const u32 *, const u32 *, u32 *, \
+			     unsigned long long *);
 C3_DECLP(zmt_dec_copy3_w4_kernel_prof)
 C3_DECLP(zmt_dec_copy3_w8_kernel_prof)
 C3_DECLP(zmt_dec_copy3_w16_kernel_prof)
@@ -826,8 +824,6 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 	CARVE(bnt, u32, nblk_max)
 	CARVE(bol, u32, nblk_max)
 	CARVE(tok, u16, ntok_max)
-	CARVE(nbat, u32, nblk_max)
-	CARVE(bl, u32, ntok_max / 2 + 64)
 #undef CARVE
 	const bool split = h->dec_variant == 0;
 	if (h->profile >= 2 && !h->d_prof) {
@@ -851,25 +847,23 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 				   (const u8 *)d_stream, d_rec_off, d_rec_len, n, d_out_len,
 				   (const u64 *)blk0, bco, bcs, rnb, rfl, d_status, ce, cv);
 		PROF1(13);
-		u32 *nbat = (u32 *)(sc + nbat_o);
-		u32 *bl = (u32 *)(sc + bl_o);
 		const int ring = h->lz4_ring < 12 ? 12 : h->lz4_ring > 14 ? 14 : h->lz4_ring;
 		PROF0(14);
 		hipLaunchKernelGGL(zmt_dec_parse3_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
 				   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
-				   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bl, bnt, nbat, bol, (u32)ring);
+				   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bnt, bol);
 		PROF1(14);
 		PROF0(15);
 #define C3_LAUNCH(NAME)                                                                                            \
 	hipLaunchKernelGGL(NAME, dim3((unsigned)nrec), dim3(64), 0, h->st[s], (const u8 *)d_stream,               \
 			   (u64)stream_bytes, 0u, n, (u8 *)d_out, d_out_off, d_out_len, (const u64 *)blk0,         \
 			   (const u64 *)bco, (const u32 *)bcs, (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, \
-			   (const u32 *)bl, (const u32 *)bnt, (const u32 *)nbat, (const u32 *)bol, d_status)
+			   (const u32 *)bnt, (const u32 *)bol, d_status)
 #define C3_LAUNCHP(NAME)                                                                                           \
 	hipLaunchKernelGGL(NAME, dim3((unsigned)nrec), dim3(64), 0, h->st[s], (const u8 *)d_stream,               \
 			   (u64)stream_bytes, 0u, n, (u8 *)d_out, d_out_off, d_out_len, (const u64 *)blk0,         \
 			   (const u64 *)bco, (const u32 *)bcs, (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, \
-			   (const u32 *)bl, (const u32 *)bnt, (const u32 *)nbat, (const u32 *)bol, d_status, h->d_prof)
+			   (const u32 *)bnt, (const u32 *)bol, d_status, h->d_prof)
 		/* (running the XXH32 verification of record slices on a second stream while the next slice is copied was
 		 * measured in round 2: the partial last round of every slice costs more than the overlap gains) */
 		if (h->profile == 8) {

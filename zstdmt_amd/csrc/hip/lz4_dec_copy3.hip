@@ -11,9 +11,10 @@
  *
  * So this kernel is built around (1) a big power-of-two LDS RING of the record's output (8 or 16 KiB per
  * wave: 19 % / 6 % of the matches are sourced before it), addressed modulo, never slid; one wave per
- * workgroup so that the LDS of a CU divides into as many waves as fit; (2) batches that the parse
- * kernel has already cut (lz4_dec_parse3.hip: <= 64 small sequences, inside one lap of the ring, inside
- * the 1 KiB stage), so the batch loop has no cut / classify / reserve code; (3) the compressed bytes of
+ * workgroup so that the LDS of a CU divides into as many waves as fit; (2) batches cut by one rule that
+ * makes everything inside them simple (<= 64 "small" sequences, inside one lap of the ring, inside the
+ * 1 KiB stage: two ballots on fields the lanes compute anyway), so the batch body has no per-sequence
+ * special cases and the ring is never slid; (3) the compressed bytes of
  * a batch staged by ONE LDS-DMA instruction (global_load_lds_dwordx4, 1 KiB per wave-instruction, no
  * VGPRs), a batch ahead, into one of two stage buffers; (4) everything unusual -- long runs, the block's
  * last sequence, lap-crossing sequences -- executed generically byte by byte THROUGH the ring, so the
@@ -38,7 +39,7 @@
 					  * batch's literals are copied its buffer holds the 64 x 16 bytes fetched for
 					  * matches sourced before the ring */
 #define C3_BLK_STORED 0x80000000u
-#define C3_SINGLE 0x80u
+#define C3_XOUT 2048u /* most output bytes of one batch: two flush pieces of 1 KiB */
 #define C3_NEEDS_SERIAL 100u
 
 #ifndef ZMT_EMU
@@ -229,8 +230,8 @@ template <u32 WIN, bool PROF = false> struct C3 {
 	body(const u8 *__restrict__ stream, u64 stream_bytes, u32 rec0, u32 nrec, u8 *out_base,
 	     const u64 *__restrict__ out_off, const u32 *__restrict__ out_len, const u64 *__restrict__ blk0,
 	     const u64 *__restrict__ blk_coff, const u32 *__restrict__ blk_csize, const u32 *__restrict__ rec_nblk,
-	     const u32 *__restrict__ rec_flags, const u16 *__restrict__ tok, const u32 *__restrict__ bl,
-	     const u32 *__restrict__ blk_ntok, const u32 *__restrict__ blk_nbat, const u32 *__restrict__ blk_olen,
+	     const u32 *__restrict__ rec_flags, const u16 *__restrict__ tok, const u32 *__restrict__ blk_ntok,
+	     const u32 *__restrict__ blk_olen,
 	     u32 *__restrict__ status, u8 *ring, u8 *cbuf, unsigned long long *prof)
 	{
 		const int lane = wv_lane();
@@ -271,103 +272,117 @@ template <u32 WIN, bool PROF = false> struct C3 {
 				st.valid_from = st.opos; /* the ring does not hold a stored block: sources in it come from memory */
 				continue;
 			}
-			if (st.opos & MASK) {
-				/* the parse kernel cut its batches for a block that starts on a lap boundary; LZ4F allows short
-				 * blocks in front (lz4-mt never writes them): the frame-serial kernel decodes this record */
-				stc = C3_NEEDS_SERIAL;
-				break;
-			}
 			const u32 ntok = wv_readfirst(blk_ntok[gb]);
-			const u32 nbat = wv_readfirst(blk_nbat[gb]);
 			const u64 tbase = c3_tok_base(coff, gb);
 			const u16 *const tk = tok + tbase;
-			const u32 *const bd = bl + (tbase >> 1);
 			const u32 low = indep ? bstart : 0;
-			/* ---- batch list three entries ahead, token positions two, compressed bytes one ----
-			 * entry = n | single << 7 | c0 << 16: n small sequences from block position c0 on, then (single) one
-			 * sequence of any shape; its token positions are n + single consecutive entries of the token list */
-#define C3_DESC(J) ((J) < nbat ? bd[(J)] : 0u)
-#define C3_NTOK(D) (((D) & 127u) + (((D) >> 7) & 1u))
-#define C3_TOK(T0, N) (((u32)lane < (N)) ? (u32)tk[(T0) + (u32)lane] : 0u)
-#define C3_STAGE(D, BUF)                                                                                           \
+			/* ---- the block's sequences in batches this kernel cuts itself ----
+			 * A batch = the longest run of "small" sequences (literal run <= 64, match <= 64, no 255 length bytes, not
+			 * the block's last) from sequence t0 on -- at most 64 -- whose compressed bytes lie inside the 1 KiB stage,
+			 * whose output is at most C3_XOUT bytes and does not cross a multiple of the ring size ("lap": stores inside a
+			 * batch never wrap).  The sequence that ends the run, if it is not small itself, is executed generically
+			 * right behind the batch.  Token positions of the next batch are loaded as soon as the cut is known, its
+			 * compressed bytes staged by one LDS-DMA into the other buffer. */
+#define C3_TOK(T0) (((T0) + (u32)lane < ntok) ? (u32)tk[(T0) + (u32)lane] : 0u)
+#define C3_TOK2(T0) (((T0) + 64u + ((u32)lane & 1u) < ntok) ? (u32)tk[(T0) + 64u + ((u32)lane & 1u)] : 0u)
+#define C3_STAGE(C0, BUF)                                                                                          \
 	do {                                                                                                       \
-		const u32 c_ = (D) >> 16;                                                                          \
-		const u8 *g_ = src + c_;                                                                           \
+		const u8 *g_ = src + (C0);                                                                         \
 		const u32 a_ = (u32)((size_t)g_ & 15u);                                                            \
-		c3_stage(cbuf + (BUF) * C3_CBUF, g_ - a_, cs - c_ + a_ + 16u, lane);                               \
+		c3_stage(cbuf + (BUF) * C3_CBUF, g_ - a_, cs - (C0) + a_ + 16u, lane);                             \
 	} while (0)
-			u32 d_cur = wv_readfirst(C3_DESC(0)), d_nxt = wv_readfirst(C3_DESC(1));
-			u32 d_nn_v = C3_DESC(2); /* lands while the current entry runs */
-			u32 t0 = 0;
-			u32 q_cur = C3_TOK(0, C3_NTOK(d_cur));
-			u32 q_nxt = C3_TOK(C3_NTOK(d_cur), C3_NTOK(d_nxt));
-			u32 cbi = 0; /* stage buffer of the first batch at or after the current entry */
-			if (d_cur & 127u)
-				C3_STAGE(d_cur, cbi);
-			for (u32 j = 0; j < nbat && stc == ST_OK; j++) {
-				const u32 d = d_cur;
-				const u32 n = d & 127u;
-				const u32 ntk = C3_NTOK(d);
-				if (t0 + ntk > ntok || ntk == 0) {
-					stc = ST_BAD_BLOCK; /* cannot happen: the lists come from the parse kernel */
+			u32 t0 = 0, cbi = 0;
+			u32 q_cur = C3_TOK(0), q2_cur = C3_TOK2(0);
+			if (ntok)
+				C3_STAGE(wv_readlane(q_cur, 0), cbi);
+			while (t0 < ntok && stc == ST_OK) {
+				C3PC(1);
+				c3_wait_vm(); /* the stage and the token positions of this batch */
+				C3PC(0);
+				const u32 q = q_cur, q2 = q2_cur;
+				u8 *const cb = cbuf + cbi * C3_CBUF;
+				cbi ^= 1u;
+				if (PROF)
+					pc[PROF ? 12 : 0]++;
+				/* ---------- fields of up to 64 sequences, lane = sequence ---------- */
+				const bool have = t0 + (u32)lane < ntok;
+				const u32 c0 = wv_readlane(q, 0);
+				const u32 al = (u32)((size_t)(src + c0) & 15u);
+				const u32 qr = q - c0 + al; /* this lane's token in the stage */
+				u32 lit, ml, off, lsrc;
+				bool small, hard;
+				{
+					const bool v1 = have & (qr + 12u <= C3_CSTAGE); /* the token's first bytes are staged */
+					const u64 w = c3_ld64s(cb, v1 ? qr : 0u);
+					const u32 wl = (u32)w;
+					const u32 tokb = wl & 255u;
+					const bool lx = (tokb >> 4) == 15u, mx = (tokb & 15u) == 15u;
+					const u32 b1 = (wl >> 8) & 255u;
+					lit = (tokb >> 4) + (lx ? b1 : 0u);
+					lsrc = qr + 1u + (lx ? 1u : 0u);
+					const u32 mo = lsrc + lit; /* where the offset sits */
+					const bool v2 = v1 & (mo + 4u <= C3_CSTAGE);
+					const u32 w2 = (u32)c3_ld64s(cb, v2 ? mo : 0u);
+					const u32 b2 = (w2 >> 16) & 255u;
+					off = w2 & 0xFFFFu;
+					ml = (tokb & 15u) + 4u + (mx ? b2 : 0u);
+					const bool is_last = t0 + (u32)lane + 1u == ntok;
+					/* needs the generic path whatever batch it would be in */
+					hard = v1 & ((lx & (b1 == 255u)) | (lit > 64u) | is_last | (v2 & ((mx & (b2 == 255u)) | (ml > 64u))));
+					small = v2 & !hard & (mo + 3u <= C3_CSTAGE);
+				}
+				C3PC(2);
+				/* ---------- cut: the run of small sequences, then output positions, then span and lap ---------- */
+				const u64 sm0 = wv_ballot(small);
+				const u32 n0 = ~sm0 ? (u32)wv_ffs(~sm0) - 1u : 64u;
+				const u32 len = (u32)lane < n0 ? lit + ml : 0u;
+				const u32 incl = wv_scan_incl(len);
+				const u32 o0 = st.opos;
+				const u32 op = o0 + incl - len;
+				const u32 lap_end = (o0 | MASK) + 1u;
+				const u32 olim = o0 + C3_XOUT < lap_end ? o0 + C3_XOUT : lap_end;
+				const u64 fit = wv_ballot(((u32)lane < n0) & (op + len <= olim));
+				const u32 n = ~fit ? (u32)wv_ffs(~fit) - 1u : 64u; /* (the conditions are monotone in the lane) */
+				/* the sequence behind the run is executed generically if it is "hard", or if it is small but crosses the
+				 * lap boundary on its own (it could not open a batch either) */
+				const u64 hard_m = wv_ballot(hard);
+				const u64 cross_m = wv_ballot(((u32)lane < n0) & (op < lap_end) & (op + len > lap_end));
+				const bool single = n < 64u && (((hard_m | cross_m) >> n) & 1u) != 0;
+				const bool single_hard = n < 64u && ((hard_m >> n) & 1u) != 0;
+				/* (a lap-crosser is small: its fields are this batch's lane n, its literals are in the stage) */
+				const u32 s_lit = wv_readlane(lit, (int)(n & 63u)), s_ml = wv_readlane(ml, (int)(n & 63u));
+				const u32 s_off = wv_readlane(off, (int)(n & 63u));
+				const u32 s_lpos = wv_readlane(q + (lsrc - qr), (int)(n & 63u)); /* block position of its literals (the stage
+												  * is overwritten by then) */
+				const bool act = (u32)lane < n;
+				if (!act) {
+					lit = 0;
+					ml = 0;
+					off = 1;
+				}
+				const u32 r = n + (single ? 1u : 0u);
+				const u32 t0n = t0 + r;
+				if (r == 0) {
+					stc = ST_BAD_BLOCK; /* cannot happen: a small sequence that does not cross the lap fits a batch alone */
 					break;
 				}
-				C3PC(1);
-				c3_wait_vm(); /* the stage of this batch, the token positions of this and the next entry */
-				C3PC(0);
-				const u32 q = q_cur;
-				const u32 d_nn = wv_readfirst(d_nn_v);
-				const u32 t2 = t0 + ntk + C3_NTOK(d_nxt);
 				/* what leaves for memory this batch (issued together, below): the ring up to the batch's start, the
-				 * token positions two entries ahead, the batch-list entry three ahead, the next stage */
+				 * token positions and the stage of the next batch */
 #define C3_ISSUE()                                                                                                 \
 	do {                                                                                                       \
 		flush_aligned(st, ring, out, st.opos & ~15u, lane);                                                \
-		q_cur = q_nxt;                                                                                     \
-		q_nxt = C3_TOK(t2, C3_NTOK(d_nn));                                                                 \
-		d_nn_v = C3_DESC(j + 3);                                                                           \
-		d_cur = d_nxt;                                                                                     \
-		d_nxt = d_nn;                                                                                      \
-		if (d_cur & 127u)                                                                                  \
-			C3_STAGE(d_cur, cbi); /* (a batch has flipped cbi to the free buffer already) */             \
+		q_cur = C3_TOK(t0n);                                                                               \
+		q2_cur = C3_TOK2(t0n);                                                                             \
+		if (t0n < ntok)                                                                                    \
+			C3_STAGE(r < 64u ? wv_readlane(q, (int)(r & 63u)) : wv_readlane(q2, (int)(r & 1u)), cbi);    \
 	} while (0)
 				if (n == 0) {
 					C3_ISSUE();
 				} else {
-					/* ---------- a batch of n small sequences, lane = sequence ---------- */
-					if (PROF)
-						pc[PROF ? 12 : 0]++;
-					const bool act = (u32)lane < n;
-					u8 *const cb = cbuf + cbi * C3_CBUF;
-					cbi ^= 1u;
-					const u32 c0 = d >> 16;
-					const u32 al = (u32)((size_t)(src + c0) & 15u);
-					const u32 qr = q - c0 + al; /* this lane's token in the stage */
-					u32 lit = 0, ml = 0, off = 1, lsrc = 0;
-					{
-						const u64 w = c3_ld64s(cb, act ? qr : 0u);
-						const u32 wl = (u32)w;
-						const u32 tokb = wl & 255u;
-						const bool lx = (tokb >> 4) == 15u, mx = (tokb & 15u) == 15u;
-						const u32 l_ = (tokb >> 4) + (lx ? (wl >> 8) & 255u : 0u);
-						const u32 h = qr + 1u + (lx ? 1u : 0u);
-						const u32 w2 = (u32)c3_ld64s(cb, act ? h + l_ : 0u);
-						if (act) {
-							lit = l_;
-							lsrc = h;
-							off = w2 & 0xFFFFu;
-							ml = (tokb & 15u) + 4u + (mx ? (w2 >> 16) & 255u : 0u);
-						}
-					}
-					C3PC(2);
-					const u32 len = lit + ml;
-					const u32 incl = wv_scan_incl(len);
-					const u32 o0 = st.opos;
-					const u32 op = o0 + incl - len;
+					const u32 total = wv_readlane(incl, (int)(n - 1u));
 					const u32 mpos = op + lit;
 					const u32 src_pos = mpos - off;
 					const u32 eff = ml < off ? ml : off;
-					const u32 total = wv_readlane(incl, 63);
 					const u32 o_end = o0 + total;
 					if (wv_any(act & ((off == 0) | (off > mpos - low))) | (total > cap - o0)) {
 						stc = ST_BAD_BLOCK;
@@ -472,11 +487,18 @@ template <u32 WIN, bool PROF = false> struct C3 {
 						st.opos = o_end;
 					}
 				}
-				if (d & C3_SINGLE) {
+				if (single && !single_hard) {
+					/* ---------- a small sequence across the lap boundary: byte by byte, wrapping ---------- */
+					if (s_off == 0 || s_off > st.opos + s_lit - low || s_lit + s_ml > cap - st.opos) {
+						stc = ST_BAD_BLOCK;
+						break;
+					}
+					generic(src + s_lpos, s_lit, s_off, s_ml, ring, out, st, lane);
+					C3PC(10);
+				} else if (single) {
 					/* ---------- one sequence of any shape (fields from memory, wave-uniform) ---------- */
-					/* (a full batch of 64 plus this one: its position did not fit the 64 lanes) */
-					const u32 qq = n < 64u ? wv_readlane(q, (int)n) : uld16((const u8 *)(tk + t0 + 64u));
-					const bool is_last = t0 + ntk == ntok;
+					const u32 qq = n < 64u ? wv_readlane(q, (int)(n & 63u)) : wv_readlane(q2, 0);
+					const bool is_last = t0 + n + 1u == ntok;
 					u32 t = uld8(src + qq), l2 = t >> 4, h = qq + 1;
 					if (l2 == 15) {
 						u32 b;
@@ -485,10 +507,10 @@ template <u32 WIN, bool PROF = false> struct C3 {
 							l2 += b;
 						} while (b == 255);
 					}
-					u32 off = 1, m2 = 0;
+					u32 goff = 1, m2 = 0;
 					if (!is_last) {
 						u32 m = h + l2;
-						off = uld16(src + m);
+						goff = uld16(src + m);
 						m += 2;
 						m2 = t & 15;
 						if (m2 == 15) {
@@ -499,7 +521,7 @@ template <u32 WIN, bool PROF = false> struct C3 {
 							} while (b == 255);
 						}
 						m2 += 4;
-						if (off == 0 || off > st.opos + l2 - low) {
+						if (goff == 0 || goff > st.opos + l2 - low) {
 							stc = ST_BAD_BLOCK;
 							break;
 						}
@@ -508,14 +530,13 @@ template <u32 WIN, bool PROF = false> struct C3 {
 						stc = ST_BAD_BLOCK;
 						break;
 					}
-					generic(src + h, l2, off, m2, ring, out, st, lane);
+					generic(src + h, l2, goff, m2, ring, out, st, lane);
 					C3PC(10);
 				}
-				t0 += ntk;
+				t0 = t0n;
 			}
-#undef C3_DESC
-#undef C3_NTOK
 #undef C3_TOK
+#undef C3_TOK2
 #undef C3_STAGE
 #undef C3_ISSUE
 			if (stc == ST_OK && (t0 != ntok || st.opos != bstart + olen))
@@ -553,14 +574,14 @@ template <u32 WIN, bool PROF = false> struct C3 {
 	NAME(const u8 *__restrict__ stream, u64 stream_bytes, u32 rec0, u32 nrec, u8 *out_base,                    \
 	     const u64 *__restrict__ out_off, const u32 *__restrict__ out_len, const u64 *__restrict__ blk0,       \
 	     const u64 *__restrict__ blk_coff, const u32 *__restrict__ blk_csize, const u32 *__restrict__ rec_nblk, \
-	     const u32 *__restrict__ rec_flags, const u16 *__restrict__ tok, const u32 *__restrict__ bl,           \
-	     const u32 *__restrict__ blk_ntok, const u32 *__restrict__ blk_nbat, const u32 *__restrict__ blk_olen, \
+	     const u32 *__restrict__ rec_flags, const u16 *__restrict__ tok, const u32 *__restrict__ blk_ntok,    \
+	     const u32 *__restrict__ blk_olen,                                                                     \
 	     u32 *__restrict__ status EXTRA)                                                                        \
 	{                                                                                                          \
 		__shared__ __attribute__((aligned(16))) u8 lds[WINSZ + 16u + 2u * C3_CBUF];                        \
 		C3<WINSZ, PROFILE>::body(stream, stream_bytes, rec0, nrec, out_base, out_off, out_len, blk0,       \
-					 blk_coff, blk_csize, rec_nblk, rec_flags, tok, bl, blk_ntok, blk_nbat,    \
-					 blk_olen, status, lds, lds + WINSZ + 16u, PROFP);                         \
+					 blk_coff, blk_csize, rec_nblk, rec_flags, tok, blk_ntok, blk_olen,       \
+					 status, lds, lds + WINSZ + 16u, PROFP);                                   \
 	}
 
 C3_KERNEL(zmt_dec_copy3_w4_kernel, 4096u)

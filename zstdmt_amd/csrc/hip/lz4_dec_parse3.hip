@@ -17,18 +17,9 @@
  *     consumes on average, so a lane that fell behind catches up;
  *   - token positions leave through an 8-entry LDS tile PER LANE: 16 bytes per lane every 8 tokens,
  *     no cross-lane transposition, no wave sync;
- *   - the kernel also cuts the token list into the BATCHES the copy kernel executes, one u32 per batch
- *     ("batch list"): n | single << 7 | c0 << 16 = n (0..64) consecutive "small" sequences (literal run
- *     <= 64, match <= 64, not the block's last) whose compressed bytes fit the copy kernel's 1 KiB stage
- *     (c0 = position of the first one), whose output is at most P3_XOUT bytes and does not cross a
- *     multiple of the copy kernel's ring size ("lap"), followed -- if `single` -- by one sequence of
- *     any kind that the copy kernel executes generically.  The copy kernel's batch loop is thereby free
- *     of cut / classify / reserve logic (15 % of its cycles in round 2).
- *
- * Lap rule: output positions are taken relative to the start of the block, which the copy kernel
- * requires to sit on a lap boundary of the record (true for every block lz4-mt writes: all but the
- * last block of a frame decode to 64 KiB); a record for which it does not hold is handed to the
- * frame-serial kernel by the copy kernel.
+ *   - nothing else: cutting the list into the batches the copy kernel executes was done here at first (one
+ *     descriptor per batch, ~85 of 190 instructions per step); the copy kernel now finds its batches itself
+ *     with two ballots on fields its lanes compute anyway, and this kernel's step lost the batch logic.
  */
 #include "lz4_common.h"
 #include "lz4_frame.h"
@@ -41,10 +32,6 @@
 #ifndef P3_CADENCE
 #define P3_CADENCE 8u
 #endif
-#define P3_XOUT 2048u    /* most output bytes of one batch (the copy kernel flushes 2 x 1 KiB) */
-#define P3_CSPAN 1016u   /* most compressed bytes of one batch, from the 16-byte floor of its first token */
-#define P3_CAP 64u       /* longest literal run / match of a "small" sequence */
-#define P3_SINGLE 0x80u
 #define P3_FAR 0x7FFFFF00u /* "the whole rest of the block is in the ring" */
 #define P3_NONE 0xFFFFFFFFu
 
@@ -55,8 +42,7 @@ static __device__ __forceinline__ u64 p3_tok_base(u64 coff, u32 gb) { return ((c
 extern "C" __global__ void __launch_bounds__(64)
 zmt_dec_parse3_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ blk_coff,
 		      const u32 *__restrict__ blk_csize, const u64 *__restrict__ nblk_ptr, u16 *__restrict__ tok,
-		      u32 *__restrict__ bl, u32 *__restrict__ blk_ntok, u32 *__restrict__ blk_nbat,
-		      u32 *__restrict__ blk_olen, u32 lap_shift)
+		      u32 *__restrict__ blk_ntok, u32 *__restrict__ blk_olen)
 {
 	__shared__ __attribute__((aligned(16))) u8 ring_lds[64 * P3_RSTRIDE];
 	__shared__ __attribute__((aligned(16))) u8 tile_lds[64 * 16];
@@ -82,7 +68,6 @@ zmt_dec_parse3_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 	if (!wv_any(parse)) {
 		if (exists) {
 			blk_ntok[gb] = 0;
-			blk_nbat[gb] = 0;
 			blk_olen[gb] = (cs_raw == P3_BLK_EMPTY) ? 0 : (cs_raw & 0x7FFFFFFFu);
 		}
 		return;
@@ -95,14 +80,10 @@ zmt_dec_parse3_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 	u8 *const myring = ring_lds + (u32)lane * P3_RSTRIDE;
 	u16 *const mytile = (u16 *)(tile_lds + (u32)lane * 16u);
 	u16 *const mytok = tok + tbase;
-	u32 *const mybl = bl + (tbase >> 1);
-	const u32 lap_low = (1u << lap_shift) - 1u;
 
-	u32 g = boff, opos = 0, n = 0, nd = 0;
+	u32 g = boff, opos = 0, n = 0;
 	/* the ring holds [ghi - 256, ghi); [ghi, greq) is in flight; ghi = P3_FAR once the block's last unit is in */
 	u32 ghi = boff & ~(P3_UNIT - 1), greq = ghi;
-	/* open batch: sequences, position of its first token, most it may reach in the stream (g) and in the output */
-	u32 b_n = 0, b_c0 = 0, b_glim = 0, b_olim = 0;
 	u32 pend0 = P3_NONE, pend1 = P3_NONE; /* g of the units this lane has in flight */
 	bool pend_any = false;
 	p3v4 pv[8];
@@ -256,30 +237,11 @@ zmt_dec_parse3_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 				}
 			}
 		}
-		/* ---------------- token list + batch list ---------------- */
+		/* ---------------- token list ---------------- */
 		if (emit) {
-			const u32 oe = opos + e_lit + e_ml;
-			const u32 pos = g - boff;
-			mytile[n & 7u] = (u16)pos;
-			/* "small": the copy kernel's lane-per-sequence path takes it; alone it must not cross a lap */
-			const bool small = fast & !last & (e_lit <= P3_CAP) & (e_ml <= P3_CAP) & (((oe - 1u) | lap_low) == (opos | lap_low));
-			const bool fits = small & (b_n - 1u < 63u) & (e_nxt <= b_glim) & (oe <= b_olim);
-			if (!fits & ((b_n != 0) | !small)) {
-				/* close the open batch; a sequence that is not small rides on the same entry */
-				mybl[nd++] = b_n | (small ? 0u : P3_SINGLE) | ((b_n ? b_c0 : pos) << 16);
-				b_n = 0;
-			}
-			if (small) {
-				if (b_n == 0) {
-					b_c0 = pos;
-					b_glim = (g & ~15u) + P3_CSPAN;
-					const u32 lap_end = (opos | lap_low) + 1u;
-					b_olim = opos + P3_XOUT < lap_end ? opos + P3_XOUT : lap_end;
-				}
-				b_n++;
-			}
+			mytile[n & 7u] = (u16)(g - boff);
 			n++;
-			opos = oe;
+			opos += e_lit + e_ml;
 			g = e_nxt;
 			if (last)
 				done = true;
@@ -293,14 +255,10 @@ zmt_dec_parse3_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 	}
 	if (exists) {
 		if (parse) {
-			if (b_n != 0 && ok)
-				mybl[nd++] = b_n | (b_c0 << 16);
 			blk_ntok[gb] = ok ? n : 0;
-			blk_nbat[gb] = ok ? nd : 0;
 			blk_olen[gb] = ok ? opos : 0xFFFFFFFFu;
 		} else {
 			blk_ntok[gb] = 0;
-			blk_nbat[gb] = 0;
 			blk_olen[gb] = (cs_raw == P3_BLK_EMPTY) ? 0 : (cs_raw & 0x7FFFFFFFu);
 		}
 	}
