@@ -30,6 +30,14 @@ int main(int argc, char **argv)
 	if (fread(buf, 1, (size_t)n, f) != (size_t)n)
 		return 4;
 	fclose(f);
+	if (argc > 2 && !strcmp(argv[2], "verdict")) {
+		/* one word: what the incremental reader does with these bytes as the start of a frame */
+		uint64_t bound = 0;
+		int flag = 0;
+		const size_t r = EXTENT(buf, (size_t)n, &bound, &flag);
+		printf("%s\n", r == 0 ? "wait" : r == (size_t)-1 ? "invalid" : "frame");
+		return 0;
+	}
 	if (argc > 2) {
 		uint64_t bound = 0;
 		int flag = 0;
@@ -38,7 +46,7 @@ int main(int argc, char **argv)
 		for (size_t k = 0; k < full; k++) {
 			bound = 0;
 			flag = 0;
-			if (EXTENT(buf, k, &bound, &flag) != 0)
+			if (EXTENT(buf, k, &bound, &flag) != 0) /* neither complete nor invalid: a prefix of a good frame only waits */
 				wrong++;
 		}
 		printf("%zu %ld\n", full, wrong);

@@ -56,3 +56,38 @@ def test_frame_extents(kind, tmp_path):
         f.write_bytes(frame)
         full, wrong = (int(x) for x in subprocess.check_output([exe, str(f), "cut"]).split())
         assert (full, wrong) == (len(frame), 0)
+
+
+@pytest.mark.parametrize("kind", ["lz4", "zstd"])
+def test_damaged_frame_starts_are_rejected_at_once(kind, tmp_path):
+    """a frame start that can never become a frame is `invalid`, not `wait`: the incremental reader of the plain
+    .lz4 / .zst paths then reports the error instead of buffering the rest of the input"""
+    if (kind == "lz4" and H.liblz4_frame(b"x") is None) or (kind == "zstd" and H.libzstd_frame(b"x") is None):
+        pytest.skip("codec library not on this box")
+    exe = build(kind)
+    f = tmp_path / "f.bin"
+
+    def verdict(b):
+        f.write_bytes(b)
+        return subprocess.check_output([exe, str(f), "verdict"]).decode().strip()
+
+    if kind == "lz4":
+        good = H.liblz4_frame(text(200_000, 4), content_size=1, checksum=1, block_checksum=0, block_id=4)
+        assert verdict(good) == "frame" and verdict(good[:1000]) == "wait"
+        bad = bytearray(good[:1000]); bad[4] ^= 0x80                 # version bits
+        assert verdict(bytes(bad)) == "invalid"
+        bad = bytearray(good[:1000]); bad[5] = 0x30                  # block size id 3
+        assert verdict(bytes(bad)) == "invalid"
+        bad = bytearray(good[:1000]); bad[15 + 2] = 0x7F             # first block header: 8 MiB in a 64 KiB frame
+        assert verdict(bytes(bad)) == "invalid"
+    else:
+        good = H.libzstd_frame(text(400_000, 4), content_size=1, checksum=1, level=1)
+        assert verdict(good) == "frame" and verdict(good[:1000]) == "wait"
+        bad = bytearray(good[:1000]); bad[4] |= 8                    # reserved bit of the frame header descriptor
+        assert verdict(bytes(bad)) == "invalid"
+        hdr = 6 + (1 << (good[4] >> 6)) - 1 if (good[4] >> 6) else 6
+        bad = bytearray(good[:1000])
+        # first block header -> reserved block type 3
+        i = 5 + (0 if (good[4] >> 5) & 1 else 1) + [0, 1, 2, 4][good[4] & 3] + ([1, 2, 4, 8][good[4] >> 6] if (good[4] >> 6) or ((good[4] >> 5) & 1) else 0)
+        bad[i] |= 6
+        assert verdict(bytes(bad)) == "invalid"

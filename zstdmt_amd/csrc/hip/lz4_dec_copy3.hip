@@ -349,11 +349,7 @@ template <u32 WIN, bool PROF = false> struct C3 {
 				const u64 cross_m = wv_ballot(((u32)lane < n0) & (op < lap_end) & (op + len > lap_end));
 				const bool single = n < 64u && (((hard_m | cross_m) >> n) & 1u) != 0;
 				const bool single_hard = n < 64u && ((hard_m >> n) & 1u) != 0;
-				/* (a lap-crosser is small: its fields are this batch's lane n, its literals are in the stage) */
-				const u32 s_lit = wv_readlane(lit, (int)(n & 63u)), s_ml = wv_readlane(ml, (int)(n & 63u));
-				const u32 s_off = wv_readlane(off, (int)(n & 63u));
-				const u32 s_lpos = wv_readlane(q + (lsrc - qr), (int)(n & 63u)); /* block position of its literals (the stage
-												  * is overwritten by then) */
+				const u32 lit_r = lit, ml_r = ml, off_r = off; /* (lane n's are the fields of a lap-crosser behind the run) */
 				const bool act = (u32)lane < n;
 				if (!act) {
 					lit = 0;
@@ -489,6 +485,10 @@ template <u32 WIN, bool PROF = false> struct C3 {
 				}
 				if (single && !single_hard) {
 					/* ---------- a small sequence across the lap boundary: byte by byte, wrapping ---------- */
+					const u32 s_lit = wv_readlane(lit_r, (int)(n & 63u)), s_ml = wv_readlane(ml_r, (int)(n & 63u));
+					const u32 s_off = wv_readlane(off_r, (int)(n & 63u));
+					/* block position of its literals (the stage has been overwritten by the fetched sources) */
+					const u32 s_lpos = wv_readlane(q + (lsrc - qr), (int)(n & 63u));
 					if (s_off == 0 || s_off > st.opos + s_lit - low || s_lit + s_ml > cap - st.opos) {
 						stc = ST_BAD_BLOCK;
 						break;

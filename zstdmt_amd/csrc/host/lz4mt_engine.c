@@ -549,6 +549,11 @@ static size_t dp_drain(void *a, int si)
  * content checksum) and decoded by the frame-serial kernel, one wave per frame; a frame that does not
  * state its content size gets blocks x block-maximum as capacity and the decoder reports the size.
  * GetFrames stays 0 as in the reference (st_decompress counts no frames). */
+/* Length of the LZ4 frame at p (n bytes are there), or 0 = the frame is not complete yet (more input may
+ * complete it), or EXTENT_INVALID = these bytes cannot become a frame however much follows (descriptor or
+ * block size out of the format): the incremental reader stops at once instead of buffering the rest of a
+ * damaged stream until its end. */
+#define EXTENT_INVALID ((size_t)-1)
 static size_t lz4_frame_extent(const uint8_t *p, size_t n, uint64_t *bound, int *supported)
 {
 	if (n < 7)
@@ -558,7 +563,9 @@ static size_t lz4_frame_extent(const uint8_t *p, size_t n, uint64_t *bound, int 
 	const int has_csize = (flg >> 3) & 1, has_dict = flg & 1, bchk = (flg >> 4) & 1, cchk = (flg >> 2) & 1;
 	size_t hp = 6 + (has_csize ? 8 : 0) + (has_dict ? 4 : 0) + 1;
 	uint64_t sum = 0, blkmax;
-	if ((flg >> 6) != 1 || bsid < 4 || n < hp)
+	if ((flg >> 6) != 1 || (flg & 2) || (bd & 0x8F) || bsid < 4)
+		return EXTENT_INVALID; /* version, reserved bits, block size id (what LZ4F_decompress rejects first) */
+	if (n < hp)
 		return 0;
 	blkmax = 1ull << (8 + 2 * bsid); /* 4 -> 64 KiB ... 7 -> 4 MiB */
 	*supported = 1; /* block checksums are verified and a dictionary id skipped by the frame-serial kernel */
@@ -571,7 +578,9 @@ static size_t lz4_frame_extent(const uint8_t *p, size_t n, uint64_t *bound, int 
 		if (bh == 0)
 			break;
 		bsz = bh & 0x7FFFFFFFu;
-		if (bsz > blkmax || n - hp < bsz + (bchk ? 4u : 0u))
+		if (bsz > blkmax)
+			return EXTENT_INVALID;
+		if (n - hp < bsz + (bchk ? 4u : 0u))
 			return 0;
 		hp += bsz + (bchk ? 4u : 0u);
 		sum += (bh & 0x80000000u) ? bsz : blkmax;
@@ -666,14 +675,15 @@ static size_t plain_decompress(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, const uint8_t 
 				jp += sk;
 				continue;
 			}
-			if (!eof && (n - jp < 8 || (rd32(raw + jp) == LZ4FMT_MAGICNUMBER &&
-						   !lz4_frame_extent(raw + jp, n - jp, &bound, &supported)))) {
-				need_more = 1; /* an incomplete frame (or a damaged one: the end of the input will tell) */
+			if (!eof && n - jp <= 0xFFFFFFF0u &&
+			    (n - jp < 8 || (rd32(raw + jp) == LZ4FMT_MAGICNUMBER &&
+					    !lz4_frame_extent(raw + jp, n - jp, &bound, &supported)))) {
+				need_more = 1; /* an incomplete frame: wait for the rest (a damaged one is EXTENT_INVALID, below) */
 				break;
 			}
 			if (n - jp < 4 || rd32(raw + jp) != LZ4FMT_MAGICNUMBER ||
-			    !(flen = lz4_frame_extent(raw + jp, n - jp, &bound, &supported)) || !supported ||
-			    flen > 0xFFFFFFF0u || bound > 0x7FFFFFFFull) {
+			    !(flen = lz4_frame_extent(raw + jp, n - jp, &bound, &supported)) || flen == EXTENT_INVALID ||
+			    !supported || flen > 0xFFFFFFF0u || bound > 0x7FFFFFFFull) {
 				err = ERROR(compression_library);
 				break;
 			}

@@ -396,6 +396,9 @@ static size_t d_read_header(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, uint32_t *csize
 	return 0;
 }
 
+/* 0 = not complete yet, EXTENT_INVALID = cannot become a frame (reserved bit, reserved block type, block larger
+ * than the format allows): see lz4mt_engine.c */
+#define EXTENT_INVALID ((size_t)-1)
 static size_t zstd_frame_extent(const uint8_t *p, size_t n, uint64_t *bound, int *sized);
 
 static size_t d_read_batch(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s, int *eof)
@@ -467,7 +470,8 @@ static size_t d_read_batch(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s,
 			 * headers bound the content; the decoder replaces the capacity by the size. */
 			uint64_t bound = 0;
 			int sized = 0;
-			if (!zstd_frame_extent(rec + 12, csize, &bound, &sized) || sized) {
+			const size_t fl = zstd_frame_extent(rec + 12, csize, &bound, &sized);
+			if (!fl || fl == EXTENT_INVALID || sized) {
 				zstdmt_errcode = GPUMT_ST_BAD_FRAME;
 				return ZSTDCB_ERROR(compression_library);
 			}
@@ -593,7 +597,9 @@ static size_t zstd_frame_extent(const uint8_t *p, size_t n, uint64_t *bound, int
 	const unsigned did_len = did == 3 ? 4 : did, fcs_len = fcs == 0 ? single : 1u << fcs;
 	size_t hp = 5;
 	uint64_t window = 0, content = 0, sum = 0;
-	if ((fhd & 8) || n < 5 + (1 - single) + did_len + fcs_len)
+	if (fhd & 8)
+		return EXTENT_INVALID; /* reserved bit */
+	if (n < 5 + (1 - single) + did_len + fcs_len)
 		return 0;
 	if (!single) {
 		const unsigned wd = p[hp++];
@@ -615,8 +621,8 @@ static size_t zstd_frame_extent(const uint8_t *p, size_t n, uint64_t *bound, int
 		const uint32_t bh = (uint32_t)p[hp] | (uint32_t)p[hp + 1] << 8 | (uint32_t)p[hp + 2] << 16;
 		const uint32_t last = bh & 1, type = (bh >> 1) & 3, bsize = bh >> 3;
 		hp += 3;
-		if (type == 3)
-			return 0;
+		if (type == 3 || (type != 1 && bsize > 131072u))
+			return EXTENT_INVALID; /* reserved block type; Block_Maximum_Size is 128 KiB at most (RFC 8878 3.1.1.2.4) */
 		if (type == 1) { /* RLE: one byte regenerates bsize */
 			if (n - hp < 1)
 				return 0;
@@ -743,13 +749,15 @@ static size_t plain_decompress(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, const uint8_
 				jp += sk;
 				continue;
 			}
-			if (!eof && (n - jp < 8 || (rd32(raw + jp) == ZSTDCB_MAGICNUMBER_MAX &&
-						   !zstd_frame_extent(raw + jp, n - jp, &bound, &sized)))) {
-				need_more = 1; /* an incomplete frame (or a damaged one: the end of the input will tell) */
+			if (!eof && n - jp <= 0xFFFFFFF0u &&
+			    (n - jp < 8 || (rd32(raw + jp) == ZSTDCB_MAGICNUMBER_MAX &&
+					    !zstd_frame_extent(raw + jp, n - jp, &bound, &sized)))) {
+				need_more = 1; /* an incomplete frame: wait for the rest (a damaged one is EXTENT_INVALID, below) */
 				break;
 			}
 			if (n - jp < 4 || rd32(raw + jp) != ZSTDCB_MAGICNUMBER_MAX ||
-			    !(flen = zstd_frame_extent(raw + jp, n - jp, &bound, &sized)) || flen > 0xFFFFFFF0u ||
+			    !(flen = zstd_frame_extent(raw + jp, n - jp, &bound, &sized)) || flen == EXTENT_INVALID ||
+			    flen > 0xFFFFFFF0u ||
 			    bound > 0x7FFFFFFFull) {
 				zstdmt_errcode = GPUMT_ST_BAD_FRAME;
 				err = ZSTDCB_ERROR(compression_library);
