@@ -204,7 +204,10 @@ template <u32 WIN, bool PROF = false> struct C3 {
 	}
 
 	/* match of 4..64 bytes at output position mpos whose source -- offset so of the region (sb, sm), see ld64m -- is
-	 * complete and does not overlap it: first and last 8 (or 4) bytes, the middle of the rare long one in 8-byte steps */
+	 * complete and does not overlap it.  Stores are 4-byte pieces placed so that ONE per-lane condition covers all
+	 * lengths up to 16 (every divergent `if` costs this kernel four scalar instructions, and the scalar pipe is what
+	 * it saturates): bytes 0-3 and the last 4 always, bytes 4-7 and the 4 before the last 4 when the match has 8 or
+	 * more; the middle of the rare long one in 8-byte steps */
 	static __device__ __forceinline__ void match(u8 *ring, u32 mpos, u32 ml, const u8 *sb, u32 so, u32 sm)
 	{
 		u8 *const d = ring + (mpos & MASK); /* a batch lies inside one lap: no wrap on the destination side */
@@ -215,14 +218,11 @@ template <u32 WIN, bool PROF = false> struct C3 {
 			for (u32 i = 8; i + 8 < ml; i += 8)
 				c3_st64(d + i, ld64m(sb, so + i, sm));
 		}
+		st32u(d, (u32)a);
+		st32u(d + ml - 4u, wide ? (u32)(b >> 32) : (u32)b);
 		if (wide) {
-			c3_st64(d, a);
-			if (ml > 8u)
-				c3_st64(d + tl, b);
-		} else {
-			st32u(d, (u32)a);
-			if (ml > 4u)
-				st32u(d + tl, (u32)b);
+			st32u(d + 4, (u32)(a >> 32));
+			st32u(d + tl, (u32)b);
 		}
 	}
 
@@ -304,51 +304,53 @@ template <u32 WIN, bool PROF = false> struct C3 {
 				cbi ^= 1u;
 				if (PROF)
 					pc[PROF ? 12 : 0]++;
-				/* ---------- fields of up to 64 sequences, lane = sequence ---------- */
-				const bool have = t0 + (u32)lane < ntok;
+				/* ---------- fields of up to 64 sequences, lane = sequence ----------
+				 * (written for the scalar pipe, which this kernel saturates: per-lane conditions are folded into the values
+				 * that are compared -- a lane that must not pass gets 0xFFFF -- instead of mask algebra on SGPR pairs) */
+				const u32 rem = ntok - t0;
 				const u32 c0 = wv_readlane(q, 0);
 				const u32 al = (u32)((size_t)(src + c0) & 15u);
 				const u32 qr = q - c0 + al; /* this lane's token in the stage */
 				u32 lit, ml, off, lsrc;
-				bool small, hard;
+				u64 sm0, hard_m;
 				{
-					const bool v1 = have & (qr + 12u <= C3_CSTAGE); /* the token's first bytes are staged */
+					const bool v1 = ((u32)lane < rem ? qr : 0xFFFFu) <= C3_CSTAGE - 12u; /* the token's first bytes are staged */
 					const u64 w = c3_ld64s(cb, v1 ? qr : 0u);
 					const u32 wl = (u32)w;
 					const u32 tokb = wl & 255u;
 					const bool lx = (tokb >> 4) == 15u, mx = (tokb & 15u) == 15u;
-					const u32 b1 = (wl >> 8) & 255u;
-					lit = (tokb >> 4) + (lx ? b1 : 0u);
+					lit = (tokb >> 4) + (lx ? (wl >> 8) & 255u : 0u);
 					lsrc = qr + 1u + (lx ? 1u : 0u);
 					const u32 mo = lsrc + lit; /* where the offset sits */
-					const bool v2 = v1 & (mo + 4u <= C3_CSTAGE);
+					const bool v2 = (v1 ? mo : 0xFFFFu) <= C3_CSTAGE - 4u; /* ... and its last ones */
 					const u32 w2 = (u32)c3_ld64s(cb, v2 ? mo : 0u);
-					const u32 b2 = (w2 >> 16) & 255u;
 					off = w2 & 0xFFFFu;
-					ml = (tokb & 15u) + 4u + (mx ? b2 : 0u);
-					const bool is_last = t0 + (u32)lane + 1u == ntok;
-					/* needs the generic path whatever batch it would be in */
-					hard = v1 & ((lx & (b1 == 255u)) | (lit > 64u) | is_last | (v2 & ((mx & (b2 == 255u)) | (ml > 64u))));
-					small = v2 & !hard & (mo + 3u <= C3_CSTAGE);
+					ml = (tokb & 15u) + 4u + (mx ? (w2 >> 16) & 255u : 0u);
+					/* a 255 length byte makes the run 270 / 274: "above 64" covers it; the block's last sequence counts as big */
+					const u32 big = (u32)lane + 1u == rem ? 0xFFFFu : (lit > (v2 ? ml : 0u) ? lit : (v2 ? ml : 0u));
+					sm0 = wv_ballot((v2 ? big : 0xFFFFu) <= 64u);  /* small: fully staged, no run above 64, not the last */
+					hard_m = wv_ballot((v1 ? big : 0u) > 64u);      /* needs the generic path whatever batch it would be in */
 				}
 				C3PC(2);
 				/* ---------- cut: the run of small sequences, then output positions, then span and lap ---------- */
-				const u64 sm0 = wv_ballot(small);
 				const u32 n0 = ~sm0 ? (u32)wv_ffs(~sm0) - 1u : 64u;
-				const u32 len = (u32)lane < n0 ? lit + ml : 0u;
+				const bool in_run = (u32)lane < n0;
+				const u32 len = in_run ? lit + ml : 0u;
 				const u32 incl = wv_scan_incl(len);
 				const u32 o0 = st.opos;
 				const u32 op = o0 + incl - len;
 				const u32 lap_end = (o0 | MASK) + 1u;
 				const u32 olim = o0 + C3_XOUT < lap_end ? o0 + C3_XOUT : lap_end;
-				const u64 fit = wv_ballot(((u32)lane < n0) & (op + len <= olim));
+				const u64 fit = wv_ballot((in_run ? op + len : 0xFFFFFFFFu) <= olim);
 				const u32 n = ~fit ? (u32)wv_ffs(~fit) - 1u : 64u; /* (the conditions are monotone in the lane) */
 				/* the sequence behind the run is executed generically if it is "hard", or if it is small but crosses the
 				 * lap boundary on its own (it could not open a batch either) */
-				const u64 hard_m = wv_ballot(hard);
-				const u64 cross_m = wv_ballot(((u32)lane < n0) & (op < lap_end) & (op + len > lap_end));
-				const bool single = n < 64u && (((hard_m | cross_m) >> n) & 1u) != 0;
-				const bool single_hard = n < 64u && ((hard_m >> n) & 1u) != 0;
+				bool single = false, single_hard = false;
+				if (n < 64u) {
+					single_hard = (hard_m >> n) & 1u;
+					const u32 op_n = wv_readlane(op, (int)n), len_n = wv_readlane(len, (int)n);
+					single = single_hard | (((sm0 >> n) & 1u) && op_n < lap_end && op_n + len_n > lap_end);
+				}
 				const u32 lit_r = lit, ml_r = ml, off_r = off; /* (lane n's are the fields of a lap-crosser behind the run) */
 				const bool act = (u32)lane < n;
 				if (!act) {
@@ -417,12 +419,12 @@ template <u32 WIN, bool PROF = false> struct C3 {
 						C3PC(4);
 						/* ---- literals: only lanes that have some; 4-byte piece for 1..4, 8-byte pieces above ---- */
 						if (act & (lit != 0)) {
+							/* 4-byte pieces; a piece may spill <= 3 bytes into the lane's own match, written below */
 							u8 *const dl = ring + (op & MASK);
 							const u64 a = c3_ld64s(cb, lsrc);
-							if (lit <= 4u) {
-								st32u(dl, (u32)a); /* may spill <= 3 bytes into the lane's own match, written below */
-							} else {
-								c3_st64(dl, a);
+							st32u(dl, (u32)a);
+							if (lit > 4u) {
+								st32u(dl + 4, (u32)(a >> 32));
 								if (lit > 8u) {
 									c3_st64(dl + lit - 8u, c3_ld64s(cb, lsrc + lit - 8u));
 									for (u32 i = 8; i + 8 < lit; i += 8)
@@ -470,13 +472,14 @@ template <u32 WIN, bool PROF = false> struct C3 {
 								pc[PROF ? 13 : 0]++;
 							const u32 first = (u32)wv_ffs(unf) - 1;
 							const u32 W = wv_readlane(mpos, (int)first);
-							if (!fin & (src_pos + eff <= W)) {
-								if (ovl)
+							const bool go = !fin & (src_pos + eff <= W);
+							if (go & !ovl)
+								match(ring, mpos, ml, ring, src_pos, MASK);
+							if (wv_any(go & ovl)) { /* (offset < length: 0.2 % of the matches) */
+								if (go & ovl)
 									match_ovl(ring, mpos, off, ml);
-								else
-									match(ring, mpos, ml, ring, src_pos, MASK);
-								fin = true;
 							}
+							fin = fin | go;
 							wv_sync();
 						}
 						C3PC(8);
