@@ -57,6 +57,23 @@
 	} while (0)
 
 static __device__ __forceinline__ void c3_st64(u8 *p, u64 v) { __builtin_memcpy(p, &v, 8); }
+/* four bytes at any LDS address as four byte stores.  tools/ubench/lds_cost.hip: an LDS access that is not dword
+ * aligned costs the pipe one cycle per ACTIVE lane (64 for a full wave), a byte store 4.6 cycles per wave
+ * instruction at any address -- so where most lanes store, four byte stores (18 cycles) beat one ds_write_b32 */
+static __device__ __forceinline__ void c3_st32b(u8 *p, u32 v)
+{
+	/* (volatile: the compiler would merge them back into one unaligned ds_write_b32; the LDS address space is
+	 * spelled out because a volatile access through a generic pointer becomes a flat_store) */
+#ifdef ZMT_EMU
+	volatile u8 *const q = p;
+#else
+	volatile __attribute__((address_space(3))) u8 *const q = (volatile __attribute__((address_space(3))) u8 *)p;
+#endif
+	q[0] = (u8)v;
+	q[1] = (u8)(v >> 8);
+	q[2] = (u8)(v >> 16);
+	q[3] = (u8)(v >> 24);
+}
 static __device__ __forceinline__ u64 c3_tok_base(u64 coff, u32 gb) { return ((coff / 3) & ~63ull) + 128ull * gb; }
 /* (the 8-byte loads of sources before the ring fetch a whole 128-byte line each; nt / sc0 / sc1 policy bits on
  * the load do not change the request size -- profiles/r03_sweeps/far_load_cache_policy.txt -- so they are plain) */
@@ -208,7 +225,7 @@ template <u32 WIN, bool PROF = false> struct C3 {
 	 * lengths up to 16 (every divergent `if` costs this kernel four scalar instructions, and the scalar pipe is what
 	 * it saturates): bytes 0-3 and the last 4 always, bytes 4-7 and the 4 before the last 4 when the match has 8 or
 	 * more; the middle of the rare long one in 8-byte steps */
-	static __device__ __forceinline__ void match(u8 *ring, u32 mpos, u32 ml, const u8 *sb, u32 so, u32 sm)
+	template <bool BYTES> static __device__ __forceinline__ void match(u8 *ring, u32 mpos, u32 ml, const u8 *sb, u32 so, u32 sm)
 	{
 		u8 *const d = ring + (mpos & MASK); /* a batch lies inside one lap: no wrap on the destination side */
 		const bool wide = ml >= 8u;
@@ -218,11 +235,20 @@ template <u32 WIN, bool PROF = false> struct C3 {
 			for (u32 i = 8; i + 8 < ml; i += 8)
 				c3_st64(d + i, ld64m(sb, so + i, sm));
 		}
-		st32u(d, (u32)a);
-		st32u(d + ml - 4u, wide ? (u32)(b >> 32) : (u32)b);
-		if (wide) {
-			st32u(d + 4, (u32)(a >> 32));
-			st32u(d + tl, (u32)b);
+		if (BYTES) { /* the pass most lanes take */
+			c3_st32b(d, (u32)a);
+			c3_st32b(d + ml - 4u, wide ? (u32)(b >> 32) : (u32)b);
+			if (wide) {
+				c3_st32b(d + 4, (u32)(a >> 32));
+				c3_st32b(d + tl, (u32)b);
+			}
+		} else {
+			st32u(d, (u32)a);
+			st32u(d + ml - 4u, wide ? (u32)(b >> 32) : (u32)b);
+			if (wide) {
+				st32u(d + 4, (u32)(a >> 32));
+				st32u(d + tl, (u32)b);
+			}
 		}
 	}
 
@@ -422,9 +448,9 @@ template <u32 WIN, bool PROF = false> struct C3 {
 							/* 4-byte pieces; a piece may spill <= 3 bytes into the lane's own match, written below */
 							u8 *const dl = ring + (op & MASK);
 							const u64 a = c3_ld64s(cb, lsrc);
-							st32u(dl, (u32)a);
+							c3_st32b(dl, (u32)a);
 							if (lit > 4u) {
-								st32u(dl + 4, (u32)(a >> 32));
+								c3_st32b(dl + 4, (u32)(a >> 32));
 								if (lit > 8u) {
 									c3_st64(dl + lit - 8u, c3_ld64s(cb, lsrc + lit - 8u));
 									for (u32 i = 8; i + 8 < lit; i += 8)
@@ -458,7 +484,7 @@ template <u32 WIN, bool PROF = false> struct C3 {
 							const bool r1 = !fin & (is_far | (src_pos + eff <= o0)) & !ovl;
 							if (r1) {
 								const u8 *const sb = is_far ? cb + 16u * (u32)lane : ring;
-								match(ring, mpos, (is_far && ml > 16u) ? 16u : ml, sb, is_far ? 0u : src_pos, is_far ? ~0u : MASK);
+								match<true>(ring, mpos, (is_far && ml > 16u) ? 16u : ml, sb, is_far ? 0u : src_pos, is_far ? ~0u : MASK);
 								fin = true;
 							}
 						}
@@ -474,7 +500,7 @@ template <u32 WIN, bool PROF = false> struct C3 {
 							const u32 W = wv_readlane(mpos, (int)first);
 							const bool go = !fin & (src_pos + eff <= W);
 							if (go & !ovl)
-								match(ring, mpos, ml, ring, src_pos, MASK);
+								match<false>(ring, mpos, ml, ring, src_pos, MASK);
 							if (wv_any(go & ovl)) { /* (offset < length: 0.2 % of the matches) */
 								if (go & ovl)
 									match_ovl(ring, mpos, off, ml);
