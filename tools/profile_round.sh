@@ -2,9 +2,8 @@
 # Runs ON THE GPU BOX (through gpurun): the default bench line, the rocprofv3 kernel-trace summary of the
 # same command, and the two separate PMC passes (FETCH_SIZE, WRITE_SIZE).  Everything lands under
 # gpurun_out/; tools/pmc_summarize.py turns it into the files committed under profiles/.
-#   gpurun --timeout 900 -- 'bash tools/profile_round.sh'            (all three codecs)
-#   gpurun --timeout 400 -- 'bash tools/profile_round.sh zstd'       (one of lz4 | zstd | brotli | snappy;
-#                                                                     snappy is not part of "all")
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh'           (all four codecs)
+#   gpurun --timeout 400 -- 'bash tools/profile_round.sh zstd'       (one of lz4 | zstd | brotli | snappy)
 ONLY=${1:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
@@ -48,7 +47,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_brotli_enc_stats
     python bench.py --only --codec brotli --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_brotli_enc_stats.err
 cat $O/bench_brotli.json
 fi
-if [ $ONLY = snappy ]; then
+if [ $ONLY = all ] || [ $ONLY = snappy ]; then
 # snappy-mt round trip at the default 64 KiB chunk (not a BASELINE config).  SNAPPY_DEC=1 selects
 # the batched decoder
 rm -rf $O/prof_snappy_stats $O/prof_snappy_fetch $O/prof_snappy_write

@@ -24,6 +24,8 @@ __global__ void zmt_lz4_enc3_u16_kernel(const u8 *, u64, u32, u32, u32, u8 *, u6
 					unsigned long long *);
 __global__ void zmt_lz4_enc3_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
 					unsigned long long *);
+__global__ void zmt_lz4_enc3_p17_prof_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
+					     unsigned long long *);
 __global__ void zmt_push_host_kernel(const u8 *, u8 *, u64, const u64 *);
 __global__ void zmt_lz4hc_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *, u8 *, int);
 __global__ void zmt_lz4_enc3_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
@@ -742,7 +744,7 @@ int gpumt_lz4_compress_batch_level(gpumt_ctx *h, const void *d_in, size_t n, siz
 		/* linked-block records; the ragged last record may be <= 64 KiB and then belongs to the
 		 * byU16 kernel (each kernel skips records of the other kind) */
 		if (chunk <= 131072)
-			hipLaunchKernelGGL(zmt_lz4_enc3_p17_kernel, dim3((unsigned)nrec), dim3(64),
+			hipLaunchKernelGGL(eprof ? zmt_lz4_enc3_p17_prof_kernel : zmt_lz4_enc3_p17_kernel, dim3((unsigned)nrec), dim3(64),
 					   (size_t)h->xflags /* developer: dynamic-LDS padding = occupancy knob */, h->st[s],
 					   (const u8 *)d_in, (u64)n, (u32)chunk, 0u, (u32)nrec, (u8 *)d_slots,
 					   (u64)slot_stride, d_rec_len, (const u32 *)chk, eprof);

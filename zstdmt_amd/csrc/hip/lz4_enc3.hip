@@ -129,12 +129,12 @@ struct InRing {
 	u32 limit;   /* never load at or beyond this chunk position (readable bytes of the input) */
 	u8 *mwin;    /* 128-byte window of the match side: mwin[i] = chunk[mbase + i] */
 	u32 mbase;
-	u64 pc[8];   /* phase cycle counters (profiling build of the kernel only) */
+	u64 pc[8];   /* phase cycle counters: only the _prof instantiation of the kernel touches them (a run-time
+	              * flag cost every sequence eight scalar compare + branch pairs and 18 SGPRs) */
 	u64 tq;
-	bool prof;
 };
 #ifndef ZMT_EMU
-#define EPC(R, i) do { if ((R).prof) { u64 t_ = (u64)clock64(); (R).pc[i] += t_ - (R).tq; (R).tq = t_; } } while (0)
+#define EPC(R, i) do { if (PROF) { u64 t_ = (u64)clock64(); (R).pc[i] += t_ - (R).tq; (R).tq = t_; } } while (0)
 #else
 #define EPC(R, i) do { } while (0)
 #endif
@@ -143,29 +143,37 @@ struct InRing {
 static __device__ __forceinline__ void ring_want(InRing &R, u32 pos, int lane)
 {
 	const u32 want_hi = pos + IAHEAD;
+	R.rhi = wv_readfirst(R.rhi); /* wave-uniform by construction; said so that the tests below are scalar */
+	R.rlo = wv_readfirst(R.rlo);
+	if (want_hi <= R.rhi) /* the common case first: one scalar compare */
+		return;
 	if (want_hi > R.rhi + 2 * IRING) {
 		/* far jump (long literal run): restart the ring at the new position */
 		R.rhi = pos & ~(IPIECE - 1);
 		R.rlo = R.rhi;
 	}
-	while (R.rhi < want_hi && R.rhi < R.limit) {
-		const u32 p = R.rhi + 8u * (u32)lane;
-		u64 a = 0;
-		if (p + 8 <= R.limit) {
-			a = ld64u(R.chunk + p);
-		} else {
-			for (u32 k = 0; k < 8; k++)
-				if (p + k < R.limit)
-					a |= (u64)R.chunk[p + k] << (8 * k);
-		}
+	/* (the piece count is fixed before the loop and the tail is read without a per-lane branch: with the exit test
+	 * inside, the compiler threaded the lanes' `p + 8 <= limit` into the loop exit, which made rhi -- and with it
+	 * every test on the ring's state in the encoder -- lane-varying: exec-mask code around each of them) */
+	const u32 stop = want_hi < R.limit ? want_hi : R.limit;
+	const u32 npiece = stop > R.rhi ? (stop - R.rhi + IPIECE - 1) / IPIECE : 0;
+	u32 rhi = R.rhi;
+	for (u32 k = 0; k < npiece; k++) {
+		const u32 p = rhi + 8u * (u32)lane;
+		/* limit >= 8: a lane whose 8 bytes cross the limit reads the last 8 readable ones and shifts */
+		const u32 pp = p + 8 <= R.limit ? p : R.limit - 8;
+		const u32 sh = p - pp;
+		u64 a = ld64u(R.chunk + pp);
+		a = sh < 8 ? a >> (8 * (sh & 7)) : 0;
 		wv_sync();
 		u8 *d = R.ring + (p & (IRING - 1));
 		*(u64 *)d = a;
 		if ((p & (IRING - 1)) < IMIRROR) /* mirror: multi-byte reads never wrap */
 			*(u64 *)(d + IRING) = a;
 		wv_sync();
-		R.rhi += IPIECE;
+		rhi += IPIECE;
 	}
+	R.rhi = rhi;
 }
 /* is chunk[p .. p+n) readable from the ring? (n <= IMIRROR beyond a wrap) */
 static __device__ __forceinline__ bool ring_has(const InRing &R, u32 p, u32 n)
@@ -237,7 +245,7 @@ static __device__ __forceinline__ void copy_literals(const InRing &R, u8 *d, u32
 	}
 }
 
-template <int TM>
+template <int TM, bool PROF>
 static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, u32 pos, u32 len, u8 *dst,
 				    u32 cap, int lane)
 {
@@ -323,7 +331,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						t_write<TM>(tlo, thi, h, cur);
 					wv_sync();
 					EPC(R, 1);
-					if (R.prof) R.pc[6] += 1;
+					if (PROF) R.pc[6] += 1;
 					if (mm) {
 						ip = wv_readlane(cur, (int)jstar);
 						match = wv_readlane(cand, (int)jstar);
@@ -534,7 +542,7 @@ last_literals:
 	return op;
 }
 
-template <int TM>
+template <int TM, bool PROF>
 static __device__ __forceinline__ void enc3_body(u32 *tlo, u32 *thi, u32 *bitmap, u8 *ring, u8 *mwin,
 						  const u8 *__restrict__ in, u64 n, u32 chunk, u32 rec0, u32 nrec,
 						  u8 *__restrict__ slots, u64 slot_stride,
@@ -588,19 +596,20 @@ static __device__ __forceinline__ void enc3_body(u32 *tlo, u32 *thi, u32 *bitmap
 	R.chunk = src;
 	R.rhi = 0;
 	R.rlo = 0;
-	R.prof = prof != nullptr;
 	for (int i = 0; i < 8; i++)
 		R.pc[i] = 0;
 #ifndef ZMT_EMU
-	R.tq = R.prof ? (u64)clock64() : 0;
+	R.tq = PROF ? (u64)clock64() : 0;
 	const u64 t_begin = R.tq;
+#else
+	R.tq = 0;
 #endif
 	/* the input buffer carries >= 8 readable bytes after its end (hash reads); never go further */
 	R.limit = (u32)((n - start) < (u64)chunk + 8 ? (n - start) + 8 : (u64)chunk + 8);
 
 	for (u32 pos = 0; pos < len; pos += ZMT_BLOCK) {
 		u32 blen = len - pos < ZMT_BLOCK ? len - pos : ZMT_BLOCK;
-		u32 c = encode_block3<TM>(tlo, thi, bitmap, R, pos, blen, dst + op + 4, blen - 1, lane);
+		u32 c = encode_block3<TM, PROF>(tlo, thi, bitmap, R, pos, blen, dst + op + 4, blen - 1, lane);
 		u32 bh = c;
 		if (c == 0) {
 			wv_sync(); /* every lane's stores of the attempt lie behind it before the same bytes are rewritten */
@@ -619,7 +628,7 @@ static __device__ __forceinline__ void enc3_body(u32 *tlo, u32 *thi, u32 *bitmap
 		rec_len[rec] = op + 8;
 	}
 #ifndef ZMT_EMU
-	if (R.prof && lane == 0) {
+	if (PROF && lane == 0) {
 		for (int i = 0; i < 8; i++)
 			atomicAdd(prof + i, (unsigned long long)R.pc[i]);
 		atomicAdd(prof + 8, (unsigned long long)((u64)clock64() - t_begin));
@@ -628,7 +637,7 @@ static __device__ __forceinline__ void enc3_body(u32 *tlo, u32 *thi, u32 *bitmap
 #endif
 }
 
-#define ENC3_KERNEL(NAME, TM, TABBYTES)                                                            \
+#define ENC3_KERNEL(NAME, TM, TABBYTES, PROFILE)                                                  \
 	extern "C" __global__ void __launch_bounds__(64)                                            \
 	NAME(const u8 *__restrict__ in, u64 n, u32 chunk, u32 rec0, u32 nrec,                       \
 	     u8 *__restrict__ slots, u64 slot_stride, u32 *__restrict__ rec_len,                   \
@@ -639,10 +648,14 @@ static __device__ __forceinline__ void enc3_body(u32 *tlo, u32 *thi, u32 *bitmap
 		__shared__ u32 bitmap[BM_BITS / 32];                                               \
 		__shared__ __attribute__((aligned(16))) u8 ring[IRING + IMIRROR];                  \
 		__shared__ __attribute__((aligned(16))) u8 mwin[MWIN + 16];                        \
-		enc3_body<TM>(tlo, thi, bitmap, ring, mwin, in, n, chunk, rec0, nrec, slots,       \
+		enc3_body<TM, PROFILE>(tlo, thi, bitmap, ring, mwin, in, n, chunk, rec0, nrec, slots, \
 			      slot_stride, rec_len, chk, prof);                                                     \
 	}
 
-ENC3_KERNEL(zmt_lz4_enc3_u16_kernel, T_U16, 16384)
-ENC3_KERNEL(zmt_lz4_enc3_p17_kernel, T_P17, 8192)
-ENC3_KERNEL(zmt_lz4_enc3_u32_kernel, T_U32, 16384)
+ENC3_KERNEL(zmt_lz4_enc3_u16_kernel, T_U16, 16384, false)
+ENC3_KERNEL(zmt_lz4_enc3_p17_kernel, T_P17, 8192, false)
+ENC3_KERNEL(zmt_lz4_enc3_u32_kernel, T_U32, 16384, false)
+#ifndef ZMT_EMU
+/* developer: the same kernel with the phase counters (gpumt_set_variant("profile", 9), tools/enc_prof.py) */
+ENC3_KERNEL(zmt_lz4_enc3_p17_prof_kernel, T_P17, 8192, true)
+#endif
