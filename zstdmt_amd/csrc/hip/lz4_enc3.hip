@@ -41,7 +41,7 @@
  * (catch-up compares 64 bytes backwards, the re-match step reads ip - 2) */
 #define IAHEAD (IRING >= 2048u ? 512u : 256u)
 static_assert(IRING >= IAHEAD + IPIECE + 64u, "the input ring must keep 64 bytes of history");
-#define IMIRROR 16u
+#define IMIRROR 32u /* the search reads 24 bytes from one wrapped address */
 /* uniform branches are what a single wave pays most for: keep the common path falling through */
 #define E_RARE(c) __builtin_expect(!!(c), 0)
 
@@ -255,7 +255,11 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 	const u32 matchlimit = iend - LASTLITERALS;
 	const u32 low = (TM == T_U16) ? pos : 0;
 	u32 ip = pos, anchor = pos, op = 0;
-	u32 match = 0, token = 0, tokhi = 0;
+	/* 1 after a match: the search opens with the reference's immediate re-match probe at ip.  That test is a
+	 * probe like the others (look T[h(ip)] up, insert ip, compare 4 bytes), the search it falls into when it
+	 * fails continues at ip + 1, ip + 2, ... -- so it rides in lane 0 of the search's first batch and the two
+	 * memory round trips (its candidate, the first batch's candidates) become one */
+	u32 rmode = 0;
 
 	if (len < MFLIMIT + 1)
 		goto last_literals;
@@ -269,29 +273,65 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 	ip++;
 
 	for (;;) {
+		u32 match = 0;
+		u32 quick = 0; /* bit 31: catch-up and match length settled from the batch's own loads; back << 8 | fwd */
 		/* ---------------- search ---------------- */
 		{
-			const u32 ip0 = ip;
+			const u32 ipr = ip;          /* position of the re-match probe (rmode) */
+			const u32 ip0 = ip + rmode;  /* probe k of the reference's search loop is at probe_pos3(ip0, k) */
 			bool found = false;
-			u32 kbase = 0, bsz = 16;
+			u32 kbase = 0, bsz = 16 + rmode, r = rmode;
 			for (u32 batch = 0;; batch++) {
-				u32 gap;
-				const u32 cur = probe_pos3(ip0, kbase + (u32)lane, &gap);
-				const bool valid = (u32)lane < bsz && cur + gap <= mflimit_p1;
-				const u32 cur0 = wv_readlane(cur, 0); /* first probe of the batch */
+				/* probes k <= 64 are consecutive positions (wave-uniform test: no divergent schedule arithmetic) */
+				const bool consec = kbase + bsz - r <= 65;
+				u32 gap = 1;
+				u32 cur = ip0 + kbase + (u32)lane - r;
+				if (E_RARE(!consec))
+					cur = probe_pos3(ip0, kbase + (u32)lane - r, &gap);
+				bool valid = (u32)lane < bsz && cur + gap <= mflimit_p1;
+				/* T[h(ip - 2)] = ip - 2 precedes the re-match lookup: an idle lane hashes it with the batch */
+				const bool ins2 = (r != 0) & (lane == 63);
+				if (r) {
+					if (lane == 0) {
+						cur = ipr;
+						valid = true; /* ipr < mflimit + 1: checked when the match before it ended */
+					}
+					if (lane == 63)
+						cur = ipr - 2;
+				}
+				const u32 cur0 = wv_readlane(cur, 0); /* first (lowest) probe of the batch */
 				const u64 vm = wv_ballot(valid);
 				if (E_RARE(vm == 0))
 					goto last_literals;
 				EPC(R, 7);
 				ring_want(R, cur0, lane);
-				/* the first 65 probes are consecutive positions: all inside the piece ring_want just made
-				 * resident, no per-lane residency test */
-				const u64 x = !valid ? 0 : (kbase + bsz <= 65) ? ld64u(R.ring + (cur & (IRING - 1))) : in_ld64(R, cur);
+				/* consecutive probes lie inside the piece ring_want just made resident: no per-lane residency
+				 * test, every lane reads (ip - 2 too unless the ring was restarted just there) */
+				const bool fastx = consec & ((r == 0) | (ipr >= R.rlo + 2));
+				/* the probe's neighbourhood [cur - 8, cur + 16): x = 8 bytes at cur for the hash, xb / x1 in front
+				 * and behind for the quick extension.  Seven ALIGNED dwords + funnel shifts: an LDS access that
+				 * is not dword aligned costs the CU's LDS pipe a cycle per active lane (tools/ubench/lds_cost.hip),
+				 * and 16 chunk-waves share that pipe */
+				u64 x, xb = 0, x1 = 0;
+				if (fastx) {
+					const u32 pb = cur - 8;
+					const u32 *const w = (const u32 *)(R.ring + (pb & (IRING - 1) & ~3u)); /* + 28 <= IRING + IMIRROR */
+					const u32 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6];
+					xb = (u64)wv_alignbyte(w1, w0, pb) | (u64)wv_alignbyte(w2, w1, pb) << 32;
+					x = (u64)wv_alignbyte(w3, w2, pb) | (u64)wv_alignbyte(w4, w3, pb) << 32;
+					x1 = (u64)wv_alignbyte(w5, w4, pb) | (u64)wv_alignbyte(w6, w5, pb) << 32;
+				} else {
+					x = (valid | ins2) ? in_ld64(R, cur) : 0;
+				}
 				const u32 h = hash3<TM>(TM == T_U16 ? (u64)(u32)x : x);
+				if (ins2)
+					t_write<TM>(tlo, thi, h, cur);
 				wv_sync();
-				u32 cand = valid ? t_read<TM>(tlo, thi, h) : 0;
+				u32 cand = t_read<TM>(tlo, thi, h); /* (idle lanes read too: no exec-mask region) */
 				u32 prev_dup = 64, next_dup = 64;
 				{
+					/* in-batch duplicates of a hash: every probe sets its bit of the folded filter (only the
+					 * probes: an LDS atomic costs by active lanes) */
 					bool d = false;
 					if (valid)
 						d = (lds_or(&bitmap[(h & (BM_BITS - 1)) >> 5], 1u << (h & 31)) >> (h & 31)) & 1;
@@ -314,15 +354,23 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				}
 				{
 					const u32 pc = wv_shfl(cur, (int)(prev_dup & 63));
-					const u32 p4 = wv_shfl((u32)x, (int)(prev_dup & 63));
 					if (prev_dup < 64)
-						cand = pc;
+						cand = pc; /* an earlier probe of this batch had put its position there */
 					const bool dist_ok = (TM == T_U16) || cand + DIST_MAX >= cur;
 					EPC(R, 0);
-					u32 c4 = p4;
-					if (valid && dist_ok && prev_dup == 64) /* recent candidates come from the ring */
-						c4 = ring_has(R, cand, 4) ? ld32u(R.ring + (cand & (IRING - 1))) : ld32u(chunk + cand);
-					const bool m = valid && dist_ok && c4 == (u32)x;
+					/* the candidate's neighbourhood [cand - 8, cand + 16) in one go -- from the ring when it is
+					 * recent, else from memory --: the 4-byte test, and for most matches all that catch-up and
+					 * the match length need, so that the 128-byte window (a second round trip) is the exception.
+					 * Lanes without a candidate read the ring's first bytes (no exec-mask region) */
+					const bool probe = valid && dist_ok;
+					const bool wide = cand >= 8; /* else (chunk start) 8 bytes at cand only, no quick extension */
+					const u32 a0 = wide ? cand - 8 : cand;
+					const u8 *gp = ring_has(R, a0, wide ? 24u : 8u) ? R.ring + (a0 & (IRING - 1)) : chunk + a0;
+					if (!probe)
+						gp = R.ring;
+					const u64 l0 = ld64u(gp), l1 = ld64u(wide ? gp + 8 : gp), l2 = ld64u(wide ? gp + 16 : gp);
+					const u64 g0 = l0, g1 = wide ? l1 : l0, g2 = l2;
+					const bool m = probe && (u32)g1 == (u32)x;
 					const u64 mm = wv_ballot(m);
 					const u32 nvalid = (u32)wv_popc(vm);
 					const u32 jstar = mm ? (u32)wv_ffs(mm) - 1 : 64;
@@ -333,28 +381,56 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					EPC(R, 1);
 					if (PROF) R.pc[6] += 1;
 					if (mm) {
+						/* every lane works its own extension out (a handful of VALU steps, no branch); the
+						 * winner's is taken.  fwd: equal bytes after the 4, 12 looked at; back: equal bytes in
+						 * front, 8 looked at.  Settled when a difference (or the limit) lies inside them */
+						const u32 room_ip = cur - anchor, room_m = cand - low;
+						const u32 nb = room_ip < room_m ? room_ip : room_m;
+						const u32 flimit = matchlimit - (cur + MINMATCH);
+						const u64 df = ((x >> 32) | (x1 << 32)) ^ ((g1 >> 32) | (g2 << 32));
+						const u32 d2 = (u32)(x1 >> 32) ^ (u32)(g2 >> 32);
+						/* (operands made non-zero so that both sides of the selects are plain VALU, no branch) */
+						u32 eqf = df ? (u32)__builtin_ctzll(df | 1ull << 63) >> 3
+							     : 8u + ((u32)__builtin_ctzll((u64)d2 | 1ull << 32) >> 3);
+						const bool fdec = eqf < 12u || flimit <= 12u;
+						if (eqf > flimit)
+							eqf = flimit;
+						const u64 db = xb ^ g0;
+						u32 eqb = db ? (u32)__builtin_clzll(db | 1ull) >> 3 : 8u;
+						const bool bdec = nb == 0 || eqb < 8u || nb <= 8u;
+						if (eqb > nb)
+							eqb = nb;
+						const bool qok = fastx && wide && cur0 >= R.rlo + 8 && fdec && bdec;
+						const u32 qi = qok ? 0x80000000u | eqb << 8 | eqf : 0u;
 						ip = wv_readlane(cur, (int)jstar);
 						match = wv_readlane(cand, (int)jstar);
+						quick = wv_readlane(qi, (int)jstar);
 						found = true;
 						break;
 					}
 					if (E_RARE(nvalid < bsz))
 						goto last_literals;
 				}
-				kbase += bsz;
+				kbase += bsz - r;
+				r = 0;
 				bsz = (batch == 0) ? 16 : (batch == 1 ? 32 : 64);
 			}
 			if (!found)
 				goto last_literals;
 		}
-		/* ---------------- extend the match both ways in one step ----------------
-		 * The match side is readable from LDS either way: from the input ring when the candidate
-		 * is recent, else from the 128-byte window fetched from global memory.  Backward
-		 * (catch-up) and forward (match length) compares are independent -- the forward count
-		 * from the probe position is the same whatever the catch-up finds -- so both LDS reads
-		 * are in flight together. */
+		/* ---------------- extend the match both ways ----------------
+		 * Usually settled by the search batch's own loads (`quick`).  Else: the match side is made readable
+		 * from LDS -- the input ring when the candidate is recent, else a 128-byte window fetched from memory
+		 * --, backward (catch-up) and forward (match length) compares are independent -- the forward count
+		 * from the probe position is the same whatever the catch-up finds -- so both LDS reads are in flight
+		 * together. */
 		u32 fwd; /* equal bytes following the 4 that matched at ip */
-		{
+		if (quick >> 31) {
+			const u32 back = (quick >> 8) & 0xFFu;
+			fwd = (quick & 0xFFu) + back;
+			ip -= back;
+			match -= back;
+		} else {
 			ring_want(R, ip, lane); /* [ip, ip + 68) resident whatever the probe spacing was */
 			mside_prepare(R, match, lane);
 			u32 room = ip - anchor;
@@ -426,19 +502,20 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			fwd += back;
 		}
 		EPC(R, 2);
+		u32 token;
 		{
-			u32 lit = ip - anchor;
+			const u32 lit = ip - anchor;
 			token = op++;
 			if (E_RARE(op + lit + (2 + 1 + LASTLITERALS) + lit / 255 > cap))
 				return 0;
-			tokhi = (lit >= 15 ? 15u : lit) << 4;
+			const u32 tokhi = (lit >= 15 ? 15u : lit) << 4;
 			if (E_RARE(lit >= 15))
 				op += put_len_ext3(dst + op, lit - 15, lane);
-			copy_literals(R, dst + op, anchor, lit, lane);
+			if (lit)
+				copy_literals(R, dst + op, anchor, lit, lane);
 			op += lit;
-		}
-		EPC(R, 3);
-		for (;;) { /* next_match: ip, match, fwd (= match length - 4) are set */
+			EPC(R, 3);
+			/* the match: offset, token, length bytes */
 			const u32 mc = fwd;
 			if (lane == 0)
 				st16u(dst + op, ip - match);
@@ -452,73 +529,10 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				op += put_len_ext3(dst + op, mc - 15, lane);
 			anchor = ip;
 			EPC(R, 4);
-			if (E_RARE(ip >= mflimit_p1))
-				goto block_done;
-			ring_want(R, ip, lane);
-			{
-				/* T[h(ip-2)] = ip-2, then the immediate re-match test at ip */
-				/* [ip - 2, ip + 8) sits in the ring right after ring_want(ip) unless the ring was
-				 * restarted within the last two bytes (wave-uniform test) */
-				const bool near = ip >= R.rlo + 2;
-				const u64 r2 = near ? ld64u(R.ring + ((ip - 2) & (IRING - 1))) : in_ld64(R, ip - 2);
-				const u64 r0 = near ? ld64u(R.ring + (ip & (IRING - 1))) : in_ld64(R, ip);
-				const u64 x2 = wv_readfirst((u32)r2) | (u64)wv_readfirst((u32)(r2 >> 32)) << 32;
-				const u64 x0 = wv_readfirst((u32)r0) | (u64)wv_readfirst((u32)(r0 >> 32)) << 32;
-				const u32 h2 = hash3<TM>(TM == T_U16 ? (u64)(u32)x2 : x2);
-				const u32 h0 = hash3<TM>(TM == T_U16 ? (u64)(u32)x0 : x0);
-				/* reference order: insert ip-2, look up ip, insert ip.  The lookup is issued first
-				 * (one LDS round trip instead of two); if both hashes collide the entry just
-				 * inserted is the answer */
-				wv_sync();
-				u32 midx = wv_readfirst(t_read<TM>(tlo, thi, h0));
-				if (h2 == h0)
-					midx = ip - 2;
-				wv_sync();
-				if (lane == 0) {
-					t_write<TM>(tlo, thi, h2, ip - 2);
-					t_write<TM>(tlo, thi, h0, ip);
-				}
-				match = midx;
-				bool rm = (TM == T_U16) || midx + DIST_MAX >= ip;
-				if (rm) {
-					/* the 4-byte test and the match count are one compare: equal prefix of
-					 * chunk[ip...] and chunk[match...], 64 bytes per step */
-					mside_prepare(R, match, lane);
-					const u32 lim = matchlimit - ip; /* > 4: ip < mflimit+1 */
-					bool stp = true;
-					if ((u32)lane < lim)
-						stp = in_fwd8(R, ip + (u32)lane) != m_fwd8(R, match + (u32)lane);
-					const u64 sm = wv_ballot(stp);
-					u32 eqn = sm ? (u32)wv_ffs(sm) - 1 : 64;
-					rm = eqn >= MINMATCH;
-					if (E_RARE(rm && !sm)) { /* rare: more than 64 equal bytes */
-						u32 base = 64;
-						for (;;) {
-							ring_want(R, ip + base, lane);
-							const u32 i2 = base + (u32)lane;
-							bool st2 = true;
-							if (i2 < lim)
-								st2 = in_ld8(R, ip + i2) != m_ld8(R, match + i2);
-							const u64 sm2 = wv_ballot(st2);
-							if (sm2) {
-								eqn = base + (u32)wv_ffs(sm2) - 1;
-								break;
-							}
-							base += 64;
-						}
-					}
-					fwd = eqn - MINMATCH;
-				}
-				EPC(R, 5);
-				if (rm) {
-					token = op++;
-					tokhi = 0;
-					continue;
-				}
-			}
-			break;
 		}
-		ip++;
+		if (E_RARE(ip >= mflimit_p1))
+			goto block_done;
+		rmode = 1; /* T[h(ip - 2)] = ip - 2, the re-match test at ip and the search behind it: next batch */
 	}
 block_done:
 last_literals:
