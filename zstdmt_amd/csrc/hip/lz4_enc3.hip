@@ -46,6 +46,12 @@ static_assert(IRING >= IAHEAD + IPIECE + 64u, "the input ring must keep 64 bytes
 #define E_RARE(c) __builtin_expect(!!(c), 0)
 
 enum { T_U16 = 0, T_P17 = 1, T_U32 = 2 };
+#ifdef ZMT_EMU
+#include <assert.h>
+#define E_ASSERT(c) assert(c)
+#else
+#define E_ASSERT(c) do { } while (0)
+#endif
 
 #ifdef ZMT_EMU
 static inline u32 lds_or(u32 *p, u32 v)
@@ -148,8 +154,11 @@ static __device__ __forceinline__ void ring_want(InRing &R, u32 pos, int lane)
 	if (want_hi <= R.rhi) /* the common case first: one scalar compare */
 		return;
 	if (want_hi > R.rhi + 2 * IRING) {
-		/* far jump (long literal run): restart the ring at the new position */
-		R.rhi = pos & ~(IPIECE - 1);
+		/* far jump (long literal run or match): restart the ring one piece in front of the new position, so that
+		 * the invariant of every other call -- [pos - 256, pos + IAHEAD) resident, clipped at the chunk's start
+		 * -- holds here too and the encoder's fast paths need no test on rlo */
+		const u32 b = pos & ~(IPIECE - 1);
+		R.rhi = b >= IPIECE ? b - IPIECE : 0;
 		R.rlo = R.rhi;
 	}
 	/* (the piece count is fixed before the loop and the tail is read without a per-lane branch: with the exit test
@@ -273,47 +282,40 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 	ip++;
 
 	for (;;) {
-		u32 match = 0;
-		u32 quick = 0; /* bit 31: catch-up and match length settled from the batch's own loads; back << 8 | fwd */
+		u32 match;
+		u32 quick; /* bit 31: catch-up and match length settled from the batch's own loads; back << 8 | fwd */
 		/* ---------------- search ---------------- */
 		{
 			const u32 ipr = ip;          /* position of the re-match probe (rmode) */
 			const u32 ip0 = ip + rmode;  /* probe k of the reference's search loop is at probe_pos3(ip0, k) */
-			bool found = false;
 			u32 kbase = 0, bsz = 16 + rmode, r = rmode;
 			for (u32 batch = 0;; batch++) {
-				/* probes k <= 64 are consecutive positions (wave-uniform test: no divergent schedule arithmetic) */
+				/* probes k <= 64 are consecutive positions (wave-uniform test: no divergent schedule arithmetic);
+				 * lane 0 of a batch that opens with the re-match probe is then at ip0 - 1 = ipr by itself */
 				const bool consec = kbase + bsz - r <= 65;
 				u32 gap = 1;
 				u32 cur = ip0 + kbase + (u32)lane - r;
 				if (E_RARE(!consec))
 					cur = probe_pos3(ip0, kbase + (u32)lane - r, &gap);
-				bool valid = (u32)lane < bsz && cur + gap <= mflimit_p1;
+				const bool valid = (u32)lane < bsz && cur + gap <= mflimit_p1;
 				/* T[h(ip - 2)] = ip - 2 precedes the re-match lookup: an idle lane hashes it with the batch */
 				const bool ins2 = (r != 0) & (lane == 63);
-				if (r) {
-					if (lane == 0) {
-						cur = ipr;
-						valid = true; /* ipr < mflimit + 1: checked when the match before it ended */
-					}
-					if (lane == 63)
-						cur = ipr - 2;
-				}
+				if (ins2)
+					cur = ipr - 2;
 				const u32 cur0 = wv_readlane(cur, 0); /* first (lowest) probe of the batch */
 				const u64 vm = wv_ballot(valid);
 				if (E_RARE(vm == 0))
 					goto last_literals;
 				EPC(R, 7);
 				ring_want(R, cur0, lane);
-				/* consecutive probes lie inside the piece ring_want just made resident: no per-lane residency
-				 * test, every lane reads (ip - 2 too unless the ring was restarted just there) */
-				const bool fastx = consec & ((r == 0) | (ipr >= R.rlo + 2));
 				/* the probe's neighbourhood [cur - 8, cur + 16): x = 8 bytes at cur for the hash, xb / x1 in front
-				 * and behind for the quick extension.  Seven ALIGNED dwords + funnel shifts: an LDS access that
-				 * is not dword aligned costs the CU's LDS pipe a cycle per active lane (tools/ubench/lds_cost.hip),
-				 * and 16 chunk-waves share that pipe */
+				 * and behind for the quick extension.  Consecutive probes lie inside what ring_want just made
+				 * resident ([cur0 - 256, cur0 + 256), ip - 2 too): no per-lane residency test, every lane reads.
+				 * Seven ALIGNED dwords + funnel shifts: an LDS access that is not dword aligned costs the CU's
+				 * LDS pipe a cycle per active lane (tools/ubench/lds_cost.hip), and 16 chunk-waves share it */
 				u64 x, xb = 0, x1 = 0;
-				if (fastx) {
+				if (consec) {
+					E_ASSERT(!(valid | ins2) || cur < 8 || ring_has(R, cur - 8, 24));
 					const u32 pb = cur - 8;
 					const u32 *const w = (const u32 *)(R.ring + (pb & (IRING - 1) & ~3u)); /* + 28 <= IRING + IMIRROR */
 					const u32 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6];
@@ -350,12 +352,14 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 									next_dup = i;
 							}
 						}
+						/* an earlier probe of this batch had put its position there (the exchange is an LDS round
+						 * trip: only on this rare path) */
+						const u32 pc = wv_shfl(cur, (int)(prev_dup & 63));
+						if (prev_dup < 64)
+							cand = pc;
 					}
 				}
 				{
-					const u32 pc = wv_shfl(cur, (int)(prev_dup & 63));
-					if (prev_dup < 64)
-						cand = pc; /* an earlier probe of this batch had put its position there */
 					const bool dist_ok = (TM == T_U16) || cand + DIST_MAX >= cur;
 					EPC(R, 0);
 					/* the candidate's neighbourhood [cand - 8, cand + 16) in one go -- from the ring when it is
@@ -372,15 +376,14 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					const u64 g0 = l0, g1 = wide ? l1 : l0, g2 = l2;
 					const bool m = probe && (u32)g1 == (u32)x;
 					const u64 mm = wv_ballot(m);
-					const u32 nvalid = (u32)wv_popc(vm);
-					const u32 jstar = mm ? (u32)wv_ffs(mm) - 1 : 64;
-					const u32 ninsert = mm ? jstar + 1 : nvalid;
-					if ((u32)lane < ninsert && !(next_dup < ninsert))
-						t_write<TM>(tlo, thi, h, cur);
-					wv_sync();
-					EPC(R, 1);
 					if (PROF) R.pc[6] += 1;
 					if (mm) {
+						/* the first probe that verifies is the match; the insertions up to it are committed */
+						const u32 jstar = (u32)wv_ffs(mm) - 1;
+						if ((u32)lane <= jstar && !(next_dup <= jstar))
+							t_write<TM>(tlo, thi, h, cur);
+						wv_sync();
+						EPC(R, 1);
 						/* every lane works its own extension out (a handful of VALU steps, no branch); the
 						 * winner's is taken.  fwd: equal bytes after the 4, 12 looked at; back: equal bytes in
 						 * front, 8 looked at.  Settled when a difference (or the limit) lies inside them */
@@ -389,34 +392,37 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						const u32 flimit = matchlimit - (cur + MINMATCH);
 						const u64 df = ((x >> 32) | (x1 << 32)) ^ ((g1 >> 32) | (g2 << 32));
 						const u32 d2 = (u32)(x1 >> 32) ^ (u32)(g2 >> 32);
-						/* (operands made non-zero so that both sides of the selects are plain VALU, no branch) */
-						u32 eqf = df ? (u32)__builtin_ctzll(df | 1ull << 63) >> 3
-							     : 8u + ((u32)__builtin_ctzll((u64)d2 | 1ull << 32) >> 3);
+						/* equal low bytes of the 96-bit difference d2 : df (ffs - 1 of 0 is the largest u32) */
+						const u32 fbits_lo = (u32)wv_ffs(df) - 1u;
+						const u32 fbits_hi = 64u + (u32)__builtin_ctzll((u64)d2 | 1ull << 32);
+						u32 eqf = (fbits_lo < fbits_hi ? fbits_lo : fbits_hi) >> 3;
 						const bool fdec = eqf < 12u || flimit <= 12u;
 						if (eqf > flimit)
 							eqf = flimit;
 						const u64 db = xb ^ g0;
-						u32 eqb = db ? (u32)__builtin_clzll(db | 1ull) >> 3 : 8u;
+						u32 eqb = ((u32)__builtin_clzll(db | 1ull) + (db == 0)) >> 3; /* equal high bytes */
 						const bool bdec = nb == 0 || eqb < 8u || nb <= 8u;
 						if (eqb > nb)
 							eqb = nb;
-						const bool qok = fastx && wide && cur0 >= R.rlo + 8 && fdec && bdec;
+						const bool qok = consec && wide && cur0 >= 8 && fdec && bdec;
 						const u32 qi = qok ? 0x80000000u | eqb << 8 | eqf : 0u;
 						ip = wv_readlane(cur, (int)jstar);
 						match = wv_readlane(cand, (int)jstar);
 						quick = wv_readlane(qi, (int)jstar);
-						found = true;
 						break;
 					}
-					if (E_RARE(nvalid < bsz))
+					/* no probe verified: all of them are inserted, and an invalid one ends the block */
+					if (valid && next_dup == 64)
+						t_write<TM>(tlo, thi, h, cur);
+					wv_sync();
+					EPC(R, 1);
+					if (E_RARE((u32)wv_popc(vm) < bsz))
 						goto last_literals;
 				}
 				kbase += bsz - r;
 				r = 0;
 				bsz = (batch == 0) ? 16 : (batch == 1 ? 32 : 64);
 			}
-			if (!found)
-				goto last_literals;
 		}
 		/* ---------------- extend the match both ways ----------------
 		 * Usually settled by the search batch's own loads (`quick`).  Else: the match side is made readable
@@ -502,29 +508,41 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			fwd += back;
 		}
 		EPC(R, 2);
-		u32 token;
 		{
+			/* ---------------- the sequence: token, literals, offset, length bytes ----------------
+			 * (the two output-limit tests first in a form without the division: lit >> 7 >= lit / 255 and
+			 * (mc >> 7) + 1 >= (mc + 240) / 255, so what passes these passes the reference's; else those decide) */
 			const u32 lit = ip - anchor;
-			token = op++;
-			if (E_RARE(op + lit + (2 + 1 + LASTLITERALS) + lit / 255 > cap))
-				return 0;
+			const u32 token = op++;
+			if (E_RARE(op + lit + (2 + 1 + LASTLITERALS) + (lit >> 7) > cap)) {
+				if (op + lit + (2 + 1 + LASTLITERALS) + lit / 255 > cap)
+					return 0;
+			}
 			const u32 tokhi = (lit >= 15 ? 15u : lit) << 4;
 			if (E_RARE(lit >= 15))
 				op += put_len_ext3(dst + op, lit - 15, lane);
-			if (lit)
+			if ((quick >> 31) && lit <= 64) {
+				/* the literals start at most 64 bytes in front of a position the search has just read: in the
+				 * ring (the slow extension may have moved it on, hence `quick`) */
+				E_ASSERT(lit == 0 || ring_has(R, anchor, lit));
+				if ((u32)lane < lit)
+					dst[op + (u32)lane] = R.ring[(anchor + (u32)lane) & (IRING - 1)];
+			} else {
 				copy_literals(R, dst + op, anchor, lit, lane);
+			}
 			op += lit;
 			EPC(R, 3);
-			/* the match: offset, token, length bytes */
 			const u32 mc = fwd;
-			if (lane == 0)
+			if (E_RARE(op + 2 + (1 + LASTLITERALS) + (mc >> 7) + 1 > cap)) {
+				if (op + 2 + (1 + LASTLITERALS) + (mc + 240) / 255 > cap)
+					return 0;
+			}
+			if (lane == 0) {
 				st16u(dst + op, ip - match);
+				dst[token] = (u8)(tokhi | (mc >= 15 ? 15u : mc));
+			}
 			op += 2;
 			ip += mc + MINMATCH;
-			if (E_RARE(op + (1 + LASTLITERALS) + (mc + 240) / 255 > cap))
-				return 0;
-			if (lane == 0)
-				dst[token] = (u8)(tokhi | (mc >= 15 ? 15u : mc));
 			if (E_RARE(mc >= 15))
 				op += put_len_ext3(dst + op, mc - 15, lane);
 			anchor = ip;
