@@ -93,8 +93,26 @@ out = {
     "detail": detail,
 }
 json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
-line = open(os.path.join(go, "bench_default.json")).read().strip().splitlines()[-1]
-json.dump(json.loads(line), open(os.path.join(root, "profiles", f"{rnd}_bench_8gib_1gpu.json"), "w"), indent=1)
+line = json.loads(open(os.path.join(go, "bench_default.json")).read().strip().splitlines()[-1])
+
+
+def refresh(obj):
+    """the bench run read the traffic table committed BEFORE these passes: put this round's figures in"""
+    if isinstance(obj, dict):
+        if "traffic" in obj and isinstance(obj.get("kernel"), str):
+            names = [k for k in per if k in obj["kernel"]]
+            if names:
+                obj["traffic"] = sum(per[k] for k in names)
+                obj["traffic_source"] = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command, not this run)"
+        for v in obj.values():
+            refresh(v)
+    elif isinstance(obj, list):
+        for v in obj:
+            refresh(v)
+
+
+refresh(line)
+json.dump(line, open(os.path.join(root, "profiles", f"{rnd}_bench_8gib_1gpu.json"), "w"), indent=1)
 print(open(stats).read())
 for d in detail:
     print(d["kernel"], f'{d["fetch_bytes_corrected"]/1e9:.2f} GB fetched, {d["write_bytes"]/1e9:.2f} GB written')
