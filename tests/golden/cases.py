@@ -178,3 +178,28 @@ BCASES = {
     "b_mixed_l7":       (7, 0, lambda: text(50000, 4) + bytes(70000) + rnd(3000, 5) + english(100000, 6)),
     "b_allbytes":       (4, 0, lambda: bytes(range(256)) * 300 + text(40000, 8)),
 }
+
+
+def enc3_path_inputs():
+    """inputs aimed at the paths of the round-3 fast encoder (lz4_enc3.hip): the re-match probe in lane 0 of the
+    search batch, the quick extension from the candidates' neighbourhoods and its fall-backs, ring restarts"""
+    t = text(40000, 77)
+    r = rnd(9000, 3)
+    return {
+        # chains of re-match hits: every match is followed at once by another one (period change every few bytes)
+        "rematch_chains": b"".join((b"abcdefgh" * 3)[: 9 + i % 11] + bytes([97 + i % 5]) for i in range(3000)),
+        # candidates in the chunk's first 8 bytes (no room for the 8 bytes in front): quick path off
+        "cand_at_start": b"wxyz0123" + b"wxyz0123wxyz" * 40 + t[:500] + b"wxyz0123" * 9,
+        # a long incompressible run (the ring restarts behind it), then text that matches what lies before the run
+        "far_jump": t[:3000] + r + t[:3000] + r[:4000] + t[1000:2500],
+        # matches longer than the 12 bytes the quick extension sees, and longer than 64 (the window loop)
+        "long_matches": t[:700] + t[:700] + t[100:400] * 5 + bytes(300) + t[:90] * 30,
+        # catch-up: matches found late (after differing prefixes), up to and beyond 8 bytes backwards
+        "catch_up": b"".join(t[i * 53 : i * 53 + 40] + bytes([i % 251]) + t[i * 53 + 8 : i * 53 + 40] for i in range(400)),
+        # matches that run into the end of the block / chunk (the last 5 / 12 bytes rules)
+        "block_end": (t[:200] * 400)[:65536 + 70] + t[:13],
+        # 4-byte matches only, dense (every probe hits, lengths 4..7)
+        "min_matches": b"".join(b"qrst" + bytes([33 + (i * 7) % 90, 33 + (i * 13) % 90]) for i in range(5000)),
+        # runs of one byte with breaks (overlapping sources, offsets 1..3)
+        "rle_breaks": b"".join(bytes([65 + i % 7]) * (1 + (i * 37) % 300) + t[i : i + i % 5] for i in range(300)),
+    }

@@ -197,3 +197,16 @@ def test_emu_fast_encoder_stored_block_after_an_attempt_that_wrote_matches():
     for data in (b"Tie sie sspfr mdot", b"abcdabcd-abcdabcd", text(4096, 1) + b"Tie sie sspfr mdot, sie sspfr"):
         for chunk in (65536, 4096):
             assert E.compress(data, chunk, 1)[0] == H.oracle_compress(data, chunk), (data[-20:], chunk)
+
+
+from cases import enc3_path_inputs as _enc3_path_inputs
+
+
+@pytest.mark.parametrize("chunk", [65536, 131072, 262144, 100000])
+@pytest.mark.parametrize("name", sorted(_enc3_path_inputs()))
+def test_emu_enc3_paths_bit_exact(name, chunk):
+    data = _enc3_path_inputs()[name]
+    got, _, _ = E.compress(data, chunk)
+    assert got == H.oracle_compress(data, chunk)
+    out, status = E.decompress(got)
+    assert status.tolist() == [0] * len(status) and out == data

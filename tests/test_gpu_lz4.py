@@ -82,6 +82,20 @@ def test_fuzz_vs_oracle(eng, seed):
         assert not status.any() and out == data
 
 
+@pytest.mark.parametrize("chunk", [65536, 131072, 262144])
+def test_fast_encoder_paths_vs_oracle(eng, chunk):
+    """the inputs aimed at the paths of lz4_enc3.hip (re-match probe in lane 0, quick extension and its fall-backs,
+    ring restarts; tests/golden/cases.py::enc3_path_inputs), each repeated over several chunks"""
+    from cases import enc3_path_inputs
+    for name, d in sorted(enc3_path_inputs().items()):
+        data = d * 3 + d[: len(d) // 3]
+        want = H.oracle_compress(data, chunk)
+        stream, ro, rl = eng.compress_bytes(data, chunk)
+        assert stream == want, name
+        out, status = eng.decompress_bytes(stream, ro, rl)
+        assert not status.any() and out == data, name
+
+
 with open(os.path.join(H.GOLDEN_DIR, "lz4hc", "manifest.json")) as _f:
     HCMAN = json.load(_f)
 
