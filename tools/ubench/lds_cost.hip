@@ -31,7 +31,9 @@ __global__ void __launch_bounds__(1024) k_lds(u32 *out, int iters, int active, i
 	case 2: off = (u32)lane * 13 + 3; break;             // sequence-shaped, byte aligned
 	case 3: off = ((h >> 20) & 1023) * 4; break;         // random dwords
 	case 4: off = ((h >> 19) & 2047) * 2 + 1; break;     // random odd bytes
-	default: off = (u32)lane * 20 + 8; break;            // 4-aligned, 8-misaligned for 64-bit, stride 20
+	case 5: off = (u32)lane * 20 + 8; break;             // 4-aligned, 8-misaligned for 64-bit, stride 20
+	case 6: off = (u32)lane * 40; break;                 // 8-aligned, stride 40 (a per-lane window)
+	default: off = ((h >> 21) & 511) * 8; break;         // random 8-aligned
 	}
 	const u32 addr = base + off;
 	u32 acc = 0;
@@ -74,10 +76,10 @@ int main()
 	u32 *dout; u64 *dcy;
 	hipMalloc(&dout, 4096 * 4); hipMalloc(&dcy, 8 * 64);
 	const char *ops[] = {"write_b8", "write_b16", "write_b32", "write_b64", "write_b128", "read_u8", "read_b32", "read_b64", "read_b128"};
-	const char *pats[] = {"dense aligned", "12*l (dword aligned)", "13*l+3 (byte aligned)", "random dwords", "random odd bytes", "20*l+8"};
+	const char *pats[] = {"dense aligned", "12*l (dword aligned)", "13*l+3 (byte aligned)", "random dwords", "random odd bytes", "20*l+8", "40*l (8-aligned)", "random 8-aligned"};
 	printf("cycles per wave instruction (16 waves on one CU), active lanes 64 / 16 / 4\n");
 	for (int op = 0; op < 9; op++)
-		for (int pat = 0; pat < 6; pat++) {
+		for (int pat = 0; pat < 8; pat++) {
 			double r[3]; int k = 0;
 			for (int active : {64, 16, 4}) {
 				double v = 0;
