@@ -18,7 +18,7 @@ def lib():
     if _lib is None:
         # EMU_STRICT=1: the build that checks every wave-uniformity claim (tests/test_emu_strict.py)
         name = "libzmt_emu_strict.so" if os.environ.get("EMU_STRICT") == "1" else "libzmt_emu.so"
-        subprocess.check_call(["make", "-C", EMU_DIR, name], stdout=subprocess.DEVNULL)
+        H.locked_make(EMU_DIR, name, stdout=subprocess.DEVNULL)
         L = C.CDLL(os.path.join(EMU_DIR, name))
         L.emu_lz4_slot_stride.restype = C.c_size_t
         L.emu_lz4_slot_stride.argtypes = [C.c_size_t]

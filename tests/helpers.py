@@ -7,6 +7,7 @@ import ctypes as C
 import hashlib
 import os
 import struct
+import fcntl
 import subprocess
 import threading
 
@@ -24,11 +25,23 @@ _ref = None
 _zref = None
 
 
+
+def locked_make(directory, target, **kw):
+    """`make -C directory target` under a file lock: the test workers of `pytest -n N` build the same libraries"""
+    os.makedirs(directory, exist_ok=True)
+    with open(os.path.join(directory, ".make.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(["make", "-C", directory, target], **kw)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 def build_oracle():
     """(Re)build liboracle.so if missing or stale.  Building the checker is not using it."""
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("lz4_oracle.c", "zstd_oracle.c", "brotli_oracle.c", "zmt_oracle.h")]
     if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < max(map(os.path.getmtime, srcs)):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"],
+        locked_make(ORACLE_DIR, "liboracle.so",
                               stdout=subprocess.DEVNULL)
     return ORACLE_SO
 

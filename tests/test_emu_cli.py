@@ -21,7 +21,7 @@ ENV = dict(os.environ, GPUMT_BATCH_KB="256")
 
 @pytest.fixture(scope="module", autouse=True)
 def built():
-    subprocess.check_call(["make", "-C", EMU_DIR, "cli"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    H.locked_make(EMU_DIR, "cli", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 def run(args, data=None, check=True):

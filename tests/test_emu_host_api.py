@@ -27,7 +27,7 @@ CHUNK = 4096
 
 @pytest.fixture(scope="module")
 def lib():
-    subprocess.check_call(["make", "-C", EMU_DIR, "libzstdmt_emu_host.so"], stdout=subprocess.DEVNULL,
+    H.locked_make(EMU_DIR, "libzstdmt_emu_host.so", stdout=subprocess.DEVNULL,
                           stderr=subprocess.DEVNULL)
     old = os.environ.get("GPUMT_BATCH_KB")
     os.environ["GPUMT_BATCH_KB"] = "16"      # read once, at the library's first batch
