@@ -67,6 +67,46 @@ def test_freed_buffers_are_reused(eng):
     eng.L.gpumt_host_free(eng.h, C.c_void_p(h2))
 
 
+def test_trim_caches_gives_idle_buffers_back(eng):
+    """gpumt_trim_caches: the cached (idle) device / pinned buffers are released and counted; a later allocation works"""
+    eng.L.gpumt_trim_caches.restype = C.c_size_t
+    eng.L.gpumt_trim_caches.argtypes = [C.c_void_p]
+    eng.L.gpumt_trim_caches(eng.h)                     # whatever earlier tests left behind
+    a = eng.alloc(41 << 20)
+    a.free()
+    h1 = _host(eng, 9 << 20)
+    eng.L.gpumt_host_free(eng.h, C.c_void_p(h1))
+    freed = eng.L.gpumt_trim_caches(eng.h)
+    assert freed >= (41 << 20) + (9 << 20)
+    assert eng.L.gpumt_trim_caches(eng.h) == 0         # nothing idle is left
+    b = eng.alloc(41 << 20)
+    b.free()
+
+
+def test_host_register_pins_caller_memory(eng):
+    """gpumt_host_register: memory the caller owns becomes a valid target of the push kernel (what the ranks of
+    bench.py --gather d2h do with their shared mapping)"""
+    import mmap
+    n = 3 << 20
+    m = mmap.mmap(-1, n)
+    buf = (C.c_ubyte * n).from_buffer(m)
+    eng.L.gpumt_host_register.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    eng.L.gpumt_host_unregister.argtypes = [C.c_void_p, C.c_void_p]
+    assert eng.L.gpumt_host_register(eng.h, C.addressof(buf), n) == 0
+    try:
+        data = np.frombuffer(rnd(n, 77), np.uint8)
+        d = eng.upload(data)
+        eng.L.gpumt_push_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        assert eng.L.gpumt_push_host(eng.h, C.addressof(buf), C.c_void_p(d.ptr), n, None, 0) == 0
+        eng.sync()
+        assert bytes(buf) == data.tobytes()
+        d.free()
+    finally:
+        assert eng.L.gpumt_host_unregister(eng.h, C.addressof(buf)) == 0
+        del buf
+        m.close()
+
+
 def test_contexts_on_several_threads():
     """four callers, each with its own contexts, at the same time: the caches and the pipelines keep
     them apart (every stream equals the oracle's, every round trip its input)"""
