@@ -368,10 +368,10 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					 * Lanes without a candidate read the ring's first bytes (no exec-mask region) */
 					const bool probe = valid && dist_ok;
 					const bool wide = cand >= 8; /* else (chunk start) 8 bytes at cand only, no quick extension */
-					const u32 a0 = wide ? cand - 8 : cand;
-					const u8 *gp = ring_has(R, a0, wide ? 24u : 8u) ? R.ring + (a0 & (IRING - 1)) : chunk + a0;
-					if (!probe)
-						gp = R.ring;
+					/* (always from memory: the ring holds the same bytes, but a batch waits for its farthest candidate
+					 * anyway, and one plain global load path is cheaper than a per-lane choice between LDS and memory) */
+					const u32 a0 = !probe ? 0u : wide ? cand - 8 : cand;
+					const u8 *const gp = chunk + a0;
 					const u64 l0 = ld64u(gp), l1 = ld64u(wide ? gp + 8 : gp), l2 = ld64u(wide ? gp + 16 : gp);
 					const u64 g0 = l0, g1 = wide ? l1 : l0, g2 = l2;
 					const bool m = probe && (u32)g1 == (u32)x;
