@@ -60,15 +60,8 @@ static inline u32 lds_or(u32 *p, u32 v)
 	*p = o | v;
 	return o;
 }
-static inline u32 lds_and(u32 *p, u32 v)
-{
-	u32 o = *p;
-	*p = o & v;
-	return o;
-}
 #else
 static __device__ __forceinline__ u32 lds_or(u32 *p, u32 v) { return atomicOr(p, v); }
-static __device__ __forceinline__ u32 lds_and(u32 *p, u32 v) { return atomicAnd(p, v); }
 #endif
 
 template <int TM> static __device__ __forceinline__ u32 hash3(u64 x)
@@ -88,8 +81,11 @@ template <int TM> static __device__ __forceinline__ u32 t_read(const u32 *lo, co
 		v |= ((hi[h >> 5] >> (h & 31)) & 1) << 16;
 	return v;
 }
-/* per-lane store; several lanes may hit different entries of one hi word -> atomics there */
-template <int TM> static __device__ __forceinline__ void t_write(u32 *lo, u32 *hi, u32 h, u32 v)
+/* per-lane store; several lanes may hit different entries of one hi word -> an atomic there.  Positions only grow
+ * inside a chunk and the table starts zeroed, so the 17th bit of an entry only ever goes 0 -> 1: the first 64 KiB
+ * block writes none, the second block ORs (`second` = this block starts at 64 KiB, wave-uniform) -- no AND, and no
+ * per-lane choice between two atomics */
+template <int TM> static __device__ __forceinline__ void t_write(u32 *lo, u32 *hi, u32 h, u32 v, bool second)
 {
 	if (TM == T_U32) {
 		lo[h] = v;
@@ -97,10 +93,9 @@ template <int TM> static __device__ __forceinline__ void t_write(u32 *lo, u32 *h
 	}
 	((u16 *)lo)[h] = (u16)v;
 	if (TM == T_P17) {
-		if (v >> 16)
+		E_ASSERT((v >> 16) == (second ? 1u : 0u));
+		if (second)
 			lds_or(&hi[h >> 5], 1u << (h & 31));
-		else
-			lds_and(&hi[h >> 5], ~(1u << (h & 31)));
 	}
 }
 
@@ -263,6 +258,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 	const u32 mflimit_p1 = iend - MFLIMIT + 1;
 	const u32 matchlimit = iend - LASTLITERALS;
 	const u32 low = (TM == T_U16) ? pos : 0;
+	const bool second = (pos >> 16) != 0; /* T_P17: the 17th bit of every position of this block */
 	u32 ip = pos, anchor = pos, op = 0;
 	/* 1 after a match: the search opens with the reference's immediate re-match probe at ip.  That test is a
 	 * probe like the others (look T[h(ip)] up, insert ip, compare 4 bytes), the search it falls into when it
@@ -277,7 +273,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 	{
 		const u64 x = wv_readfirst((u32)in_ld64(R, ip)) | (u64)wv_readfirst((u32)(in_ld64(R, ip) >> 32)) << 32;
 		if (lane == 0)
-			t_write<TM>(tlo, thi, hash3<TM>(TM == T_U16 ? (u64)(u32)x : x), ip);
+			t_write<TM>(tlo, thi, hash3<TM>(TM == T_U16 ? (u64)(u32)x : x), ip, second);
 	}
 	ip++;
 
@@ -327,7 +323,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				}
 				const u32 h = hash3<TM>(TM == T_U16 ? (u64)(u32)x : x);
 				if (ins2)
-					t_write<TM>(tlo, thi, h, cur);
+					t_write<TM>(tlo, thi, h, cur, second);
 				wv_sync();
 				u32 cand = t_read<TM>(tlo, thi, h); /* (idle lanes read too: no exec-mask region) */
 				u32 prev_dup = 64, next_dup = 64;
@@ -381,7 +377,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						/* the first probe that verifies is the match; the insertions up to it are committed */
 						const u32 jstar = (u32)wv_ffs(mm) - 1;
 						if ((u32)lane <= jstar && !(next_dup <= jstar))
-							t_write<TM>(tlo, thi, h, cur);
+							t_write<TM>(tlo, thi, h, cur, second);
 						wv_sync();
 						EPC(R, 1);
 						/* every lane works its own extension out (a handful of VALU steps, no branch); the
@@ -413,7 +409,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					}
 					/* no probe verified: all of them are inserted, and an invalid one ends the block */
 					if (valid && next_dup == 64)
-						t_write<TM>(tlo, thi, h, cur);
+						t_write<TM>(tlo, thi, h, cur, second);
 					wv_sync();
 					EPC(R, 1);
 					if (E_RARE((u32)wv_popc(vm) < bsz))
