@@ -6,7 +6,8 @@ import numpy as np
 import zstdmt_amd as z
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 # variants: 0 | ring << 4 = frames + parse3 + copy3 (ring 12 if omitted), 1 = frame-serial
-variants = [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "1"])]
+# bits 8..11 = parse stage (0 = default, 3 = parse3, 4 = parse4), bits 12..15 = copy stage (0 = default, 3 = copy3, 4 = copy4)
+variants = [int(v, 0) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "1"])]
 eng = z.Engine(0); L, h = eng.L, eng.h
 T = C.CDLL(os.path.join(ROOT, "zstdmt_amd", "lib", "libzmt_tools.so"))
 T.zmt_gen_text.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int]
@@ -25,7 +26,11 @@ eng.sync()
 names = ["stage", "spec", "walk", "decode+scan+classify", "literals", "fence+far", "rounds", "flush", "slowpath", "batches", "seqs", "total"]
 for v in variants:
     eng.set_variant("lz4_dec", v & 15)
-    eng.set_variant("lz4_ring", (v >> 4) or 12)
+    eng.set_variant("lz4_ring", ((v >> 4) & 15) or 12)
+    if (v >> 8) & 15:
+        eng.set_variant("lz4_parse", (v >> 8) & 15)
+    if (v >> 12) & 15:
+        eng.set_variant("lz4_copy", (v >> 12) & 15)
     eng.set_variant("profile", 1)
     for rep in range(2):
         cnt = (C.c_ulonglong * 16)()
@@ -42,7 +47,7 @@ for v in variants:
         eng.lz4_decompress(d_stream, nrec * stride, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st); eng.sync()
         L.gpumt_debug_counters(h, cnt, 16); c = list(cnt); nbat = max(c[12], 1)
         nm = ["wait(stage,tokens,stores)", "prefetch+loop", "fields", "scan+check+classify", "far-issue", "literals", "far-land", "match-r1", "rounds", "flush", "singles"]
-        print(f"   copy3 prof ring {v >> 4} (cycles per batch): " + ", ".join(f"{nm[i]}={c[i]/nbat:.0f}" for i in range(11)) + f" total={c[11]/nbat:.0f} batches={c[12]} rounds/batch={c[13]/nbat:.2f}")
+        print(f"   copy3 prof ring {(v >> 4) & 15} (cycles per batch): " + ", ".join(f"{nm[i]}={c[i]/nbat:.0f}" for i in range(11)) + f" total={c[11]/nbat:.0f} batches={c[12]} rounds/batch={c[13]/nbat:.2f}")
         eng.set_variant("profile", 1)
     if (v & 15) == 0:
         print("   split: frames %.3f ms, parse %.3f ms, copy %.3f ms, xxh %.3f ms" % (eng.timer_ms(13), eng.timer_ms(14), eng.timer_ms(15), eng.timer_ms(12)))

@@ -36,6 +36,7 @@ __global__ void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 __global__ void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *,
 				      const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
 __global__ void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *, u32 *, u32 *);
+__global__ void zmt_dec_parse4_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *, u32 *, u32 *);
 #define C3_DECL(NAME)                                                                                              \
 	__global__ void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *,  \
 			     const u32 *, const u32 *, const u32 *, const u16 *, const u32 *, const u32 *, u32 *);
@@ -96,6 +97,8 @@ struct gpumt_ctx {
 	unsigned long long *d_prof; /* 16 phase counters of the profiling decoder */
 	int xflags;  /* experiment switches of the parse kernel (developer) */
 	int lz4_ring; /* copy3: log2 of the LDS ring per wave (12, 13 or 14) */
+	int lz4_parse; /* parse stage: 4 = parse4 (default), 3 = parse3 (round 3) */
+	int lz4_copy;  /* copy stage: 4 = copy4 (default), 3 = copy3 (round 3; the only one with 8 / 16 KiB rings) */
 	int profile; /* record events in timer slots 8.. around individual kernels */
 	int num_cus;
 	int zenc_waves[3]; /* resident waves of the persistent zstd encoder kernels (whole device), per level tier */
@@ -245,6 +248,11 @@ int gpumt_open(int device, gpumt_ctx **out)
 		h->dec_variant = e && *e ? atoi(e) : 0;
 		e = getenv("GPUMT_LZ4_RING");
 		h->lz4_ring = e && *e ? atoi(e) : 12;
+		/* GPUMT_LZ4_PARSE / GPUMT_LZ4_COPY: 3 = the round-3 kernels (parse3 / copy3), default the round-4 ones */
+		e = getenv("GPUMT_LZ4_PARSE");
+		h->lz4_parse = e && *e ? atoi(e) : 4;
+		e = getenv("GPUMT_LZ4_COPY");
+		h->lz4_copy = e && *e ? atoi(e) : 3;
 	}
 	*out = h;
 	return GPUMT_OK;
@@ -851,9 +859,14 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 		PROF1(13);
 		const int ring = h->lz4_ring < 12 ? 12 : h->lz4_ring > 14 ? 14 : h->lz4_ring;
 		PROF0(14);
-		hipLaunchKernelGGL(zmt_dec_parse3_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
-				   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
-				   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bnt, bol);
+		if (h->lz4_parse == 3)
+			hipLaunchKernelGGL(zmt_dec_parse3_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
+					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
+					   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bnt, bol);
+		else
+			hipLaunchKernelGGL(zmt_dec_parse4_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
+					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
+					   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bnt, bol);
 		PROF1(14);
 		PROF0(15);
 #define C3_LAUNCH(NAME)                                                                                            \
@@ -1250,6 +1263,12 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	} else if (!strcmp(what, "lz4_ring")) {
 		prev = h->lz4_ring;
 		h->lz4_ring = variant;
+	} else if (!strcmp(what, "lz4_parse")) {
+		prev = h->lz4_parse;
+		h->lz4_parse = variant;
+	} else if (!strcmp(what, "lz4_copy")) {
+		prev = h->lz4_copy;
+		h->lz4_copy = variant;
 	} else if (!strcmp(what, "k2x")) {
 		prev = h->xflags;
 		h->xflags = variant;
