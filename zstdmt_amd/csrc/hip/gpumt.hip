@@ -41,6 +41,7 @@ __global__ void zmt_dec_parse4_kernel(const u8 *, u64, const u64 *, const u32 *,
 	__global__ void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *,  \
 			     const u32 *, const u32 *, const u32 *, const u16 *, const u32 *, const u32 *, u32 *);
 C3_DECL(zmt_dec_copy3_w4_kernel)
+C3_DECL(zmt_dec_copy4_kernel)
 C3_DECL(zmt_dec_copy3_w8_kernel)
 C3_DECL(zmt_dec_copy3_w16_kernel)
 #define C3_DECLP(NAME)                                                                                             \
@@ -48,6 +49,7 @@ C3_DECL(zmt_dec_copy3_w16_kernel)
 			     const u32 *, const u32 *, const u32 *, const u16 *, const u32 *, const u32 *, u32 *, \
 			     unsigned long long *);
 C3_DECLP(zmt_dec_copy3_w4_kernel_prof)
+C3_DECLP(zmt_dec_copy4_kernel_prof)
 C3_DECLP(zmt_dec_copy3_w8_kernel_prof)
 C3_DECLP(zmt_dec_copy3_w16_kernel_prof)
 __global__ void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
@@ -252,7 +254,7 @@ int gpumt_open(int device, gpumt_ctx **out)
 		e = getenv("GPUMT_LZ4_PARSE");
 		h->lz4_parse = e && *e ? atoi(e) : 4;
 		e = getenv("GPUMT_LZ4_COPY");
-		h->lz4_copy = e && *e ? atoi(e) : 3;
+		h->lz4_copy = e && *e ? atoi(e) : 4;
 	}
 	*out = h;
 	return GPUMT_OK;
@@ -881,7 +883,12 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 			   (const u32 *)bnt, (const u32 *)bol, d_status, h->d_prof)
 		/* (running the XXH32 verification of record slices on a second stream while the next slice is copied was
 		 * measured in round 2: the partial last round of every slice costs more than the overlap gains) */
-		if (h->profile == 8) {
+		if (h->lz4_copy != 3 && ring == 12) {
+			if (h->profile == 8)
+				C3_LAUNCHP(zmt_dec_copy4_kernel_prof);
+			else
+				C3_LAUNCH(zmt_dec_copy4_kernel);
+		} else if (h->profile == 8) {
 			if (ring == 12)
 				C3_LAUNCHP(zmt_dec_copy3_w4_kernel_prof);
 			else if (ring == 13)
