@@ -252,6 +252,27 @@ template <u32 WIN, bool PROF = false> struct C3 {
 		}
 	}
 
+	/* the same for the dependency rounds, where few lanes are active: misaligned 8- or 4-byte LDS accesses; the source
+	 * does not wrap around the ring's end (the caller checks) */
+	static __device__ __forceinline__ void match_mis(u8 *ring, u32 mpos, u32 ml, u32 src_pos)
+	{
+		u8 *const d = ring + (mpos & MASK);
+		const u8 *const s = ring + (src_pos & MASK);
+		if (ml >= 8u) {
+			const u64 a = ld64u(s), b = ld64u(s + ml - 8u);
+			if (ml > 16u) {
+				for (u32 i = 8; i + 8 < ml; i += 8)
+					c3_st64(d + i, ld64u(s + i));
+			}
+			c3_st64(d, a);
+			c3_st64(d + ml - 8u, b);
+		} else {
+			const u32 a = ld32u(s), b = ld32u(s + ml - 4u);
+			st32u(d, a);
+			st32u(d + ml - 4u, b);
+		}
+	}
+
 	static __device__ __forceinline__ void
 	body(const u8 *__restrict__ stream, u64 stream_bytes, u32 rec0, u32 nrec, u8 *out_base,
 	     const u64 *__restrict__ out_off, const u32 *__restrict__ out_len, const u64 *__restrict__ blk0,
@@ -444,7 +465,11 @@ template <u32 WIN, bool PROF = false> struct C3 {
 						}
 						C3PC(4);
 						/* ---- literals: only lanes that have some; 4-byte piece for 1..4, 8-byte pieces above ---- */
+#ifdef C3X_NO_LIT
+						if (false) {
+#else
 						if (act & (lit != 0)) {
+#endif
 							/* 4-byte pieces; a piece may spill <= 3 bytes into the lane's own match, written below */
 							u8 *const dl = ring + (op & MASK);
 							const u64 a = c3_ld64s(cb, lsrc);
@@ -482,7 +507,13 @@ template <u32 WIN, bool PROF = false> struct C3 {
 						bool fin = !(act & (ml != 0));
 						{
 							const bool r1 = !fin & (is_far | (src_pos + eff <= o0)) & !ovl;
+#ifdef C3X_NO_R1
+							if (r1)
+								fin = true;
+							if (false) {
+#else
 							if (r1) {
+#endif
 								const u8 *const sb = is_far ? cb + 16u * (u32)lane : ring;
 								match<true>(ring, mpos, (is_far && ml > 16u) ? 16u : ml, sb, is_far ? 0u : src_pos, is_far ? ~0u : MASK);
 								fin = true;
@@ -491,6 +522,9 @@ template <u32 WIN, bool PROF = false> struct C3 {
 						wv_sync();
 						C3PC(7);
 						for (;;) {
+#ifdef C3X_NO_ROUNDS
+							break;
+#endif
 							const u64 unf = wv_ballot(!fin);
 							if (!unf)
 								break;
@@ -499,8 +533,20 @@ template <u32 WIN, bool PROF = false> struct C3 {
 							const u32 first = (u32)wv_ffs(unf) - 1;
 							const u32 W = wv_readlane(mpos, (int)first);
 							const bool go = !fin & (src_pos + eff <= W);
+#ifdef C3X_MIS_ROUNDS
+							/* few lanes are active in a round: misaligned LDS accesses (one pipe cycle per active lane) instead
+							 * of aligned reads + funnel shifts; a source that wraps around the end of the ring takes the old way */
+							const bool wrap = (src_pos & MASK) + ml > WIN;
+							if (go & !ovl & !wrap)
+								match_mis(ring, mpos, ml, src_pos);
+							if (wv_any(go & !ovl & wrap)) {
+								if (go & !ovl & wrap)
+									match<false>(ring, mpos, ml, ring, src_pos, MASK);
+							}
+#else
 							if (go & !ovl)
 								match<false>(ring, mpos, ml, ring, src_pos, MASK);
+#endif
 							if (wv_any(go & ovl)) { /* (offset < length: 0.2 % of the matches) */
 								if (go & ovl)
 									match_ovl(ring, mpos, off, ml);
