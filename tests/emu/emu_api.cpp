@@ -136,7 +136,7 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 	const int ring = ((variant >> 4) & 15) ? ((variant >> 4) & 15) : 12;
 	/* bits 8..11: parse stage (0 = the product's default, parse4; 3 = parse3); bits 12..15: copy stage (0 = default, 3 = copy3) */
 	const int parse = ((variant >> 8) & 15) ? ((variant >> 8) & 15) : 4;
-	const int copy = ((variant >> 12) & 15) ? ((variant >> 12) & 15) : 4;
+	const int copy = ((variant >> 12) & 15) ? ((variant >> 12) & 15) : 3;
 	variant &= 15;
 	if (variant == 1) {
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {

@@ -254,7 +254,7 @@ int gpumt_open(int device, gpumt_ctx **out)
 		e = getenv("GPUMT_LZ4_PARSE");
 		h->lz4_parse = e && *e ? atoi(e) : 4;
 		e = getenv("GPUMT_LZ4_COPY");
-		h->lz4_copy = e && *e ? atoi(e) : 4;
+		h->lz4_copy = e && *e ? atoi(e) : 3;
 	}
 	*out = h;
 	return GPUMT_OK;
