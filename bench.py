@@ -240,7 +240,7 @@ def generate(ctx, n, corpus_off):
     return d_in, time.time() - t0
 
 
-def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True, main=True):
+def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True, main=True, dec_only=None):
     """configs[1] (lz4), configs[2] (lz4 --mode decompress), configs[3] (zstd)"""
     args, eng, rank, world, dist = ctx.args, ctx.eng, ctx.rank, ctx.world, ctx.dist
     zstd = codec == "zstd"
@@ -253,7 +253,7 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
     n, corpus_off, total_n = shard(args, world, rank, chunk)
     gib = args.gib
     args.gib = saved_gib
-    dec_only = args.mode == "decompress" and main
+    dec_only = (args.mode == "decompress" and main) if dec_only is None else dec_only
     nrec = eng.record_count(n, chunk)
     stride = eng.zstd_slot_stride(chunk) if zstd else eng.slot_stride(chunk)
 
@@ -375,8 +375,8 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
     if zstd:
         zl = args.zstd_level if main else 1
         name, what = f"zstd-mt level {zl}", f"zstd-mt -{zl}"
-        r_enc = None if dec_only else roof("zmt_zstd_enc_kernel(+assemble)", ms["k_lz4_enc"], alg,
-                                           ("zmt_zstd_enc_kernel", "zmt_zstd_assemble_kernel"))
+        zk = ("zmt_zstd_enc_kernel", "zmt_zstd_enc_t2_kernel", "zmt_zstd_enc_t3_kernel")[eng.L.gpumt_zstd_level_tier(zl)]
+        r_enc = None if dec_only else roof(zk + "(+assemble)", ms["k_lz4_enc"], alg, (zk, "zmt_zstd_assemble_kernel"))
         r_dec = roof("zmt_zstd_dec_small_kernel(+zmt_zstd_dec_kernel for frames with full-size tables)",
                      ms["k_lz4_dec"], alg, ("zmt_zstd_dec_small_kernel", "zmt_zstd_dec_kernel"))
     else:
@@ -384,7 +384,7 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
         ek = ("zmt_lz4_enc3_p17_kernel" if 65536 < chunk <= 131072 else
               ("zmt_lz4_enc3_u16_kernel" if chunk <= 65536 else "zmt_lz4_enc3_u32_kernel"))
         r_enc = None if dec_only else roof(ek, ms["k_lz4_enc"], alg, (ek,))
-        k_parse = "zmt_dec_parse3_kernel"
+        k_parse = "zmt_dec_parse4_kernel"
         k_copy = "zmt_dec_copy3_w%d_kernel" % (1 << (args.lz4_ring - 10))
         r_dec = roof(f"zmt_dec_frames_kernel + {k_parse} + {k_copy}" if split else "zmt_lz4_dec_serial", ms["k_lz4_dec"], alg,
                      ("zmt_dec_frames_kernel", k_parse, k_copy) if split else ())
@@ -401,7 +401,8 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
         "config": {"workload": f"{what}{' decompress-only' if dec_only else ''}, {U_all / (1 << 30):g} GiB enwik-style "
                                f"synthetic ({'whole job' if args.scaling == 'strong' or world == 1 else 'per GPU x ' + str(world)}), "
                                f"{chunk // 1024} KiB chunks, device-resident",
-                   "chunk": chunk, "records_per_gpu": nrec, "records": int(total_n // chunk), "level": 1,
+                   "chunk": chunk, "records_per_gpu": nrec, "records": int(total_n // chunk),
+                   "level": (args.zstd_level if main else 1) if zstd else 1,
                    "ratio": round(ctx_ratio(U_all, Cb_all), 4), "dec_variant": args.dec_variant,
                    "lz4_ring": args.lz4_ring if args.dec_variant == 0 else None,
                    "parallelism": f"chunk-sharded x{world}"},
@@ -437,12 +438,11 @@ def ctx_ratio(u, c):
     return u / c if c else 0.0
 
 
-def reference_brotli_stream(data, chunk, level, threads):
-    """The workload's input: `data` compressed by the REFERENCE's brotli-mt (oracle/_ref, SURVEY 8d
+def reference_stream(data, chunk, level, threads, so="libbrotlimt_ref.so", pfx="BROTLIMT"):
+    """The workload's input: `data` compressed by the REFERENCE's brotli-mt / zstd-mt (oracle/_ref, SURVEY 8d
     "cfg5: the same text compressed by own/oracle brotli at 1 MiB chunks").  Input preparation on the
     host, outside the timed region; the device encoder's streams are timed as well (device_encoder)."""
-    so = os.path.join(ROOT, "oracle", "_ref", "libbrotlimt_ref.so")
-    lib = C.CDLL(so)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", so))
 
     class Buf(C.Structure):
         _fields_ = [("buf", C.c_void_p), ("size", C.c_size_t), ("allocated", C.c_size_t)]
@@ -450,12 +450,14 @@ def reference_brotli_stream(data, chunk, level, threads):
 
     class RdWr(C.Structure):
         _fields_ = [("fn_read", FN), ("arg_read", C.c_void_p), ("fn_write", FN), ("arg_write", C.c_void_p)]
-    lib.BROTLIMT_createCCtx.restype = C.c_void_p
-    lib.BROTLIMT_createCCtx.argtypes = [C.c_int, C.c_int, C.c_int]
-    lib.BROTLIMT_compressCCtx.restype = C.c_size_t
-    lib.BROTLIMT_compressCCtx.argtypes = [C.c_void_p, C.POINTER(RdWr)]
-    lib.BROTLIMT_freeCCtx.argtypes = [C.c_void_p]
-    lib.BROTLIMT_isError.argtypes = [C.c_size_t]
+    create, compress = getattr(lib, pfx + "_createCCtx"), getattr(lib, pfx + "_compressCCtx")
+    free, is_error = getattr(lib, pfx + "_freeCCtx"), getattr(lib, pfx + "_isError")
+    create.restype = C.c_void_p
+    create.argtypes = [C.c_int, C.c_int, C.c_int]
+    compress.restype = C.c_size_t
+    compress.argtypes = [C.c_void_p, C.POINTER(RdWr)]
+    free.argtypes = [C.c_void_p]
+    is_error.argtypes = [C.c_size_t]
     src = data.ctypes.data
     n = data.nbytes
     state = {"pos": 0}
@@ -476,12 +478,102 @@ def reference_brotli_stream(data, chunk, level, threads):
         return 0
     frd, fwr = FN(rd), FN(wr)
     io = RdWr(frd, None, fwr, None)
-    ctx = lib.BROTLIMT_createCCtx(threads, level, chunk)
-    rv = lib.BROTLIMT_compressCCtx(ctx, C.byref(io))
-    lib.BROTLIMT_freeCCtx(ctx)
-    if lib.BROTLIMT_isError(rv):
-        raise RuntimeError("reference brotli-mt compress failed")
+    ctx = create(threads, level, chunk)
+    rv = compress(ctx, C.byref(io))
+    free(ctx)
+    if is_error(rv):
+        raise RuntimeError("reference %s compress failed" % pfx)
     return b"".join(out)
+
+
+def reference_brotli_stream(data, chunk, level, threads):
+    return reference_stream(data, chunk, level, threads)
+
+
+def bench_zstd_ref(ctx, gib, steps, warmup):
+    """zstd-mt decompress of streams the REFERENCE wrote (lib/zstd-mt_compress.c + libzstd at level 1, 1 MiB
+    chunks): what a drop-in decoder meets in the wild.  1 GiB is compressed on the host by
+    oracle/_ref/libzstdmt_ref.so, outside the timed region, and replicated in HBM; one step = zstd_probe +
+    gpumt_zstd_decompress_batch over all records; one GPU."""
+    import struct
+    eng = ctx.eng
+    L, h = eng.L, eng.h
+    chunk = 1 << 20
+    n_all = int(gib * (1 << 30)) // chunk * chunk
+    base_n = min(n_all, 1 << 30)
+    reps = max(1, n_all // base_n)
+    n = base_n * reps
+    threads = min(os.cpu_count() or 1, 128)
+    t0 = time.time()
+    text = np.empty(base_n, np.uint8)
+    tools().zmt_gen_text(text.ctypes.data, base_n, SEED, 0, threads)
+    stream = reference_stream(text, chunk, 1, threads, "libzstdmt_ref.so", "ZSTDCB")
+    ro, rl = [], []
+    ip = 0
+    while ip < len(stream):
+        magic, four, csize = struct.unpack_from("<III", stream, ip)
+        assert magic == 0x184D2A50 and four == 4
+        ro.append(ip)
+        rl.append(12 + csize)
+        ip += 12 + csize
+    gen_s = time.time() - t0
+    nb = len(ro)
+    nrec = nb * reps
+    seg = (len(stream) + 511) & ~255
+    rec_off = np.concatenate([np.asarray(ro, np.uint64) + np.uint64(r * seg) for r in range(reps)])
+    rec_len = np.tile(np.asarray(rl, np.uint32), reps)
+    d_stream = eng.alloc(seg * reps + 512)
+    hs = np.frombuffer(stream, np.uint8)
+    for r in range(reps):
+        eng._ck(L.gpumt_memcpy_h2d(h, d_stream.ptr + r * seg, hs.ctypes.data, hs.nbytes, 0), "h2d")
+    eng.sync(0)
+    d_ro, d_rl = eng.upload(rec_off), eng.upload(rec_len)
+    d_ol, d_oo, d_st = eng.alloc(nrec * 4), eng.alloc((nrec + 1) * 8), eng.alloc(nrec * 4)
+    d_out = eng.alloc(n + 64)
+    bufs = [d_stream, d_ro, d_rl, d_ol, d_oo, d_st, d_out]
+
+    def step():
+        eng.timer_start(3)
+        eng.zstd_probe(d_stream, d_ro, d_rl, nrec, d_ol, d_oo, d_st)
+        eng.zstd_decompress(d_stream, seg * reps, d_ro, d_rl, nrec, d_out, n, d_oo, d_ol, d_st)
+        eng.timer_stop(3)
+
+    for _ in range(warmup):
+        step()
+    ctx.barrier()
+    acc = {"decompress": 0.0, "k_zstd_dec": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        eng.sync(0)
+        acc["decompress"] += eng.timer_ms(3)
+        acc["k_zstd_dec"] += eng.timer_ms(11)
+    wall = time.perf_counter() - t0
+    ms = {k: v / steps for k, v in acc.items()}
+    status = eng.download(d_st, nrec * 4, np.uint32)
+    bad = int((status != 0).sum())
+    ok = bad == 0 and bool((eng.download(d_out, base_n) == text).all())
+    for b in bufs:
+        b.free()
+    U, Cb = float(n), float(len(stream)) * reps
+    alg = U + Cb
+    a = alg / (ms["k_zstd_dec"] * 1e-3) / 1e9
+    return {
+        "metric": f"MB/s decompress, {U / (1 << 30):g} GiB synthetic, zstd-mt streams written by the reference (level 1); % HBM roofline",
+        "value": round(U / 1e6 / (wall / steps), 1), "unit": "MB/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(wall / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"zstd-mt decompress, {U / (1 << 30):g} GiB enwik-style synthetic, 1024 KiB chunks compressed at "
+                               f"level 1 by the reference build ({base_n >> 20} MiB compressed on the host, replicated x{reps} "
+                               "in HBM), device-resident decode", "chunk": chunk, "records_per_gpu": nrec, "level": 1,
+                   "ratio": round(U / Cb, 4)},
+        "decompress_MBps": round(U / 1e6 / (ms["decompress"] * 1e-3), 1),
+        "roofline": {"kernel": "zmt_zstd_dec kernels (reference-written frames)", "bound": "hbm", "achieved": round(a, 2),
+                     "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(a * 1e9 / HBM_PEAK, 5),
+                     "alg_bytes_per_launch": alg, "avg_launch_ms": round(ms["k_zstd_dec"], 4), "traffic": None},
+        "kernels": {"k_zstd_dec": {"ms": round(ms["k_zstd_dec"], 4)}},
+        "decode_errors": bad, "roundtrip_verified": ok, "gen_s": round(gen_s, 2),
+    }
 
 
 def bench_brotli(ctx, gib_args=None, steps=None, warmup=None, cpu=True, main=True):
@@ -908,39 +1000,137 @@ def main():
     if rank == 0 and default_run:
         # the other BASELINE configs, short, in the same line
         cfgs = {}
-        try:
-            cfgs["zstd-mt level 1 (configs[3])"] = bench_lz4_zstd(ctx, "zstd", gib_args=args.extra_gib, steps=2,
-                                                                  warmup=1, main=False)
-        except Exception as e:
-            cfgs["zstd-mt level 1 (configs[3])"] = {"error": repr(e)}
-        try:
-            cfgs["brotli-mt decompress (configs[4])"] = bench_brotli(ctx, gib_args=args.extra_gib, steps=2,
-                                                                     warmup=1, main=False)
-        except Exception as e:
-            cfgs["brotli-mt decompress (configs[4])"] = {"error": repr(e)}
-        try:
-            cfgs["snappy-mt, 64 KiB chunks (SURVEY 8f-4, not a BASELINE config)"] = bench_snappy(
-                ctx, gib_args=args.extra_gib, steps=2, warmup=1, main=False)
-        except Exception as e:
-            cfgs["snappy-mt, 64 KiB chunks (SURVEY 8f-4, not a BASELINE config)"] = {"error": repr(e)}
+
+        def leg(name, fn):
+            try:
+                cfgs[name] = fn()
+            except Exception as e:  # report, never hide
+                cfgs[name] = {"error": repr(e)}
+        leg(K_DEC, lambda: bench_lz4_zstd(ctx, "lz4", gib_args=args.extra_gib, steps=5, warmup=1, cpu=False, main=False,
+                                          dec_only=True))
+        leg(K_ZSTD, lambda: bench_lz4_zstd(ctx, "zstd", gib_args=args.extra_gib, steps=2, warmup=1, main=False))
+        leg(K_ZREF, lambda: bench_zstd_ref(ctx, args.extra_gib, 2, 1))
+        leg(K_BROTLI, lambda: bench_brotli(ctx, gib_args=args.extra_gib, steps=2, warmup=1, main=False))
+        leg(K_SNAPPY, lambda: bench_snappy(ctx, gib_args=args.extra_gib, steps=2, warmup=1, main=False))
         eng.close()
         api = bench_api(int(args.api_gib * 1024))
         hc = "lz4 level 3 (lz4-mt CLI default, LZ4HC)"
         if isinstance(api.get(hc), dict) and not args.no_cpu:
             api[hc]["cpu_reference"] = cpu_reference_level(3, 131072, 1024)
-        for codec, leg in (("lz4", res), ("zstd", cfgs["zstd-mt level 1 (configs[3])"]),
-                           ("brotli", cfgs["brotli-mt decompress (configs[4])"])):
-            cb = (leg or {}).get("cpu_baseline") or {}
+        for codec, leg_ in (("lz4", res), ("zstd", cfgs[K_ZSTD]), ("brotli", cfgs[K_BROTLI])):
+            cb = (leg_ or {}).get("cpu_baseline") or {}
             if isinstance(api.get(codec), dict) and cb.get("compress_MBps"):
                 api[codec]["cpu_reference"] = {"compress_MBps": cb["compress_MBps"],
                                                "decompress_MBps": cb["decompress_MBps"],
                                                "threads": cb.get("cores"), "kind": cb.get("kind")}
-        cfgs["drop-in API, PCIe-inclusive (LZ4MT_*/ZSTDCB_*/BROTLIMT_* with memcpy callbacks)"] = api
+        # the decode-only leg's CPU side is the decompress half of the main leg's reference run
+        cb = res.get("cpu_baseline") or {}
+        if isinstance(cfgs.get(K_DEC), dict) and cb.get("decompress_MBps"):
+            cfgs[K_DEC]["cpu_baseline"] = {"value": cb["decompress_MBps"], "unit": "MB/s", "cores": cb.get("cores"),
+                                           "kind": cb.get("kind"), "decompress_MBps": cb["decompress_MBps"],
+                                           "sample": cb.get("sample")}
+        cfgs[K_API] = api
         res["configs"] = cfgs
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        if world > 1:
+            import torch
+            res["world_size"] = dist.get_world_size()     # as RCCL formed it
+            try:
+                res["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # report, never hide
+                res["rccl_version"] = repr(e)
+        # everything measured goes to bench_detail.json and to an earlier line; the LAST line is the contract's
+        # line, short enough (< 7 KB) for a reader that keeps only the tail of stdout
+        try:
+            with open(os.path.join(ROOT, "bench_detail.json"), "w") as f:
+                json.dump(res, f, indent=1)
+        except OSError:
+            pass
+        print("DETAIL " + json.dumps(res), flush=True)
+        print(json.dumps(compact_line(res)), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+K_DEC = "lz4-mt decompress-only (configs[2])"
+K_ZSTD = "zstd-mt level 1 (configs[3])"
+K_ZREF = "zstd-mt decompress of reference-written level-1 streams"
+K_BROTLI = "brotli-mt decompress (configs[4])"
+K_SNAPPY = "snappy-mt, 64 KiB chunks (SURVEY 8f-4, not a BASELINE config)"
+K_API = "drop-in API, PCIe-inclusive (LZ4MT_*/ZSTDCB_*/BROTLIMT_* with memcpy callbacks)"
+
+
+def _roof_short(r, nested=False):
+    if not isinstance(r, dict):
+        return r
+    keep = ("kernel", "achieved", "frac", "avg_launch_ms", "traffic") if nested else \
+        ("kernel", "bound", "achieved", "peak", "unit", "frac", "alg_bytes_per_launch", "avg_launch_ms", "traffic")
+    o = {k: r[k] for k in keep if k in r}
+    if nested and isinstance(o.get("kernel"), str):
+        o["kernel"] = o["kernel"][:60]
+    return o
+
+
+def _cpu_short(c, nested=False):
+    if not isinstance(c, dict):
+        return c
+    keep = ("value", "unit", "cores", "kind", "compress_MBps", "decompress_MBps", "host_cpus", "error")
+    o = {k: c[k] for k in keep if k in c}
+    if c.get("sample") and not nested:
+        o["sample"] = c["sample"][:120]
+    return o
+
+
+def _leg_short(r):
+    """one extra leg, as the final line carries it"""
+    if not isinstance(r, dict) or "error" in r:
+        return r
+    o = {k: r[k] for k in ("value", "unit", "steps", "ms_per_step", "compress_MBps", "decompress_MBps", "decode_errors",
+                           "roundtrip_verified") if k in r}
+    o["workload"] = (r.get("config") or {}).get("workload", "")[:110]
+    o["ratio"] = (r.get("config") or {}).get("ratio")
+    o["roofline"] = _roof_short(r.get("roofline"), True)
+    if r.get("roofline_decompress") and r["roofline_decompress"] != r.get("roofline"):
+        o["roofline_decompress"] = _roof_short(r["roofline_decompress"], True)
+    if r.get("cpu_baseline"):
+        o["cpu_baseline"] = _cpu_short(r["cpu_baseline"], True)
+    if isinstance(r.get("device_encoder"), dict) and "compress_MBps" in r["device_encoder"]:
+        o["device_encoder"] = {k: r["device_encoder"][k] for k in ("compress_MBps", "ratio", "decompress_MBps",
+                                                                   "roundtrip_verified")}
+    return o
+
+
+def compact_line(res):
+    """The contract's JSON line: every contract key, the rooflines of both directions, the CPU baseline and one short
+    entry per extra leg; per-kernel tables, per-thread CPU runs and the API legs' verbose fields stay in DETAIL /
+    bench_detail.json."""
+    o = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                             "scaling", "vs_baseline", "dtype", "data", "config") if k in res}
+    o["roofline"] = _roof_short(res.get("roofline"))
+    for k in ("roofline_decompress", "roofline_compress"):
+        if res.get(k) and res[k] != res.get("roofline"):
+            o[k] = _roof_short(res[k])
+    if res.get("cpu_baseline"):
+        o["cpu_baseline"] = _cpu_short(res["cpu_baseline"])
+    for k in ("compress_MBps", "decompress_MBps", "decode_errors", "roundtrip_verified", "device", "gather", "gather_ms",
+              "value_with_gather", "world_size", "rccl_version", "device_encoder"):
+        if k in res:
+            o[k] = res[k]
+    if res.get("kernels"):
+        o["kernels_ms"] = {k: v["ms"] for k, v in res["kernels"].items()}
+    if res.get("per_rank_ms") and res.get("n_gpus", 1) > 1:
+        o["per_rank_ms"] = res["per_rank_ms"]
+    if "configs" in res:
+        c = {}
+        for name, r in res["configs"].items():
+            if name == K_API and isinstance(r, dict):
+                c[name] = {k: ({kk: v[kk] for kk in ("compress_MBps", "decompress_MBps", "error") if kk in v}
+                               if isinstance(v, dict) else v) for k, v in r.items()}
+            else:
+                c[name] = _leg_short(r)
+        o["configs"] = c
+    o["detail"] = "bench_detail.json + the DETAIL line above"
+    return o
 
 
 if __name__ == "__main__":
