@@ -252,6 +252,46 @@ template <u32 WIN, bool PROF = false> struct C3 {
 		}
 	}
 
+	/* eight bytes at LDS address p (any alignment), no wrap handling: three aligned dword reads off ONE address */
+	static __device__ __forceinline__ u64 ld64p(const u8 *p)
+	{
+#ifdef ZMT_EMU
+		return ld64u(p);
+#else
+		const u32 a = (u32)(size_t)(const __attribute__((address_space(3))) u8 *)p;
+		const __attribute__((address_space(3))) u32 *w = (const __attribute__((address_space(3))) u32 *)(size_t)(a & ~3u);
+		const u32 a0 = w[0], a1 = w[1], a2 = w[2];
+		return (u64)wv_alignbyte(a1, a0, a) | ((u64)wv_alignbyte(a2, a1, a) << 32);
+#endif
+	}
+	/* match<> with the source given as an LDS address whose ml bytes do not wrap around the ring's end */
+	template <bool BYTES> static __device__ __forceinline__ void match_p(u8 *ring, u32 mpos, u32 ml, const u8 *sp)
+	{
+		u8 *const d = ring + (mpos & MASK);
+		const bool wide = ml >= 8u;
+		const u32 tl = wide ? ml - 8u : ml - 4u;
+		const u64 a = ld64p(sp), b = ld64p(sp + tl);
+		if (ml > 16u) {
+			for (u32 i = 8; i + 8 < ml; i += 8)
+				c3_st64(d + i, ld64p(sp + i));
+		}
+		if (BYTES) {
+			c3_st32b(d, (u32)a);
+			c3_st32b(d + ml - 4u, wide ? (u32)(b >> 32) : (u32)b);
+			if (wide) {
+				c3_st32b(d + 4, (u32)(a >> 32));
+				c3_st32b(d + tl, (u32)b);
+			}
+		} else {
+			st32u(d, (u32)a);
+			st32u(d + ml - 4u, wide ? (u32)(b >> 32) : (u32)b);
+			if (wide) {
+				st32u(d + 4, (u32)(a >> 32));
+				st32u(d + tl, (u32)b);
+			}
+		}
+	}
+
 	/* the same for the dependency rounds, where few lanes are active: misaligned 8- or 4-byte LDS accesses; the source
 	 * does not wrap around the ring's end (the caller checks) */
 	static __device__ __forceinline__ void match_mis(u8 *ring, u32 mpos, u32 ml, u32 src_pos)
@@ -514,8 +554,20 @@ template <u32 WIN, bool PROF = false> struct C3 {
 #else
 							if (r1) {
 #endif
+#ifdef C3X_UNMASKED
+								/* one source address for both kinds; a ring source that wraps around the ring's end (rare)
+								 * takes the masked reads */
+								const u32 mlc = (is_far && ml > 16u) ? 16u : ml;
+								const bool wrap = !is_far & ((src_pos & MASK) + ml > WIN);
+								const u8 *const sp = is_far ? cb + 16u * (u32)lane : ring + (src_pos & MASK);
+								if (!wrap)
+									match_p<true>(ring, mpos, mlc, sp);
+								else
+									match<true>(ring, mpos, ml, ring, src_pos, MASK);
+#else
 								const u8 *const sb = is_far ? cb + 16u * (u32)lane : ring;
 								match<true>(ring, mpos, (is_far && ml > 16u) ? 16u : ml, sb, is_far ? 0u : src_pos, is_far ? ~0u : MASK);
+#endif
 								fin = true;
 							}
 						}
@@ -539,6 +591,14 @@ template <u32 WIN, bool PROF = false> struct C3 {
 							const bool wrap = (src_pos & MASK) + ml > WIN;
 							if (go & !ovl & !wrap)
 								match_mis(ring, mpos, ml, src_pos);
+							if (wv_any(go & !ovl & wrap)) {
+								if (go & !ovl & wrap)
+									match<false>(ring, mpos, ml, ring, src_pos, MASK);
+							}
+#elif defined(C3X_UNMASKED)
+							const bool wrap = (src_pos & MASK) + ml > WIN;
+							if (go & !ovl & !wrap)
+								match_p<false>(ring, mpos, ml, ring + (src_pos & MASK));
 							if (wv_any(go & !ovl & wrap)) {
 								if (go & !ovl & wrap)
 									match<false>(ring, mpos, ml, ring, src_pos, MASK);
