@@ -97,7 +97,6 @@ zmt_dec_parse4_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 	u32 pend0 = P4_NONE, pend1 = P4_NONE; /* g of the units this lane's row has in flight */
 	p4v4 pv[8];
 	bool ok = true, done = !parse;
-	u32 tk = 0, b1 = 0;
 
 	/* requests: up to two units per row; the loads are unconditional (a row that asked for nothing reads the wave's
 	 * first line again), 16-byte aligned; they may run up to 63 bytes past the block, inside the stream's slack */
@@ -168,18 +167,11 @@ zmt_dec_parse4_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 			break;
 		P4_LAND();
 		P4_ISSUE();
-		{
-			/* the ring has changed: what a lane read ahead of its data is stale */
-			const u8 *const a = myring + (g & (P4_RING - 1));
-			tk = a[0];
-			b1 = a[1];
-		}
 		ZMT_UNROLL
 		for (u32 sub = 0; sub < P4_CADENCE; sub++) {
 			/* ---------------- one sequence per lane ---------------- */
-			/* (tk, b1) = the ring's bytes at g and g + 1, read a step ahead: the reads for the position this step moves
-			 * to -- if it moves -- are issued together with the match-length byte's, before the step's outcome is
-			 * known, so one LDS round trip per step sits on the chain from g to the next g instead of two */
+			const u8 *const a = myring + (g & (P4_RING - 1));
+			const u32 tk = a[0], b1 = a[1]; /* a[1] of the ring's last byte is the mirror's first */
 			const u32 avail = ghi - g;      /* as a signed number: bytes of the ring in front of g */
 			const u32 L4 = tk >> 4, M4 = tk & 15u;
 			const bool lx = L4 == 15u, mx = M4 == 15u;
@@ -191,8 +183,6 @@ zmt_dec_parse4_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 			const u32 x2 = mx ? b2 : 0u;
 			const u32 ml = M4 + 4u + x2;
 			const u32 nxt = gi + (mx ? 1u : 0u);
-			const u8 *const an = myring + (nxt & (P4_RING - 1));
-			const u32 tkn = an[0], b1n = an[1]; /* an[1] of the ring's last byte is the mirror's first */
 			const bool have = (int)idx < (int)avail; /* token .. match-length byte are in the ring (idx >= 3) */
 			/* not in the step: a literal run above 120 (a 255 length byte is one), a 255 match-length byte, the block's
 			 * last sequence (or anything else that leaves no room for a next token).  A long run may never fit the
@@ -249,9 +239,6 @@ zmt_dec_parse4_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 					n++;
 					opos += l2 + m2;
 					g = boff + m;
-					const u8 *const a = myring + (g & (P4_RING - 1));
-					tk = a[0];
-					b1 = a[1];
 				}
 				if (!ok || last)
 					done = true;
@@ -262,8 +249,6 @@ zmt_dec_parse4_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 				n++;
 				opos += lit + ml;
 				g = nxt;
-				tk = tkn;
-				b1 = b1n;
 			}
 		}
 	}
