@@ -11,8 +11,8 @@
  *     (complete RFC 7932 decoder, zstdmt_amd/csrc/hip/brotli_dec.hip);
  *   - BROTLIMT_compressCCtx writes valid brotli streams that the reference (and any brotli decoder)
  *     decodes to the input: the bar for this codec is decompress-identical (brotli's bytes are version
- *     dependent); `level` is validated (0..11) and sets the default chunk size, the device encoder has
- *     a single setting (zstdmt_amd/csrc/hip/brotli_enc.hip).
+ *     dependent); `level` is validated (0..11), sets the default chunk size and selects one of the device
+ *     encoder's three tiers (0-3 / 4-8 / 9-11, zstdmt_amd/csrc/hip/brotli_enc.hip).
  */
 #ifndef BROTLIMT_H
 #define BROTLIMT_H

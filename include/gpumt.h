@@ -72,6 +72,9 @@ const char *gpumt_device_name(gpumt_ctx *h);
 /* Freed buffers go to process-wide caches (device: GPUMT_DEVICE_CACHE_MB, pinned host:
  * GPUMT_PINNED_CACHE_MB, 16384 each by default; 0 disables) and from there to the next allocation of a
  * similar size, without a device-wide wait: free a buffer only when no queued work uses it. */
+/* Debug guard for that contract: with GPUMT_DEBUG_FREE=1 in the environment (or gpumt_set_variant(h, "debug_free", 1))
+ * gpumt_free / gpumt_host_free first ask every stream of the context whether work is still queued; if so they count the
+ * call (gpumt_debug_free_busy), report it on stderr and wait for the streams before the buffer is recycled. */
 void *gpumt_malloc(gpumt_ctx *h, size_t bytes);
 void  gpumt_free(gpumt_ctx *h, void *dptr);
 void *gpumt_host_alloc(gpumt_ctx *h, size_t bytes);          /* pinned */
@@ -83,6 +86,8 @@ int gpumt_host_unregister(gpumt_ctx *h, void *p);
 /* Freed device and pinned buffers stay in process-wide caches (GPUMT_DEVICE_CACHE_MB / GPUMT_PINNED_CACHE_MB, 16 GiB
  * each by default) for the next context; this releases whatever is idle and returns the bytes given back. */
 size_t gpumt_trim_caches(gpumt_ctx *h);
+/* calls of gpumt_free / gpumt_host_free the debug guard caught with work queued, process-wide, since the last call */
+unsigned long gpumt_debug_free_busy(void);
 int   gpumt_memcpy_h2d(gpumt_ctx *h, void *dst, const void *src, size_t n, int stream);
 int   gpumt_memcpy_d2h(gpumt_ctx *h, void *dst, const void *src, size_t n, int stream);
 int   gpumt_memcpy_d2d(gpumt_ctx *h, void *dst, const void *src, size_t n, int stream);

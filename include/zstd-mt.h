@@ -11,7 +11,8 @@
  * version dependent):
  *   - ZSTDCB_decompressDCtx decodes what the reference writes, at any level, on the device;
  *   - ZSTDCB_compressCCtx writes valid zstd frames that the reference (and any zstd) decodes to the
- *     input; `level` is validated (1..22) but the device encoder has a single setting.
+ *     input; `level` is validated (1..22) and selects one of the device encoder's three tiers (1-2 / 3-9 /
+ *     10-22: table size and hash length, zstdmt_amd/csrc/hip/zstd_enc.hip) and the default chunk size.
  * Differences a caller can observe are listed in INTEGRATION.md.
  */
 #ifndef ZSTDCB_H

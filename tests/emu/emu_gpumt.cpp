@@ -120,6 +120,7 @@ void gpumt_host_free(gpumt_ctx *, void *p) { free(p); }
 int gpumt_host_register(gpumt_ctx *h, void *p, size_t bytes) { return (h && p && bytes) ? GPUMT_OK : GPUMT_E_ARG; }
 int gpumt_host_unregister(gpumt_ctx *h, void *p) { return (h && p) ? GPUMT_OK : GPUMT_E_ARG; }
 size_t gpumt_trim_caches(gpumt_ctx *) { return 0; }
+unsigned long gpumt_debug_free_busy(void) { return 0; }
 
 static int copy(gpumt_ctx *h, void *dst, const void *src, size_t n, int s)
 {

@@ -217,3 +217,28 @@ def test_pipeline_knobs_round_trip(env):
             assert c.stdout == want
         d = subprocess.run([os.path.join(BIN, cat)], input=c.stdout, capture_output=True, env=e, timeout=300)
         assert d.returncode == 0 and d.stdout == data, (tool, d.stderr[-300:])
+
+
+def test_batches_are_dealt_over_device_contexts_in_order():
+    """Multi-device readiness (the in-order multi-worker writer of lib/lz4-mt_compress.c:178-205): with
+    GPUMT_DEVICES=0,0 one LZ4MT_compressCCtx / decompressDCtx drives TWO device contexts.  Batch b goes to slot
+    b % nslot, slot s to device context s % 2 -- asserted from the engine's own launch trace -- and the frames leave
+    in input order: the stream is the reference's, byte for byte.  (Same GPU opened twice: the box has one.)"""
+    import re
+    import subprocess
+    data = cases.text(160 << 20, seed=23)
+    e = dict(os.environ, GPUMT_DEVICES="0,0", GPUMT_BATCH_MB="16", GPUMT_SLOTS="4", GPUMT_TRACE="2")
+    c = subprocess.run([LZ4, "-1", "-b", "1", "-c"], input=data, capture_output=True, env=e, timeout=300)
+    assert c.returncode == 0, c.stderr[-300:]
+    assert c.stdout == H.oracle_compress(data, 1 << 20)            # order preserved across the two contexts
+    tr = re.findall(r"\[lz4mt compress\] launch slot (\d+) -> device context (\d+) of (\d+), stream (\d+), (\d+) records",
+                    c.stderr.decode())
+    assert len(tr) >= 8, c.stderr[-500:]                            # 16 MiB batches: ten of them
+    for b, (slot, dev, ndev, stream, nrec) in enumerate(tr):
+        assert int(ndev) == 2 and int(slot) == b % 4 and int(dev) == int(slot) % 2, (b, slot, dev)
+    assert {int(t[1]) for t in tr} == {0, 1}                        # both contexts worked
+    assert sum(int(t[4]) for t in tr) == 160                        # every record exactly once
+    d = subprocess.run([os.path.join(BIN, "lz4cat-mt")], input=c.stdout, capture_output=True, env=e, timeout=300)
+    assert d.returncode == 0 and d.stdout == data
+    td = re.findall(r"\[lz4mt decompress\] launch slot (\d+) -> device context (\d+) of 2", d.stderr.decode())
+    assert len(td) >= 2 and all(int(s_) % 2 == int(dv) for s_, dv in td) and {int(t[1]) for t in td} == {0, 1}

@@ -131,3 +131,45 @@ def test_contexts_on_several_threads():
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_debug_free_guard_counts_busy_frees(eng):
+    """GPUMT_DEBUG_FREE / gpumt_set_variant("debug_free", 1): a buffer freed while the context's streams still have work
+    queued is counted and the streams are drained first (include/gpumt.h: "free a buffer only when no queued work uses
+    it" -- a violation is a cross-context use-after-free through the caches); an idle free counts nothing"""
+    eng.L.gpumt_debug_free_busy()
+    prev = eng.set_variant("debug_free", 1)
+    try:
+        n = 256 << 20
+        data = np.frombuffer(text(1 << 20, 3), np.uint8)
+        d_in = eng.upload(np.tile(data, n >> 20))
+        stride = eng.slot_stride(131072)
+        nrec = n // 131072
+        d_slots, d_rl = eng.alloc(nrec * stride), eng.alloc(nrec * 4)
+        victim = eng.alloc(1 << 20)
+        eng.sync()
+        eng.lz4_compress(d_in, n, 131072, d_slots, stride, d_rl)      # ~10 ms of kernels queued
+        victim.free()                                                  # busy: counted, drained
+        assert eng.L.gpumt_debug_free_busy() == 1
+        other = eng.alloc(1 << 20)
+        eng.sync()
+        other.free()                                                   # idle: not counted
+        assert eng.L.gpumt_debug_free_busy() == 0
+        for b in (d_in, d_slots, d_rl):
+            b.free()
+    finally:
+        eng.set_variant("debug_free", prev)
+
+
+def test_host_engines_never_free_busy_buffers(tmp_path):
+    """the drop-in engines under the guard: a round trip through LZ4MT_* / ZSTDCB_* with GPUMT_DEBUG_FREE=1 reports no
+    busy free on stderr"""
+    import os
+    import subprocess
+    exe = os.path.join(H.ROOT, "zstdmt_amd", "bin", "api_bench")
+    lib = os.path.join(H.ROOT, "zstdmt_amd", "lib", "libzstdmt_amd.so")
+    for codec, chunk in (("lz4", 131072), ("zstd", 1 << 20)):
+        p = subprocess.run([exe, codec, str(256 << 20), str(chunk), lib, "1"], capture_output=True, timeout=300,
+                           env=dict(os.environ, GPUMT_DEBUG_FREE="1"))
+        assert p.returncode == 0, p.stderr[-300:]
+        assert b"with work queued" not in p.stderr, p.stderr[-500:]

@@ -30,6 +30,7 @@ GPUMT_SYMBOLS = {
     "gpumt_host_register": (_i, [_vp, _vp, _sz]),
     "gpumt_host_unregister": (_i, [_vp, _vp]),
     "gpumt_trim_caches": (_sz, [_vp]),
+    "gpumt_debug_free_busy": (C.c_ulong, []),
     "gpumt_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz, _i]),
     "gpumt_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz, _i]),
     "gpumt_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz, _i]),

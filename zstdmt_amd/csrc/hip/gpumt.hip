@@ -99,6 +99,7 @@ struct gpumt_ctx {
 	unsigned long long *d_prof; /* 16 phase counters of the profiling decoder */
 	int xflags;  /* experiment switches of the parse kernel (developer) */
 	int lz4_ring; /* copy3: log2 of the LDS ring per wave (12, 13 or 14) */
+	int debug_free; /* GPUMT_DEBUG_FREE: gpumt_free / gpumt_host_free check that the streams are idle */
 	int lz4_parse; /* parse stage: 4 = parse4 (default), 3 = parse3 (round 3) */
 	int lz4_copy;  /* copy stage: 4 = copy4 (default), 3 = copy3 (round 3; the only one with 8 / 16 KiB rings) */
 	int profile; /* record events in timer slots 8.. around individual kernels */
@@ -251,6 +252,8 @@ int gpumt_open(int device, gpumt_ctx **out)
 		e = getenv("GPUMT_LZ4_RING");
 		h->lz4_ring = e && *e ? atoi(e) : 12;
 		/* GPUMT_LZ4_PARSE / GPUMT_LZ4_COPY: 3 = the round-3 kernels (parse3 / copy3), default the round-4 ones */
+		e = getenv("GPUMT_DEBUG_FREE");
+		h->debug_free = e && *e ? atoi(e) : 0;
 		e = getenv("GPUMT_LZ4_PARSE");
 		h->lz4_parse = e && *e ? atoi(e) : 4;
 		e = getenv("GPUMT_LZ4_COPY");
@@ -385,12 +388,35 @@ void *gpumt_malloc(gpumt_ctx *h, size_t bytes)
 		return NULL;
 	return dev_alloc(h, bytes);
 }
+/* debug guard of the "free only idle buffers" contract (include/gpumt.h): a buffer handed back while any stream of its
+ * context still has work queued is counted and reported, and the streams are drained before it is recycled */
+static unsigned long g_free_busy;
+static int free_guard(gpumt_ctx *h, const char *who, void *p)
+{
+	if (!h->debug_free)
+		return 0;
+	int busy = 0;
+	for (int i = 0; i < GPUMT_NSTREAMS; i++)
+		if (hipStreamQuery(h->st[i]) == hipErrorNotReady) {
+			busy = 1;
+			(void)hipStreamSynchronize(h->st[i]);
+		}
+	if (busy) {
+		__atomic_fetch_add(&g_free_busy, 1ul, __ATOMIC_RELAXED);
+		fprintf(stderr, "gpumt: %s(%p) with work queued on the context's streams (drained; GPUMT_DEBUG_FREE)\n", who, p);
+	}
+	return busy;
+}
+unsigned long gpumt_debug_free_busy(void) { return __atomic_exchange_n(&g_free_busy, 0ul, __ATOMIC_RELAXED); }
+
 void gpumt_free(gpumt_ctx *h, void *p)
 {
 	/* the buffer must be idle: it may go to the cache and from there to another context without the
 	 * device-wide wait hipFree implies */
-	if (h && p && !use(h))
+	if (h && p && !use(h)) {
+		(void)free_guard(h, "gpumt_free", p);
 		dev_free(h, p);
+	}
 }
 /*
  * Pinned host memory costs ~0.3 s per GiB to allocate and to free (page pinning), which used to be
@@ -454,6 +480,8 @@ void gpumt_host_free(gpumt_ctx *h, void *p)
 {
 	if (!h || !p)
 		return;
+	if (h->debug_free && !use(h))
+		(void)free_guard(h, "gpumt_host_free", p);
 	struct pin_hdr *hd = (struct pin_hdr *)((u8 *)p - sizeof(struct pin_hdr));
 	const size_t cap = hd->cap;
 	pthread_mutex_lock(&g_pin.mu);
@@ -1270,6 +1298,9 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	} else if (!strcmp(what, "lz4_ring")) {
 		prev = h->lz4_ring;
 		h->lz4_ring = variant;
+	} else if (!strcmp(what, "debug_free")) {
+		prev = h->debug_free;
+		h->debug_free = variant;
 	} else if (!strcmp(what, "lz4_parse")) {
 		prev = h->lz4_parse;
 		h->lz4_parse = variant;

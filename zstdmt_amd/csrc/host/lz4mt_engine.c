@@ -215,6 +215,7 @@ static size_t cp_fill(void *a, int si, int *has_data, int *eof)
 static size_t cp_launch(void *a, int si)
 {
 	LZ4MT_CCtx *ctx = (LZ4MT_CCtx *)a;
+	mt_trace_launch(&ctx->gpus, "lz4mt compress", si, ctx->s[si].nrec);
 	size_t err = c_launch(ctx, &ctx->s[si]);
 	if (!err && gpumt_mark(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si), mt_stream_of(&ctx->gpus, si)))
 		err = ERROR(compression_library);
@@ -498,6 +499,7 @@ static size_t dp_fill(void *a, int si, int *has_data, int *eof)
 static size_t dp_launch(void *a, int si)
 {
 	LZ4MT_DCtx *ctx = (LZ4MT_DCtx *)a;
+	mt_trace_launch(&ctx->gpus, "lz4mt decompress", si, ctx->s[si].nrec);
 	size_t err = d_launch(ctx, &ctx->s[si]);
 	if (!err && gpumt_mark(mt_gpu_of(&ctx->gpus, si), mt_mark_of(&ctx->gpus, si), 2))
 		err = ERROR(compression_library);

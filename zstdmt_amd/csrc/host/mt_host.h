@@ -7,6 +7,7 @@
 #define ZMT_MT_HOST_H
 
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -104,6 +105,19 @@ static inline int mt_gpus_open(mt_gpus *m)
 	return m->n ? 0 : -1;
 }
 static inline gpumt_ctx *mt_gpu_of(const mt_gpus *m, int slot) { return m->g[slot % m->n]; }
+/* GPUMT_TRACE >= 2: which device context a batch went to (the order tests/test_gpu_cli.py asserts: batch b uses slot
+ * b % nslot, slot s the device context s % n -- the in-order writer of lib/lz4-mt_compress.c:178-205 re-expressed) */
+static inline void mt_trace_launch(const mt_gpus *m, const char *who, int slot, size_t nrec)
+{
+	static int trace = -1;
+	if (trace < 0) {
+		const char *e = getenv("GPUMT_TRACE");
+		trace = e && *e ? atoi(e) : 0;
+	}
+	if (trace > 1)
+		fprintf(stderr, "[%s] launch slot %d -> device context %d of %d, stream %d, %zu records\n", who, slot,
+			slot % m->n, m->n, 4 + (slot / m->n) % 12, nrec);
+}
 /* the slot's own kernel stream (4..15) and completion mark on its device */
 static inline int mt_stream_of(const mt_gpus *m, int slot) { return 4 + (slot / m->n) % 12; }
 static inline int mt_mark_of(const mt_gpus *m, int slot) { return (slot / m->n) % GPUMT_NMARKS; }
