@@ -92,6 +92,14 @@ def test_emu_hc_optimal_bit_exact(name, level):
     assert stream == H.oracle_compress_level(data, chunk, level)
 
 
+def test_emu_hc_optimal_1mib_chunk():
+    """level 10 at a 1 MiB chunk (16 linked blocks, one table set carried across them) on the emulator: the slowest test
+    of the CPU suite (~3.5 minutes of one core), kept because the chunk size above 256 KiB was untested at levels >= 10"""
+    data = text(1 << 20, seed=77)
+    stream, rec_off, rec_len = E.compress(data, 1 << 20, 10)
+    assert stream == H.oracle_compress_level(data, 1 << 20, 10)
+
+
 # decoder variants of the emulator API: 0 | ring << 4 = frames + parse3 + copy3 with a 4 / 8 / 16 KiB ring
 # (plain 0 = the product's default, 4 KiB), 1 = frame-serial
 DEC_VARIANTS = [0, 1, 0 | 13 << 4, 0 | 14 << 4]

@@ -115,6 +115,17 @@ def test_hc_compress_golden(eng, level):
     assert n >= 20
 
 
+@pytest.mark.parametrize("level", [10, 11, 12])
+def test_hc_optimal_levels_at_a_1mib_chunk(eng, level):
+    """levels 10..12 (the optimal parser) with ONE wave walking a 1 MiB chunk of 16 linked blocks: slow on the device
+    (seconds per chunk -- a wave per chunk and a 4 096-position price table), bit-exact all the same"""
+    data = text(1 << 20, seed=77) + text(300000, seed=78)
+    stream, ro, rl = eng.compress_bytes(data, 1 << 20, level=level)
+    assert stream == H.oracle_compress_level(data, 1 << 20, level)
+    out, status = eng.decompress_bytes(stream, ro, rl)
+    assert not status.any() and out == data
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_hc_fuzz_vs_oracle(eng, seed):
     import random
