@@ -25,6 +25,7 @@
  *                               decoder must provide, lib/brotli-mt_compress.c:294-304), the chunk's
  *                               blocks moved together, the final empty meta-block.
  */
+#include <cstddef>
 #include "lz4_common.h"
 #include "lz4_frame.h"
 
@@ -355,7 +356,9 @@ brotli_enc_body(BEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nbl
 		u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch)
 {
 	const int lane = wv_lane();
-	u16 *const tab = L.table; /* 2^HLOG entries: runs on behind the struct for the larger tiers */
+	/* 2^HLOG entries: runs on behind the struct for the larger tiers -- derived from the byte address of the enclosing
+	 * object, not from the member array (zstd_enc.hip has the reason) */
+	u16 *const tab = (u16 *)((u8 *)&L + offsetof(BEncLds, table));
 	u8 *const wscr = scratch + (u64)blockIdx.x * BE_WSCRATCH;
 	u32 *const sq_ll = (u32 *)wscr;
 	u32 *const sq_ml = sq_ll + BE_MAXSEQ, *const sq_of = sq_ml + BE_MAXSEQ;

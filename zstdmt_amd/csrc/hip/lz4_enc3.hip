@@ -363,7 +363,9 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					 * the match length need, so that the 128-byte window (a second round trip) is the exception.
 					 * Lanes without a candidate read the ring's first bytes (no exec-mask region) */
 					const bool probe = valid && dist_ok;
-					const bool wide = cand >= 8; /* else (chunk start) 8 bytes at cand only, no quick extension */
+					/* (lanes without a probe read chunk[0, 8) only: a final record of 13..15 bytes has nothing readable at
+					 * chunk + 16) */
+					const bool wide = probe && cand >= 8; /* else (chunk start) 8 bytes at cand only, no quick extension */
 					/* (always from memory: the ring holds the same bytes, but a batch waits for its farthest candidate
 					 * anyway, and one plain global load path is cheaper than a per-lane choice between LDS and memory) */
 					const u32 a0 = !probe ? 0u : wide ? cand - 8 : cand;

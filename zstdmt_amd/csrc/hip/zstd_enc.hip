@@ -30,6 +30,7 @@
  *
  * Matches stay inside their block (blocks are independent: 65536 of them per 8 GiB).
  */
+#include <cstddef>
 #include "lz4_common.h"
 #include "lz4_frame.h"
 
@@ -873,7 +874,10 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		 * Table entries are positions mod 64 Ki; a candidate is rebuilt as the newest position
 		 * below p with those low bits and then verified, so stale or aliased entries only cost a
 		 * missed match. */
-		u16 *const tab = L.table; /* (2^HLOG entries: runs on behind the struct for the larger tiers) */
+		/* 2^HLOG entries: for the larger tiers the table runs on into ZEncLdsExt::more, right behind the struct -- so
+		 * the pointer is derived from the byte address of the enclosing object, never from the 4 Ki-entry member array
+		 * (indexing that array past its end would be undefined) */
+		u16 *const tab = (u16 *)((u8 *)&L + offsetof(ZEncLds, table));
 		for (u32 i = (u32)lane; i < (1u << HLOG); i += 64)
 			tab[i] = 0;
 		wv_sync();

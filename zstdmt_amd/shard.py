@@ -69,11 +69,22 @@ class SharedHostStream:
         self.path = "/dev/shm/" + name
         self.total = max(1, int(total_bytes))
         self.owner = owner
+        nofollow = getattr(os, "O_NOFOLLOW", 0)
         if owner:
-            fd = os.open(self.path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+            # a stale segment of a crashed run is removed, never reused; O_EXCL | O_NOFOLLOW: a file or symbolic link
+            # planted under the (predictable) name is neither followed nor truncated -- the open fails instead
+            try:
+                os.unlink(self.path)
+            except FileNotFoundError:
+                pass
+            fd = os.open(self.path, os.O_CREAT | os.O_EXCL | os.O_RDWR | nofollow, 0o600)
             os.ftruncate(fd, self.total)
         else:
-            fd = os.open(self.path, os.O_RDWR)
+            fd = os.open(self.path, os.O_RDWR | nofollow)
+            st = os.fstat(fd)
+            if st.st_uid != os.getuid() or st.st_size < self.total:
+                os.close(fd)
+                raise OSError("shared segment %s is not the owner rank's (uid / size mismatch)" % self.path)
         try:
             self.map = mmap.mmap(fd, self.total)
         finally:
