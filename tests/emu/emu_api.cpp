@@ -35,7 +35,8 @@ void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 
 void zmt_brotli_enc_t2_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 void zmt_brotli_enc_t3_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 void zmt_brotli_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
-void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u8 *, const u8 *);
+void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u8 *, const u8 *, u32);
+void zmt_brotli_dec4_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
 void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *);
 void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *, u32 *);
 void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
@@ -257,8 +258,21 @@ void emu_brotli_decompress_batch(const u8 *stream, const u64 *rec_off, const u32
 		grid = nrec;
 	std::vector<u8> scr((size_t)grid * 825856u, 0xA5);
 	u8 *sp = scr.data();
+	/* EMU_BROTLI_DEC=1: the general kernel alone (gpumt_set_variant("brotli_dec", 1)); default: dec4 first, the
+	 * general kernel for the records it hands over (status 102) */
+	const char *v = getenv("EMU_BROTLI_DEC");
+	u32 want = 0xFFFFFFFFu;
+	if (!(v && atoi(v) == 1)) {
+		emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{64, 1, 1}, [=]() {
+			zmt_brotli_dec4_kernel(stream, rec_off, rec_len, nrec, out, out_off, out_cap, out_len, status);
+		});
+		if (getenv("ZMT_EMU_DEBUG"))
+			for (u32 r = 0; r < nrec; r++)
+				fprintf(stderr, "brotli dec4: rec %u status %u\n", r, status[r]);
+		want = 102u;
+	}
 	emu::launch(dim3{grid, 1, 1}, dim3{64, 1, 1}, [=]() {
-		zmt_brotli_dec_kernel(stream, rec_off, rec_len, nrec, out, out_off, out_cap, out_len, status, sp, blob);
+		zmt_brotli_dec_kernel(stream, rec_off, rec_len, nrec, out, out_off, out_cap, out_len, status, sp, blob, want);
 	});
 }
 

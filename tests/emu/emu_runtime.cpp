@@ -53,8 +53,9 @@ static void run_block(Block &b)
 	b.fib.resize(n);
 	b.slot.assign(n, 0);
 	b.nwaves = (n + 63) / 64;
-	b.arrived.assign(b.nwaves + 1, 0);
-	b.gen.assign(b.nwaves + 1, 0);
+	const unsigned nbar = b.nwaves + 1 + (n + 15) / 16; /* wave barriers, the block barrier, 16-lane group barriers */
+	b.arrived.assign(nbar, 0);
+	b.gen.assign(nbar, 0);
 	for (unsigned i = 0; i < n; i++) {
 		Fiber &f = b.fib[i];
 		if (g_stacks.size() <= i)
@@ -105,7 +106,7 @@ static void run_block(Block &b)
 		}
 		/* deadlock detector: every live fiber is parked in a barrier that can never fill */
 		unsigned waiting = 0;
-		for (unsigned k = 0; k <= b.nwaves; k++)
+		for (unsigned k = 0; k < nbar; k++)
 			waiting += b.arrived[k];
 		if (live && !progressed && waiting == live) {
 			if (++idle_rounds > 4) {

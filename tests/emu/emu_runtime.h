@@ -99,6 +99,17 @@ inline void wave_barrier()
 	barrier(w, wave_size_of(w));
 }
 inline void block_barrier() { barrier(g_blk->nwaves, g_blk->nthreads); }
+/* barrier over the 16 lanes of a lane group (kernels that run one stream per 16-lane group in divergent control
+ * flow, brotli_dec4.hip): slots nwaves + 1 + group */
+inline void group_barrier16()
+{
+	Block *b = g_blk;
+	const unsigned g = tid() / 16, lo = g * 16;
+	unsigned hi = lo + 16;
+	if (hi > b->nthreads)
+		hi = b->nthreads;
+	barrier(b->nwaves + 1 + g, hi - lo);
+}
 
 void launch(dim3 grid, dim3 block, std::function<void()> body);
 

@@ -1,0 +1,551 @@
+/*
+ * brotli_dec4.hip -- brotli stream decoder for gfx950, FOUR records per wave ("dec4").
+ *
+ * Replaces BrotliDecoderDecompress as called per record by the reference
+ * (/root/reference/lib/brotli-mt_decompress.c:344-346) for the streams that make up BASELINE configs[4]: what
+ * the reference's compressor writes at levels 0..4 -- meta-blocks with ONE block type per category, ONE literal
+ * tree (no context modelling), ONE distance tree.  Every other stream (block switching, context maps, static
+ * dictionary references) is handed to the general kernel (brotli_dec.hip) by status B4_HANDOFF, so the pair
+ * decodes everything RFC 7932 allows.
+ *
+ * Why: a brotli stream is one serial bitstream, and brotli_dec.hip walks it in wave-uniform control flow -- one
+ * record per wave, 70 % of its instructions on the scalar pipe, which the 16 waves of a CU saturate
+ * (profiles/r03_sq_counters.json: 31 wave-instructions per output byte).  Here a wave runs FOUR streams side by
+ * side, one per 16-lane group, in lockstep at the command level: one pass of the loop decodes one insert&copy
+ * command of each of the four records, so every instruction of the command and distance decode serves four
+ * commands, and the literal loop runs max(insert lengths) times instead of their sum.  All per-stream state is
+ * "group-uniform" vector state (every lane of a group holds the same value); the canonical prefix decode of
+ * brotli_dec.hip -- lane l of a tree's vector holds the left-aligned end of the code range of length l, one compare
+ * finds the length -- works unchanged on 16 lanes: the ballot's 16 bits of the group, ds_bpermute inside the
+ * group.  Headers and prefix-code tables are rare (a few per record) and use all 64 lanes through the shared
+ * wave-cooperative code (brotli_dec_common.h), one group at a time.
+ *
+ * Per group: a 256-byte window of its stream in LDS (two aligned dword reads + one v_alignbit per symbol, no
+ * accumulator), its three tree records in LDS, up to 16 copies pending in its 16 lanes (executed side by side with
+ * watermark rounds, as in brotli_dec.hip), literals stored straight to their final positions.
+ */
+#include "brotli_dec_common.h"
+
+#define B4_HANDOFF 102u /* internal status: zmt_brotli_dec_kernel decodes the record afterwards (gpumt.hip) */
+#define B4_WIN 256u
+#define B4_WSTRIDE (B4_WIN + 16u)
+#define B4_NB 16u
+
+enum { B4_S_HDR = 0, B4_S_DEC = 1, B4_S_FIN = 2, B4_S_DONE = 3 };
+
+struct B4Lds {
+	BrLds L; /* the shared header / table code works in here; L.lit slots 0..3, L.cmd and L.dist are group 0..3's / group 0's */
+	__attribute__((aligned(8))) u8 cmd[3 * BR_CMD_STRIDE];   /* groups 1..3 */
+	__attribute__((aligned(8))) u8 dist[3 * BR_DIST_STRIDE]; /* groups 1..3 */
+	__attribute__((aligned(16))) u8 win[4 * B4_WSTRIDE];
+};
+
+#ifdef ZMT_EMU
+static inline u32 b4_alignbit(u32 hi, u32 lo, u32 sh) { return (u32)((((u64)hi << 32) | lo) >> (sh & 31)); }
+#else
+static __device__ __forceinline__ u32 b4_alignbit(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+#endif
+
+/* order a group's earlier global stores before its later global loads, inside group-divergent control flow (the hardware
+ * fence is the wave's; the fiber harness must not wait for lanes of other groups) */
+static __device__ __forceinline__ void b4_grp_fence()
+{
+#ifdef ZMT_EMU
+	grp_sync();
+#else
+	wave_mem_fence();
+#endif
+}
+
+/* 32 bits of the group's stream at bit position bp (the window holds them: B4_ENSURE) */
+static __device__ __forceinline__ u32 b4_peek(const u8 *win, u32 wbyte, u32 bp)
+{
+	const u32 o = (bp >> 3) - wbyte;
+	const u32 *w = (const u32 *)(win + (o & ~3u));
+	return b4_alignbit(w[1], w[0], bp & 31u); /* wbyte is a multiple of 4 */
+}
+
+/* index of the next symbol in the sorted array of the tree whose vector this group's lanes hold (lane l of the group:
+ * va / vi of code length l); *len = its code length */
+static __device__ __forceinline__ u32 b4_sym_index(u32 bits, u32 va, u32 vi, u32 *len, bool &bad)
+{
+	const u32 c = br_rev15(bits & 0x7FFFu);
+	const u32 m = grp_ballot(c < (va & 0xFFFFu));
+	if (!m)
+		bad = true;
+	const int l = m ? wv_ffs((u64)m) - 1 : 0;
+	const u32 a = grp_shfl(va, l), i0 = grp_shfl(vi, l);
+	*len = (u32)l;
+	return i0 + ((c - (a >> 16)) >> (15 - l));
+}
+
+/* copy of `ml` bytes at distance `off` by the 16 lanes of a group (long copies; plain or overlapping) */
+static __device__ __forceinline__ void b4_grp_match(u8 *d, u32 off, u32 ml, u32 l16)
+{
+	const u8 *s = d - off;
+	if (off >= ml) {
+		const u32 body = ml & ~7u;
+		for (u32 i = 8u * l16; i < body; i += 128u)
+			st64g(d + i, ld64u(s + i));
+		for (u32 i = body + l16; i < ml; i += 16u)
+			d[i] = s[i];
+	} else if (off >= 16u) {
+		for (u32 done = 0; done < ml; done += off) {
+			const u32 n = ml - done < off ? ml - done : off;
+			for (u32 i = l16; i < n; i += 16u)
+				d[done + i] = s[done + i];
+			b4_grp_fence();
+		}
+	} else {
+		for (u32 i = l16; i < ml; i += 16u)
+			d[i] = s[i % off];
+	}
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec_off, const u32 *__restrict__ rec_len,
+		       u32 nrec, u8 *out_base, const u64 *__restrict__ out_off, const u32 *__restrict__ out_cap,
+		       u32 *__restrict__ out_len, u32 *__restrict__ status)
+{
+	__shared__ __attribute__((aligned(16))) B4Lds S;
+	BrLds &L = S.L;
+	const int lane = wv_lane();
+	const u32 grp = (u32)lane >> 4, l16 = (u32)lane & 15u;
+	if (lane < 24) {
+		L.kins[lane] = (u32)BR_INS_BASE[lane] | (u32)BR_INS_BITS[lane] << 24;
+		L.kcopy[lane] = (u32)BR_COPY_BASE[lane] | (u32)BR_COPY_BITS[lane] << 24;
+	}
+	wv_sync();
+	/* this group's tree records and window */
+	u8 *const lit_rec = L.lit + grp * BR_LIT_STRIDE;
+	u8 *const cmd_rec = grp == 0 ? L.cmd : S.cmd + (grp - 1u) * BR_CMD_STRIDE;
+	u8 *const dist_rec = grp == 0 ? L.dist : S.dist + (grp - 1u) * BR_DIST_STRIDE;
+	u8 *const win = S.win + grp * B4_WSTRIDE;
+
+	const u32 rec = blockIdx.x * 4u + grp;
+	const bool exists = rec < nrec;
+	const u8 *const sp = stream + (exists ? rec_off[rec] : 0);
+	const u32 slen = exists ? rec_len[rec] : 0;
+	u8 *const out = out_base + (exists ? out_off[rec] : 0);
+	const u32 cap = exists ? out_cap[rec] : 0;
+
+	/* ---- per-stream state, the same in the 16 lanes of a group ---- */
+	u32 st = exists ? B4_S_HDR : B4_S_DONE;
+	u32 stc = ST_OK;
+	u32 bitpos = 0, wbyte = 0xFFFFFF00u; /* wbyte: first stream byte in the window (none yet) */
+	u32 pos = 0, left = 0;
+	bool first = true, was_last = false;
+	u32 max_backward = 0, npostfix = 0, ndirect = 0;
+	u32 rb0 = 16, rb1 = 15, rb2 = 11, rb3 = 4; /* rb3 = last distance */
+	u32 lva = 0, lvi = 0, cva = 0, cvi = 0, dva = 0, dvi = 0;
+	u32 bm_pos = 0, bm_dist = 0, bm_len = 0, nbatch = 0; /* lane j of the group: pending copy j */
+	if (exists && slen >= (1u << 28)) { /* 32-bit bit positions */
+		stc = B4_HANDOFF;
+		st = B4_S_FIN;
+	}
+
+	/* the window must hold the 8 bytes at the read position */
+#define B4_ENSURE(cond)                                                                                            \
+	do {                                                                                                       \
+		const bool need_ = (cond) && ((bitpos >> 3) - wbyte > B4_WIN - 8u);                                \
+		if (wv_any(need_)) {                                                                               \
+			if (need_) {                                                                               \
+				wbyte = (bitpos >> 3) & ~3u;                                                       \
+				const u8 *g_ = sp + wbyte + 16u * l16;                                             \
+				const u64 a_ = ld64u(g_), b_ = ld64u(g_ + 8);                                      \
+				*(u64 *)(win + 16u * l16) = a_;                                                    \
+				*(u64 *)(win + 16u * l16 + 8) = b_;                                                \
+				if (l16 == 0)                                                                      \
+					*(u64 *)(win + B4_WIN) = ld64u(sp + wbyte + B4_WIN);                       \
+				grp_sync();                                                                        \
+			}                                                                                          \
+		}                                                                                                  \
+	} while (0)
+	/* pending copies of the groups with `cond`: every lane its own copy once its source lies below the watermark (the
+	 * destination of the group's first unfinished copy), long ones by the group together */
+#define B4_EXEC(cond)                                                                                              \
+	do {                                                                                                       \
+		const bool ex_ = (cond) && nbatch != 0;                                                            \
+		if (wv_any(ex_)) {                                                                                 \
+			wave_mem_fence();                                                                          \
+			if (ex_) {                                                                                 \
+				const bool act_ = l16 < nbatch;                                                    \
+				const u32 ml_ = act_ ? bm_len : 0;                                                 \
+				const u32 src_ = bm_pos - bm_dist, eff_ = ml_ < bm_dist ? ml_ : bm_dist;           \
+				bool fin_ = !act_;                                                                 \
+				for (;;) {                                                                         \
+					const u32 unf_ = grp_ballot(!fin_);                                        \
+					if (!unf_)                                                                 \
+						break;                                                             \
+					const int fst_ = wv_ffs((u64)unf_) - 1;                                    \
+					const u32 W_ = grp_shfl(bm_pos, fst_), hl_ = grp_shfl(ml_, fst_);          \
+					if (hl_ > BR_CAP) {                                                        \
+						b4_grp_match(out + W_, grp_shfl(bm_dist, fst_), hl_, l16);         \
+						if ((int)l16 == fst_)                                              \
+							fin_ = true;                                               \
+					} else {                                                                   \
+						const bool rdy_ = !fin_ && ml_ <= BR_CAP && src_ + eff_ <= W_;     \
+						if (rdy_) {                                                        \
+							g_match(out + bm_pos, bm_dist, ml_);                       \
+							fin_ = true;                                               \
+						}                                                                  \
+					}                                                                          \
+					b4_grp_fence();                                                            \
+				}                                                                                  \
+				nbatch = 0;                                                                        \
+			}                                                                                          \
+		}                                                                                                  \
+	} while (0)
+
+	for (;;) {
+		/* ================= headers: wave-cooperative, one group at a time ================= */
+		for (u32 g = 0; g < 4; g++) {
+			if (wv_readlane(st, (int)(16u * g)) != B4_S_HDR)
+				continue;
+			const int gl = (int)(16u * g);
+			const bool mine = grp == g;
+			BrBits b;
+			{
+				const u32 r_ = blockIdx.x * 4u + g;
+				b.p = stream + rec_off[r_];
+				b.n = wv_readfirst(rec_len[r_]);
+			}
+			const u32 g_cap = wv_readlane(cap, gl);
+			const u32 bp = wv_readlane(bitpos, gl);
+			u32 g_pos = wv_readlane(pos, gl);
+			u8 *const g_out = out_base + out_off[blockIdx.x * 4u + g];
+			br_seek(b, bp >> 3, lane);
+			if (bp & 7u)
+				(void)br_get(b, bp & 7u, lane);
+			u32 g_stc = ST_OK, g_st = B4_S_HDR;
+			u32 g_left = 0, g_npostfix = 0, g_ndirect = 0, g_maxb = wv_readlane(max_backward, gl);
+			bool g_last = wv_readlane((u32)was_last, gl) != 0;
+			if (wv_readlane((u32)first, gl)) {
+				/* 9.1 window bits */
+				u32 wbits = 16;
+				if (br_get(b, 1, lane)) {
+					u32 v = br_get(b, 3, lane);
+					if (v) {
+						wbits = 17 + v;
+					} else {
+						v = br_get(b, 3, lane);
+						if (v == 1)
+							g_stc = BRBAD(); /* large-window streams are not brotli-mt's */
+						wbits = v ? 8 + v : 17;
+					}
+				}
+				g_maxb = (1u << wbits) - 16u;
+			}
+			while (g_stc == ST_OK && g_st == B4_S_HDR) {
+				if (g_last) { /* the last meta-block is done: zero padding up to the byte boundary, nothing after counts */
+					g_st = B4_S_FIN;
+					break;
+				}
+				if (br_over(b)) {
+					g_stc = BRBAD();
+					break;
+				}
+				const u32 is_last = br_get(b, 1, lane);
+				if (is_last && br_get(b, 1, lane)) { /* ISLASTEMPTY */
+					g_last = true;
+					continue;
+				}
+				const u32 nib = br_get(b, 2, lane);
+				if (nib == 3) {
+					/* metadata meta-block: skipped */
+					if (br_get(b, 1, lane)) {
+						g_stc = BRBAD();
+						break;
+					}
+					const u32 nb = br_get(b, 2, lane);
+					u32 skip = 0;
+					bool e = false;
+					for (u32 i = 0; i < nb; i++) {
+						const u32 v = br_get(b, 8, lane);
+						if (i + 1 == nb && nb > 1 && v == 0)
+							e = true;
+						skip |= v << (8 * i);
+					}
+					if (nb)
+						skip++;
+					if ((br_used(b) & 7) && br_get(b, 8 - (u32)(br_used(b) & 7), lane))
+						e = true;
+					const u64 at = br_used(b) >> 3;
+					if (e || br_over(b) || at + skip > b.n) {
+						g_stc = BRBAD();
+						break;
+					}
+					br_seek(b, (u32)at + skip, lane);
+					if (is_last)
+						g_last = true;
+					continue;
+				}
+				u32 mlen = 0;
+				{
+					bool e = false;
+					for (u32 i = 0; i < nib + 4; i++) {
+						const u32 v = br_get(b, 4, lane);
+						if (i + 1 == nib + 4 && nib && v == 0)
+							e = true;
+						mlen |= v << (4 * i);
+					}
+					if (e) {
+						g_stc = BRBAD();
+						break;
+					}
+				}
+				mlen++;
+				if (!is_last && br_get(b, 1, lane)) {
+					/* uncompressed meta-block (pending copies read nothing it writes and it reads nothing at all) */
+					if ((br_used(b) & 7) && br_get(b, 8 - (u32)(br_used(b) & 7), lane)) {
+						g_stc = BRBAD();
+						break;
+					}
+					const u64 at = br_used(b) >> 3;
+					if (br_over(b) || at + mlen > b.n) {
+						g_stc = BRBAD();
+						break;
+					}
+					if (mlen > g_cap - g_pos) {
+						g_stc = ST_SIZE_MISMATCH;
+						break;
+					}
+					wave_copy(g_out + g_pos, b.p + at, mlen, lane);
+					wave_mem_fence();
+					g_pos += mlen;
+					br_seek(b, (u32)at + mlen, lane);
+					continue;
+				}
+				/* ---------------- compressed meta-block header (9.2): the simple shape only ---------------- */
+				bool simple = true;
+				for (u32 k = 0; k < 3 && simple; k++)
+					simple = br_varlen8(b, lane) == 0; /* NBLTYPES == 1: no block-switch codes follow */
+				if (!simple) {
+					g_stc = B4_HANDOFF;
+					break;
+				}
+				g_npostfix = br_get(b, 2, lane);
+				g_ndirect = br_get(b, 4, lane) << g_npostfix;
+				(void)br_get(b, 2, lane);                          /* context mode of the one literal block type */
+				if (br_varlen8(b, lane) != 0 || br_varlen8(b, lane) != 0) { /* NTREESL, NTREESD: context maps */
+					g_stc = B4_HANDOFF;
+					break;
+				}
+				if (br_over(b)) {
+					g_stc = BRBAD();
+					break;
+				}
+				const u32 dist_alphabet = 16 + g_ndirect + (48u << g_npostfix);
+				u8 *const g_lit = L.lit + g * BR_LIT_STRIDE;
+				u8 *const g_cmd = g == 0 ? L.cmd : S.cmd + (g - 1u) * BR_CMD_STRIDE;
+				u8 *const g_dist = g == 0 ? L.dist : S.dist + (g - 1u) * BR_DIST_STRIDE;
+				bool bad = !br_read_code(b, L, g_lit, 256, false, lane) || br_over(b);
+				if (!bad) {
+					bad = !br_read_code(b, L, g_cmd, 704, true, lane) || br_over(b);
+					/* insert&copy symbol -> insert code | copy code << 5 | "distance is the last one" << 10
+					 * (RFC 7932 section 5; as in brotli_dec.hip) */
+					u16 *sy = (u16 *)(g_cmd + 128);
+					for (u32 k = (u32)lane; k < 704; k += 64) {
+						const u32 v = sy[k];
+						if (v < 704) {
+							const u32 cell = v >> 6;
+							const u32 icode = (((0x298500u >> (2 * cell)) & 3u) << 3) + ((v >> 3) & 7);
+							const u32 ccode = (((0x262444u >> (2 * cell)) & 3u) << 3) + (v & 7);
+							sy[k] = (u16)(icode | ccode << 5 | (v < 128 ? 1u << 10 : 0u));
+						}
+					}
+					wv_sync();
+				}
+				if (!bad)
+					bad = !br_read_code(b, L, g_dist, dist_alphabet, true, lane) || br_over(b);
+				if (bad) {
+					g_stc = BRBAD();
+					break;
+				}
+				if (mlen > g_cap - g_pos) {
+					g_stc = ST_SIZE_MISMATCH;
+					break;
+				}
+				g_left = mlen;
+				g_last = is_last != 0;
+				g_st = B4_S_DEC;
+			}
+			if (g_stc == ST_OK && g_st == B4_S_FIN) {
+				if ((br_used(b) & 7) && br_get(b, 8 - (u32)(br_used(b) & 7), lane))
+					g_stc = BRBAD();
+				if (br_over(b))
+					g_stc = BRBAD();
+			}
+			if (g_stc != ST_OK)
+				g_st = B4_S_FIN;
+			const u64 used = br_used(b);
+			wv_sync();
+			if (mine) {
+				st = g_st;
+				stc = g_stc;
+				bitpos = (u32)used;
+				wbyte = 0xFFFFFF00u; /* the window is reloaded at the new position */
+				pos = g_pos;
+				left = g_left;
+				first = false;
+				was_last = g_last;
+				max_backward = g_maxb;
+				npostfix = g_npostfix;
+				ndirect = g_ndirect;
+				if (g_st == B4_S_DEC) {
+					const u64 el = *(const u64 *)(lit_rec + 8u * l16);
+					const u64 ec = *(const u64 *)(cmd_rec + 8u * l16);
+					const u64 ed = *(const u64 *)(dist_rec + 8u * l16);
+					lva = (u32)el;
+					lvi = (u32)(el >> 32);
+					cva = (u32)ec;
+					cvi = (u32)(ec >> 32);
+					dva = (u32)ed;
+					dvi = (u32)(ed >> 32);
+				}
+			}
+		}
+		/* ================= finished streams: pending copies, status ================= */
+		if (wv_any(st == B4_S_FIN)) {
+			B4_EXEC(st == B4_S_FIN && stc == ST_OK);
+			wave_mem_fence();
+			if (st == B4_S_FIN) {
+				if (l16 == 0) {
+					status[rec] = stc;
+					out_len[rec] = stc == ST_OK ? pos : 0;
+				}
+				st = B4_S_DONE;
+			}
+		}
+		if (!wv_any(st != B4_S_DONE))
+			break;
+		/* ================= commands (section 10): the groups in lockstep, one command each per pass ================= */
+		while (wv_any(st == B4_S_DEC) && !wv_any(st == B4_S_HDR || st == B4_S_FIN)) {
+			const bool act = st == B4_S_DEC;
+			bool hbad = false;
+			u32 ins = 0, copy = 0;
+			bool last_dist = false;
+			B4_ENSURE(act);
+			if (act) {
+				/* ---- insert&copy symbol, the extra bits of both lengths ---- */
+				u32 len;
+				const u32 k = b4_sym_index(b4_peek(win, wbyte, bitpos), cva, cvi, &len, hbad);
+				bitpos += len;
+				const u32 cs = *(const u16 *)(cmd_rec + 128 + 2 * (k < 704u ? k : 0u));
+				const u32 icode = cs & 31u, ccode = (cs >> 5) & 31u;
+				last_dist = (cs >> 10) & 1u;
+				const u32 ki = L.kins[icode < 24u ? icode : 0u], kc = L.kcopy[ccode < 24u ? ccode : 0u];
+				const u32 ib = ki >> 24, cb = kc >> 24;
+				const u32 x = b4_peek(win, wbyte, bitpos); /* at most 24 bits each: two reads */
+				ins = (ki & 0xFFFFFFu) + (x & ((1u << ib) - 1u));
+				bitpos += ib;
+				const u32 y = b4_peek(win, wbyte, bitpos);
+				copy = (kc & 0xFFFFFFu) + (y & ((1u << cb) - 1u));
+				bitpos += cb;
+				if (ins > left)
+					hbad = true;
+			}
+			/* ---- literals: max(insert lengths) passes, a group without literals left idles ---- */
+			u32 todo = (act && !hbad) ? ins : 0;
+			if (act && !hbad)
+				left -= ins;
+			while (wv_any(todo != 0)) {
+				B4_ENSURE(todo != 0);
+				if (todo != 0) {
+					u32 len;
+					const u32 k = b4_sym_index(b4_peek(win, wbyte, bitpos), lva, lvi, &len, hbad);
+					bitpos += len;
+					const u8 sym = lit_rec[128 + (k & 255u)];
+					if (l16 == 0)
+						out[pos] = sym;
+					pos++;
+					todo--;
+					if (hbad)
+						todo = 0;
+				}
+			}
+			/* ---- distance (section 4), the copy goes to the group's batch ---- */
+			const bool dact = act && !hbad && left != 0;
+			B4_ENSURE(dact);
+			bool handoff = false;
+			if (dact) {
+				u32 dist = rb3;
+				bool push = false;
+				if (!last_dist) {
+					u32 len;
+					const u32 k = b4_sym_index(b4_peek(win, wbyte, bitpos), dva, dvi, &len, hbad);
+					bitpos += len;
+					const u32 dc = *(const u16 *)(dist_rec + 128 + 2 * (k < 544u ? k : 0u));
+					push = true;
+					if (dc < 16u) {
+						const u32 which = dc < 4u ? dc : dc < 10u ? 0u : 1u;
+						const u32 r = which == 0 ? rb3 : which == 1 ? rb2 : which == 2 ? rb1 : rb0;
+						int del = 0;
+						if (dc >= 4u) {
+							const u32 q = (dc - 4u) % 6u; /* -1 +1 -2 +2 -3 +3 */
+							del = (int)(q / 2u + 1u);
+							if (!(q & 1u))
+								del = -del;
+						}
+						const long dd = (long)r + del;
+						if (dd <= 0)
+							hbad = true;
+						dist = (u32)dd;
+						push = dc != 0;
+					} else if (dc < 16u + ndirect) {
+						dist = dc - 15u;
+					} else {
+						const u32 d = dc - ndirect - 16u;
+						const u32 hcode = d >> npostfix, lcode = d & ((1u << npostfix) - 1u);
+						const u32 nbits = 1u + (hcode >> 1);
+						const u64 offset = ((2ull + (hcode & 1u)) << nbits) - 4u;
+						const u32 xb = b4_peek(win, wbyte, bitpos) & ((1u << (nbits & 31u)) - 1u); /* nbits <= 24 */
+						bitpos += nbits;
+						const u64 dd = ((offset + xb) << npostfix) + lcode + ndirect + 1u;
+						if (dd > 0x7FFFFFFCull || nbits > 24u)
+							hbad = true;
+						dist = (u32)dd;
+					}
+				}
+				const u32 max_dist = pos < max_backward ? pos : max_backward;
+				if (!hbad) {
+					if (dist > max_dist) {
+						handoff = true; /* static dictionary reference: the general kernel's */
+					} else if (copy > left) {
+						hbad = true;
+					} else {
+						if (push) {
+							rb0 = rb1;
+							rb1 = rb2;
+							rb2 = rb3;
+							rb3 = dist;
+						}
+						if (l16 == nbatch) {
+							bm_pos = pos;
+							bm_dist = dist;
+							bm_len = copy;
+						}
+						nbatch++;
+						pos += copy;
+						left -= copy;
+					}
+				}
+			}
+			B4_EXEC(act && nbatch == B4_NB);
+			if (act) {
+				if (handoff) {
+					stc = B4_HANDOFF;
+					st = B4_S_FIN;
+				} else if (hbad || (left == 0 && (u64)bitpos > 8ull * slen)) {
+					/* (a truncated stream shows at the end of the meta-block: the loop is bounded by MLEN) */
+					stc = BRBAD();
+					st = B4_S_FIN;
+				} else if (left == 0) {
+					st = B4_S_HDR;
+				}
+			}
+		}
+	}
+#undef B4_ENSURE
+#undef B4_EXEC
+}

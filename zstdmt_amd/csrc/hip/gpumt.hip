@@ -60,9 +60,11 @@ __global__ void zmt_snappy_dec_kernel(const u8 *, const u64 *, const u32 *, u32,
 __global__ void zmt_snappy_dec2_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
 __global__ void zmt_brotli_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 __global__ void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *,
-				      u32 *, u32 *, u8 *, const u8 *);
+				      u32 *, u32 *, u8 *, const u8 *, u32);
 __global__ void zmt_brotli_dec_kernel_prof(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
-					   const u32 *, u32 *, u32 *, u8 *, const u8 *, unsigned long long *);
+					   const u32 *, u32 *, u32 *, u8 *, const u8 *, u32, unsigned long long *);
+__global__ void zmt_brotli_dec4_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *,
+				       u32 *, u32 *);
 __global__ void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
 					  u32 *, u8 *, u32 *, u32 *, u32 *);
 __global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
@@ -108,6 +110,7 @@ struct gpumt_ctx {
 	int hc_waves;     /* developer: grid of the LZ4HC encoder (0 = GPUMT_LZ4HC_WAVES) */
 	int zdec_variant; /* 0 = small-table kernel, then general; 1 = general only */
 	int sdec_variant; /* snappy decoder: 0 = element by element, 1 = 64 elements per batch (snappy.hip) */
+	int bdec_variant; /* brotli decoder: 0 = dec4 (four records per wave) + the general kernel for what it hands over, 1 = general only */
 	int bdec_waves;   /* resident waves of the persistent brotli decoder kernel (whole device) */
 	int benc_waves[3]; /* resident waves of the persistent brotli encoder kernels (whole device), per quality tier */
 	int senc_waves, sdec_waves, sdec2_waves; /* ... of the snappy kernels */
@@ -252,6 +255,8 @@ int gpumt_open(int device, gpumt_ctx **out)
 		e = getenv("GPUMT_LZ4_RING");
 		h->lz4_ring = e && *e ? atoi(e) : 12;
 		/* GPUMT_LZ4_PARSE / GPUMT_LZ4_COPY: 3 = the round-3 kernels (parse3 / copy3), default the round-4 ones */
+		e = getenv("GPUMT_BROTLI_DEC");
+		h->bdec_variant = e && *e ? atoi(e) : 0;
 		e = getenv("GPUMT_DEBUG_FREE");
 		h->debug_free = e && *e ? atoi(e) : 0;
 		e = getenv("GPUMT_LZ4_PARSE");
@@ -1195,14 +1200,23 @@ int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
 	}
 	PROF0(12);
+	/* bdec_variant 0 (default): four records per wave for the streams without context modelling / block switching
+	 * (brotli_dec4.hip); what it hands over (status 102) goes to the general kernel.  1: the general kernel alone */
+	u32 want = 0xFFFFFFFFu;
+	if (h->bdec_variant == 0 && h->profile != 7) {
+		hipLaunchKernelGGL(zmt_brotli_dec4_kernel, dim3((unsigned)((nrec + 3) / 4)), dim3(64), 0, h->st[s],
+				   (const u8 *)d_stream, d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap,
+				   d_out_len, d_status);
+		want = 102u;
+	}
 	if (h->profile == 7)
 		hipLaunchKernelGGL(zmt_brotli_dec_kernel_prof, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_stream,
 				   d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap, d_out_len,
-				   d_status, (u8 *)h->scratch[1][s], (const u8 *)h->d_brotli_static, h->d_prof);
+				   d_status, (u8 *)h->scratch[1][s], (const u8 *)h->d_brotli_static, want, h->d_prof);
 	else
 		hipLaunchKernelGGL(zmt_brotli_dec_kernel, dim3(grid), dim3(64), 0, h->st[s], (const u8 *)d_stream,
 				   d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap, d_out_len,
-				   d_status, (u8 *)h->scratch[1][s], (const u8 *)h->d_brotli_static);
+				   d_status, (u8 *)h->scratch[1][s], (const u8 *)h->d_brotli_static, want);
 	PROF1(12);
 	CK(hipGetLastError());
 	return GPUMT_OK;
@@ -1298,6 +1312,9 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	} else if (!strcmp(what, "lz4_ring")) {
 		prev = h->lz4_ring;
 		h->lz4_ring = variant;
+	} else if (!strcmp(what, "brotli_dec")) {
+		prev = h->bdec_variant;
+		h->bdec_variant = variant;
 	} else if (!strcmp(what, "debug_free")) {
 		prev = h->debug_free;
 		h->debug_free = variant;

@@ -67,6 +67,32 @@ static inline int wv_ffs(u64 m) { return __builtin_ffsll((long long)m); } /* 1-b
 /* number of set bits of m below this lane */
 static inline u32 wv_mbcnt(u64 m) { return (u32)__builtin_popcountll(m & ((1ull << wv_lane()) - 1)); }
 static inline void wv_sleep() {}
+/* ---- 16-lane groups (one stream per group, groups in divergent control flow: brotli_dec4.hip): every lane of the
+ * group arrives, other groups need not */
+static inline u64 grp_xchg_(u64 v, int src16)
+{
+	emu::Block *b = emu::g_blk;
+	unsigned base = emu::tid() & ~15u;
+	b->slot[emu::tid()] = v;
+	emu::group_barrier16();
+	u64 r = b->slot[base + ((unsigned)src16 & 15)];
+	emu::group_barrier16();
+	return r;
+}
+static inline u32 grp_shfl(u32 v, int src16) { return (u32)grp_xchg_(v, src16); }
+static inline u32 grp_ballot(bool p)
+{
+	emu::Block *b = emu::g_blk;
+	unsigned base = emu::tid() & ~15u;
+	b->slot[emu::tid()] = p ? 1 : 0;
+	emu::group_barrier16();
+	u32 m = 0;
+	for (unsigned i = 0; i < 16 && base + i < b->nthreads; i++)
+		m |= (u32)(b->slot[base + i] & 1) << i;
+	emu::group_barrier16();
+	return m;
+}
+static inline void grp_sync() { emu::group_barrier16(); }
 /* value of lane k (0..3) of this lane's group of four */
 static inline u32 wv_quad(u32 v, int k) { return wv_shfl(v, (wv_lane() & ~3) + k); }
 #define ZMT_UNROLL
@@ -104,6 +130,19 @@ static __device__ __forceinline__ u32 wv_mbcnt(u64 m)
 	return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0));
 }
 static __device__ __forceinline__ void wv_sleep() { __builtin_amdgcn_s_sleep(2); }
+/* ---- 16-lane groups (one stream per group, groups in divergent control flow: brotli_dec4.hip).  The hardware
+ * runs the lanes of a wave in lockstep, so a group needs no barrier of its own: a ballot sees the active lanes, each
+ * group takes its 16 bits; ds_bpermute reads inside the group */
+static __device__ __forceinline__ u32 grp_shfl(u32 v, int src16)
+{
+	return (u32)__builtin_amdgcn_ds_bpermute((int)((((u32)__lane_id() & 48u) + ((u32)src16 & 15u)) << 2), (int)v);
+}
+static __device__ __forceinline__ u32 grp_ballot(bool p)
+{
+	const u64 m = __builtin_amdgcn_ballot_w64(p);
+	return (u32)(m >> ((u32)__lane_id() & 48u)) & 0xFFFFu;
+}
+static __device__ __forceinline__ void grp_sync() { wv_sync(); }
 /* value of lane k (constant 0..3) of this lane's group of four: one DPP quad_perm move */
 #define wv_quad(v, k) ((u32)__builtin_amdgcn_update_dpp(0, (int)(v), (k) * 0x55, 0xf, 0xf, true))
 #define ZMT_UNROLL _Pragma("unroll")
