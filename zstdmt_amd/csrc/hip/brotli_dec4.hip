@@ -151,12 +151,21 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 		if (wv_any(need_)) {                                                                               \
 			if (need_) {                                                                               \
 				wbyte = (bitpos >> 3) & ~3u;                                                       \
-				const u8 *g_ = sp + wbyte + 16u * l16;                                             \
-				const u64 a_ = ld64u(g_), b_ = ld64u(g_ + 8);                                      \
+				/* (a damaged stream may run far past its end inside a meta-block: beyond the record + most of the  \
+				 * stream's 256-byte slack the window reads as zeros, never from memory) */                  \
+				const u32 o_ = wbyte + 16u * l16;                                                  \
+				u64 a_ = 0, b_ = 0, c_ = 0;                                                        \
+				if (o_ + 16u <= slen + 240u) {                                                     \
+					a_ = ld64u(sp + o_);                                                       \
+					b_ = ld64u(sp + o_ + 8);                                                   \
+				}                                                                                  \
 				*(u64 *)(win + 16u * l16) = a_;                                                    \
 				*(u64 *)(win + 16u * l16 + 8) = b_;                                                \
-				if (l16 == 0)                                                                      \
-					*(u64 *)(win + B4_WIN) = ld64u(sp + wbyte + B4_WIN);                       \
+				if (l16 == 0) {                                                                    \
+					if (wbyte + B4_WIN + 8u <= slen + 240u)                                    \
+						c_ = ld64u(sp + wbyte + B4_WIN);                                   \
+					*(u64 *)(win + B4_WIN) = c_;                                               \
+				}                                                                                  \
 				grp_sync();                                                                        \
 			}                                                                                          \
 		}                                                                                                  \
