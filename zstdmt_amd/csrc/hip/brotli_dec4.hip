@@ -20,9 +20,16 @@
  * group.  Headers and prefix-code tables are rare (a few per record) and use all 64 lanes through the shared
  * wave-cooperative code (brotli_dec_common.h), one group at a time.
  *
- * Per group: a 256-byte window of its stream in LDS (two aligned dword reads + one v_alignbit per symbol, no
- * accumulator), its three tree records in LDS, up to 16 copies pending in its 16 lanes (executed side by side with
- * watermark rounds, as in brotli_dec.hip), literals stored straight to their final positions.
+ * A wave with four streams is bound by the LATENCY of its dependent chain, not by issue (first version, measured:
+ * one pass of the command loop ~6 400 cycles, most of them LDS round trips -- 26.2 GB/s), so the chain carries as few
+ * LDS round trips as possible:
+ *   - the bit buffer of a group is a 64-bit register pair; the next dword of the stream is read from the group's
+ *     256-byte LDS window a whole refill ahead of its use, so no LDS access sits between two symbols;
+ *   - every tree has a 256-entry direct table (payload | code length + 1 << 12) built with the tree: a symbol whose
+ *     code has at most 8 bits costs ONE LDS read; longer codes (rare) take the canonical path -- the ballot's 16 bits
+ *     of the group, two ds_bpermute, the sorted-symbol array;
+ *   - up to 16 copies wait in a group's 16 lanes and are executed side by side with watermark rounds, as in
+ *     brotli_dec.hip; literals are stored straight to their final positions.
  */
 #include "brotli_dec_common.h"
 
@@ -32,19 +39,47 @@
 #define B4_NB 16u
 
 enum { B4_S_HDR = 0, B4_S_DEC = 1, B4_S_FIN = 2, B4_S_DONE = 3 };
+#define B4_DIST_MAX 128u /* distance alphabet this kernel takes (NPOSTFIX = NDIRECT = 0 make 64); larger ones are handed over */
+#define B4_DIST_STRIDE (128u + 2u * B4_DIST_MAX)
+#define B4_T_LIT 0u
+#define B4_T_CMD 1u
+#define B4_T_DIST 2u
 
 struct B4Lds {
-	BrLds L; /* the shared header / table code works in here; L.lit slots 0..3, L.cmd and L.dist are group 0..3's / group 0's */
-	__attribute__((aligned(8))) u8 cmd[3 * BR_CMD_STRIDE];   /* groups 1..3 */
-	__attribute__((aligned(8))) u8 dist[3 * BR_DIST_STRIDE]; /* groups 1..3 */
-	__attribute__((aligned(16))) u8 win[4 * B4_WSTRIDE];
+	/* scratch of the shared prefix-code reader (br_read_code: one group at a time) */
+	__attribute__((aligned(8))) u8 clrec[128 + 32];
+	u8 lens[704];
+	u8 tmp[64];
+	u32 kins[24], kcopy[24]; /* insert / copy length codes: base | extra bits << 24 */
+	/* per group: tree records (16 x u64 vector + sorted symbols), direct tables, stream window */
+	__attribute__((aligned(8))) u8 lit[4][BR_LIT_STRIDE];
+	__attribute__((aligned(8))) u8 cmd[4][BR_CMD_STRIDE];
+	__attribute__((aligned(8))) u8 dist[4][B4_DIST_STRIDE];
+	u16 tab[4][3][256]; /* payload | (code length + 1) << 12; 0 = the code is longer than 8 bits */
+	__attribute__((aligned(16))) u8 win[4][B4_WSTRIDE];
 };
 
-#ifdef ZMT_EMU
-static inline u32 b4_alignbit(u32 hi, u32 lo, u32 sh) { return (u32)((((u64)hi << 32) | lo) >> (sh & 31)); }
-#else
-static __device__ __forceinline__ u32 b4_alignbit(u32 hi, u32 lo, u32 sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
-#endif
+/* direct table of a tree record: entry e = the symbol whose code opens the 8 stream bits e (first bit = bit 0), if
+ * that code has at most 8 bits.  With the unknown bits behind the 8 taken as zeros the canonical compare finds the
+ * same length as with the real ones whenever that length is <= 8 (the bounds of such lengths are multiples of 2^7) */
+static __device__ __forceinline__ void b4_build_tab(const u8 *rec, u16 *tab, bool sym16, int lane)
+{
+	for (u32 e = (u32)lane; e < 256u; e += 64u) {
+		const u32 c = br_rev15(e);
+		u32 l = 9;
+		for (int k = 8; k >= 0; k--)
+			if (c < (*(const u32 *)(rec + 8 * k) & 0xFFFFu))
+				l = (u32)k;
+		u32 ent = 0;
+		if (l <= 8u) {
+			const u32 a = *(const u32 *)(rec + 8 * l), i0 = *(const u32 *)(rec + 8 * l + 4);
+			const u32 idx = i0 + ((c - (a >> 16)) >> (15 - l));
+			const u32 sym = sym16 ? (u32) * (const u16 *)(rec + 128 + 2 * idx) : (u32)rec[128 + idx];
+			ent = (sym & 0xFFFu) | (l + 1u) << 12;
+		}
+		tab[e] = (u16)ent;
+	}
+}
 
 /* order a group's earlier global stores before its later global loads, inside group-divergent control flow (the hardware
  * fence is the wave's; the fiber harness must not wait for lanes of other groups) */
@@ -55,14 +90,6 @@ static __device__ __forceinline__ void b4_grp_fence()
 #else
 	wave_mem_fence();
 #endif
-}
-
-/* 32 bits of the group's stream at bit position bp (the window holds them: B4_ENSURE) */
-static __device__ __forceinline__ u32 b4_peek(const u8 *win, u32 wbyte, u32 bp)
-{
-	const u32 o = (bp >> 3) - wbyte;
-	const u32 *w = (const u32 *)(win + (o & ~3u));
-	return b4_alignbit(w[1], w[0], bp & 31u); /* wbyte is a multiple of 4 */
 }
 
 /* index of the next symbol in the sorted array of the tree whose vector this group's lanes hold (lane l of the group:
@@ -107,8 +134,7 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 		       u32 nrec, u8 *out_base, const u64 *__restrict__ out_off, const u32 *__restrict__ out_cap,
 		       u32 *__restrict__ out_len, u32 *__restrict__ status)
 {
-	__shared__ __attribute__((aligned(16))) B4Lds S;
-	BrLds &L = S.L;
+	__shared__ __attribute__((aligned(16))) B4Lds L;
 	const int lane = wv_lane();
 	const u32 grp = (u32)lane >> 4, l16 = (u32)lane & 15u;
 	if (lane < 24) {
@@ -116,11 +142,12 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 		L.kcopy[lane] = (u32)BR_COPY_BASE[lane] | (u32)BR_COPY_BITS[lane] << 24;
 	}
 	wv_sync();
-	/* this group's tree records and window */
-	u8 *const lit_rec = L.lit + grp * BR_LIT_STRIDE;
-	u8 *const cmd_rec = grp == 0 ? L.cmd : S.cmd + (grp - 1u) * BR_CMD_STRIDE;
-	u8 *const dist_rec = grp == 0 ? L.dist : S.dist + (grp - 1u) * BR_DIST_STRIDE;
-	u8 *const win = S.win + grp * B4_WSTRIDE;
+	/* this group's tree records, direct tables and window */
+	const u8 *const lit_rec = L.lit[grp];
+	const u8 *const cmd_rec = L.cmd[grp];
+	const u8 *const dist_rec = L.dist[grp];
+	const u16 *const tab_lit = L.tab[grp][B4_T_LIT], *const tab_cmd = L.tab[grp][B4_T_CMD], *const tab_dist = L.tab[grp][B4_T_DIST];
+	u8 *const win = L.win[grp];
 
 	const u32 rec = blockIdx.x * 4u + grp;
 	const bool exists = rec < nrec;
@@ -132,7 +159,12 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 	/* ---- per-stream state, the same in the 16 lanes of a group ---- */
 	u32 st = exists ? B4_S_HDR : B4_S_DONE;
 	u32 stc = ST_OK;
-	u32 bitpos = 0, wbyte = 0xFFFFFF00u; /* wbyte: first stream byte in the window (none yet) */
+	u32 bitpos = 0; /* valid in B4_S_HDR / B4_S_FIN; while decoding the position is 8 * wptr - navail */
+	/* bit buffer: acc holds the next navail (33..64) bits of the stream, nextw the dword behind them (stream byte wptr),
+	 * read from the window [wbyte, wbyte + 264) a refill ahead */
+	u64 acc = 0;
+	u32 navail = 0, wptr = 0, nextw = 0, wbyte = 0;
+	bool primed = false; /* the bit buffer is set up for the meta-block being decoded */
 	u32 pos = 0, left = 0;
 	bool first = true, was_last = false;
 	u32 max_backward = 0, npostfix = 0, ndirect = 0;
@@ -144,31 +176,62 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 		st = B4_S_FIN;
 	}
 
-	/* the window must hold the 8 bytes at the read position */
-#define B4_ENSURE(cond)                                                                                            \
+	/* window = stream bytes [W, W + 264), W a multiple of 4 (a damaged stream may run far past its end inside a
+	 * meta-block: beyond the record + most of the stream's 256-byte slack the window reads as zeros, never from memory) */
+#define B4_LOAD_WIN(W)                                                                                             \
 	do {                                                                                                       \
-		const bool need_ = (cond) && ((bitpos >> 3) - wbyte > B4_WIN - 8u);                                \
+		wbyte = (W);                                                                                       \
+		const u32 o_ = wbyte + 16u * l16;                                                                  \
+		u64 a_ = 0, b_ = 0, c_ = 0;                                                                        \
+		if (o_ + 16u <= slen + 240u) {                                                                     \
+			a_ = ld64u(sp + o_);                                                                       \
+			b_ = ld64u(sp + o_ + 8);                                                                   \
+		}                                                                                                  \
+		*(u64 *)(win + 16u * l16) = a_;                                                                    \
+		*(u64 *)(win + 16u * l16 + 8) = b_;                                                                \
+		if (l16 == 0) {                                                                                    \
+			if (wbyte + B4_WIN + 8u <= slen + 240u)                                                    \
+				c_ = ld64u(sp + wbyte + B4_WIN);                                                   \
+			*(u64 *)(win + B4_WIN) = c_;                                                               \
+		}                                                                                                  \
+		grp_sync();                                                                                        \
+	} while (0)
+	/* the next MARGIN stream bytes behind nextw must be in the window */
+#define B4_ENSURE(cond, MARGIN)                                                                                    \
+	do {                                                                                                       \
+		const bool need_ = (cond) && (wptr - wbyte > B4_WIN - (MARGIN));                                   \
 		if (wv_any(need_)) {                                                                               \
-			if (need_) {                                                                               \
-				wbyte = (bitpos >> 3) & ~3u;                                                       \
-				/* (a damaged stream may run far past its end inside a meta-block: beyond the record + most of the  \
-				 * stream's 256-byte slack the window reads as zeros, never from memory) */                  \
-				const u32 o_ = wbyte + 16u * l16;                                                  \
-				u64 a_ = 0, b_ = 0, c_ = 0;                                                        \
-				if (o_ + 16u <= slen + 240u) {                                                     \
-					a_ = ld64u(sp + o_);                                                       \
-					b_ = ld64u(sp + o_ + 8);                                                   \
-				}                                                                                  \
-				*(u64 *)(win + 16u * l16) = a_;                                                    \
-				*(u64 *)(win + 16u * l16 + 8) = b_;                                                \
-				if (l16 == 0) {                                                                    \
-					if (wbyte + B4_WIN + 8u <= slen + 240u)                                    \
-						c_ = ld64u(sp + wbyte + B4_WIN);                                   \
-					*(u64 *)(win + B4_WIN) = c_;                                               \
-				}                                                                                  \
-				grp_sync();                                                                        \
+			if (need_)                                                                                 \
+				B4_LOAD_WIN(wptr);                                                                 \
+		}                                                                                                  \
+	} while (0)
+	/* drop n (<= 24) bits; top the buffer up from nextw when 32 or fewer are left, and read the dword behind it */
+#define B4_CONSUME(n)                                                                                              \
+	do {                                                                                                       \
+		acc >>= (n);                                                                                       \
+		navail -= (n);                                                                                     \
+		const bool rf_ = navail <= 32u;                                                                    \
+		acc |= rf_ ? (u64)nextw << (navail & 63u) : 0ull;                                                  \
+		navail += rf_ ? 32u : 0u;                                                                          \
+		wptr += rf_ ? 4u : 0u;                                                                             \
+		nextw = *(const u32 *)(win + (wptr - wbyte));                                                      \
+	} while (0)
+	/* next symbol of a tree: direct table first (codes of <= 8 bits: one LDS read), the canonical walk otherwise */
+#define B4_SYMBOL(cond, TAB, REC, VA, VI, SYM16, PAY)                                                              \
+	do {                                                                                                       \
+		u32 e_ = (cond) ? (u32)(TAB)[(u32)acc & 255u] : 0x1000u;                                           \
+		if (wv_any((cond) && (e_ >> 12) == 0)) {                                                           \
+			if ((cond) && (e_ >> 12) == 0) {                                                           \
+				u32 len_;                                                                          \
+				const u32 k_ = b4_sym_index((u32)acc, VA, VI, &len_, hbad);                        \
+				const u32 s_ = (SYM16) ? (u32) * (const u16 *)((REC) + 128 + 2 * (k_ & 1023u))     \
+						       : (u32)(REC)[128 + (k_ & 255u)];                            \
+				e_ = (s_ & 0xFFFu) | (len_ + 1u) << 12;                                            \
 			}                                                                                          \
 		}                                                                                                  \
+		PAY = e_ & 0xFFFu;                                                                                 \
+		if (cond)                                                                                          \
+			B4_CONSUME((e_ >> 12) - 1u);                                                               \
 	} while (0)
 	/* pending copies of the groups with `cond`: every lane its own copy once its source lies below the watermark (the
 	 * destination of the group's first unfinished copy), long ones by the group together */
@@ -345,9 +408,11 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 					break;
 				}
 				const u32 dist_alphabet = 16 + g_ndirect + (48u << g_npostfix);
-				u8 *const g_lit = L.lit + g * BR_LIT_STRIDE;
-				u8 *const g_cmd = g == 0 ? L.cmd : S.cmd + (g - 1u) * BR_CMD_STRIDE;
-				u8 *const g_dist = g == 0 ? L.dist : S.dist + (g - 1u) * BR_DIST_STRIDE;
+				if (dist_alphabet > B4_DIST_MAX) {
+					g_stc = B4_HANDOFF;
+					break;
+				}
+				u8 *const g_lit = L.lit[g], *const g_cmd = L.cmd[g], *const g_dist = L.dist[g];
 				bool bad = !br_read_code(b, L, g_lit, 256, false, lane) || br_over(b);
 				if (!bad) {
 					bad = !br_read_code(b, L, g_cmd, 704, true, lane) || br_over(b);
@@ -375,6 +440,10 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 					g_stc = ST_SIZE_MISMATCH;
 					break;
 				}
+				wv_sync();
+				b4_build_tab(g_lit, L.tab[g][B4_T_LIT], false, lane);
+				b4_build_tab(g_cmd, L.tab[g][B4_T_CMD], true, lane);
+				b4_build_tab(g_dist, L.tab[g][B4_T_DIST], true, lane);
 				g_left = mlen;
 				g_last = is_last != 0;
 				g_st = B4_S_DEC;
@@ -393,7 +462,7 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 				st = g_st;
 				stc = g_stc;
 				bitpos = (u32)used;
-				wbyte = 0xFFFFFF00u; /* the window is reloaded at the new position */
+				primed = false;
 				pos = g_pos;
 				left = g_left;
 				first = false;
@@ -428,45 +497,54 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 		}
 		if (!wv_any(st != B4_S_DONE))
 			break;
+		/* ================= bit buffers of the groups that start a meta-block ================= */
+		if (wv_any(st == B4_S_DEC && !primed)) {
+			if (st == B4_S_DEC && !primed) {
+				B4_LOAD_WIN((bitpos >> 3) & ~3u);
+				const u32 sh = bitpos - 8u * wbyte; /* 0..31 */
+				const u32 w0 = *(const u32 *)win, w1 = *(const u32 *)(win + 4);
+				acc = (((u64)w1 << 32) | w0) >> sh;
+				navail = 64u - sh;
+				wptr = wbyte + 8u;
+				nextw = *(const u32 *)(win + 8);
+				primed = true;
+			}
+		}
 		/* ================= commands (section 10): the groups in lockstep, one command each per pass ================= */
 		while (wv_any(st == B4_S_DEC) && !wv_any(st == B4_S_HDR || st == B4_S_FIN)) {
 			const bool act = st == B4_S_DEC;
 			bool hbad = false;
 			u32 ins = 0, copy = 0;
 			bool last_dist = false;
-			B4_ENSURE(act);
-			if (act) {
+			B4_ENSURE(act, 40u); /* a command's own fields refill at most five times */
+			{
 				/* ---- insert&copy symbol, the extra bits of both lengths ---- */
-				u32 len;
-				const u32 k = b4_sym_index(b4_peek(win, wbyte, bitpos), cva, cvi, &len, hbad);
-				bitpos += len;
-				const u32 cs = *(const u16 *)(cmd_rec + 128 + 2 * (k < 704u ? k : 0u));
-				const u32 icode = cs & 31u, ccode = (cs >> 5) & 31u;
-				last_dist = (cs >> 10) & 1u;
-				const u32 ki = L.kins[icode < 24u ? icode : 0u], kc = L.kcopy[ccode < 24u ? ccode : 0u];
-				const u32 ib = ki >> 24, cb = kc >> 24;
-				const u32 x = b4_peek(win, wbyte, bitpos); /* at most 24 bits each: two reads */
-				ins = (ki & 0xFFFFFFu) + (x & ((1u << ib) - 1u));
-				bitpos += ib;
-				const u32 y = b4_peek(win, wbyte, bitpos);
-				copy = (kc & 0xFFFFFFu) + (y & ((1u << cb) - 1u));
-				bitpos += cb;
-				if (ins > left)
-					hbad = true;
+				u32 cs;
+				B4_SYMBOL(act, tab_cmd, cmd_rec, cva, cvi, true, cs);
+				if (act) {
+					const u32 icode = cs & 31u, ccode = (cs >> 5) & 31u;
+					last_dist = (cs >> 10) & 1u;
+					const u32 ki = L.kins[icode < 24u ? icode : 0u], kc = L.kcopy[ccode < 24u ? ccode : 0u];
+					const u32 ib = ki >> 24, cb = kc >> 24; /* at most 24 bits each */
+					ins = (ki & 0xFFFFFFu) + ((u32)acc & ((1u << ib) - 1u));
+					B4_CONSUME(ib);
+					copy = (kc & 0xFFFFFFu) + ((u32)acc & ((1u << cb) - 1u));
+					B4_CONSUME(cb);
+					if (ins > left)
+						hbad = true;
+				}
 			}
 			/* ---- literals: max(insert lengths) passes, a group without literals left idles ---- */
 			u32 todo = (act && !hbad) ? ins : 0;
 			if (act && !hbad)
 				left -= ins;
 			while (wv_any(todo != 0)) {
-				B4_ENSURE(todo != 0);
+				B4_ENSURE(todo != 0, 8u);
+				u32 sym;
+				B4_SYMBOL(todo != 0, tab_lit, lit_rec, lva, lvi, false, sym);
 				if (todo != 0) {
-					u32 len;
-					const u32 k = b4_sym_index(b4_peek(win, wbyte, bitpos), lva, lvi, &len, hbad);
-					bitpos += len;
-					const u8 sym = lit_rec[128 + (k & 255u)];
 					if (l16 == 0)
-						out[pos] = sym;
+						out[pos] = (u8)sym;
 					pos++;
 					todo--;
 					if (hbad)
@@ -475,16 +553,15 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 			}
 			/* ---- distance (section 4), the copy goes to the group's batch ---- */
 			const bool dact = act && !hbad && left != 0;
-			B4_ENSURE(dact);
+			const bool dsym = dact && !last_dist;
+			B4_ENSURE(dact, 16u);
 			bool handoff = false;
+			u32 dc;
+			B4_SYMBOL(dsym, tab_dist, dist_rec, dva, dvi, true, dc);
 			if (dact) {
 				u32 dist = rb3;
 				bool push = false;
 				if (!last_dist) {
-					u32 len;
-					const u32 k = b4_sym_index(b4_peek(win, wbyte, bitpos), dva, dvi, &len, hbad);
-					bitpos += len;
-					const u32 dc = *(const u16 *)(dist_rec + 128 + 2 * (k < 544u ? k : 0u));
 					push = true;
 					if (dc < 16u) {
 						const u32 which = dc < 4u ? dc : dc < 10u ? 0u : 1u;
@@ -506,10 +583,10 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 					} else {
 						const u32 d = dc - ndirect - 16u;
 						const u32 hcode = d >> npostfix, lcode = d & ((1u << npostfix) - 1u);
-						const u32 nbits = 1u + (hcode >> 1);
+						const u32 nbits = 1u + (hcode >> 1); /* <= 24: the alphabet has at most B4_DIST_MAX symbols */
 						const u64 offset = ((2ull + (hcode & 1u)) << nbits) - 4u;
-						const u32 xb = b4_peek(win, wbyte, bitpos) & ((1u << (nbits & 31u)) - 1u); /* nbits <= 24 */
-						bitpos += nbits;
+						const u32 xb = (u32)acc & ((1u << (nbits & 31u)) - 1u);
+						B4_CONSUME(nbits & 31u);
 						const u64 dd = ((offset + xb) << npostfix) + lcode + ndirect + 1u;
 						if (dd > 0x7FFFFFFCull || nbits > 24u)
 							hbad = true;
@@ -542,19 +619,24 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 			}
 			B4_EXEC(act && nbatch == B4_NB);
 			if (act) {
+				const u64 used = 8ull * wptr - navail;
 				if (handoff) {
 					stc = B4_HANDOFF;
 					st = B4_S_FIN;
-				} else if (hbad || (left == 0 && (u64)bitpos > 8ull * slen)) {
+				} else if (hbad || (left == 0 && used > 8ull * slen)) {
 					/* (a truncated stream shows at the end of the meta-block: the loop is bounded by MLEN) */
 					stc = BRBAD();
 					st = B4_S_FIN;
 				} else if (left == 0) {
+					bitpos = (u32)used;
 					st = B4_S_HDR;
 				}
 			}
 		}
 	}
+#undef B4_LOAD_WIN
 #undef B4_ENSURE
+#undef B4_CONSUME
+#undef B4_SYMBOL
 #undef B4_EXEC
 }

@@ -315,7 +315,9 @@ static __device__ ZMT_NOINLINE void br_build(u8 *rec, const u8 *lens, u32 A, boo
 }
 
 /* RFC 7932 3.4 / 3.5: read one prefix code over `A` symbols and build its record at rec */
-static __device__ ZMT_NOINLINE BrBits br_read_code_core(BrBits b, BrLds &L, u8 *rec, u32 A, bool sym16, int lane, u32 *ok)
+/* (LT: an LDS layout with lens[704], tmp[64] and clrec[160] -- BrLds, or the leaner one of brotli_dec4.hip) */
+template <typename LT>
+static __device__ ZMT_NOINLINE BrBits br_read_code_core(BrBits b, LT &L, u8 *rec, u32 A, bool sym16, int lane, u32 *ok)
 {
 	*ok = 0;
 	for (u32 i = (u32)lane; i < 704; i += 64)
@@ -452,7 +454,8 @@ static __device__ ZMT_NOINLINE BrBits br_read_code_core(BrBits b, BrLds &L, u8 *
 	return b;
 }
 
-static __device__ __forceinline__ bool br_read_code(BrBits &b, BrLds &L, u8 *rec, u32 A, bool sym16, int lane)
+template <typename LT>
+static __device__ __forceinline__ bool br_read_code(BrBits &b, LT &L, u8 *rec, u32 A, bool sym16, int lane)
 {
 	u32 ok;
 	b = br_pin(br_read_code_core(b, L, rec, A, sym16, lane, &ok));
