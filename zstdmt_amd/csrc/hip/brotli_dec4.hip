@@ -539,16 +539,36 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 			if (act && !hbad)
 				left -= ins;
 			while (wv_any(todo != 0)) {
-				B4_ENSURE(todo != 0, 8u);
-				u32 sym;
-				B4_SYMBOL(todo != 0, tab_lit, lit_rec, lva, lvi, false, sym);
-				if (todo != 0) {
-					if (l16 == 0)
-						out[pos] = (u8)sym;
-					pos++;
-					todo--;
-					if (hbad)
-						todo = 0;
+				/* two literals per pass: the second one's table entry is read behind the first one's code length; a
+				 * code of more than 8 bits (rare) sends the pass through the general symbol path, one literal */
+				const bool la = todo != 0;
+				B4_ENSURE(la, 12u);
+				const bool two = todo >= 2u;
+				const u32 e0 = la ? (u32)tab_lit[(u32)acc & 255u] : 0x1000u;
+				const u32 l0 = ((e0 >> 12) - 1u) & 15u;
+				const u32 e1 = two ? (u32)tab_lit[(u32)(acc >> l0) & 255u] : 0x1000u;
+				if (wv_any(la && ((e0 >> 12) == 0 || (e1 >> 12) == 0))) {
+					u32 sym;
+					B4_SYMBOL(la, tab_lit, lit_rec, lva, lvi, false, sym);
+					if (la) {
+						if (l16 == 0)
+							out[pos] = (u8)sym;
+						pos++;
+						todo--;
+						if (hbad)
+							todo = 0;
+					}
+				} else if (la) {
+					const u32 l1 = (e1 >> 12) - 1u; /* 0 bits when there is no second one */
+					if (l16 == 0) {
+						out[pos] = (u8)e0;
+						if (two)
+							out[pos + 1] = (u8)e1;
+					}
+					const u32 adv = two ? 2u : 1u;
+					pos += adv;
+					todo -= adv;
+					B4_CONSUME(l0 + l1);
 				}
 			}
 			/* ---- distance (section 4), the copy goes to the group's batch ---- */
