@@ -511,7 +511,8 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 			}
 		}
 		/* ================= commands (section 10): the groups in lockstep, one command each per pass ================= */
-		while (wv_any(st == B4_S_DEC) && !wv_any(st == B4_S_HDR || st == B4_S_FIN)) {
+		bool moved = !wv_any(st == B4_S_DEC) || wv_any(st == B4_S_HDR || st == B4_S_FIN); /* a group left B4_S_DEC: headers / status first */
+		while (!moved) {
 			const bool act = st == B4_S_DEC;
 			bool hbad = false;
 			u32 ins = 0, copy = 0;
@@ -574,7 +575,7 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 			/* ---- distance (section 4), the copy goes to the group's batch ---- */
 			const bool dact = act && !hbad && left != 0;
 			const bool dsym = dact && !last_dist;
-			B4_ENSURE(dact, 16u);
+			/* (the window margin left by the command's and the literal loop's checks covers the distance's two refills) */
 			bool handoff = false;
 			u32 dc;
 			B4_SYMBOL(dsym, tab_dist, dist_rec, dva, dvi, true, dc);
@@ -593,7 +594,7 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 							if (!(q & 1u))
 								del = -del;
 						}
-						const long dd = (long)r + del;
+						const int dd = (int)r + del;
 						if (dd <= 0)
 							hbad = true;
 						dist = (u32)dd;
@@ -601,14 +602,15 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 					} else if (dc < 16u + ndirect) {
 						dist = dc - 15u;
 					} else {
+						/* (at most B4_DIST_MAX symbols: hcode < 48, nbits <= 24, the distance below 2^28 -- 32-bit arithmetic) */
 						const u32 d = dc - ndirect - 16u;
 						const u32 hcode = d >> npostfix, lcode = d & ((1u << npostfix) - 1u);
-						const u32 nbits = 1u + (hcode >> 1); /* <= 24: the alphabet has at most B4_DIST_MAX symbols */
-						const u64 offset = ((2ull + (hcode & 1u)) << nbits) - 4u;
-						const u32 xb = (u32)acc & ((1u << (nbits & 31u)) - 1u);
-						B4_CONSUME(nbits & 31u);
-						const u64 dd = ((offset + xb) << npostfix) + lcode + ndirect + 1u;
-						if (dd > 0x7FFFFFFCull || nbits > 24u)
+						const u32 nbits = (1u + (hcode >> 1)) & 31u;
+						const u32 offset = ((2u + (hcode & 1u)) << nbits) - 4u;
+						const u32 xb = (u32)acc & ((1u << nbits) - 1u);
+						B4_CONSUME(nbits);
+						const u32 dd = ((offset + xb) << npostfix) + lcode + ndirect + 1u;
+						if (nbits > 24u)
 							hbad = true;
 						dist = (u32)dd;
 					}
@@ -652,6 +654,7 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 					st = B4_S_HDR;
 				}
 			}
+			moved = wv_any(st != B4_S_DEC && act);
 		}
 	}
 #undef B4_LOAD_WIN
