@@ -216,8 +216,9 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 		wptr += rf_ ? 4u : 0u;                                                                             \
 		nextw = *(const u32 *)(win + (wptr - wbyte));                                                      \
 	} while (0)
-	/* next symbol of a tree: direct table first (codes of <= 8 bits: one LDS read), the canonical walk otherwise */
-#define B4_SYMBOL(cond, TAB, REC, VA, VI, SYM16, PAY)                                                              \
+	/* next symbol of a tree, not consumed yet: direct table first (codes of <= 8 bits: one LDS read), the canonical walk
+	 * otherwise.  PAY = the symbol's payload, LEN = its code length */
+#define B4_SYMLEN(cond, TAB, REC, VA, VI, SYM16, PAY, LEN)                                                         \
 	do {                                                                                                       \
 		u32 e_ = (cond) ? (u32)(TAB)[(u32)acc & 255u] : 0x1000u;                                           \
 		if (wv_any((cond) && (e_ >> 12) == 0)) {                                                           \
@@ -230,8 +231,14 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 			}                                                                                          \
 		}                                                                                                  \
 		PAY = e_ & 0xFFFu;                                                                                 \
+		LEN = (e_ >> 12) - 1u;                                                                             \
+	} while (0)
+#define B4_SYMBOL(cond, TAB, REC, VA, VI, SYM16, PAY)                                                              \
+	do {                                                                                                       \
+		u32 l_;                                                                                            \
+		B4_SYMLEN(cond, TAB, REC, VA, VI, SYM16, PAY, l_);                                                 \
 		if (cond)                                                                                          \
-			B4_CONSUME((e_ >> 12) - 1u);                                                               \
+			B4_CONSUME(l_);                                                                            \
 	} while (0)
 	/* pending copies of the groups with `cond`: every lane its own copy once its source lies below the watermark (the
 	 * destination of the group's first unfinished copy), long ones by the group together */
@@ -520,20 +527,38 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 			B4_ENSURE(act, 40u); /* a command's own fields refill at most five times */
 			{
 				/* ---- insert&copy symbol, the extra bits of both lengths ---- */
-				u32 cs;
-				B4_SYMBOL(act, tab_cmd, cmd_rec, cva, cvi, true, cs);
+				u32 cs, clen;
+				B4_SYMLEN(act, tab_cmd, cmd_rec, cva, cvi, true, cs, clen);
+				u32 ki = 0, kc = 0;
+				bool wide = false;
 				if (act) {
 					const u32 icode = cs & 31u, ccode = (cs >> 5) & 31u;
 					last_dist = (cs >> 10) & 1u;
-					const u32 ki = L.kins[icode < 24u ? icode : 0u], kc = L.kcopy[ccode < 24u ? ccode : 0u];
+					ki = L.kins[icode < 24u ? icode : 0u];
+					kc = L.kcopy[ccode < 24u ? ccode : 0u];
 					const u32 ib = ki >> 24, cb = kc >> 24; /* at most 24 bits each */
-					ins = (ki & 0xFFFFFFu) + ((u32)acc & ((1u << ib) - 1u));
-					B4_CONSUME(ib);
-					copy = (kc & 0xFFFFFFu) + ((u32)acc & ((1u << cb) - 1u));
-					B4_CONSUME(cb);
-					if (ins > left)
-						hbad = true;
+					const u32 tot = clen + ib + cb;
+					wide = tot > 32u;
+					if (!wide) {
+						/* symbol and both extra fields inside the low word (nearly always): one step of the bit buffer */
+						const u32 x = (u32)acc >> clen;
+						ins = (ki & 0xFFFFFFu) + (x & ((1u << ib) - 1u));
+						copy = (kc & 0xFFFFFFu) + ((x >> ib) & ((1u << cb) - 1u));
+						B4_CONSUME(tot);
+					}
 				}
+				if (wv_any(wide)) {
+					if (wide) {
+						const u32 ib = ki >> 24, cb = kc >> 24;
+						B4_CONSUME(clen);
+						ins = (ki & 0xFFFFFFu) + ((u32)acc & ((1u << ib) - 1u));
+						B4_CONSUME(ib);
+						copy = (kc & 0xFFFFFFu) + ((u32)acc & ((1u << cb) - 1u));
+						B4_CONSUME(cb);
+					}
+				}
+				if (act && ins > left)
+					hbad = true;
 			}
 			/* ---- literals: max(insert lengths) passes, a group without literals left idles ---- */
 			u32 todo = (act && !hbad) ? ins : 0;
@@ -577,14 +602,15 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 			const bool dsym = dact && !last_dist;
 			/* (the window margin left by the command's and the literal loop's checks covers the distance's two refills) */
 			bool handoff = false;
-			u32 dc;
-			B4_SYMBOL(dsym, tab_dist, dist_rec, dva, dvi, true, dc);
+			u32 dc, dlen;
+			B4_SYMLEN(dsym, tab_dist, dist_rec, dva, dvi, true, dc, dlen);
 			if (dact) {
 				u32 dist = rb3;
 				bool push = false;
 				if (!last_dist) {
 					push = true;
 					if (dc < 16u) {
+						B4_CONSUME(dlen);
 						const u32 which = dc < 4u ? dc : dc < 10u ? 0u : 1u;
 						const u32 r = which == 0 ? rb3 : which == 1 ? rb2 : which == 2 ? rb1 : rb0;
 						int del = 0;
@@ -600,19 +626,28 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 						dist = (u32)dd;
 						push = dc != 0;
 					} else if (dc < 16u + ndirect) {
+						B4_CONSUME(dlen);
 						dist = dc - 15u;
 					} else {
 						/* (at most B4_DIST_MAX symbols: hcode < 48, nbits <= 24, the distance below 2^28 -- 32-bit arithmetic) */
 						const u32 d = dc - ndirect - 16u;
 						const u32 hcode = d >> npostfix, lcode = d & ((1u << npostfix) - 1u);
-						const u32 nbits = (1u + (hcode >> 1)) & 31u;
-						const u32 offset = ((2u + (hcode & 1u)) << nbits) - 4u;
-						const u32 xb = (u32)acc & ((1u << nbits) - 1u);
-						B4_CONSUME(nbits);
-						const u32 dd = ((offset + xb) << npostfix) + lcode + ndirect + 1u;
-						if (nbits > 24u)
+						u32 nbits = (1u + (hcode >> 1)) & 31u;
+						if (nbits > 24u) {
 							hbad = true;
-						dist = (u32)dd;
+							nbits = 0;
+						}
+						const u32 offset = ((2u + (hcode & 1u)) << nbits) - 4u;
+						u32 xb;
+						if (dlen + nbits <= 32u) { /* the symbol and its extra bits in one step of the bit buffer (nearly always) */
+							xb = (u32)(acc >> dlen) & ((1u << nbits) - 1u);
+							B4_CONSUME(dlen + nbits);
+						} else {
+							B4_CONSUME(dlen);
+							xb = (u32)acc & ((1u << nbits) - 1u);
+							B4_CONSUME(nbits);
+						}
+						dist = ((offset + xb) << npostfix) + lcode + ndirect + 1u;
 					}
 				}
 				const u32 max_dist = pos < max_backward ? pos : max_backward;
