@@ -263,7 +263,7 @@ void emu_brotli_decompress_batch(const u8 *stream, const u64 *rec_off, const u32
 	const char *v = getenv("EMU_BROTLI_DEC");
 	u32 want = 0xFFFFFFFFu;
 	if (!(v && atoi(v) == 1)) {
-		emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{64, 1, 1}, [=]() {
+		emu::launch(dim3{(nrec + 3) / 4, 1, 1}, dim3{64, 1, 1}, [=]() { /* B4_NG = 4 streams per wave */
 			zmt_brotli_dec4_kernel(stream, rec_off, rec_len, nrec, out, out_off, out_cap, out_len, status);
 		});
 		if (getenv("ZMT_EMU_DEBUG"))

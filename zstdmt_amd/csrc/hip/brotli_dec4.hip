@@ -37,6 +37,9 @@
 #define B4_WIN 256u
 #define B4_WSTRIDE (B4_WIN + 16u)
 #define B4_NB 16u
+#ifndef B4_NG
+#define B4_NG 4u /* streams per wave (16-lane groups in use); gpumt.hip sizes the grid with the same number */
+#endif
 
 enum { B4_S_HDR = 0, B4_S_DEC = 1, B4_S_FIN = 2, B4_S_DONE = 3 };
 #define B4_DIST_MAX 128u /* distance alphabet this kernel takes (NPOSTFIX = NDIRECT = 0 make 64); larger ones are handed over */
@@ -52,11 +55,11 @@ struct B4Lds {
 	u8 tmp[64];
 	u32 kins[24], kcopy[24]; /* insert / copy length codes: base | extra bits << 24 */
 	/* per group: tree records (16 x u64 vector + sorted symbols), direct tables, stream window */
-	__attribute__((aligned(8))) u8 lit[4][BR_LIT_STRIDE];
-	__attribute__((aligned(8))) u8 cmd[4][BR_CMD_STRIDE];
-	__attribute__((aligned(8))) u8 dist[4][B4_DIST_STRIDE];
-	u16 tab[4][3][256]; /* payload | (code length + 1) << 12; 0 = the code is longer than 8 bits */
-	__attribute__((aligned(16))) u8 win[4][B4_WSTRIDE];
+	__attribute__((aligned(8))) u8 lit[B4_NG][BR_LIT_STRIDE];
+	__attribute__((aligned(8))) u8 cmd[B4_NG][BR_CMD_STRIDE];
+	__attribute__((aligned(8))) u8 dist[B4_NG][B4_DIST_STRIDE];
+	u16 tab[B4_NG][3][256]; /* payload | (code length + 1) << 12; 0 = the code is longer than 8 bits */
+	__attribute__((aligned(16))) u8 win[B4_NG][B4_WSTRIDE];
 };
 
 /* direct table of a tree record: entry e = the symbol whose code opens the 8 stream bits e (first bit = bit 0), if
@@ -143,14 +146,15 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 	}
 	wv_sync();
 	/* this group's tree records, direct tables and window */
-	const u8 *const lit_rec = L.lit[grp];
-	const u8 *const cmd_rec = L.cmd[grp];
-	const u8 *const dist_rec = L.dist[grp];
-	const u16 *const tab_lit = L.tab[grp][B4_T_LIT], *const tab_cmd = L.tab[grp][B4_T_CMD], *const tab_dist = L.tab[grp][B4_T_DIST];
-	u8 *const win = L.win[grp];
+	const u32 gi = grp < B4_NG ? grp : 0u; /* (lanes of groups not in use idle; their pointers stay valid) */
+	const u8 *const lit_rec = L.lit[gi];
+	const u8 *const cmd_rec = L.cmd[gi];
+	const u8 *const dist_rec = L.dist[gi];
+	const u16 *const tab_lit = L.tab[gi][B4_T_LIT], *const tab_cmd = L.tab[gi][B4_T_CMD], *const tab_dist = L.tab[gi][B4_T_DIST];
+	u8 *const win = L.win[gi];
 
-	const u32 rec = blockIdx.x * 4u + grp;
-	const bool exists = rec < nrec;
+	const u32 rec = blockIdx.x * B4_NG + grp;
+	const bool exists = grp < B4_NG && rec < nrec;
 	const u8 *const sp = stream + (exists ? rec_off[rec] : 0);
 	const u32 slen = exists ? rec_len[rec] : 0;
 	u8 *const out = out_base + (exists ? out_off[rec] : 0);
@@ -278,21 +282,21 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 
 	for (;;) {
 		/* ================= headers: wave-cooperative, one group at a time ================= */
-		for (u32 g = 0; g < 4; g++) {
+		for (u32 g = 0; g < B4_NG; g++) {
 			if (wv_readlane(st, (int)(16u * g)) != B4_S_HDR)
 				continue;
 			const int gl = (int)(16u * g);
 			const bool mine = grp == g;
 			BrBits b;
 			{
-				const u32 r_ = blockIdx.x * 4u + g;
+				const u32 r_ = blockIdx.x * B4_NG + g;
 				b.p = stream + rec_off[r_];
 				b.n = wv_readfirst(rec_len[r_]);
 			}
 			const u32 g_cap = wv_readlane(cap, gl);
 			const u32 bp = wv_readlane(bitpos, gl);
 			u32 g_pos = wv_readlane(pos, gl);
-			u8 *const g_out = out_base + out_off[blockIdx.x * 4u + g];
+			u8 *const g_out = out_base + out_off[blockIdx.x * B4_NG + g];
 			br_seek(b, bp >> 3, lane);
 			if (bp & 7u)
 				(void)br_get(b, bp & 7u, lane);

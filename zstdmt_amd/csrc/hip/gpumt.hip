@@ -63,6 +63,9 @@ __global__ void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32,
 				      u32 *, u32 *, u8 *, const u8 *, u32);
 __global__ void zmt_brotli_dec_kernel_prof(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
 					   const u32 *, u32 *, u32 *, u8 *, const u8 *, u32, unsigned long long *);
+#ifndef B4_NG
+#define B4_NG 4 /* streams per wave of zmt_brotli_dec4_kernel (brotli_dec4.hip) */
+#endif
 __global__ void zmt_brotli_dec4_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *,
 				       u32 *, u32 *);
 __global__ void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
@@ -1204,7 +1207,7 @@ int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint
 	 * (brotli_dec4.hip); what it hands over (status 102) goes to the general kernel.  1: the general kernel alone */
 	u32 want = 0xFFFFFFFFu;
 	if (h->bdec_variant == 0 && h->profile != 7) {
-		hipLaunchKernelGGL(zmt_brotli_dec4_kernel, dim3((unsigned)((nrec + 3) / 4)), dim3(64), 0, h->st[s],
+		hipLaunchKernelGGL(zmt_brotli_dec4_kernel, dim3((unsigned)((nrec + B4_NG - 1) / B4_NG)), dim3(64), 0, h->st[s],
 				   (const u8 *)d_stream, d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap,
 				   d_out_len, d_status);
 		want = 102u;
