@@ -132,7 +132,12 @@ static __device__ __forceinline__ void b4_grp_match(u8 *d, u32 off, u32 ml, u32 
 	}
 }
 
-extern "C" __global__ void __launch_bounds__(64)
+#ifdef B4_WPE
+#define B4_OCC __attribute__((amdgpu_waves_per_eu(B4_WPE, B4_WPE)))
+#else
+#define B4_OCC
+#endif
+extern "C" __global__ void __launch_bounds__(64) B4_OCC
 zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ rec_off, const u32 *__restrict__ rec_len,
 		       u32 nrec, u8 *out_base, const u64 *__restrict__ out_off, const u32 *__restrict__ out_cap,
 		       u32 *__restrict__ out_len, u32 *__restrict__ status)
