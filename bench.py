@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--chunk", type=int, default=0, help="0 = 128 KiB for lz4 (configs[1]), 1 MiB for zstd / brotli")
     ap.add_argument("--dec-variant", type=int, default=0,
-                    help="lz4 decoder: 0 = frames + parse3 + copy3 (default), 1 = frame-serial")
+                    help="lz4 decoder: 0 = frames + parse4 + copy3 (default), 1 = frame-serial")
     ap.add_argument("--lz4-ring", type=int, default=12, help="log2 of copy3's LDS ring per wave (12..14)")
     ap.add_argument("--snappy-dec", type=int, default=0,
                     help="--codec snappy: 1 = the batched decoder (zmt_snappy_dec2_kernel), 0 = element by element")

@@ -20,11 +20,9 @@ void zmt_lz4hc_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32
 void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u32 *, u32 *, u32 *, u32);
 void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
-void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *);
 void zmt_dec_parse4_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *);
 #define C3_DECL(NAME) void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, u32 *);
 C3_DECL(zmt_dec_copy3_w4_kernel)
-C3_DECL(zmt_dec_copy4_kernel)
 C3_DECL(zmt_dec_copy3_w8_kernel)
 C3_DECL(zmt_dec_copy3_w16_kernel)
 void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
@@ -132,12 +130,9 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 {
 	std::vector<u32> ce(nrec), cv(nrec);
 	u32 *cep = ce.data(), *cvp = cv.data();
-	/* variant: low 4 bits = pipeline (0 frames + parse3 + copy3, 1 frame-serial), bits 4.. = log2 of copy3's
+	/* variant: low 4 bits = pipeline (0 frames + parse4 + copy3, 1 frame-serial), bits 4.. = log2 of copy3's
 	 * ring (0 = 12, the default of the product) */
 	const int ring = ((variant >> 4) & 15) ? ((variant >> 4) & 15) : 12;
-	/* bits 8..11: parse stage (0 = the product's default, parse4; 3 = parse3); bits 12..15: copy stage (0 = default, 3 = copy3) */
-	const int parse = ((variant >> 8) & 15) ? ((variant >> 8) & 15) : 4;
-	const int copy = ((variant >> 12) & 15) ? ((variant >> 12) & 15) : 3;
 	variant &= 15;
 	if (variant == 1) {
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
@@ -159,10 +154,7 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 			zmt_dec_frames_kernel(stream, rec_off, rec_len, nrec, out_len, blk0p, bcop, bcsp, rnbp, rflp, status, cep, cvp);
 		});
 		emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
-			if (parse == 3)
-				zmt_dec_parse3_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bntp, bolp);
-			else
-				zmt_dec_parse4_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bntp, bolp);
+			zmt_dec_parse4_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bntp, bolp);
 		});
 		if (getenv("ZMT_EMU_DEBUG")) {
 			for (size_t b = 0; b < blk0[nrec]; b++)
@@ -171,9 +163,7 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 				fprintf(stderr, "rec %u status=%u nblk=%u\n", r, status[r], rnb[r]);
 		}
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
-				if (ring == 12 && copy != 3)
-					zmt_dec_copy4_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
-				else if (ring == 12)
+				if (ring == 12)
 					zmt_dec_copy3_w4_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
 				else if (ring == 13)
 					zmt_dec_copy3_w8_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);

@@ -77,7 +77,7 @@ def walk_records(stream: bytes):
 
 
 def decompress(stream: bytes, variant: int = 0, rec=None):
-    """-> (content bytes, status[n]); variant 0 | ring << 4 = frames + parse3 + copy3 kernels (ring 12 if omitted), 1 = serial decoder"""
+    """-> (content bytes, status[n]); variant 0 | ring << 4 = frames + parse4 + copy3 kernels (ring 12 if omitted), 1 = serial decoder"""
     L = lib()
     ro, rl = rec if rec is not None else walk_records(stream)
     nrec = len(ro)

@@ -100,7 +100,7 @@ def test_emu_hc_optimal_1mib_chunk():
     assert stream == H.oracle_compress_level(data, 1 << 20, 10)
 
 
-# decoder variants of the emulator API: 0 | ring << 4 = frames + parse3 + copy3 with a 4 / 8 / 16 KiB ring
+# decoder variants of the emulator API: 0 | ring << 4 = frames + parse4 + copy3 with a 4 / 8 / 16 KiB ring
 # (plain 0 = the product's default, 4 KiB), 1 = frame-serial
 DEC_VARIANTS = [0, 1, 0 | 13 << 4, 0 | 14 << 4]
 

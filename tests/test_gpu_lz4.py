@@ -12,7 +12,7 @@ from cases import CASES, KNOWN_HEX, rnd, text
 pytestmark = pytest.mark.gpu
 
 # decoder kernel variants under test (include/gpumt.h gpumt_set_variant "lz4_dec")
-# 0 | ring << 4 = frames + parse3 + copy3 pipeline with a 4 / 8 / 16 KiB LDS ring per wave ("lz4_ring" = 12 / 13 / 14;
+# 0 | ring << 4 = frames + parse4 + copy3 pipeline with a 4 / 8 / 16 KiB LDS ring per wave ("lz4_ring" = 12 / 13 / 14;
 # the default is 12), 1 = serial wave-per-record decoder
 VARIANTS = [0 | 12 << 4, 1, 0 | 13 << 4, 0 | 14 << 4]
 

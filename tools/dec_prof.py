@@ -5,8 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import zstdmt_amd as z
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-# variants: 0 | ring << 4 = frames + parse3 + copy3 (ring 12 if omitted), 1 = frame-serial
-# bits 8..11 = parse stage (0 = default, 3 = parse3, 4 = parse4), bits 12..15 = copy stage (0 = default, 3 = copy3, 4 = copy4)
+# variants: 0 | ring << 4 = frames + parse4 + copy3 (ring 12 if omitted), 1 = frame-serial
 variants = [int(v, 0) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "1"])]
 eng = z.Engine(0); L, h = eng.L, eng.h
 T = C.CDLL(os.path.join(ROOT, "zstdmt_amd", "lib", "libzmt_tools.so"))
@@ -27,10 +26,6 @@ names = ["stage", "spec", "walk", "decode+scan+classify", "literals", "fence+far
 for v in variants:
     eng.set_variant("lz4_dec", v & 15)
     eng.set_variant("lz4_ring", ((v >> 4) & 15) or 12)
-    if (v >> 8) & 15:
-        eng.set_variant("lz4_parse", (v >> 8) & 15)
-    if (v >> 12) & 15:
-        eng.set_variant("lz4_copy", (v >> 12) & 15)
     eng.set_variant("profile", 1)
     for rep in range(2):
         cnt = (C.c_ulonglong * 16)()

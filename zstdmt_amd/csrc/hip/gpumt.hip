@@ -35,13 +35,11 @@ __global__ void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8
 __global__ void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 __global__ void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *,
 				      const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
-__global__ void zmt_dec_parse3_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *, u32 *, u32 *);
 __global__ void zmt_dec_parse4_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *, u32 *, u32 *);
 #define C3_DECL(NAME)                                                                                              \
 	__global__ void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *,  \
 			     const u32 *, const u32 *, const u32 *, const u16 *, const u32 *, const u32 *, u32 *);
 C3_DECL(zmt_dec_copy3_w4_kernel)
-C3_DECL(zmt_dec_copy4_kernel)
 C3_DECL(zmt_dec_copy3_w8_kernel)
 C3_DECL(zmt_dec_copy3_w16_kernel)
 #define C3_DECLP(NAME)                                                                                             \
@@ -49,7 +47,6 @@ C3_DECL(zmt_dec_copy3_w16_kernel)
 			     const u32 *, const u32 *, const u32 *, const u16 *, const u32 *, const u32 *, u32 *, \
 			     unsigned long long *);
 C3_DECLP(zmt_dec_copy3_w4_kernel_prof)
-C3_DECLP(zmt_dec_copy4_kernel_prof)
 C3_DECLP(zmt_dec_copy3_w8_kernel_prof)
 C3_DECLP(zmt_dec_copy3_w16_kernel_prof)
 __global__ void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
@@ -105,8 +102,6 @@ struct gpumt_ctx {
 	int xflags;  /* experiment switches of the parse kernel (developer) */
 	int lz4_ring; /* copy3: log2 of the LDS ring per wave (12, 13 or 14) */
 	int debug_free; /* GPUMT_DEBUG_FREE: gpumt_free / gpumt_host_free check that the streams are idle */
-	int lz4_parse; /* parse stage: 4 = parse4 (default), 3 = parse3 (round 3) */
-	int lz4_copy;  /* copy stage: 4 = copy4 (default), 3 = copy3 (round 3; the only one with 8 / 16 KiB rings) */
 	int profile; /* record events in timer slots 8.. around individual kernels */
 	int num_cus;
 	int zenc_waves[3]; /* resident waves of the persistent zstd encoder kernels (whole device), per level tier */
@@ -251,21 +246,12 @@ int gpumt_open(int device, gpumt_ctx **out)
 		 * gpumt_set_variant on: GPUMT_SNAPPY_DEC=1 selects the batched snappy decoder */
 		const char *e = getenv("GPUMT_SNAPPY_DEC");
 		h->sdec_variant = e && *e ? atoi(e) : 0;
-		/* GPUMT_LZ4_DEC: 0 = frames + parse3 + copy3 (default), 1 = frame-serial;
+		/* GPUMT_LZ4_DEC: 0 = frames + parse4 + copy3 (default), 1 = frame-serial;
 		 * GPUMT_LZ4_RING: log2 of copy3's LDS ring per wave (12 = 4 KiB, the default; 13; 14) */
 		e = getenv("GPUMT_LZ4_DEC");
 		h->dec_variant = e && *e ? atoi(e) : 0;
 		e = getenv("GPUMT_LZ4_RING");
 		h->lz4_ring = e && *e ? atoi(e) : 12;
-		/* GPUMT_LZ4_PARSE / GPUMT_LZ4_COPY: 3 = the round-3 kernels (parse3 / copy3), default the round-4 ones */
-		e = getenv("GPUMT_BROTLI_DEC");
-		h->bdec_variant = e && *e ? atoi(e) : 0;
-		e = getenv("GPUMT_DEBUG_FREE");
-		h->debug_free = e && *e ? atoi(e) : 0;
-		e = getenv("GPUMT_LZ4_PARSE");
-		h->lz4_parse = e && *e ? atoi(e) : 4;
-		e = getenv("GPUMT_LZ4_COPY");
-		h->lz4_copy = e && *e ? atoi(e) : 3;
 	}
 	*out = h;
 	return GPUMT_OK;
@@ -897,14 +883,9 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 		PROF1(13);
 		const int ring = h->lz4_ring < 12 ? 12 : h->lz4_ring > 14 ? 14 : h->lz4_ring;
 		PROF0(14);
-		if (h->lz4_parse == 3)
-			hipLaunchKernelGGL(zmt_dec_parse3_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
-					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
-					   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bnt, bol);
-		else
-			hipLaunchKernelGGL(zmt_dec_parse4_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
-					   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
-					   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bnt, bol);
+		hipLaunchKernelGGL(zmt_dec_parse4_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
+				   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
+				   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bnt, bol);
 		PROF1(14);
 		PROF0(15);
 #define C3_LAUNCH(NAME)                                                                                            \
@@ -919,12 +900,7 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 			   (const u32 *)bnt, (const u32 *)bol, d_status, h->d_prof)
 		/* (running the XXH32 verification of record slices on a second stream while the next slice is copied was
 		 * measured in round 2: the partial last round of every slice costs more than the overlap gains) */
-		if (h->lz4_copy != 3 && ring == 12) {
-			if (h->profile == 8)
-				C3_LAUNCHP(zmt_dec_copy4_kernel_prof);
-			else
-				C3_LAUNCH(zmt_dec_copy4_kernel);
-		} else if (h->profile == 8) {
+		if (h->profile == 8) {
 			if (ring == 12)
 				C3_LAUNCHP(zmt_dec_copy3_w4_kernel_prof);
 			else if (ring == 13)
@@ -1321,12 +1297,6 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	} else if (!strcmp(what, "debug_free")) {
 		prev = h->debug_free;
 		h->debug_free = variant;
-	} else if (!strcmp(what, "lz4_parse")) {
-		prev = h->lz4_parse;
-		h->lz4_parse = variant;
-	} else if (!strcmp(what, "lz4_copy")) {
-		prev = h->lz4_copy;
-		h->lz4_copy = variant;
 	} else if (!strcmp(what, "k2x")) {
 		prev = h->xflags;
 		h->xflags = variant;

@@ -2,7 +2,7 @@
  * lz4_dec_copy3.hip -- copy stage of the LZ4 frame decoder, round 3 ("copy3").
  *
  * Wave per record, the token and batch lists of the parse kernel in, the content out (replaces LZ4F_decompress at
- * /root/reference/lib/lz4-mt_decompress.c:349-362 together with the frames / parse3 kernels).
+ * /root/reference/lib/lz4-mt_decompress.c:349-362 together with the frames / parse4 kernels).
  *
  * What the round-3 counters said about its predecessor, round 2's copy2 (profiles/r03_tcc_requests.json): it fetched 45.0 GB per
  * 8 GiB in 351.6 M requests, every one of them a full 128-byte line from memory -- one per match whose
@@ -252,67 +252,6 @@ template <u32 WIN, bool PROF = false> struct C3 {
 		}
 	}
 
-	/* eight bytes at LDS address p (any alignment), no wrap handling: three aligned dword reads off ONE address */
-	static __device__ __forceinline__ u64 ld64p(const u8 *p)
-	{
-#ifdef ZMT_EMU
-		return ld64u(p);
-#else
-		const u32 a = (u32)(size_t)(const __attribute__((address_space(3))) u8 *)p;
-		const __attribute__((address_space(3))) u32 *w = (const __attribute__((address_space(3))) u32 *)(size_t)(a & ~3u);
-		const u32 a0 = w[0], a1 = w[1], a2 = w[2];
-		return (u64)wv_alignbyte(a1, a0, a) | ((u64)wv_alignbyte(a2, a1, a) << 32);
-#endif
-	}
-	/* match<> with the source given as an LDS address whose ml bytes do not wrap around the ring's end */
-	template <bool BYTES> static __device__ __forceinline__ void match_p(u8 *ring, u32 mpos, u32 ml, const u8 *sp)
-	{
-		u8 *const d = ring + (mpos & MASK);
-		const bool wide = ml >= 8u;
-		const u32 tl = wide ? ml - 8u : ml - 4u;
-		const u64 a = ld64p(sp), b = ld64p(sp + tl);
-		if (ml > 16u) {
-			for (u32 i = 8; i + 8 < ml; i += 8)
-				c3_st64(d + i, ld64p(sp + i));
-		}
-		if (BYTES) {
-			c3_st32b(d, (u32)a);
-			c3_st32b(d + ml - 4u, wide ? (u32)(b >> 32) : (u32)b);
-			if (wide) {
-				c3_st32b(d + 4, (u32)(a >> 32));
-				c3_st32b(d + tl, (u32)b);
-			}
-		} else {
-			st32u(d, (u32)a);
-			st32u(d + ml - 4u, wide ? (u32)(b >> 32) : (u32)b);
-			if (wide) {
-				st32u(d + 4, (u32)(a >> 32));
-				st32u(d + tl, (u32)b);
-			}
-		}
-	}
-
-	/* the same for the dependency rounds, where few lanes are active: misaligned 8- or 4-byte LDS accesses; the source
-	 * does not wrap around the ring's end (the caller checks) */
-	static __device__ __forceinline__ void match_mis(u8 *ring, u32 mpos, u32 ml, u32 src_pos)
-	{
-		u8 *const d = ring + (mpos & MASK);
-		const u8 *const s = ring + (src_pos & MASK);
-		if (ml >= 8u) {
-			const u64 a = ld64u(s), b = ld64u(s + ml - 8u);
-			if (ml > 16u) {
-				for (u32 i = 8; i + 8 < ml; i += 8)
-					c3_st64(d + i, ld64u(s + i));
-			}
-			c3_st64(d, a);
-			c3_st64(d + ml - 8u, b);
-		} else {
-			const u32 a = ld32u(s), b = ld32u(s + ml - 4u);
-			st32u(d, a);
-			st32u(d + ml - 4u, b);
-		}
-	}
-
 	static __device__ __forceinline__ void
 	body(const u8 *__restrict__ stream, u64 stream_bytes, u32 rec0, u32 nrec, u8 *out_base,
 	     const u64 *__restrict__ out_off, const u32 *__restrict__ out_len, const u64 *__restrict__ blk0,
@@ -554,20 +493,8 @@ template <u32 WIN, bool PROF = false> struct C3 {
 #else
 							if (r1) {
 #endif
-#ifdef C3X_UNMASKED
-								/* one source address for both kinds; a ring source that wraps around the ring's end (rare)
-								 * takes the masked reads */
-								const u32 mlc = (is_far && ml > 16u) ? 16u : ml;
-								const bool wrap = !is_far & ((src_pos & MASK) + ml > WIN);
-								const u8 *const sp = is_far ? cb + 16u * (u32)lane : ring + (src_pos & MASK);
-								if (!wrap)
-									match_p<true>(ring, mpos, mlc, sp);
-								else
-									match<true>(ring, mpos, ml, ring, src_pos, MASK);
-#else
 								const u8 *const sb = is_far ? cb + 16u * (u32)lane : ring;
 								match<true>(ring, mpos, (is_far && ml > 16u) ? 16u : ml, sb, is_far ? 0u : src_pos, is_far ? ~0u : MASK);
-#endif
 								fin = true;
 							}
 						}
@@ -585,28 +512,8 @@ template <u32 WIN, bool PROF = false> struct C3 {
 							const u32 first = (u32)wv_ffs(unf) - 1;
 							const u32 W = wv_readlane(mpos, (int)first);
 							const bool go = !fin & (src_pos + eff <= W);
-#ifdef C3X_MIS_ROUNDS
-							/* few lanes are active in a round: misaligned LDS accesses (one pipe cycle per active lane) instead
-							 * of aligned reads + funnel shifts; a source that wraps around the end of the ring takes the old way */
-							const bool wrap = (src_pos & MASK) + ml > WIN;
-							if (go & !ovl & !wrap)
-								match_mis(ring, mpos, ml, src_pos);
-							if (wv_any(go & !ovl & wrap)) {
-								if (go & !ovl & wrap)
-									match<false>(ring, mpos, ml, ring, src_pos, MASK);
-							}
-#elif defined(C3X_UNMASKED)
-							const bool wrap = (src_pos & MASK) + ml > WIN;
-							if (go & !ovl & !wrap)
-								match_p<false>(ring, mpos, ml, ring + (src_pos & MASK));
-							if (wv_any(go & !ovl & wrap)) {
-								if (go & !ovl & wrap)
-									match<false>(ring, mpos, ml, ring, src_pos, MASK);
-							}
-#else
 							if (go & !ovl)
 								match<false>(ring, mpos, ml, ring, src_pos, MASK);
-#endif
 							if (wv_any(go & ovl)) { /* (offset < length: 0.2 % of the matches) */
 								if (go & ovl)
 									match_ovl(ring, mpos, off, ml);

@@ -3,12 +3,13 @@
  *
  * Second kernel of the pipeline described in lz4_dec_split.hip (replaces, together with the frames and copy
  * kernels, LZ4F_decompress at /root/reference/lib/lz4-mt_decompress.c:349-362): lane per 64 KiB block, serial
- * token walk, u16 token positions to the token list -- the same contract as parse3 (lz4_dec_parse3.hip), which
- * stays in the tree as variant 3 of gpumt_set_variant("lz4_parse", ...).
+ * token walk, u16 token positions to the token list.
  *
- * parse3 was measured at 147 instructions per step with two waves per SIMD (a wave issues one instruction per
- * 5-8 cycles: the step IS the time, 5 500 steps per block).  What this kernel does differently, all of it to
- * shrink the step:
+ * Its predecessor (round 3's parse3, deleted; numbers in profiles/r04_sweeps/parse4_vs_parse3.txt) was measured at 147
+ * instructions per step with two waves per SIMD (a wave issues one instruction per 5-8 cycles: the step IS the
+ * time, 5 500 steps per block): 3.34 ms per 8 GiB.  What this kernel does differently, all of it to shrink the step
+ * (80 instructions, 2.35 - 2.5 ms; the rest is the latency of the chain -- three LDS round trips and ~60 dependent
+ * vector instructions per step, with only the 131 072 blocks of an 8 GiB batch to run side by side):
  *
  *   - the step reads exactly the three bytes it needs (token, literal-length byte, match-length byte) with three
  *     byte reads of the lane's LDS ring -- byte reads cost the LDS pipe the same at any address (tools/ubench/

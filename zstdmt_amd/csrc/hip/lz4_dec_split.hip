@@ -11,7 +11,7 @@
  *
  *   K1 zmt_dec_frames_kernel  thread per record: record + frame header checks, block-header walk
  *                             -> block table (offset, size, stored flag), expected checksum.
- *   K2 zmt_dec_parse3_kernel  (lz4_dec_parse3.hip) lane per block: serial token walk -> u16 token
+ *   K2 zmt_dec_parse4_kernel  (lz4_dec_parse4.hip) lane per block: serial token walk -> u16 token
  *                             positions (2 B per sequence), the batch list, block decoded sizes.
  *   K3 zmt_dec_copy3_*_kernel (lz4_dec_copy3.hip) wave per record: up to 64 sequences per step.
  *
