@@ -149,11 +149,14 @@ def test_debug_free_guard_counts_busy_frees(eng):
         victim = eng.alloc(1 << 20)
         eng.sync()
         eng.lz4_compress(d_in, n, 131072, d_slots, stride, d_rl)      # ~10 ms of kernels queued
-        victim.free()                                                  # busy: counted, drained
+        # (DevBuf.free() waits for the device first, as the contract wants: the raw call is what breaks it)
+        eng.L.gpumt_free(eng.h, C.c_void_p(victim.ptr))                # busy: counted, drained
+        victim.ptr = None
         assert eng.L.gpumt_debug_free_busy() == 1
         other = eng.alloc(1 << 20)
         eng.sync()
-        other.free()                                                   # idle: not counted
+        eng.L.gpumt_free(eng.h, C.c_void_p(other.ptr))                 # idle: not counted
+        other.ptr = None
         assert eng.L.gpumt_debug_free_busy() == 0
         for b in (d_in, d_slots, d_rl):
             b.free()
