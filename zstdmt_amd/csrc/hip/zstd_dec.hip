@@ -1365,7 +1365,14 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 						 * slack below the window).  Both LDS reads of the step are issued
 						 * together: one round trip per sequence. */
 						const int tb = (bp - 1) >> 3;
-						const u64 w1 = ld64u(winb + tb), w0 = ld64u(winb + tb + 8);
+						/* only the three state lanes read the window: a misaligned 8-byte LDS read costs the CU's LDS
+						 * pipe one cycle per ACTIVE lane (tools/ubench/lds_cost.hip) -- with all 64 lanes reading the
+						 * same two addresses this loop was bound by that pipe, 128 cycles per sequence and wave */
+						u64 w1 = 0, w0 = 0;
+						if (lane < 3) {
+							w1 = ld64u(winb + tb);
+							w0 = ld64u(winb + tb + 8);
+						}
 						const u32 cell = mytab[state];
 						const u32 skip = (u32)(8 * (tb + 1) - bp);
 						const u32 nb = sbase + i + 1 == nseq ? 0u : ZC_NB(cell), ab = ZC_AB(cell);
