@@ -214,6 +214,23 @@ static __device__ int fse_build(u32 *cell, const short *norm, int nsym, int log,
 }
 
 /* `width` (<= 32) bits that start `topoff` bits below the top of the 128-bit window w0:w1 */
+/* 16 LDS bytes at any address as w1 (bytes 0..7) and w0 (bytes 8..15) from five ALIGNED dword reads + funnel shifts: a
+ * misaligned 8-byte LDS read costs the LDS pipe one cycle per active lane (tools/ubench/lds_cost.hip), and the unit
+ * decoder has 48 of them active */
+static __device__ __forceinline__ void lds_ld128(const u8 *p, u64 &w1, u64 &w0)
+{
+#ifdef ZMT_EMU
+	w1 = ld64u(p);
+	w0 = ld64u(p + 8);
+#else
+	const u32 a = (u32)(size_t)(const __attribute__((address_space(3))) u8 *)p;
+	const __attribute__((address_space(3))) u32 *d = (const __attribute__((address_space(3))) u32 *)(size_t)(a & ~3u);
+	const u32 d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4];
+	w1 = (u64)wv_alignbyte(d1, d0, a) | (u64)wv_alignbyte(d2, d1, a) << 32;
+	w0 = (u64)wv_alignbyte(d3, d2, a) | (u64)wv_alignbyte(d4, d3, a) << 32;
+#endif
+}
+
 static __device__ __forceinline__ u32 xbits(u64 w0, u64 w1, u32 topoff, u32 width)
 {
 	const u32 sh = 128u - topoff - width;
@@ -1254,7 +1271,8 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 										const bool on = act && done + (u32)i < g_n;
 										int tb = (bp - 1) >> 3;
 										tb = tb < wlo + 15 ? wlo + 15 : tb; /* a stream gone bad stays inside its window */
-										const u64 w1 = ld64u(winb + tb), w0 = ld64u(winb + tb + 8);
+										u64 w1, w0;
+										lds_ld128(winb + tb, w1, w0);
 										const u32 cell = mytab[state & tmask];
 										const u32 skip = (u32)(8 * (tb + 1) - bp) & 127u;
 										const u32 nb = done + (u32)i + 1 == g_n ? 0u : ZC_NB(cell), ab = ZC_AB(cell);
