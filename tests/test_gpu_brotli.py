@@ -21,10 +21,14 @@ needs_lib = pytest.mark.skipif(not H.have_libbrotli(), reason="libbrotli 1.0.9 n
 needs_ref = pytest.mark.skipif(not H.have_bref(), reason="reference build not on this box")
 
 
-@pytest.fixture(scope="module")
-def eng():
+# decoder variants (gpumt_set_variant("brotli_dec", v)): 2 = zmt_brotli_dec4_kernel (four records per wave) first and
+# the general kernel for what it hands over -- what a large batch takes by itself; 1 = the general kernel alone -- what a
+# small batch takes.  Every test runs both.
+@pytest.fixture(scope="module", params=[2, 1], ids=["dec4", "general"])
+def eng(request):
     import zstdmt_amd as z
     e = z.Engine(0)
+    e.set_variant("brotli_dec", request.param)
     yield e
     e.close()
 

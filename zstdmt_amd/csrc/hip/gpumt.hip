@@ -108,7 +108,7 @@ struct gpumt_ctx {
 	int hc_waves;     /* developer: grid of the LZ4HC encoder (0 = GPUMT_LZ4HC_WAVES) */
 	int zdec_variant; /* 0 = small-table kernel, then general; 1 = general only */
 	int sdec_variant; /* snappy decoder: 0 = element by element, 1 = 64 elements per batch (snappy.hip) */
-	int bdec_variant; /* brotli decoder: 0 = dec4 (four records per wave) + the general kernel for what it hands over, 1 = general only */
+	int bdec_variant; /* brotli decoder: 0 = by batch size, 1 = the general kernel only, 2 = dec4 (four records per wave) + general for what it hands over */
 	int bdec_waves;   /* resident waves of the persistent brotli decoder kernel (whole device) */
 	int benc_waves[3]; /* resident waves of the persistent brotli encoder kernels (whole device), per quality tier */
 	int senc_waves, sdec_waves, sdec2_waves; /* ... of the snappy kernels */
@@ -1179,10 +1179,14 @@ int gpumt_brotli_decompress_batch(gpumt_ctx *h, const void *d_stream, const uint
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
 	}
 	PROF0(12);
-	/* bdec_variant 0 (default): four records per wave for the streams without context modelling / block switching
-	 * (brotli_dec4.hip); what it hands over (status 102) goes to the general kernel.  1: the general kernel alone */
+	/* Two kernels.  zmt_brotli_dec4_kernel runs four records per wave (streams without context modelling / block
+	 * switching; what it hands over -- status 102 -- goes to the general kernel): a quarter of the waves per record, each
+	 * twice as slow as a one-record wave.  That wins as soon as the one-record kernel would need more than one round of
+	 * its resident waves (8 192 records: 283 ms against 500), and loses below (1 024 records: 308 ms against 151), so
+	 * the batch size chooses.  bdec_variant: 0 = that rule, 1 = the general kernel alone, 2 = dec4 first whatever the size */
 	u32 want = 0xFFFFFFFFu;
-	if (h->bdec_variant == 0 && h->profile != 7) {
+	const bool use4 = h->bdec_variant == 2 || (h->bdec_variant == 0 && nrec > (size_t)h->bdec_waves);
+	if (use4 && h->profile != 7) {
 		hipLaunchKernelGGL(zmt_brotli_dec4_kernel, dim3((unsigned)((nrec + B4_NG - 1) / B4_NG)), dim3(64), 0, h->st[s],
 				   (const u8 *)d_stream, d_rec_off, d_rec_len, (u32)nrec, (u8 *)d_out, d_out_off, d_out_cap,
 				   d_out_len, d_status);
