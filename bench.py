@@ -1070,7 +1070,7 @@ def _roof_short(r, nested=False):
         ("kernel", "bound", "achieved", "peak", "unit", "frac", "alg_bytes_per_launch", "avg_launch_ms", "traffic")
     o = {k: r[k] for k in keep if k in r}
     if nested and isinstance(o.get("kernel"), str):
-        o["kernel"] = o["kernel"][:60]
+        o["kernel"] = o["kernel"][:96]
     return o
 
 

@@ -14,6 +14,13 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 go = os.path.join(root, "gpurun_out")
 
 
+def bench_line(path):
+    """the full result of a bench run: its DETAIL line (the last line is the short one the driver keeps)"""
+    ls = open(path).read().strip().splitlines()
+    det = [l for l in ls if l.startswith("DETAIL ")]
+    return json.loads(det[-1][7:] if det else ls[-1])
+
+
 def biggest(pattern):
     files = glob.glob(os.path.join(go, pattern), recursive=True)
     # several processes write files (rocprofv3 wraps python and its children): keep the ones of the
@@ -47,7 +54,7 @@ if zstats:
             for k, v in counter_avg(f).items():
                 if "zstd" in k:
                     part[k] = v
-    zl = open(os.path.join(go, "bench_zstd.json")).read().strip().splitlines()[-1]
+    zl = json.dumps(bench_line(os.path.join(go, "bench_zstd.json")))
     json.dump(json.loads(zl), open(os.path.join(root, "profiles", f"{rnd}_bench_zstd_8gib_1gpu.json"), "w"), indent=1)
 sstats = biggest("prof_snappy_stats/**/*_kernel_stats.csv")
 if sstats:
@@ -58,7 +65,7 @@ if sstats:
             for k, v in counter_avg(f).items():
                 if "snappy" in k:
                     part[k] = v
-    sl = open(os.path.join(go, "bench_snappy.json")).read().strip().splitlines()[-1]
+    sl = json.dumps(bench_line(os.path.join(go, "bench_snappy.json")))
     json.dump(json.loads(sl), open(os.path.join(root, "profiles", f"{rnd}_bench_snappy_8gib_1gpu.json"), "w"), indent=1)
 bstats = biggest("prof_brotli_stats/**/*_kernel_stats.csv")
 if bstats:
@@ -72,7 +79,7 @@ if bstats:
     best = biggest("prof_brotli_enc_stats/**/*_kernel_stats.csv")
     if best:
         shutil.copy(best, os.path.join(root, "profiles", f"{rnd}_brotli_enc_kernel_stats.csv"))
-    bl = open(os.path.join(go, "bench_brotli.json")).read().strip().splitlines()[-1]
+    bl = json.dumps(bench_line(os.path.join(go, "bench_brotli.json")))
     json.dump(json.loads(bl), open(os.path.join(root, "profiles", f"{rnd}_bench_brotli_8gib_1gpu.json"), "w"), indent=1)
 detail, per = [], {}
 for k in sorted(set(fetch) | set(write)):
@@ -93,7 +100,7 @@ out = {
     "detail": detail,
 }
 json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
-line = json.loads(open(os.path.join(go, "bench_default.json")).read().strip().splitlines()[-1])
+line = bench_line(os.path.join(go, "bench_default.json"))
 
 
 def refresh(obj):
