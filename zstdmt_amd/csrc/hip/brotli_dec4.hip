@@ -209,8 +209,8 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 #define B4_ENSURE(cond, MARGIN)                                                                                    \
 	do {                                                                                                       \
 		const bool need_ = (cond) && (wptr - wbyte > B4_WIN - (MARGIN));                                   \
-		if (wv_any(need_)) {                                                                               \
-			if (need_)                                                                                 \
+		if (wv_any(need_)) { /* (every group with `cond` reloads: one memory round trip for the wave, not one per group) */ \
+			if (cond)                                                                                  \
 				B4_LOAD_WIN(wptr);                                                                 \
 		}                                                                                                  \
 	} while (0)
@@ -683,7 +683,10 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 					}
 				}
 			}
-			B4_EXEC(act && nbatch == B4_NB);
+			/* (as soon as one group's 16 slots are full every group runs what it has pending: one fence and one memory
+			 * round trip for the wave instead of one per group -- the groups fill their slots a pass or two apart) */
+			if (wv_any(act && nbatch == B4_NB))
+				B4_EXEC(act);
 			if (act) {
 				const u64 used = 8ull * wptr - navail;
 				if (handoff) {
