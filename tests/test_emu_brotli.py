@@ -46,6 +46,34 @@ def test_multi_record_persistent_waves():
 
 
 @needs_lib
+@pytest.mark.parametrize("seed", range(4))
+def test_four_streams_per_wave_mixed_records(seed):
+    """zmt_brotli_dec4_kernel runs four records per wave in lockstep: records of very different lengths and shapes in
+    one wave -- empty, tiny, 100 KiB+, streams it decodes itself (qualities 0..4) next to streams it hands over to the
+    general kernel (context modelling, qualities 5+) and a damaged one -- must not disturb each other"""
+    import random
+    rng = random.Random(900 + seed)
+    parts, want = [], []
+    nrec = rng.choice([3, 5, 6, 9])
+    for i in range(nrec):
+        n = rng.choice([0, 1, 5, 100, 3000, 20000, 70000, rng.randrange(1, 150000)])
+        d = cases.text(n, seed=rng.randrange(1 << 30)) if rng.random() < 0.7 else H.soup(rng, n)
+        q = rng.choice([0, 1, 1, 2, 3, 4, 5, 9])
+        st = bytearray(H.libbrotli_compress(d, quality=q, lgwin=rng.choice([16, 18, 22])))
+        if i == 1 and len(st) > 20:
+            st[len(st) // 2] ^= 0x55                      # one damaged record among them
+            d = H.oracle_brotli_decompress(bytes(st), ((n >> 16) + 1) << 16)    # (the record's capacity; a negative status when the oracle rejects it)
+        parts.append(H.brotli_record(bytes(st), (n >> 16) + 1))
+        want.append(d)
+    recs, status = E.brotli_decompress(b"".join(parts), grid=rng.choice([1, 2, 3]))
+    for i in range(nrec):
+        if isinstance(want[i], int):                        # the oracle's negative status: it rejects the damaged record
+            assert status[i] != 0
+        else:
+            assert status[i] == 0 and recs[i] == want[i], i
+
+
+@needs_lib
 @pytest.mark.parametrize("quality", [0, 2, 5, 9, 11])
 def test_live_streams_match_oracle(quality):
     d = cases.english(14000, 40 + quality) + cases.text(6000, 41) + bytes(300) + cases.rnd(500, 42)

@@ -141,6 +141,37 @@ def test_more_records_than_resident_waves(eng):
     assert all(recs[i] == want[i % 4] for i in range(6000))
 
 
+@needs_lib
+def test_large_batch_takes_dec4_and_hands_over():
+    """the product's own rule (variant 0): a batch of more records than the one-record kernel keeps resident goes to
+    zmt_brotli_dec4_kernel, which decodes the quality 0..4 streams itself and hands the others (context modelling) and
+    nothing else over; a damaged record gets the oracle's verdict, the rest of the batch is untouched by it"""
+    import zstdmt_amd as z
+    e = z.Engine(0)
+    try:
+        datas = [cases.text(3000, 1), cases.english(9000, 2), b"", cases.text(70000, 3), bytes(5000), cases.text(200, 4)]
+        quals = [1, 5, 2, 0, 9, 4]
+        streams = [H.libbrotli_compress(d, quality=q, lgwin=22) for d, q in zip(datas, quals)]
+        bad = bytearray(streams[3])
+        bad[len(bad) // 2] ^= 0x5A
+        want_bad = H.oracle_brotli_decompress(bytes(bad), ((len(datas[3]) >> 16) + 1) << 16)   # the record's capacity
+        n = 6000                                             # > 16 waves x 256 CUs
+        parts = []
+        for i in range(n):
+            k = i % 6
+            parts.append(H.brotli_record(bytes(bad) if i == 4001 else streams[k], (len(datas[k]) >> 16) + 1))
+        st = b"".join(parts)
+        ro, rl, cap = E.walk_brotli_records(st)
+        recs, status = e.brotli_decompress_bytes(st, ro, rl, cap)
+        for i in range(n):
+            if i == 4001:
+                assert (status[i] != 0) if isinstance(want_bad, int) else (status[i] == 0 and recs[i] == want_bad)
+            else:
+                assert status[i] == 0 and recs[i] == datas[i % 6], i
+    finally:
+        e.close()
+
+
 def test_garbage_streams_same_verdict_as_oracle(eng):
     """Records of random bytes (and of random bytes behind a plausible header): nothing hangs, nothing
     is written outside the record's slot, and the verdict -- in the rare accepted case also the
