@@ -159,12 +159,12 @@ def test_large_batch_takes_dec4_and_hands_over():
         parts = []
         for i in range(n):
             k = i % 6
-            parts.append(H.brotli_record(bytes(bad) if i == 4001 else streams[k], (len(datas[k]) >> 16) + 1))
+            parts.append(H.brotli_record(bytes(bad) if i == 4005 else streams[k], (len(datas[k]) >> 16) + 1))
         st = b"".join(parts)
         ro, rl, cap = E.walk_brotli_records(st)
         recs, status = e.brotli_decompress_bytes(st, ro, rl, cap)
         for i in range(n):
-            if i == 4001:
+            if i == 4005:                                  # (4005 % 6 == 3: the damaged copy sits in a slot of its own capacity)
                 assert (status[i] != 0) if isinstance(want_bad, int) else (status[i] == 0 and recs[i] == want_bad)
             else:
                 assert status[i] == 0 and recs[i] == datas[i % 6], i
