@@ -83,6 +83,9 @@ def parse():
     ap.add_argument("--api-gib", type=float, default=8.0, help="input size of the drop-in API legs of the default run")
     ap.add_argument("--no-encoder", action="store_true",
                     help="--codec brotli: skip the device-encoder leg (profiling runs of the decoder alone)")
+    ap.add_argument("--zref-only", action="store_true",
+                    help="developer: only the 'zstd-mt decompress of reference-written streams' leg, printed as JSON")
+    ap.add_argument("--zstd-seq", type=int, default=0, help="1 = no sequence pre-pass in front of the zstd frame decoder")
     ap.add_argument("--master-port", type=int, default=0)
     ap.add_argument("--dry-run", action="store_true",
                     help="start the ranks, report who runs where (gloo, no GPU touched) and exit")
@@ -991,6 +994,10 @@ def main():
     eng.set_variant("snappy_dec", args.snappy_dec)
     eng.set_variant("profile", 1)
     ctx = Ctx(args, eng, rank, world, dist)
+    eng.set_variant("zstd_seq", args.zstd_seq)
+    if args.zref_only:
+        print(json.dumps(bench_zstd_ref(ctx, args.gib, args.steps, args.warmup)))
+        return
 
     if args.codec == "brotli":
         res = bench_brotli(ctx)

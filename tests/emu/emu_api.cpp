@@ -28,14 +28,15 @@ C3_DECL(zmt_dec_copy3_w16_kernel)
 void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 void zmt_scan_kernel(const u32 *, u32, u64 *);
 void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
-void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *, u32);
+void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *, u32, u8 *);
+void zmt_zstd_seq_kernel(const u8 *, u64, const u64 *, const u32 *, u32, const u64 *, const u32 *, const u32 *, u8 *);
 void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 void zmt_brotli_enc_t2_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 void zmt_brotli_enc_t3_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 void zmt_brotli_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u8 *, const u8 *, u32);
 void zmt_brotli_dec4_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
-void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *);
+void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *, u8 *);
 void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *, u32 *);
 void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
 void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
@@ -186,6 +187,8 @@ void emu_zstd_probe(const u8 *stream, const u64 *rec_off, const u32 *rec_len, u3
 		    [=]() { zmt_zstd_probe_kernel(stream, rec_off, rec_len, nrec, out_len, status); });
 }
 
+static u32 g_zstd_marks;
+u32 emu_zstd_last_marks() { return g_zstd_marks; }
 void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *rec_off, const u32 *rec_len,
 			       u32 nrec, u8 *out, const u64 *out_off, u32 *out_len, u32 *status)
 {
@@ -193,15 +196,40 @@ void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *re
 	u8 *litp = lit.data();
 	std::vector<u32> ce(nrec, 0xA5A5A5A5u), cv(nrec, 0xA5A5A5A5u);
 	u32 *cep = ce.data(), *cvp = cv.data();
+	/* the sequence pre-pass first (as gpumt_zstd_decompress_batch; EMU_ZSTD_SEQ=1: none), into a buffer as large as the
+	 * output that starts as garbage */
+	u64 total = 0;
+	for (u32 r = 0; r < nrec; r++)
+		total = out_off[r] + out_len[r] > total ? out_off[r] + out_len[r] : total;
+	const char *e = getenv("EMU_ZSTD_SEQ");
+	const bool seq_on = !(e && atoi(e) == 1);
+	std::vector<u8> seqv(seq_on ? (size_t)total + 16 : 0, 0xA5);
+	u8 *seqbuf = seq_on ? seqv.data() : nullptr;
+	if (seq_on)
+		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
+			zmt_zstd_seq_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out_off, out_len, status, seqbuf);
+		});
+	/* (test hook: how many blocks the pre-pass marked, read back from the record headers of zstd_dec_seq.h) */
+	g_zstd_marks = 0;
+	if (seq_on)
+		for (u32 r = 0; r < nrec; r++) {
+			if (out_len[r] <= 131072u || status[r] != 0)
+				continue;
+			u32 nh = (out_len[r] >> 14) & ~1u;
+			nh = nh < 64 ? 64 : nh > 8192 ? 8192 : nh;
+			const u32 *hdr = (const u32 *)(seqbuf + ((out_off[r] + 7) & ~7ull));
+			for (u32 i = 0; i < nh; i++)
+				g_zstd_marks += hdr[i] != 0;
+		}
 	/* small-table variant first, then the general one for the records it handed over (status 101) */
 	emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
-		zmt_zstd_dec_small_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status, cep, cvp);
+		zmt_zstd_dec_small_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status, cep, cvp, seqbuf);
 	});
 	if (getenv("ZMT_EMU_DEBUG"))
 		for (u32 r = 0; r < nrec; r++)
 			fprintf(stderr, "zstd rec %u after small kernel: status %u\n", r, status[r]);
 	emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
-		zmt_zstd_dec_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status, cep, cvp, 101u);
+		zmt_zstd_dec_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status, cep, cvp, 101u, seqbuf);
 	});
 	emu::launch(dim3{(nrec * 4 + 255) / 256, 1, 1}, dim3{256, 1, 1},
 		    [=]() { zmt_xxh64_verify_kernel(out, out_off, out_len, nrec, cep, cvp, status); });

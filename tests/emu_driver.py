@@ -115,6 +115,13 @@ def zstd_decompress(stream: bytes, rec=None):
     return out[:total].tobytes(), status
 
 
+def zstd_last_marks():
+    """blocks whose sequences the pre-pass (zstd_dec_seq.hip) decoded ahead in the last zstd_decompress call"""
+    L = lib()
+    L.emu_zstd_last_marks.restype = C.c_uint32
+    return int(L.emu_zstd_last_marks())
+
+
 def walk_brotli_records(stream: bytes):
     """16-byte brotli-mt headers -> (payload offsets u64[n], payload sizes u32[n], capacities u32[n]);
     what the host engine does while reading (lib/brotli-mt_decompress.c:187-284)"""

@@ -35,6 +35,8 @@ def main():
     e = z.Engine(0)
     if os.environ.get("ZDEC_VARIANT"):
         e.set_variant("zstd_dec", int(os.environ["ZDEC_VARIANT"]))
+    if os.environ.get("ZSEQ"):
+        e.set_variant("zstd_seq", int(os.environ["ZSEQ"]))     # 1 = no sequence pre-pass
     d_stream = e.upload(st)
     d_ro, d_rl = e.upload(ro.copy()), e.upload(rl.copy())
     d_ol, d_oo, d_st = e.alloc(nrec * 4), e.alloc((nrec + 1) * 8), e.alloc(nrec * 4)

@@ -206,3 +206,96 @@ def test_emu_corrupt_unit_streams():
             assert status[0] != 0, f"flip at {pos}: oracle rejects, kernel accepted"
         else:
             assert status[0] == 0 and out == want, f"flip at {pos}"
+
+
+# ------------------------------------------------------------------------------- sequence pre-pass
+def _both_ways(stream, rec=None):
+    """decode with the sequence pre-pass (default) and without it; returns (out, status, marks) of the first after
+    checking that the second says the same"""
+    import os
+    out, status = E.zstd_decompress(stream, rec=rec)
+    marks = E.zstd_last_marks()
+    os.environ["EMU_ZSTD_SEQ"] = "1"
+    try:
+        out1, status1 = E.zstd_decompress(stream, rec=rec)
+        assert E.zstd_last_marks() == 0
+    finally:
+        del os.environ["EMU_ZSTD_SEQ"]
+    assert status.tolist() == status1.tolist() and out == out1
+    return out, status, marks
+
+
+@pytest.mark.skipif(not H.have_zref(), reason="reference build not present")
+@pytest.mark.parametrize("level", [1, 3, 19])
+def test_emu_seq_prepass_reference_frames(level):
+    """frames of several blocks written by the reference (every block with its own fitted tables): the pre-pass
+    (zstd_dec_seq.hip) decodes the sequences of all blocks side by side, the frame decoder only executes them"""
+    data = cases.text(700000, 41) + bytes(5000) + cases.rnd(2000, 3) + cases.text(300000, 42)
+    rv, st, _, _ = H.zstdmt_compress_via(H.zref(), data, 1 << 20, threads=2, level=level)
+    assert rv == 0
+    blocks = H.zstd_walk_blocks(st[12:])
+    assert len([b for b in blocks if b["type"] == 2 and b.get("nseq")]) >= 6
+    out, status, marks = _both_ways(st)
+    assert (status == 0).all() and out == data
+    assert marks >= 6, "the pre-pass did not take the frame"
+
+
+@pytest.mark.skipif(not H.have_zref(), reason="reference build not present")
+def test_emu_seq_prepass_more_blocks_than_one_group():
+    """a 2.5 MiB frame = 20 blocks = three groups of eight; repetitive stretches make the writer use repeat /
+    predefined / RLE table modes, also across the boundary of a group"""
+    parts = [cases.text(300000, 7), cases.rep(cases.rnd(300, 9), 500000), cases.text(200000, 8),
+             cases.rep(cases.rnd(5000, 10), 700000), bytes(200000), cases.text(700000, 9)]
+    data = b"".join(parts)
+    for level in (1, 5):
+        rv, st, _, _ = H.zstdmt_compress_via(H.zref(), data, 4 << 20, threads=1, level=level)
+        assert rv == 0
+        modes = [b.get("modes") for b in H.zstd_walk_blocks(st[12:]) if b["type"] == 2 and b.get("nseq")]
+        assert len(modes) > 16
+        out, status, marks = _both_ways(st)
+        assert (status == 0).all() and out == data
+        assert marks > 8, (marks, modes)
+
+
+@pytest.mark.skipif(not H.have_zref(), reason="reference build not present")
+def test_emu_seq_prepass_leaves_what_it_cannot_hold():
+    """one sequence per 8 bytes of content is what a record's region holds: denser frames are decoded ahead as far as
+    they fit (or not at all) and the frame decoder does the rest; frames with more blocks than the region's header
+    has words are left alone"""
+    dense = H.dense_sequences(600000)
+    rv, st, _, _ = H.zstdmt_compress_via(H.zref(), dense, 1 << 20, threads=1, level=1)
+    assert rv == 0
+    out, status, marks = _both_ways(st)
+    assert (status == 0).all() and out == dense
+    # 70 empty raw blocks spliced in front of the first block: 64 header words do not reach the frame's end
+    data = cases.text(400000, 12)
+    rv, st, _, _ = H.zstdmt_compress_via(H.zref(), data, 1 << 20, threads=1, level=1)
+    fr = st[12:]
+    fhd = fr[4]
+    hdr_len = 5 + (0 if (fhd >> 5) & 1 else 1) + ((1 if (fhd >> 5) & 1 else 0), 2, 4, 8)[fhd >> 6]
+    fr2 = fr[:hdr_len] + bytes(3) * 70 + fr[hdr_len:]
+    st2 = H.mt_record(fr2)
+    assert H.oracle_zstdmt_decompress(st2, len(data) + 64) == data
+    out, status, marks = _both_ways(st2)
+    assert (status == 0).all() and out == data and marks == 0
+
+
+@pytest.mark.skipif(not H.have_zref(), reason="reference build not present")
+def test_emu_seq_prepass_corrupt_streams():
+    """damage anywhere in a frame the pre-pass takes: verdict, and content where the stream stays valid, are the
+    oracle's -- with and without the pre-pass"""
+    data = cases.text(500000, 33)
+    rv, st, _, _ = H.zstdmt_compress_via(H.zref(), data, 1 << 20, threads=1, level=1)
+    assert rv == 0
+    rng = np.random.default_rng(5)
+    ro, rl = np.array([0], np.uint64), np.array([len(st)], np.uint32)
+    for pos in sorted(set(rng.integers(12, len(st), 10).tolist())):   # (more flips: tools/emu_fuzz_zstd_seq.py, test_gpu_zstd.py)
+        bad = bytearray(st)
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        bad = bytes(bad)
+        want = H.oracle_zstdmt_decompress(bad, len(data) + 64)
+        out, status, _ = _both_ways(bad, rec=(ro, rl))
+        if want is None:
+            assert status[0] != 0, f"flip at {pos}: oracle rejects, kernel accepted"
+        else:
+            assert status[0] == 0 and out == want, f"flip at {pos}"

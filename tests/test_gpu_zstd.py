@@ -17,10 +17,13 @@ ZDIR = os.path.join(H.GOLDEN_DIR, "zstd")
 MAN = json.load(open(os.path.join(ZDIR, "manifest.json")))["cases"]
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=[0, 1], ids=["seq", "noseq"])
+def eng(request):
+    """every test runs with the sequence pre-pass (zstd_dec_seq.hip) in front of the frame decoder, the default, and
+    without it: the two must agree with the oracle on every verdict and every byte"""
     import zstdmt_amd as z
     e = z.Engine(0)
+    e.set_variant("zstd_seq", request.param)
     yield e
     e.close()
 
@@ -212,3 +215,34 @@ def test_chunk_beyond_128_mib_has_a_window_descriptor(eng):
     if H.have_zref():
         rv, back, _, _ = H.zstdmt_decompress_via(H.zref(), st)
         assert rv == 0 and back == data
+
+
+@pytest.mark.skipif(not H.have_zref(), reason="reference build not on this box")
+def test_seq_prepass_frames_of_many_blocks_and_their_damage(eng):
+    """4 MiB chunks = 32 blocks a frame = four groups of the pre-pass; repetitive stretches make the writer use repeat /
+    predefined / RLE table modes, also across a group's boundary; then 60 damaged copies of one record, each judged
+    like the oracle judges it"""
+    parts = [cases.text(3000000, 7), cases.rep(cases.rnd(300, 9), 1500000), cases.text(200000, 8),
+             cases.rep(cases.rnd(5000, 10), 2700000), bytes(900000), cases.text(2500000, 9), H.dense_sequences(700000)]
+    data = b"".join(parts)
+    for level in (1, 5):
+        rv, st, _, _ = H.zstdmt_compress_via(H.zref(), data, 4 << 20, threads=4, level=level)
+        assert rv == 0
+        ro, rl = E.walk_records(st)
+        out, status = eng.decompress_bytes(st, ro, rl, codec="zstd")
+        assert (status == 0).all() and out == data
+    rec = st[int(ro[1]):int(ro[1]) + int(rl[1])]
+    r1 = (np.array([0], np.uint64), np.array([len(rec)], np.uint32))
+    rng = np.random.default_rng(77)
+    for pos in sorted(set(rng.integers(12, len(rec), 60).tolist())):
+        bad = bytearray(rec)
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        bad = bytes(bad)
+        want = H.oracle_zstdmt_decompress(bad, (4 << 20) + 64)
+        out, status = eng.decompress_bytes(bad, r1[0], r1[1], codec="zstd")
+        if status[0] == 7 and want is not None:
+            continue                # the damage took the content size away: the probe leaves the frame to the caller
+        if want is None:
+            assert status[0] != 0, f"flip at {pos}: oracle rejects, device accepted"
+        else:
+            assert status[0] == 0 and out == want, f"flip at {pos}"

@@ -66,11 +66,13 @@ __global__ void zmt_brotli_dec_kernel_prof(const u8 *, const u64 *, const u32 *,
 __global__ void zmt_brotli_dec4_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *,
 				       u32 *, u32 *);
 __global__ void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-					  u32 *, u8 *, u32 *, u32 *, u32 *);
+					  u32 *, u8 *, u32 *, u32 *, u32 *, u8 *);
 __global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-				    u32 *, u8 *, u32 *, u32 *, u32 *, u32);
+				    u32 *, u8 *, u32 *, u32 *, u32 *, u32, u8 *);
 __global__ void zmt_zstd_dec_kernel_prof(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-					 u32 *, u8 *, u32 *, u32 *, u32 *, u32, unsigned long long *);
+					 u32 *, u8 *, u32 *, u32 *, u32 *, u32, unsigned long long *, u8 *);
+__global__ void zmt_zstd_seq_kernel(const u8 *, u64, const u64 *, const u32 *, u32, const u64 *, const u32 *,
+				    const u32 *, u8 *);
 __global__ void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *,
 					u32 *);
 __global__ void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
@@ -107,6 +109,7 @@ struct gpumt_ctx {
 	int zenc_waves[3]; /* resident waves of the persistent zstd encoder kernels (whole device), per level tier */
 	int hc_waves;     /* developer: grid of the LZ4HC encoder (0 = GPUMT_LZ4HC_WAVES) */
 	int zdec_variant; /* 0 = small-table kernel, then general; 1 = general only */
+	int zseq_variant; /* 0 = sequence pre-pass (zstd_dec_seq.hip) in front of the frame decoder; 1 = none */
 	int sdec_variant; /* snappy decoder: 0 = element by element, 1 = 64 elements per batch (snappy.hip) */
 	int bdec_variant; /* brotli decoder: 0 = by batch size, 1 = the general kernel only, 2 = dec4 (four records per wave) + general for what it hands over */
 	int bdec_waves;   /* resident waves of the persistent brotli decoder kernel (whole device) */
@@ -252,6 +255,9 @@ int gpumt_open(int device, gpumt_ctx **out)
 		h->dec_variant = e && *e ? atoi(e) : 0;
 		e = getenv("GPUMT_LZ4_RING");
 		h->lz4_ring = e && *e ? atoi(e) : 12;
+		/* GPUMT_ZSTD_SEQ=1: no sequence pre-pass in front of the zstd frame decoder */
+		e = getenv("GPUMT_ZSTD_SEQ");
+		h->zseq_variant = e && *e ? atoi(e) : 0;
 	}
 	*out = h;
 	return GPUMT_OK;
@@ -1038,7 +1044,6 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 				void *d_out, size_t out_bytes, const uint64_t *d_out_off,
 				uint32_t *d_out_len, uint32_t *d_status, int s)
 {
-	(void)out_bytes;
 	if (!h || !STREAM_OK(s) || nrec == 0 || nrec > 0x3FFFFFFFu)
 		return GPUMT_E_ARG;
 	if (use(h))
@@ -1048,9 +1053,15 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 	const size_t ZD_SLICE = 16384;
 	const size_t slice = nrec < ZD_SLICE ? nrec : ZD_SLICE;
 	const size_t lit_bytes = slice * (size_t)GPUMT_ZSTD_DEC_SCRATCH;
-	if (want_scratch(h, 1, s, lit_bytes + nrec * 8 + 64))
+	/* the sequence pre-pass (zstd_dec_seq.hip) writes into a buffer as large as the output, record i at its d_out_off:
+	 * only batches that can hold frames of more than one block have one */
+	const size_t chk_bytes = (nrec * 8 + 64 + 15) & ~(size_t)15;
+	const bool seq_on = h->zseq_variant == 0 && h->profile != 5 && out_bytes / nrec > 131072;
+	const size_t seq_bytes = seq_on ? out_bytes + 16 : 0;
+	if (want_scratch(h, 1, s, lit_bytes + chk_bytes + seq_bytes))
 		return GPUMT_E_HIP;
 	u32 *chk_e = (u32 *)((u8 *)h->scratch[1][s] + lit_bytes), *chk_v = chk_e + nrec;
+	u8 *seqbuf = seq_on ? (u8 *)h->scratch[1][s] + lit_bytes + chk_bytes : NULL;
 	if (h->profile == 5 && !h->d_prof) {
 		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
@@ -1062,20 +1073,24 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 			hipLaunchKernelGGL(zmt_zstd_dec_kernel_prof, dim3((unsigned)m), dim3(64), 0, h->st[s],
 					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
 					   (u8 *)d_out, d_out_off + b, d_out_len + b, (u8 *)h->scratch[1][s], d_status + b,
-					   chk_e + b, chk_v + b, 0u, h->d_prof);
+					   chk_e + b, chk_v + b, 0u, h->d_prof, (u8 *)NULL);
 		} else {
 			/* small-table variant first (16 waves per CU); records that need the full-size tables
 			 * come back with status 101 and are decoded by the general variant (12 waves per CU) */
 			const u32 want = h->zdec_variant == 1 ? 0u : 101u;
+			if (seqbuf)
+				hipLaunchKernelGGL(zmt_zstd_seq_kernel, dim3((unsigned)m), dim3(64), 0, h->st[s],
+						   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
+						   d_out_off + b, (const u32 *)(d_out_len + b), (const u32 *)(d_status + b), seqbuf);
 			if (h->zdec_variant != 1)
 				hipLaunchKernelGGL(zmt_zstd_dec_small_kernel, dim3((unsigned)m), dim3(64), 0, h->st[s],
 						   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
 						   (u8 *)d_out, d_out_off + b, d_out_len + b, (u8 *)h->scratch[1][s],
-						   d_status + b, chk_e + b, chk_v + b);
+						   d_status + b, chk_e + b, chk_v + b, seqbuf);
 			hipLaunchKernelGGL(zmt_zstd_dec_kernel, dim3((unsigned)m), dim3(64), 0, h->st[s],
 					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
 					   (u8 *)d_out, d_out_off + b, d_out_len + b, (u8 *)h->scratch[1][s], d_status + b,
-					   chk_e + b, chk_v + b, want);
+					   chk_e + b, chk_v + b, want, seqbuf);
 		}
 	}
 	/* XXH64 content checksums, for the frames that carry one */
@@ -1310,6 +1325,9 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	} else if (!strcmp(what, "zstd_dec")) {
 		prev = h->zdec_variant;
 		h->zdec_variant = variant;
+	} else if (!strcmp(what, "zstd_seq")) {
+		prev = h->zseq_variant;
+		h->zseq_variant = variant;
 	} else if (!strcmp(what, "snappy_dec")) {
 		prev = h->sdec_variant;
 		h->sdec_variant = variant;
