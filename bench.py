@@ -381,7 +381,7 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
         zk = ("zmt_zstd_enc_kernel", "zmt_zstd_enc_t2_kernel", "zmt_zstd_enc_t3_kernel")[eng.L.gpumt_zstd_level_tier(zl)]
         r_enc = None if dec_only else roof(zk + "(+assemble)", ms["k_lz4_enc"], alg, (zk, "zmt_zstd_assemble_kernel"))
         r_dec = roof("zmt_zstd_dec_small_kernel(+zmt_zstd_dec_kernel for frames with full-size tables)",
-                     ms["k_lz4_dec"], alg, ("zmt_zstd_dec_small_kernel", "zmt_zstd_dec_kernel"))
+                     ms["k_lz4_dec"], alg, ("zmt_zstd_seq_kernel", "zmt_zstd_dec_small_kernel", "zmt_zstd_dec_kernel"))
     else:
         name, what = "lz4-mt", "lz4-mt -1"
         ek = ("zmt_lz4_enc3_p17_kernel" if 65536 < chunk <= 131072 else
@@ -571,7 +571,8 @@ def bench_zstd_ref(ctx, gib, steps, warmup):
                                "in HBM), device-resident decode", "chunk": chunk, "records_per_gpu": nrec, "level": 1,
                    "ratio": round(U / Cb, 4)},
         "decompress_MBps": round(U / 1e6 / (ms["decompress"] * 1e-3), 1),
-        "roofline": {"kernel": "zmt_zstd_dec kernels (reference-written frames)", "bound": "hbm", "achieved": round(a, 2),
+        "roofline": {"kernel": "zmt_zstd_seq_kernel + zmt_zstd_dec_small_kernel (sequence pre-pass, then the frame decoder; "
+                               "reference-written frames)", "bound": "hbm", "achieved": round(a, 2),
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(a * 1e9 / HBM_PEAK, 5),
                      "alg_bytes_per_launch": alg, "avg_launch_ms": round(ms["k_zstd_dec"], 4), "traffic": None},
         "kernels": {"k_zstd_dec": {"ms": round(ms["k_zstd_dec"], 4)}},

@@ -328,12 +328,28 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				u32 cand = t_read<TM>(tlo, thi, h); /* (idle lanes read too: no exec-mask region) */
 				u32 prev_dup = 64, next_dup = 64;
 				{
-					/* in-batch duplicates of a hash: every probe sets its bit of the folded filter (only the
-					 * probes: an LDS atomic costs by active lanes) */
-					bool d = false;
+					EPC(R, 0);
+					/* the candidate's neighbourhood [cand - 8, cand + 16) in one go, always from memory (the ring holds
+					 * the same bytes for recent candidates, but a batch waits for its farthest one anyway, and one plain
+					 * global load path is cheaper than a per-lane choice between LDS and memory): the 4-byte test, and
+					 * for most matches all that catch-up and the match length need, so that the 128-byte window (a second
+					 * round trip) is the exception.  The loads leave with the table's answer, BEFORE the duplicate filter
+					 * has spoken: its atomic returns while they are under way, and the rare batch with a duplicate asks
+					 * again for the lanes whose candidate an earlier probe of the batch replaces.
+					 * Lanes without a candidate read chunk[0, 8) (no exec-mask region; a final record of 13..15 bytes has
+					 * nothing readable at chunk + 16) */
+					bool dist_ok = (TM == T_U16) || cand + DIST_MAX >= cur;
+					bool probe = valid && dist_ok;
+					bool wide = probe && cand >= 8; /* else (chunk start) 8 bytes at cand only, no quick extension */
+					u32 a0 = !probe ? 0u : wide ? cand - 8 : cand;
+					const u8 *gp = chunk + a0;
+					u64 l0 = ld64u(gp), l1 = ld64u(wide ? gp + 8 : gp), l2 = ld64u(wide ? gp + 16 : gp);
+					/* in-batch duplicates of a hash: every probe sets its bit of the folded filter (only the probes: an LDS
+					 * atomic costs by active lanes) -- behind the loads, its wait would stand in front of them */
+					u32 dold = 0;
 					if (valid)
-						d = (lds_or(&bitmap[(h & (BM_BITS - 1)) >> 5], 1u << (h & 31)) >> (h & 31)) & 1;
-					const bool any_dup = wv_any(d);
+						dold = lds_or(&bitmap[(h & (BM_BITS - 1)) >> 5], 1u << (h & 31));
+					const bool any_dup = wv_any(((dold >> (h & 31)) & 1) != 0);
 					wv_sync();
 					if (valid)
 						bitmap[(h & (BM_BITS - 1)) >> 5] = 0;
@@ -353,24 +369,15 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						const u32 pc = wv_shfl(cur, (int)(prev_dup & 63));
 						if (prev_dup < 64)
 							cand = pc;
+						dist_ok = (TM == T_U16) || cand + DIST_MAX >= cur;
+						probe = valid && dist_ok;
+						wide = probe && cand >= 8;
+						a0 = !probe ? 0u : wide ? cand - 8 : cand;
+						gp = chunk + a0;
+						l0 = ld64u(gp);
+						l1 = ld64u(wide ? gp + 8 : gp);
+						l2 = ld64u(wide ? gp + 16 : gp);
 					}
-				}
-				{
-					const bool dist_ok = (TM == T_U16) || cand + DIST_MAX >= cur;
-					EPC(R, 0);
-					/* the candidate's neighbourhood [cand - 8, cand + 16) in one go -- from the ring when it is
-					 * recent, else from memory --: the 4-byte test, and for most matches all that catch-up and
-					 * the match length need, so that the 128-byte window (a second round trip) is the exception.
-					 * Lanes without a candidate read the ring's first bytes (no exec-mask region) */
-					const bool probe = valid && dist_ok;
-					/* (lanes without a probe read chunk[0, 8) only: a final record of 13..15 bytes has nothing readable at
-					 * chunk + 16) */
-					const bool wide = probe && cand >= 8; /* else (chunk start) 8 bytes at cand only, no quick extension */
-					/* (always from memory: the ring holds the same bytes, but a batch waits for its farthest candidate
-					 * anyway, and one plain global load path is cheaper than a per-lane choice between LDS and memory) */
-					const u32 a0 = !probe ? 0u : wide ? cand - 8 : cand;
-					const u8 *const gp = chunk + a0;
-					const u64 l0 = ld64u(gp), l1 = ld64u(wide ? gp + 8 : gp), l2 = ld64u(wide ? gp + 16 : gp);
 					const u64 g0 = l0, g1 = wide ? l1 : l0, g2 = l2;
 					const bool m = probe && (u32)g1 == (u32)x;
 					const u64 mm = wv_ballot(m);
