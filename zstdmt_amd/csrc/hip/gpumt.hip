@@ -1056,7 +1056,7 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 	/* the sequence pre-pass (zstd_dec_seq.hip) writes into a buffer as large as the output, record i at its d_out_off:
 	 * only batches that can hold frames of more than one block have one */
 	const size_t chk_bytes = (nrec * 8 + 64 + 15) & ~(size_t)15;
-	const bool seq_on = h->zseq_variant == 0 && h->profile != 5 && out_bytes / nrec > 131072;
+	const bool seq_on = h->zseq_variant == 0 && out_bytes / nrec > 131072;
 	const size_t seq_bytes = seq_on ? out_bytes + 16 : 0;
 	if (want_scratch(h, 1, s, lit_bytes + chk_bytes + seq_bytes))
 		return GPUMT_E_HIP;
@@ -1069,19 +1069,19 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 	PROF0(11);
 	for (size_t b = 0; b < nrec; b += slice) {
 		const size_t m = nrec - b < slice ? nrec - b : slice;
+		if (seqbuf)
+			hipLaunchKernelGGL(zmt_zstd_seq_kernel, dim3((unsigned)m), dim3(64), 0, h->st[s],
+					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
+					   d_out_off + b, (const u32 *)(d_out_len + b), (const u32 *)(d_status + b), seqbuf);
 		if (h->profile == 5) {
 			hipLaunchKernelGGL(zmt_zstd_dec_kernel_prof, dim3((unsigned)m), dim3(64), 0, h->st[s],
 					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
 					   (u8 *)d_out, d_out_off + b, d_out_len + b, (u8 *)h->scratch[1][s], d_status + b,
-					   chk_e + b, chk_v + b, 0u, h->d_prof, (u8 *)NULL);
+					   chk_e + b, chk_v + b, 0u, h->d_prof, seqbuf);
 		} else {
 			/* small-table variant first (16 waves per CU); records that need the full-size tables
 			 * come back with status 101 and are decoded by the general variant (12 waves per CU) */
 			const u32 want = h->zdec_variant == 1 ? 0u : 101u;
-			if (seqbuf)
-				hipLaunchKernelGGL(zmt_zstd_seq_kernel, dim3((unsigned)m), dim3(64), 0, h->st[s],
-						   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
-						   d_out_off + b, (const u32 *)(d_out_len + b), (const u32 *)(d_status + b), seqbuf);
 			if (h->zdec_variant != 1)
 				hipLaunchKernelGGL(zmt_zstd_dec_small_kernel, dim3((unsigned)m), dim3(64), 0, h->st[s],
 						   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,

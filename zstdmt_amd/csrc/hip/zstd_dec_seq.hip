@@ -30,8 +30,8 @@
 #include "zstd_dec_seq.h"
 
 struct ZSeqLds {
-	u32 ll[ZS_NB][512], of[ZS_NB][256], ml[ZS_NB][512]; /* FSE cells (ZC_*), slot s of every kind */
-	u32 pre_ll[64], pre_of[32], pre_ml[64];               /* the predefined tables, built once */
+	u16 ll[ZS_NB][512], of[ZS_NB][256], ml[ZS_NB][512]; /* FSE cells (16 bits, see zs_build16), slot s of every kind */
+	u16 pre_ll[64], pre_of[32], pre_ml[64];               /* the predefined tables, built once */
 	u8 below[16];
 	u8 stage[ZS_NB][256]; /* table descriptions of the group's blocks; afterwards their 160-byte bitstream windows */
 	u8 above[32];
@@ -41,7 +41,7 @@ struct ZSeqLds {
 	u32 valx[4][64]; /* value base of code `sym` for the lane kinds LL / OF / ML / idle: one branch-free read per step */
 	u32 blk[ZS_NB + 1][8]; /* per block of the group, see ZB_* (one more row: the group may end at its last block) */
 	u32 spec[ZS_NB][4];    /* what the block says about its table of kind t: ZS_PRE / ZS_RLE | symbol / ZS_REP / nsym | log << 8 */
-	u32 tp[ZS_NB][4];      /* the table of kind t block g decodes with: word offset from L.ll[0][0] | log << 24; ~0 = none */
+	u32 tp[ZS_NB][4];      /* the table of kind t block g decodes with: cell offset from L.ll[0][0] | log << 24; ~0 = none */
 	u32 bld[ZS_NB][4];     /* 1: lane (g, t) builds it */
 };
 enum { ZB_DESC = 0, ZB_END, ZB_NSEQ, ZB_MODES, ZB_BI, ZB_HDR, ZB_ERR };
@@ -76,6 +76,54 @@ static __device__ __forceinline__ u32 zs_bits(u32 d0, u32 d1, u32 d2, u32 d3, u3
 	const u32 lo = odd ? a1 : a0, hi = odd ? a2 : a1;
 	const u32 v = (u32)((((u64)hi << 32) | lo) >> (sh & 31u));
 	return v & ((1u << width) - 1u);
+}
+
+/* Decoding cells of 16 bits: sym (6) | x << 6, x = the cell's "next state number" of RFC 8878 4.1.1 (next[sym]++ while the
+ * table is numbered).  x lies in [2^(log - nb), 2^(log - nb + 1)), so the number of state bits is nb = log - floor(log2 x)
+ * and the next state is ((x << nb) + bits) & (size - 1): both fall out of x with a count-leading-zeros and a shift, and
+ * the extra bits of the code are a function of sym (zs_extra_bits).  At 2 bytes a cell the three tables of a block take
+ * 2.5 KiB (5 KiB with zstd_dec.hip's 32-bit cells), which is what lets five of these waves share a CU.
+ * Spread + numbering as fse_build (serial, one lane per table); returns 0 or -1. */
+static __device__ int zs_build16(u16 *cell, const short *norm, int nsym, int log, u16 *next)
+{
+	const u32 size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+	u32 high = size - 1, pos = 0;
+	for (int s = 0; s < nsym; s++) {
+		if (norm[s] == -1) {
+			cell[high--] = (u16)s;
+			next[s] = 1;
+		} else {
+			next[s] = (u16)norm[s];
+		}
+	}
+	for (int s = 0; s < nsym; s++) {
+		const int c = norm[s];
+		for (int i = 0; i < c; i++) {
+			cell[pos] = (u16)s;
+			do
+				pos = (pos + step) & mask;
+			while (pos > high);
+		}
+	}
+	if (pos != 0)
+		return -1;
+	for (u32 u = 0; u < size; u++) {
+		const u32 s = cell[u];
+		const u32 x = next[s]++;
+		cell[u] = (u16)(s | x << 6);
+	}
+	return 0;
+}
+/* Number_of_Bits of code `sym` for the lane's kind, without a table (the extra bits are on the state's chain; a lookup
+ * would be a second LDS round trip per sequence): 0 below `lo`, sym - hoff from `hi` on, three bits of `lut` per code in
+ * between.  LL: lo 16, hi 26, hoff 19; ML: lo 32, hi 44, hoff 36; OF: lo = hi = hoff = 0 (the code is the count). */
+#define ZS_LUT_LL 0x346D2249ull /* 1 1 1 1 2 2 3 3 4 6 (codes 16..25), three bits each, low code first */
+#define ZS_LUT_ML 0xF646D2249ull /* 1 1 1 1 2 2 3 3 4 4 5 7 (codes 32..43) */
+static __device__ __forceinline__ u32 zs_extra_bits(u32 sym, u32 lo, u32 hi, u32 hoff, u64 lut)
+{
+	const u32 i = sym - lo;
+	const u32 mid = (u32)(lut >> ((3u * i) & 63u)) & 7u;
+	return sym >= hi ? sym - hoff : sym >= lo ? mid : 0u;
 }
 
 #define ZS_PRE 0x40000000u
@@ -145,8 +193,7 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 		const int n = lane == 0 ? 36 : lane == 1 ? 29 : 53;
 		for (int i = 0; i < n; i++)
 			L.norm[0][lane][i] = def[i];
-		fse_build(lane == 0 ? L.pre_ll : lane == 1 ? L.pre_of : L.pre_ml, L.norm[0][lane], n, lane == 1 ? 5 : 6,
-			  L.next[0][lane], lane == 0 ? L.llx : lane == 2 ? L.mlx : (const u32 *)nullptr, lane);
+		zs_build16(lane == 0 ? L.pre_ll : lane == 1 ? L.pre_of : L.pre_ml, L.norm[0][lane], n, lane == 1 ? 5 : 6, L.next[0][lane]);
 	}
 	wv_sync();
 	L.valx[0][lane] = lane < 36 ? L.llx[lane] & 0xFFFFFFu : 0u;
@@ -345,7 +392,7 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 					w = (u32)((lane == 0 ? L.pre_ll : lane == 1 ? L.pre_of : L.pre_ml) - &L.ll[0][0]) | (u32)(lane == 1 ? 5 : 6) << 24;
 				} else {
 					const u32 slot = (cslot + j) % ZS_NB;
-					const u32 *cells = lane == 0 ? L.ll[slot] : lane == 1 ? L.of[slot] : L.ml[slot];
+					const u16 *cells = lane == 0 ? L.ll[slot] : lane == 1 ? L.of[slot] : L.ml[slot];
 					w = (u32)(cells - &L.ll[0][0]) | ((spec & ZS_RLE) ? 0u : (spec >> 8) & 255) << 24;
 					b = 1;
 					cs = slot;
@@ -368,14 +415,11 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 		bool terr = false;
 		if (sl < 3 && g < nok && L.bld[g][sl]) {
 			const u32 w = L.tp[g][sl], spec = L.spec[g][sl];
-			u32 *cells = &L.ll[0][0] + (w & 0xFFFFFFu);
-			if (spec & ZS_RLE) {
-				const u32 sy = spec & 255; /* RLE: one cell, no state bits */
-				cells[0] = sy | (sl == 1 ? sy : (sl == 0 ? L.llx[sy] : L.mlx[sy]) >> 24) << 10;
-			} else {
-				terr = fse_build(cells, L.norm[g][sl], (int)(spec & 255), (int)(w >> 24), L.next[g][sl],
-						 sl == 0 ? L.llx : sl == 2 ? L.mlx : (const u32 *)nullptr, (int)sl) != 0;
-			}
+			u16 *cells = &L.ll[0][0] + (w & 0xFFFFFFu);
+			if (spec & ZS_RLE)
+				cells[0] = (u16)((spec & 255) | 1u << 6); /* RLE: one cell, log 0, x = 1: no state bits */
+			else
+				terr = zs_build16(cells, L.norm[g][sl], (int)(spec & 255), (int)(w >> 24), L.next[g][sl]) != 0;
 		}
 		{
 			const u64 em = wv_ballot(terr);
@@ -396,7 +440,10 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 		/* ---- the bitstreams: group g = block g, lanes LL / OF / ML / idle ---- */
 		bool act = g < n, gbad = false;
 		const u32 w_my = act && sl < 3 ? L.tp[g][sl] : 0;
-		const u32 *mytab = &L.ll[0][0] + (w_my & 0xFFFFFFu);
+		const u16 *mytab = &L.ll[0][0] + (w_my & 0xFFFFFFu);
+		const u32 x_lo = sl == 0 ? 16u : sl == 2 ? 32u : 0u, x_hi = sl == 0 ? 26u : sl == 2 ? 44u : sl == 1 ? 0u : 64u;
+		const u32 x_off = sl == 0 ? 19u : sl == 2 ? 36u : 0u;
+		const u64 x_lut = sl == 0 ? ZS_LUT_LL : ZS_LUT_ML;
 		const u32 mylog = sl < 3 ? w_my >> 24 : 0u;
 		const u32 ll_log = wv_quad(mylog, 0), of_log = wv_quad(mylog, 1), ml_log = wv_quad(mylog, 2);
 		const u32 tmask = (1u << mylog) - 1;
@@ -490,10 +537,12 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 						u32 d0, d1, d2, d3;
 						zs_ld128(winb + tb, d0, d1, d2, d3);
 						const u32 cell = mytab[state & tmask];
-						const u32 sym = ZC_SYM(cell);
+						const u32 sym = cell & 63u, x = cell >> 6;
 						const u32 vbase = myval[sym]; /* (asked for as soon as the cell is there: off the state's chain) */
 						const u32 skip = (u32)(8 * (tb + 1) - bp) & 127u;
-						const u32 nb = done + (u32)i + 1 == g_n ? 0u : ZC_NB(cell), ab = ZC_AB(cell);
+						const u32 nbx = (mylog + (u32)__builtin_clz(x | 1u) - 31u) & 15u; /* log - floor(log2 x) */
+						const u32 nb = done + (u32)i + 1 == g_n ? 0u : nbx;
+						const u32 ab = zs_extra_bits(sym, x_lo, x_hi, x_off, x_lut);
 						const u32 pk = ab | nb << 8;
 						const u32 p_ll = wv_quad(pk, 0), p_of = wv_quad(pk, 1), p_ml = wv_quad(pk, 2);
 						const u32 a_ll = p_ll & 255, n_ll = p_ll >> 8, a_of = p_of & 255, n_of = p_of >> 8;
@@ -514,7 +563,7 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 							else
 								r0 = rcd;
 						}
-						state = on ? ZC_BASE(cell) + sbits : state;
+						state = on ? (x << nbx) + sbits : state; /* (masked where it is used) */
 						bp -= on ? (int)(base3 - skip + n_ll + n_ml + n_of) : 0;
 					}
 					if (act && done + 2 * sl < g_n)
