@@ -561,6 +561,8 @@ def bench_zstd_ref(ctx, gib, steps, warmup):
     U, Cb = float(n), float(len(stream)) * reps
     alg = U + Cb
     a = alg / (ms["k_zstd_dec"] * 1e-3) / 1e9
+    tt = traffic_table(gib, chunk, chunk)
+    tr = [tt[k] for k in ("zref:zmt_zstd_seq_kernel", "zref:zmt_zstd_dec_small_kernel", "zref:zmt_zstd_dec_kernel") if k in tt]
     return {
         "metric": f"MB/s decompress, {U / (1 << 30):g} GiB synthetic, zstd-mt streams written by the reference (level 1); % HBM roofline",
         "value": round(U / 1e6 / (wall / steps), 1), "unit": "MB/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
@@ -574,7 +576,9 @@ def bench_zstd_ref(ctx, gib, steps, warmup):
         "roofline": {"kernel": "zmt_zstd_seq_kernel + zmt_zstd_dec_small_kernel (sequence pre-pass, then the frame decoder; "
                                "reference-written frames)", "bound": "hbm", "achieved": round(a, 2),
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(a * 1e9 / HBM_PEAK, 5),
-                     "alg_bytes_per_launch": alg, "avg_launch_ms": round(ms["k_zstd_dec"], 4), "traffic": None},
+                     "alg_bytes_per_launch": alg, "avg_launch_ms": round(ms["k_zstd_dec"], 4),
+                     "traffic": sum(tr) if tr else None,
+                     "traffic_source": (TRAFFIC_FILE + " (separate rocprofv3 --pmc passes of this leg, not this run)") if tr else None},
         "kernels": {"k_zstd_dec": {"ms": round(ms["k_zstd_dec"], 4)}},
         "decode_errors": bad, "roundtrip_verified": ok, "gen_s": round(gen_s, 2),
     }

@@ -44,7 +44,7 @@ def compress(data: bytes, chunk: int, level: int = 1):
     n = len(data)
     nrec = max(1, (n + chunk - 1) // chunk)
     stride = L.emu_lz4_slot_stride(chunk)
-    inp = np.frombuffer(data + b"\0" * 16, np.uint8).copy()   # slack: hash reads 8 bytes
+    inp = np.frombuffer(data + b"\0" * 64, np.uint8).copy()   # the device contract: 64 readable bytes past the input
     slots = np.full(nrec * stride, 0xEE, np.uint8)
     rec_len = np.zeros(nrec, np.uint32)
     if level >= 3:

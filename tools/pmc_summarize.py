@@ -56,6 +56,16 @@ if zstats:
                     part[k] = v
     zl = json.dumps(bench_line(os.path.join(go, "bench_zstd.json")))
     json.dump(json.loads(zl), open(os.path.join(root, "profiles", f"{rnd}_bench_zstd_8gib_1gpu.json"), "w"), indent=1)
+rstats = biggest("prof_zref_stats/**/*_kernel_stats.csv")
+if rstats:
+    # the reference-stream leg runs the same decode kernels on another workload: its figures go under "zref:<kernel>"
+    shutil.copy(rstats, os.path.join(root, "profiles", f"{rnd}_zstd_ref_kernel_stats.csv"))
+    for part, name in ((fetch, "prof_zref_fetch"), (write, "prof_zref_write")):
+        f = biggest(name + "/**/*_counter_collection.csv")
+        if f:
+            for k, v in counter_avg(f).items():
+                if "zstd" in k:
+                    part["zref:" + k] = v
 sstats = biggest("prof_snappy_stats/**/*_kernel_stats.csv")
 if sstats:
     shutil.copy(sstats, os.path.join(root, "profiles", f"{rnd}_snappy_kernel_stats.csv"))
@@ -107,7 +117,9 @@ def refresh(obj):
     """the bench run read the traffic table committed BEFORE these passes: put this round's figures in"""
     if isinstance(obj, dict):
         if "traffic" in obj and isinstance(obj.get("kernel"), str):
-            names = [k for k in per if k in obj["kernel"]]
+            names = [k for k in per if k in obj["kernel"] and not k.startswith("zref:")]
+            if "reference-written frames" in obj["kernel"]:
+                names = [k for k in per if k.startswith("zref:") and k[5:] in obj["kernel"]]
             if names:
                 obj["traffic"] = sum(per[k] for k in names)
                 obj["traffic_source"] = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes of this command, not this run)"

@@ -30,6 +30,17 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_zstd_wr
     python bench.py --only --codec zstd --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_zstd_write.err
 cat $O/bench_zstd.json
 fi
+if [ $ONLY = all ] || [ $ONLY = zstd ] || [ $ONLY = zref ]; then
+# zstd-mt decompress of reference-written level-1 streams (the leg of the default line): sequence pre-pass + frame decoder
+rm -rf $O/prof_zref_stats $O/prof_zref_fetch $O/prof_zref_write
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_zref_stats -- \
+    python bench.py --zref-only --gib 8 --steps 2 --warmup 1 --no-cpu > $O/bench_zref_prof.json 2> $O/prof_zref_stats.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_zref_fetch -- \
+    python bench.py --zref-only --gib 8 --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_zref_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_zref_write -- \
+    python bench.py --zref-only --gib 8 --steps 1 --warmup 0 --no-cpu > /dev/null 2> $O/prof_zref_write.err
+cat $O/bench_zref_prof.json
+fi
 if [ $ONLY = all ] || [ $ONLY = brotli ]; then
 # configs[4]: brotli-mt decompress (level-1 streams written by the reference build, 1 MiB chunks)
 rm -rf $O/prof_brotli_stats $O/prof_brotli_fetch $O/prof_brotli_write
