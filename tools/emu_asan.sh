@@ -14,7 +14,8 @@ if [ "$1" = kernels ]; then
   make -s libzmt_emu.so > /dev/null
   A=/tmp/zmt_kasan; mkdir -p $A
   SAN="-fsanitize=address -fno-omit-frame-pointer"
-  for k in xxh32 lz4_enc3 lz4_enc_hc lz4_dec lz4_dec_split lz4_dec_parse3 lz4_dec_copy3 pack zstd_dec zstd_enc brotli_dec brotli_enc snappy; do
+  rm -f $A/*.o
+  for k in $(sed -n 's/^KERNELS := //p' Makefile); do
     g++ -O1 -g -std=c++17 -fPIC -DZMT_EMU $SAN -I. -I../../zstdmt_amd/csrc/hip -w -x c++ -c ../../zstdmt_amd/csrc/hip/$k.hip -o $A/$k.o &
   done
   wait
@@ -27,7 +28,7 @@ if [ "$1" = kernels ]; then
   cp $A/libzmt_emu.so libzmt_emu.so; touch libzmt_emu.so
   cd ../..
   LD_PRELOAD="$(gcc -print-file-name=libasan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 \
-    python -m pytest tests/test_emu_kernels.py tests/test_emu_zstd.py tests/test_emu_brotli.py tests/test_emu_snappy.py \
+    python -m pytest ${ASAN_TESTS:-tests/test_emu_kernels.py tests/test_emu_zstd.py tests/test_emu_brotli.py tests/test_emu_snappy.py} \
       -q -x -p no:cacheprovider
   exit $?
 fi
