@@ -29,20 +29,20 @@
 #include "zstd_dec_common.h"
 #include "zstd_dec_seq.h"
 
+#define ZS_PB 2u /* blocks whose tables are read and built at a time */
 struct ZSeqLds {
 	u16 ll[ZS_NB][512], of[ZS_NB][256], ml[ZS_NB][512]; /* FSE cells (16 bits, see zs_build16), slot s of every kind */
 	u16 pre_ll[64], pre_of[32], pre_ml[64];               /* the predefined tables, built once */
 	u8 below[16];
 	u8 stage[ZS_NB][256]; /* table descriptions of the group's blocks; afterwards their 160-byte bitstream windows */
 	u8 above[32];
-	short norm[ZS_NB][3][64];
-	u16 next[ZS_NB][3][64];
+	short norm[ZS_PB][3][64]; /* tables are read and built ZS_PB blocks at a time: LDS for six waves per CU */
+	u16 next[ZS_PB][3][64];
 	u32 llx[36], mlx[53];
 	u32 valx[4][64]; /* value base of code `sym` for the lane kinds LL / OF / ML / idle: one branch-free read per step */
 	u32 blk[ZS_NB + 1][8]; /* per block of the group, see ZB_* (one more row: the group may end at its last block) */
 	u32 spec[ZS_NB][4];    /* what the block says about its table of kind t: ZS_PRE / ZS_RLE | symbol / ZS_REP / nsym | log << 8 */
 	u32 tp[ZS_NB][4];      /* the table of kind t block g decodes with: cell offset from L.ll[0][0] | log << 24; ~0 = none */
-	u32 bld[ZS_NB][4];     /* 1: lane (g, t) builds it */
 };
 enum { ZB_DESC = 0, ZB_END, ZB_NSEQ, ZB_MODES, ZB_BI, ZB_HDR, ZB_ERR };
 
@@ -340,50 +340,67 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 		}
 		(void)mem_lo;
 		wv_sync();
-		/* ---- one lane per block reads its three descriptions ---- */
-		if (sl == 0 && g < n) {
-			const u8 *d = L.stage[g];
-			const u32 room = L.blk[g][ZB_END] - L.blk[g][ZB_DESC];
-			const u32 avail = room < 256 ? room : 256;
-			const u32 modes = L.blk[g][ZB_MODES];
-			u32 p = 0, err = 0;
-			for (int t = 0; t < 3 && !err; t++) {
-				const int mode = (int)(modes >> (6 - 2 * t)) & 3;
-				const int max_sym = t == 0 ? 36 : t == 1 ? 32 : 53, max_log = t == 1 ? 8 : 9;
-				u32 spec = ZS_REP;
-				if (mode == 0) {
-					spec = ZS_PRE;
-				} else if (mode == 1) {
-					if (p >= avail || d[p] >= max_sym)
-						err = 1;
-					else
-						spec = ZS_RLE | d[p++];
-				} else if (mode == 2) {
-					int nsym = 0, lg = 0;
-					const int u = p < avail ? fse_read_ncount(d + p, avail - p, L.norm[g][t], max_sym, max_log, &nsym, &lg) : -1;
-					if (u < 0) {
-						err = 1;
-					} else {
-						p += (u32)u;
-						spec = (u32)nsym | (u32)lg << 8;
+		/* ---- tables, ZS_PB blocks at a time: one lane per block reads its three descriptions, then lane (block, kind)
+		 * builds the table the block describes into slot (cslot of the kind + j) mod ZS_NB, j = the block's place in the
+		 * group: block 0 gets the slot of the table a repeat mode would refer to (it either repeats it or replaces it),
+		 * so nothing that is still needed is overwritten ---- */
+		const u32 cs_kind = wv_readlane(cslot, (int)(sl < 3 ? sl : 0u)); /* (lanes 0..2 hold the kinds' carried slots) */
+		for (u32 j0 = 0; j0 < n; j0 += ZS_PB) {
+			const u32 j = j0 + g;
+			if (sl == 0 && g < ZS_PB && j < n) {
+				const u8 *d = L.stage[j];
+				const u32 room = L.blk[j][ZB_END] - L.blk[j][ZB_DESC];
+				const u32 avail = room < 256 ? room : 256;
+				const u32 modes = L.blk[j][ZB_MODES];
+				u32 p = 0, err = 0;
+				for (int t = 0; t < 3 && !err; t++) {
+					const int mode = (int)(modes >> (6 - 2 * t)) & 3;
+					const int max_sym = t == 0 ? 36 : t == 1 ? 32 : 53, max_log = t == 1 ? 8 : 9;
+					u32 spec = ZS_REP;
+					if (mode == 0) {
+						spec = ZS_PRE;
+					} else if (mode == 1) {
+						if (p >= avail || d[p] >= max_sym)
+							err = 1;
+						else
+							spec = ZS_RLE | d[p++];
+					} else if (mode == 2) {
+						int nsym = 0, lg = 0;
+						const int u = p < avail ? fse_read_ncount(d + p, avail - p, L.norm[g][t], max_sym, max_log, &nsym, &lg) : -1;
+						if (u < 0) {
+							err = 1;
+						} else {
+							p += (u32)u;
+							spec = (u32)nsym | (u32)lg << 8;
+						}
 					}
+					L.spec[j][t] = err ? ZS_REP : spec;
 				}
-				L.spec[g][t] = spec;
+				L.blk[j][ZB_HDR] = p;
+				L.blk[j][ZB_ERR] = err;
 			}
-			L.blk[g][ZB_HDR] = p;
-			L.blk[g][ZB_ERR] = err;
+			wv_sync();
+			if (sl < 3 && g < ZS_PB && j < n && !L.blk[j][ZB_ERR]) {
+				const u32 spec = L.spec[j][sl];
+				if (spec != ZS_REP && spec != ZS_PRE) {
+					const u32 slot = (cs_kind + j) % ZS_NB;
+					u16 *cells = sl == 0 ? L.ll[slot] : sl == 1 ? L.of[slot] : L.ml[slot];
+					if (spec & ZS_RLE)
+						cells[0] = (u16)((spec & 255) | 1u << 6); /* RLE: one cell, log 0, x = 1: no state bits */
+					else if (zs_build16(cells, L.norm[g][sl], (int)(spec & 255), (int)((spec >> 8) & 255), L.next[g][sl]) != 0)
+						L.blk[j][ZB_ERR] = 2; /* (the three lanes of a block may all write this: the same value) */
+				}
+			}
+			wv_sync();
 		}
-		wv_sync();
-		/* ---- slots and pointers: lane t < 3 walks the blocks of the group for kind t.  A block's own table of kind t
-		 * goes to slot (cslot + j) mod ZS_NB, j = its place in the group: block 0 gets the slot of the carried table
-		 * (it either repeats it or replaces it), so nothing a repeat mode still needs is overwritten ---- */
+		/* ---- which table every block decodes with: lane t < 3 walks the blocks of the group for kind t ---- */
 		u32 nok = n; /* blocks of the group whose tables are sound */
 		if (lane < 3) {
 			u32 cur = carried, cs = cslot;
 			bool have = have_carried;
 			for (u32 j = 0; j < n; j++) {
 				const u32 spec = L.spec[j][lane];
-				u32 w = 0xFFFFFFFFu, b = 0;
+				u32 w = 0xFFFFFFFFu;
 				if (L.blk[j][ZB_ERR] || (spec == ZS_REP && !have)) {
 					nok = nok < j ? nok : j;
 				} else if (spec == ZS_REP) {
@@ -394,7 +411,6 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 					const u32 slot = (cslot + j) % ZS_NB;
 					const u16 *cells = lane == 0 ? L.ll[slot] : lane == 1 ? L.of[slot] : L.ml[slot];
 					w = (u32)(cells - &L.ll[0][0]) | ((spec & ZS_RLE) ? 0u : (spec >> 8) & 255) << 24;
-					b = 1;
 					cs = slot;
 				}
 				if (w != 0xFFFFFFFFu) {
@@ -402,7 +418,6 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 					have = true;
 				}
 				L.tp[j][lane] = w;
-				L.bld[j][lane] = b;
 			}
 			carried = cur;
 			cslot = cs;
@@ -410,24 +425,6 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 		}
 		nok = wv_readlane(nok, 0) < wv_readlane(nok, 1) ? wv_readlane(nok, 0) : wv_readlane(nok, 1);
 		nok = nok < wv_readlane(nok, 2) ? nok : wv_readlane(nok, 2);
-		wv_sync();
-		/* ---- build: lane (g, t) its own table ---- */
-		bool terr = false;
-		if (sl < 3 && g < nok && L.bld[g][sl]) {
-			const u32 w = L.tp[g][sl], spec = L.spec[g][sl];
-			u16 *cells = &L.ll[0][0] + (w & 0xFFFFFFu);
-			if (spec & ZS_RLE)
-				cells[0] = (u16)((spec & 255) | 1u << 6); /* RLE: one cell, log 0, x = 1: no state bits */
-			else
-				terr = zs_build16(cells, L.norm[g][sl], (int)(spec & 255), (int)(w >> 24), L.next[g][sl]) != 0;
-		}
-		{
-			const u64 em = wv_ballot(terr);
-			if (em) {
-				const u32 gb = (u32)(wv_ffs(em) - 1) >> 2;
-				nok = gb < nok ? gb : nok;
-			}
-		}
 		wv_sync();
 		if (nok < n) {
 			/* an unsound table: the decoder will reject the frame at that block; nothing from here on is marked, and
