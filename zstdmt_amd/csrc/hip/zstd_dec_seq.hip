@@ -30,11 +30,15 @@
 #include "zstd_dec_seq.h"
 
 #define ZS_PB 2u /* blocks whose tables are read and built at a time */
+#define ZS_WSTRIDE 288u
 struct ZSeqLds {
 	u16 ll[ZS_NB][512], of[ZS_NB][256], ml[ZS_NB][512]; /* FSE cells (16 bits, see zs_build16), slot s of every kind */
 	u16 pre_ll[64], pre_of[32], pre_ml[64];               /* the predefined tables, built once */
 	u8 below[16];
-	u8 stage[ZS_NB][256]; /* table descriptions of the group's blocks; afterwards their 160-byte bitstream windows */
+	u8 stage[ZS_NB][ZS_WSTRIDE]; /* table descriptions of the group's blocks (256 bytes); afterwards their 160-byte bitstream
+	                              * windows.  The stride puts block g's window 8 banks behind block g - 1's: the eight blocks read
+	                              * five dwords each at nearly the same offset of their windows (their streams advance at the same
+	                              * pace), which at a stride of 256 bytes = all 64 banks was an eight-way conflict on every read */
 	u8 above[32];
 	short norm[ZS_PB][3][64]; /* tables are read and built ZS_PB blocks at a time: LDS for six waves per CU */
 	u16 next[ZS_PB][3][64];
@@ -485,7 +489,7 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 		if (ngrp) {
 			const u32 e_of = sl == 1 ? 0u : ~0u, e_ml = sl == 0 ? ~0u : 0u;
 			const u32 s_ll = sl == 0 ? 0u : ~0u, s_ml = sl == 1 ? ~0u : 0u;
-			u8 *gwin = &L.stage[0][0] + 256u * (g < ZS_NB ? g : 0u); /* 160-byte window per block, 40 per lane */
+			u8 *gwin = &L.stage[0][0] + ZS_WSTRIDE * (g < ZS_NB ? g : 0u); /* 160-byte window per block, 40 per lane */
 			const u32 *myval = L.valx[sl];
 			u32 state = 0, done = 0;
 			bool first = true;
