@@ -193,8 +193,12 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
  * d_out_len[i] is the exact content size for frames that state one (what the probe returns); for a
  * frame without a content size (streaming writers, plain .zst files) the caller passes a capacity
  * there and the decoder replaces it by the decoded size.
+ * out_bytes is the size of the output the batch produces (every record's [d_out_off[i], d_out_off[i] + d_out_len[i]) lies
+ * inside it).
  * Internal scratch: GPUMT_ZSTD_DEC_SCRATCH (320 KiB) per record of a launch slice (at most 16384
- * records, 5 GiB) + 8 B per record.
+ * records, 5 GiB) + 8 B per record; batches whose records average more than 128 KiB of content (frames of several blocks)
+ * take out_bytes + 16 more for the sequence pre-pass (zmt_zstd_seq_kernel: the FSE sequence streams of a frame's blocks
+ * decoded side by side ahead of the frame decoder; GPUMT_ZSTD_SEQ=1 or gpumt_set_variant(h, "zstd_seq", 1) turn it off).
  */
 /* Bytes one zstd record slot occupies: room for the record + frame header and one padded area per
  * 128 KiB block (the blocks are compressed independently and then moved together), rounded to 256. */
