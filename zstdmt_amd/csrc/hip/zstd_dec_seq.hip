@@ -119,15 +119,17 @@ static __device__ int zs_build16(u16 *cell, const short *norm, int nsym, int log
 	return 0;
 }
 /* Number_of_Bits of code `sym` for the lane's kind, without a table (the extra bits are on the state's chain; a lookup
- * would be a second LDS round trip per sequence): 0 below `lo`, sym - hoff from `hi` on, three bits of `lut` per code in
- * between.  LL: lo 16, hi 26, hoff 19; ML: lo 32, hi 44, hoff 36; OF: lo = hi = hoff = 0 (the code is the count). */
-#define ZS_LUT_LL 0x346D2249ull /* 1 1 1 1 2 2 3 3 4 6 (codes 16..25), three bits each, low code first */
-#define ZS_LUT_ML 0xF646D2249ull /* 1 1 1 1 2 2 3 3 4 4 5 7 (codes 32..43) */
-static __device__ __forceinline__ u32 zs_extra_bits(u32 sym, u32 lo, u32 hi, u32 hoff, u64 lut)
+ * would be a second LDS round trip per sequence): 0 below `lo`, three bits of `lut` per code for the ten codes from `lo`
+ * on, sym - hoff (- 1 for the one code `fix`) above them.  LL: lo 16, hoff 19; ML: lo 32, hoff 36, fix 42 (5 bits, not 6);
+ * OF: lo = hoff = 0 and no table codes (the code is the count). */
+#define ZS_LUT_LL 0x346D2249u /* 1 1 1 1 2 2 3 3 4 6 (codes 16..25), three bits each, low code first */
+#define ZS_LUT_ML 0x246D2249u /* 1 1 1 1 2 2 3 3 4 4 (codes 32..41) */
+static __device__ __forceinline__ u32 zs_extra_bits(u32 sym, u32 lo, u32 hi, u32 hoff, u32 fix, u32 lut)
 {
-	const u32 i = sym - lo;
-	const u32 mid = (u32)(lut >> ((3u * i) & 63u)) & 7u;
-	return sym >= hi ? sym - hoff : sym >= lo ? mid : 0u;
+	const u32 mid = (lut >> ((3u * (sym - lo)) & 31u)) & 7u;
+	const u32 up = sym - hoff - (sym == fix ? 1u : 0u);
+	const u32 low = sym >= lo ? mid : 0u;
+	return sym >= hi ? up : low;
 }
 
 #define ZS_PRE 0x40000000u
@@ -442,9 +444,9 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 		bool act = g < n, gbad = false;
 		const u32 w_my = act && sl < 3 ? L.tp[g][sl] : 0;
 		const u16 *mytab = &L.ll[0][0] + (w_my & 0xFFFFFFu);
-		const u32 x_lo = sl == 0 ? 16u : sl == 2 ? 32u : 0u, x_hi = sl == 0 ? 26u : sl == 2 ? 44u : sl == 1 ? 0u : 64u;
-		const u32 x_off = sl == 0 ? 19u : sl == 2 ? 36u : 0u;
-		const u64 x_lut = sl == 0 ? ZS_LUT_LL : ZS_LUT_ML;
+		const u32 x_lo = sl == 0 ? 16u : sl == 2 ? 32u : 0u, x_hi = sl == 0 ? 26u : sl == 2 ? 42u : sl == 1 ? 0u : 64u;
+		const u32 x_off = sl == 0 ? 19u : sl == 2 ? 36u : 0u, x_fix = sl == 2 ? 42u : 255u;
+		const u32 x_lut = sl == 0 ? ZS_LUT_LL : ZS_LUT_ML;
 		const u32 mylog = sl < 3 ? w_my >> 24 : 0u;
 		const u32 ll_log = wv_quad(mylog, 0), of_log = wv_quad(mylog, 1), ml_log = wv_quad(mylog, 2);
 		const u32 tmask = (1u << mylog) - 1;
@@ -528,44 +530,57 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 					bp -= (int)(ll_log + of_log + ml_log);
 				}
 				for (;;) {
-					/* eight sequences of every block; lane sl keeps 2 sl, 2 sl + 1 */
+					/* eight sequences of every block; lane sl keeps 2 sl, 2 sl + 1.  While every block that is still being
+					 * walked has more than eight sequences left, the steps carry no per-sequence tests (FAST): an idle
+					 * lane's state and bit position may then run on, nothing reads them again */
 					u64 r0 = 0, r1 = 0;
-					ZMT_UNROLL
-					for (int i = 0; i < 8; i++) {
-						const bool on = act && done + (u32)i < g_n;
-						int tb = (bp - 1) >> 3;
-						tb = tb < wlo + 15 ? wlo + 15 : tb; /* a stream gone bad stays inside its window */
-						u32 d0, d1, d2, d3;
-						zs_ld128(winb + tb, d0, d1, d2, d3);
-						const u32 cell = mytab[state & tmask];
-						const u32 sym = cell & 63u, x = cell >> 6;
-						const u32 vbase = myval[sym]; /* (asked for as soon as the cell is there: off the state's chain) */
-						const u32 skip = (u32)(8 * (tb + 1) - bp) & 127u;
-						const u32 nbx = (mylog + (u32)__builtin_clz(x | 1u) - 31u) & 15u; /* log - floor(log2 x) */
-						const u32 nb = done + (u32)i + 1 == g_n ? 0u : nbx;
-						const u32 ab = zs_extra_bits(sym, x_lo, x_hi, x_off, x_lut);
-						const u32 pk = ab | nb << 8;
-						const u32 p_ll = wv_quad(pk, 0), p_of = wv_quad(pk, 1), p_ml = wv_quad(pk, 2);
-						const u32 a_ll = p_ll & 255, n_ll = p_ll >> 8, a_of = p_of & 255, n_of = p_of >> 8;
-						const u32 a_ml = p_ml & 255, n_ml = p_ml >> 8;
-						const u32 base3 = skip + a_of + a_ml + a_ll;
-						const u32 eo = skip + (a_of & e_of) + (a_ml & e_ml);
-						const u32 so = base3 + (n_ll & s_ll) + (n_ml & s_ml);
-						const u32 extra = zs_bits(d0, d1, d2, d3, eo, ab);
-						const u32 sbits = zs_bits(d0, d1, d2, d3, so, nb);
-						const u32 val = vbase + extra;
-						if (on && sl == 1 && sym > 27)
-							gbad = true; /* does not fit the packing: left to the decoder */
-						const u32 v_ll = wv_quad(val, 0), v_of = wv_quad(val, 1), v_ml = wv_quad(val, 2);
-						const u64 rcd = (u64)v_ll | (u64)v_ml << 18 | (u64)v_of << 36;
-						if ((u32)(i >> 1) == sl) {
-							if (i & 1)
-								r1 = rcd;
-							else
-								r0 = rcd;
-						}
-						state = on ? (x << nbx) + sbits : state; /* (masked where it is used) */
-						bp -= on ? (int)(base3 - skip + n_ll + n_ml + n_of) : 0;
+#define ZS_STEPS8(FAST)                                                                                            \
+	ZMT_UNROLL                                                                                                 \
+	for (int i = 0; i < 8; i++) {                                                                              \
+		const bool on = (FAST) ? act : (act && done + (u32)i < g_n);                                       \
+		int tb = (bp - 1) >> 3;                                                                            \
+		tb = tb < wlo + 15 ? wlo + 15 : tb; /* a stream gone bad stays inside its window */                \
+		u32 d0, d1, d2, d3;                                                                                \
+		zs_ld128(winb + tb, d0, d1, d2, d3);                                                               \
+		const u32 cell = mytab[state & tmask];                                                             \
+		const u32 sym = cell & 63u, x = cell >> 6;                                                         \
+		const u32 vbase = myval[sym]; /* (asked for as soon as the cell is there: off the state's chain) */ \
+		const u32 skip = (u32)(8 * (tb + 1) - bp) & 127u;                                                  \
+		const u32 nbx = (mylog + (u32)__builtin_clz(x | 1u) - 31u) & 15u; /* log - floor(log2 x) */       \
+		const u32 nb = (FAST) ? nbx : (done + (u32)i + 1 == g_n ? 0u : nbx);                               \
+		const u32 ab = zs_extra_bits(sym, x_lo, x_hi, x_off, x_fix, x_lut);                                \
+		const u32 pk = ab | nb << 8;                                                                       \
+		const u32 p_ll = wv_quad(pk, 0), p_of = wv_quad(pk, 1), p_ml = wv_quad(pk, 2);                     \
+		const u32 a_ll = p_ll & 255, n_ll = p_ll >> 8, a_of = p_of & 255, n_of = p_of >> 8;                \
+		const u32 a_ml = p_ml & 255, n_ml = p_ml >> 8;                                                     \
+		const u32 base3 = skip + a_of + a_ml + a_ll;                                                       \
+		const u32 eo = skip + (a_of & e_of) + (a_ml & e_ml);                                               \
+		const u32 so = base3 + (n_ll & s_ll) + (n_ml & s_ml);                                              \
+		const u32 extra = zs_bits(d0, d1, d2, d3, eo, ab);                                                 \
+		const u32 sbits = zs_bits(d0, d1, d2, d3, so, nb);                                                 \
+		const u32 val = vbase + extra;                                                                     \
+		if (on && sl == 1 && sym > 27)                                                                     \
+			gbad = true; /* does not fit the packing: left to the decoder */                           \
+		const u32 v_ll = wv_quad(val, 0), v_of = wv_quad(val, 1), v_ml = wv_quad(val, 2);                  \
+		const u64 rcd = (u64)v_ll | (u64)v_ml << 18 | (u64)v_of << 36;                                     \
+		if ((u32)(i >> 1) == sl) {                                                                         \
+			if (i & 1)                                                                                 \
+				r1 = rcd;                                                                          \
+			else                                                                                       \
+				r0 = rcd;                                                                          \
+		}                                                                                                  \
+		if (FAST) {                                                                                        \
+			state = (x << nbx) + sbits; /* (masked where it is used) */                                \
+			bp -= (int)(base3 - skip + n_ll + n_ml + n_of);                                            \
+		} else {                                                                                           \
+			state = on ? (x << nbx) + sbits : state;                                                   \
+			bp -= on ? (int)(base3 - skip + n_ll + n_ml + n_of) : 0;                                   \
+		}                                                                                                  \
+	}
+					if (!wv_any(act && done + 8u >= g_n)) {
+						ZS_STEPS8(true)
+					} else {
+						ZS_STEPS8(false)
 					}
 					if (act && done + 2 * sl < g_n)
 						st64g((u8 *)(myseq + done + 2 * sl), r0);
