@@ -93,9 +93,10 @@ def test_emu_hc_optimal_bit_exact(name, level):
 
 
 def test_emu_hc_optimal_1mib_chunk():
-    """level 10 at a 1 MiB chunk (16 linked blocks, one table set carried across them) on the emulator: the slowest test
-    of the CPU suite (~3.5 minutes of one core), kept because the chunk size above 256 KiB was untested at levels >= 10"""
-    data = text(1 << 20, seed=77)
+    """level 10 at a 1 MiB chunk on the emulator: 272 KiB of input = five linked blocks with one table set carried across
+    them (chunks above 256 KiB were untested at levels >= 10).  About a minute of one core; the whole MiB, levels 10..12,
+    runs on the device (tests/test_gpu_lz4.py::test_hc_optimal_levels_at_a_1mib_chunk)"""
+    data = text(272 << 10, seed=77)
     stream, rec_off, rec_len = E.compress(data, 1 << 20, 10)
     assert stream == H.oracle_compress_level(data, 1 << 20, 10)
 
