@@ -1,6 +1,7 @@
 """GPU fuzz of the four drop-in APIs (developer tool, run through gpurun): random inputs, chunk sizes,
 thread counts (1 = the inline decompress path) and levels; every stream must decode back through this
-library and, where oracle/_ref is present, through the reference library.
+library and, where oracle/_ref is present, through the reference library; and what the reference library writes
+(zstd, brotli) must decode through this one.
     python tools/gpu_fuzz_api.py [seconds] [first seed]"""
 import ctypes as C, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,6 +43,11 @@ while time.time() - t0 < budget:
         if ref_z is not None:
             rv, out, _, _ = H.lz4mt_decompress_via(ref_z, s, threads=2, pfx="ZSTDCB_")
             assert rv == 0 and out == data, (seed, "zstd reference decompress")
+            # and what the reference writes decodes here (frames of several blocks take the sequence pre-pass)
+            rv, rs, _, _ = H.lz4mt_compress_via(ref_z, data, chunk, threads=2, level=rng.choice([1, 2, 3, 7, 19]), pfx="ZSTDCB_")
+            assert rv == 0, (seed, "zstd reference compress", rv)
+            rv, out, _, _ = H.lz4mt_decompress_via(zs, rs, threads=th, pfx="ZSTDCB_")
+            assert rv == 0 and out == data, (seed, "zstd foreign decompress")
     elif codec == "snappy":
         chunk = rng.choice([65536, 4096, 1 << 20, 100000, 0])
         rv, s, _, _ = H.lz4mt_compress_via(sn, data, chunk, threads=th, level=0, pfx="SNAPPYMT_")
@@ -61,5 +67,15 @@ while time.time() - t0 < budget:
         if ref_b is not None:
             rv, out, _, _ = H.lz4mt_decompress_via(ref_b, s, threads=2, pfx="BROTLIMT_")
             assert rv == 0 and out == data, (seed, "brotli reference decompress")
+            rv, rs, _, _ = H.lz4mt_compress_via(ref_b, data, chunk, threads=2, level=rng.choice([0, 1, 5, 9]), pfx="BROTLIMT_")
+            assert rv == 0, (seed, "brotli reference compress", rv)
+            # (the reference cannot always read its own streams back -- e.g. level >= 2 at a chunk size that is no multiple of
+            # 64 KiB, SURVEY row B2 --: then this library must refuse them too)
+            rv0, out0, _, _ = H.lz4mt_decompress_via(ref_b, rs, threads=2, pfx="BROTLIMT_")
+            rv, out, _, _ = H.lz4mt_decompress_via(br, rs, threads=th, pfx="BROTLIMT_")
+            if rv0 == 0:
+                assert rv == 0 and out == data, (seed, "brotli foreign decompress")
+            else:
+                assert rv != 0, (seed, "brotli foreign stream: the reference refuses it, this library took it")
     n_ok += 1; seed += 1
 print(f"{n_ok} cases ok in {time.time() - t0:.0f} s (next seed {seed})")
