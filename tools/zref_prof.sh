@@ -1,5 +1,6 @@
 #!/bin/bash
-# Developer session (GPU box): the reference-stream zstd leg and its per-kernel times.  $1 = extra bench flags
+# Runs ON THE GPU BOX (through gpurun): the leg "zstd-mt decompress of reference-written streams" by itself and the
+# rocprofv3 per-kernel times of the same command.   bash tools/zref_prof.sh ["extra bench flags"]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 python bench.py --zref-only --gib 8 --steps 3 --warmup 1 --no-cpu $1 > $O/zq.json 2> $O/zq.err
