@@ -485,7 +485,7 @@ template <u32 WIN, bool PROF = false> struct C3 {
 						const bool ovl = off < ml;
 						bool fin = !(act & (ml != 0));
 						{
-							const bool r1 = !fin & (is_far | (src_pos + eff <= o0)) & !ovl;
+							const bool r1 = (!fin) & (is_far | (src_pos + eff <= o0)) & (!ovl);
 #ifdef C3X_NO_R1
 							if (r1)
 								fin = true;
@@ -511,8 +511,8 @@ template <u32 WIN, bool PROF = false> struct C3 {
 								pc[PROF ? 13 : 0]++;
 							const u32 first = (u32)wv_ffs(unf) - 1;
 							const u32 W = wv_readlane(mpos, (int)first);
-							const bool go = !fin & (src_pos + eff <= W);
-							if (go & !ovl)
+							const bool go = (!fin) & (src_pos + eff <= W);
+							if (go & (!ovl))
 								match<false>(ring, mpos, ml, ring, src_pos, MASK);
 							if (wv_any(go & ovl)) { /* (offset < length: 0.2 % of the matches) */
 								if (go & ovl)
