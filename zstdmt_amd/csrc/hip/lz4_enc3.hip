@@ -5,9 +5,9 @@
  *
  *  - The chunk's input is streamed through a 1 KiB LDS ring (512-byte coalesced refills), so hashing,
  *    the ip side of catch-up / match counting, the re-match test and literal sources are LDS reads.
- *  - The search evaluates the reference's probe sequence in batches of 16, 16, 32, 64, 64, ...
- *    lanes (lane j = probe kbase + j).  Most matches sit within the first 16 probes, so the one
- *    candidate gather per batch usually touches <= 16 cache lines.  In-batch duplicate hashes
+ *  - The search evaluates the reference's probe sequence in batches of 10, 16, 32, 64, 64, ...
+ *    lanes (lane j = probe kbase + j).  Most matches sit within the first few probes, and every probe
+ *    is a candidate fetched from memory: the first batch is as small as pays (ENC3_B0 below).  In-batch duplicate hashes
  *    are detected exactly (LDS atomic-or bitmap) and resolved by a readlane loop only when present.
  *  - One cooperative fetch of [match-32, match+96) then serves catch-up (backward) and the match
  *    length (forward) for the common case; longer runs continue 64 bytes at a time.
@@ -35,6 +35,15 @@
 #define BM_BITS 2048u /* bits of the in-batch duplicate filter (a power of two >= 1024): hashes are folded onto
                        * it, a false "duplicate" only sends the batch through the exact readlane loop */
 #endif
+/* probes of a search's first batch (+ the re-match probe) and of its second; the later ones take 32 and 64.  Most matches
+ * sit within the first few probes, and every probe is a candidate fetched from memory: [MI355X, 8 GiB] 4 + 12: 308.8 ms,
+ * 8 + 16: 288.7, 10 + 16: 287.6, 12 + 16: 290.1, 16 + 16: 304.4 (rounds 1-3), 24 + 24: 369.2, 32 + 32: 479.8
+ * (profiles/r04_sweeps/lz4_enc3_steps.txt).  The split does not change what is found, only in how many steps */
+#ifndef ENC3_B0
+#define ENC3_B0 10u
+#define ENC3_B1 16u
+#endif
+
 #define IPIECE 512u /* refill granule: 8 bytes per lane */
 /* bytes ring_want() makes resident ahead of a position: >= 72 (a batch of 64 consecutive probes reads
  * 8 bytes each) and small enough that IRING - IAHEAD - IPIECE >= 64 bytes of history stay behind it
@@ -284,7 +293,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		{
 			const u32 ipr = ip;          /* position of the re-match probe (rmode) */
 			const u32 ip0 = ip + rmode;  /* probe k of the reference's search loop is at probe_pos3(ip0, k) */
-			u32 kbase = 0, bsz = 16 + rmode, r = rmode;
+			u32 kbase = 0, bsz = ENC3_B0 + rmode, r = rmode;
 			for (u32 batch = 0;; batch++) {
 				/* probes k <= 64 are consecutive positions (wave-uniform test: no divergent schedule arithmetic);
 				 * lane 0 of a batch that opens with the re-match probe is then at ip0 - 1 = ipr by itself */
@@ -426,7 +435,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				}
 				kbase += bsz - r;
 				r = 0;
-				bsz = (batch == 0) ? 16 : (batch == 1 ? 32 : 64);
+				bsz = (batch == 0) ? ENC3_B1 : (batch == 1 ? 32 : 64);
 			}
 		}
 		/* ---------------- extend the match both ways ----------------
