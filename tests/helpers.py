@@ -466,6 +466,56 @@ def libzstd_frame(data: bytes, level=1, checksum=0, content_size=1):
     return dst.raw[:n]
 
 
+def zstd_rle_mode_frame(nblocks=3, repeat_from=0):
+    """A hand-made zstd frame (test vector generator): one raw block, then `nblocks` compressed blocks with raw literals
+    whose three sequence tables are in RLE mode -- every sequence has the same LL / OF / ML code, so a sequence costs only its
+    extra bits --; the blocks from index `repeat_from` on (0 = none) say Repeat_Mode for all three.  libzstd does not write such
+    blocks on ordinary data.  -> (frame bytes, content bytes); RFC 8878 3.1.1.3.2."""
+    cases = _cases()
+    ll_base = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024,
+               2048, 4096, 8192, 16384, 32768, 65536]
+    ll_bits = [0] * 16 + [1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]
+    ml_base = [3 + i for i in range(32)] + [35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195,
+                                            16387, 32771, 65539]
+    ml_bits = [0] * 32 + [1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]
+
+    def block(lits, seqs, last, modes):
+        acc, codes = 1, None
+        for ll, ml, off in seqs:
+            lc = max(i for i in range(36) if ll_base[i] <= ll)
+            mc = max(i for i in range(53) if ml_base[i] <= ml)
+            oc = (off + 3).bit_length() - 1
+            assert codes in (None, (lc, oc, mc))
+            codes = (lc, oc, mc)
+            # read order of a sequence: offset, match length, literals length extra bits (the stream is read from its end)
+            for v, nb in ((off + 3 - (1 << oc), oc), (ml - ml_base[mc], ml_bits[mc]), (ll - ll_base[lc], ll_bits[lc])):
+                acc = (acc << nb) | v
+        n = len(seqs)
+        sq = (bytes([n]) if n < 128 else bytes([128 + (n >> 8), n & 255])) + bytes([modes])
+        if modes == 0x54:
+            sq += bytes(codes)
+        sq += acc.to_bytes((acc.bit_length() + 7) // 8, "little")
+        body = (0 | 3 << 2 | len(lits) << 4).to_bytes(3, "little") + lits + sq      # Raw_Literals_Block, 20-bit size
+        return ((1 if last else 0) | 2 << 1 | len(body) << 3).to_bytes(3, "little") + body
+
+    head = cases.rnd(8192, 3)
+    content = bytearray(head)
+    blocks = [(len(head) << 3).to_bytes(3, "little") + head]                          # Raw_Block
+    for b in range(nblocks):
+        lits = cases.text(50 * 1000 + 2000, seed=100 + b)
+        seqs = [(1000, 100, 5000)] * 50
+        lp = 0
+        for ll, ml, off in seqs:
+            content += lits[lp:lp + ll]
+            lp += ll
+            for _ in range(ml):
+                content.append(content[-off])
+        content += lits[lp:]
+        blocks.append(block(lits, seqs, b == nblocks - 1, 0xFC if (repeat_from and b >= repeat_from) else 0x54))
+    frame = bytes([0x28, 0xB5, 0x2F, 0xFD, 2 << 6 | 1 << 5]) + struct.pack("<I", len(content)) + b"".join(blocks)
+    return frame, bytes(content)
+
+
 def mt_record(frame: bytes) -> bytes:
     """12-byte skippable header + frame (lib/zstd-mt_compress.c:296-302)."""
     import struct

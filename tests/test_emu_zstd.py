@@ -299,3 +299,31 @@ def test_emu_seq_prepass_corrupt_streams():
             assert status[0] != 0, f"flip at {pos}: oracle rejects, kernel accepted"
         else:
             assert status[0] == 0 and out == want, f"flip at {pos}"
+
+
+@pytest.mark.parametrize("repeat", [0, 2, 1])
+def test_emu_seq_prepass_rle_mode_tables(repeat):
+    """blocks whose three sequence tables are in RLE mode (and blocks that repeat them): hand-made, libzstd does not write
+    them on ordinary data; the oracle (and, where built, the reference library) must read the frame the same way"""
+    fr, content = H.zstd_rle_mode_frame(4, repeat)
+    st = H.mt_record(fr)
+    assert H.oracle_zstdmt_decompress(st, len(content) + 64) == content
+    if H.have_zref():
+        rv, back, _, _ = H.zstdmt_decompress_via(H.zref(), st, threads=1)
+        assert rv == 0 and back == content
+    out, status, marks = _both_ways(st)
+    # (a second block that repeats all three tables looks like a unit of the device encoder: left to the decoder)
+    assert (status == 0).all() and out == content and marks == (0 if repeat == 1 else 4)
+    # one flipped bit in every block's sequences section: a wrong extra bit changes a length or an offset, the frame then
+    # misses its content size or reaches outside it -- verdict (and content, should it survive) as the oracle's
+    at = 12 + 9
+    ro, rl = np.array([0], np.uint64), np.array([len(st)], np.uint32)
+    for blk in H.zstd_walk_blocks(fr):
+        if blk["type"] == 2:
+            bad = bytearray(st)
+            bad[at + 3 + blk["size"] - 3] ^= 0x04
+            bad = bytes(bad)
+            want = H.oracle_zstdmt_decompress(bad, len(content) + 64)
+            out, status, _ = _both_ways(bad, rec=(ro, rl))
+            assert (status[0] != 0) if want is None else (status[0] == 0 and out == want)
+        at += 3 + (1 if blk["type"] == 1 else blk["size"])

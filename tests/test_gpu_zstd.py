@@ -246,3 +246,15 @@ def test_seq_prepass_frames_of_many_blocks_and_their_damage(eng):
             assert status[0] != 0, f"flip at {pos}: oracle rejects, device accepted"
         else:
             assert status[0] == 0 and out == want, f"flip at {pos}"
+
+
+@pytest.mark.parametrize("repeat_from", [0, 2])
+def test_rle_mode_sequence_tables(eng, repeat_from):
+    """hand-made blocks whose three sequence tables are in RLE mode, and blocks that repeat them (H.zstd_rle_mode_frame):
+    libzstd does not write these on ordinary data, the format allows them"""
+    fr, content = H.zstd_rle_mode_frame(6, repeat_from)
+    st = H.mt_record(fr) + H.mt_record(fr)
+    assert H.oracle_zstdmt_decompress(st, 2 * len(content) + 64) == content + content
+    ro, rl = E.walk_records(st)
+    out, status = eng.decompress_bytes(st, ro, rl, codec="zstd")
+    assert status.tolist() == [0, 0] and out == content + content
