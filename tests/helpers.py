@@ -466,7 +466,7 @@ def libzstd_frame(data: bytes, level=1, checksum=0, content_size=1):
     return dst.raw[:n]
 
 
-def zstd_rle_mode_frame(nblocks=3, repeat_from=0):
+def zstd_rle_mode_frame(nblocks=3, repeat_from=0, seq=(1000, 100, 5000), nseq=50):
     """A hand-made zstd frame (test vector generator): one raw block, then `nblocks` compressed blocks with raw literals
     whose three sequence tables are in RLE mode -- every sequence has the same LL / OF / ML code, so a sequence costs only its
     extra bits --; the blocks from index `repeat_from` on (0 = none) say Repeat_Mode for all three.  libzstd does not write such
@@ -502,8 +502,8 @@ def zstd_rle_mode_frame(nblocks=3, repeat_from=0):
     content = bytearray(head)
     blocks = [(len(head) << 3).to_bytes(3, "little") + head]                          # Raw_Block
     for b in range(nblocks):
-        lits = cases.text(50 * 1000 + 2000, seed=100 + b)
-        seqs = [(1000, 100, 5000)] * 50
+        lits = cases.text(nseq * seq[0] + 2000, seed=100 + b)
+        seqs = [seq] * nseq
         lp = 0
         for ll, ml, off in seqs:
             content += lits[lp:lp + ll]

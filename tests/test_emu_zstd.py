@@ -327,3 +327,16 @@ def test_emu_seq_prepass_rle_mode_tables(repeat):
             out, status, _ = _both_ways(bad, rec=(ro, rl))
             assert (status[0] != 0) if want is None else (status[0] == 0 and out == want)
         at += 3 + (1 if blk["type"] == 1 else blk["size"])
+
+
+@pytest.mark.parametrize("repeat_from,marks_want", [(0, 2), (2, 0)])
+def test_emu_seq_prepass_stops_where_its_region_is_full(repeat_from, marks_want):
+    """four-byte sequences: a record's region (one sequence per 8 bytes of content) holds the first two blocks' and not the
+    third's.  The decoder goes on by itself from there -- if that block describes its tables itself; if it repeats the
+    tables of a block decoded ahead, the pre-pass drops all its marks and the decoder does the whole frame"""
+    fr, content = H.zstd_rle_mode_frame(4, repeat_from, seq=(1, 3, 1), nseq=20000)
+    st = H.mt_record(fr)
+    assert H.oracle_zstdmt_decompress(st, len(content) + 64) == content
+    out, status, marks = _both_ways(st)
+    assert (status == 0).all() and out == content
+    assert marks == marks_want
