@@ -203,8 +203,10 @@ void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *re
 		total = out_off[r] + out_len[r] > total ? out_off[r] + out_len[r] : total;
 	const char *e = getenv("EMU_ZSTD_SEQ");
 	const bool seq_on = !(e && atoi(e) == 1);
-	std::vector<u8> seqv(seq_on ? (size_t)total + 16 : 0, 0xA5);
-	u8 *seqbuf = seq_on ? seqv.data() : nullptr;
+	std::vector<u8> seqv(seq_on ? (size_t)total + 32 : 0, 0xA5);
+	u8 *seqbuf = seq_on ? seqv.data() + 16 : nullptr;
+	if (seq_on)
+		memcpy(seqbuf - 16, &total, 8); /* the capacity word of zstd_dec_seq.h */
 	if (seq_on)
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
 			zmt_zstd_seq_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out_off, out_len, status, seqbuf);

@@ -175,4 +175,5 @@ def test_host_engines_never_free_busy_buffers(tmp_path):
         p = subprocess.run([exe, codec, str(256 << 20), str(chunk), lib, "1"], capture_output=True, timeout=300,
                            env=dict(os.environ, GPUMT_DEBUG_FREE="1"))
         assert p.returncode == 0, p.stderr[-300:]
+        assert b"free guard on" in p.stderr, "the guard was not enabled through the environment: " + repr(p.stderr[-300:])
         assert b"with work queued" not in p.stderr, p.stderr[-500:]

@@ -258,6 +258,14 @@ int gpumt_open(int device, gpumt_ctx **out)
 		/* GPUMT_ZSTD_SEQ=1: no sequence pre-pass in front of the zstd frame decoder */
 		e = getenv("GPUMT_ZSTD_SEQ");
 		h->zseq_variant = e && *e ? atoi(e) : 0;
+		/* GPUMT_BROTLI_DEC: 0 = the batch size chooses (default), 1 = the general kernel, 2 = dec4 first */
+		e = getenv("GPUMT_BROTLI_DEC");
+		h->bdec_variant = e && *e ? atoi(e) : 0;
+		/* GPUMT_DEBUG_FREE=1: the guard of the buffer contract (include/gpumt.h) for callers without a handle */
+		e = getenv("GPUMT_DEBUG_FREE");
+		h->debug_free = e && *e ? atoi(e) : 0;
+		if (h->debug_free)
+			fprintf(stderr, "gpumt: free guard on for device %d (GPUMT_DEBUG_FREE)\n", device);
 	}
 	*out = h;
 	return GPUMT_OK;
@@ -1057,11 +1065,17 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 	 * only batches that can hold frames of more than one block have one */
 	const size_t chk_bytes = (nrec * 8 + 64 + 15) & ~(size_t)15;
 	const bool seq_on = h->zseq_variant == 0 && out_bytes / nrec > 131072;
-	const size_t seq_bytes = seq_on ? out_bytes + 16 : 0;
+	const size_t seq_bytes = seq_on ? out_bytes + 32 : 0;
 	if (want_scratch(h, 1, s, lit_bytes + chk_bytes + seq_bytes))
 		return GPUMT_E_HIP;
 	u32 *chk_e = (u32 *)((u8 *)h->scratch[1][s] + lit_bytes), *chk_v = chk_e + nrec;
-	u8 *seqbuf = seq_on ? (u8 *)h->scratch[1][s] + lit_bytes + chk_bytes : NULL;
+	/* the region's capacity sits 16 bytes in front of it (zstd_dec_seq.h): records whose [out_off, out_off + out_len)
+	 * does not fit out_bytes are decoded without the pre-pass instead of writing past the scratch */
+	u8 *seqbuf = seq_on ? (u8 *)h->scratch[1][s] + lit_bytes + chk_bytes + 16 : NULL;
+	if (seqbuf) {
+		CK(hipMemsetD32Async((hipDeviceptr_t)(seqbuf - 16), (int)(u32)out_bytes, 1, h->st[s]));
+		CK(hipMemsetD32Async((hipDeviceptr_t)(seqbuf - 12), (int)(u32)((u64)out_bytes >> 32), 1, h->st[s]));
+	}
 	if (h->profile == 5 && !h->d_prof) {
 		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));

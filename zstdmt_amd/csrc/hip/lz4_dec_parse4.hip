@@ -18,7 +18,10 @@
  *     sequence" -- 255-continuation bytes, literal runs above 124, the block's last sequence, malformed input --
  *     leaves the step through ONE wave-wide test into a path that parses the token from global memory with all
  *     the checks; the step itself carries no end-of-block logic;
- *   - the output-size check moved out of the step (the sum is checked once, at the end);
+ *   - the output-size check moved out of the step (the sum is checked once, at the end).  That is safe because a
+ *     block's compressed size is capped at 64 KiB by zmt_dec_frames_kernel (bsz > ZMT_BLOCK is ST_BAD_BLOCK there,
+ *     lz4_dec_split.hip): at most cs / 3 tokens of at most cs bytes each cannot overflow the u32 sum, a malformed
+ *     block is merely walked to its end before it is flagged;
  *   - refill: 4 lanes of a quad move the 64-byte units of the quad's 4 rows, the unit positions travel by DPP
  *     quad broadcasts (parse3: ds_bpermute), twice 4 loads every 8 steps;
  *   - token positions leave through a 16-entry tile per lane at wave-uniform points (every 8 steps, with the

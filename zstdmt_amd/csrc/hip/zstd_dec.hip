@@ -184,7 +184,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 	int my_tab_log = 0;
 	u32 opos = 0, ip = hp;
 	/* sequences decoded ahead by zmt_zstd_seq_kernel (zstd_dec_seq.hip): hdr[i] != 0 says block i's are at seq[hdr[i] - 1] */
-	const bool pre_on = seqbuf != nullptr && zs_eligible(cap);
+	const bool pre_on = seqbuf != nullptr && zs_eligible(seqbuf, out_off[rec], cap);
 	const u32 *pre_hdr = pre_on ? (const u32 *)zs_region(seqbuf, out_off[rec]) : nullptr;
 	const u64 *pre_seq = pre_on ? zs_region(seqbuf, out_off[rec]) + zs_nhdr(cap) / 2 : nullptr;
 	const u32 pre_nhdr = pre_on ? zs_nhdr(cap) : 0;

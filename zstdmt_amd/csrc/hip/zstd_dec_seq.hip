@@ -149,7 +149,7 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 	if (rec >= nrec)
 		return;
 	const u32 cap = wv_readfirst(out_len[rec]);
-	if (!zs_eligible(cap))
+	if (!zs_eligible(seqbuf, out_off[rec], cap))
 		return;
 	u64 *const reg = zs_region(seqbuf, out_off[rec]);
 	u32 *const hdr = (u32 *)reg;
@@ -598,7 +598,10 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 					if (gbad)
 						act = false;
 					const bool more = act && done < g_n;
-					/* 8 x 76 more bits and the 16-byte read must stay inside the 160 bytes */
+					/* a sequence consumes at most 27 + 16 + 16 offset / match / literal extra bits + 9 + 9 + 8 state
+					 * bits = 85; with 544 bits already behind the cursor, the 8th sequence's 16-byte read -- issued with
+					 * 544 + 7 x 85 bits consumed -- still lies inside the 160-byte window (13 bits of margin) */
+					static_assert(544 + 7 * 85 + 8 * 16 <= 8 * 160, "the 16-byte read of the 8th sequence leaves the window");
 					if (!wv_any(more) || wv_any(more && 8 * whi - bp > 544))
 						break;
 				}

@@ -60,6 +60,7 @@ static inline uint64_t rd64(const uint8_t *p)
 typedef struct {
 	gpumt_ctx *g[MT_NGPU_MAX];
 	int n;
+	int trace; /* GPUMT_TRACE, read once in mt_gpus_open (the pipeline threads only test the field) */
 } mt_gpus;
 
 static inline void mt_gpus_close(mt_gpus *m)
@@ -71,7 +72,9 @@ static inline void mt_gpus_close(mt_gpus *m)
 /* 0 on success; nothing is left open on failure */
 static inline int mt_gpus_open(mt_gpus *m)
 {
-	const char *e = getenv("GPUMT_DEVICES");
+	const char *e = getenv("GPUMT_TRACE");
+	m->trace = e && *e ? atoi(e) : 0;
+	e = getenv("GPUMT_DEVICES");
 	m->n = 0;
 	if (!e || !*e) {
 		if (gpumt_open(GPUMT_DEVICE_DEFAULT, &m->g[0]) != GPUMT_OK)
@@ -109,12 +112,7 @@ static inline gpumt_ctx *mt_gpu_of(const mt_gpus *m, int slot) { return m->g[slo
  * b % nslot, slot s the device context s % n -- the in-order writer of lib/lz4-mt_compress.c:178-205 re-expressed) */
 static inline void mt_trace_launch(const mt_gpus *m, const char *who, int slot, size_t nrec)
 {
-	static int trace = -1;
-	if (trace < 0) {
-		const char *e = getenv("GPUMT_TRACE");
-		trace = e && *e ? atoi(e) : 0;
-	}
-	if (trace > 1)
+	if (m->trace > 1)
 		fprintf(stderr, "[%s] launch slot %d -> device context %d of %d, stream %d, %zu records\n", who, slot,
 			slot % m->n, m->n, 4 + (slot / m->n) % 12, nrec);
 }
