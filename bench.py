@@ -555,7 +555,8 @@ def bench_zstd_ref(ctx, gib, steps, warmup):
     ms = {k: v / steps for k, v in acc.items()}
     status = eng.download(d_st, nrec * 4, np.uint32)
     bad = int((status != 0).sum())
-    ok = bad == 0 and bool((eng.download(d_out, base_n) == text).all())
+    # replica 0 against the text byte for byte, every other replica against replica 0 (device-side XXH32 per MiB)
+    ok = bad == 0 and bool((eng.download(d_out, base_n) == text).all()) and eng.replicas_equal(d_out, base_n, reps)
     for b in bufs:
         b.free()
     U, Cb = float(n), float(len(stream)) * reps
@@ -669,6 +670,8 @@ def bench_brotli(ctx, gib_args=None, steps=None, warmup=None, cpu=True, main=Tru
     if ok:
         got = eng.download(d_out, base_n)              # capacities == chunk sizes for full chunks
         ok = bool((got == text).all()) if int(out_off[nb]) == base_n else None
+        if ok:                                         # ... and every other replica against replica 0
+            ok = eng.replicas_equal(d_out, base_n, reps)
     ok_all = ctx.all_true(bool(ok)) if ok is not None else None
     bad_all = int(ctx.sum_over_ranks(float(bad)))
     # ---- the device encoder on the same text (not part of `value`: configs[4] is decompress) ----
@@ -710,7 +713,8 @@ def bench_brotli(ctx, gib_args=None, steps=None, warmup=None, cpu=True, main=Tru
             eng.sync(0)
         t_dec = eng.timer_ms(2)
         st2 = eng.download(d_st, nrec_c * 4, np.uint32)
-        ok2 = bool((st2 == 0).all()) and bool((eng.download(d_out, base_n) == text).all())
+        ok2 = (bool((st2 == 0).all()) and bool((eng.download(d_out, base_n) == text).all())
+               and eng.replicas_equal(d_out, base_n, reps))
         own = {"what": "zmt_brotli_enc_kernel(+assemble+compact) on the same text, and the decode of its streams",
                "compress_ms": round(t_enc, 3), "compress_MBps": round(n / 1e6 / (t_enc * 1e-3), 1),
                "ratio": round(n / c_own, 4), "decompress_ms": round(t_dec, 3),
@@ -1107,6 +1111,8 @@ def _leg_short(r):
     o["roofline"] = _roof_short(r.get("roofline"), True)
     if r.get("roofline_decompress") and r["roofline_decompress"] != r.get("roofline"):
         o["roofline_decompress"] = _roof_short(r["roofline_decompress"], True)
+    if isinstance(r.get("roofline_decompress_path"), dict):   # decode + the checksum verify LZ4F_decompress includes
+        o["roofline_decompress_path"] = {k: r["roofline_decompress_path"][k] for k in ("achieved", "frac")}
     if r.get("cpu_baseline"):
         o["cpu_baseline"] = _cpu_short(r["cpu_baseline"], True)
     if isinstance(r.get("device_encoder"), dict) and "compress_MBps" in r["device_encoder"]:
@@ -1125,6 +1131,8 @@ def compact_line(res):
     for k in ("roofline_decompress", "roofline_compress"):
         if res.get(k) and res[k] != res.get("roofline"):
             o[k] = _roof_short(res[k])
+    if isinstance(res.get("roofline_decompress_path"), dict):
+        o["roofline_decompress_path"] = {k: res["roofline_decompress_path"][k] for k in ("what", "achieved", "unit", "frac")}
     if res.get("cpu_baseline"):
         o["cpu_baseline"] = _cpu_short(res["cpu_baseline"])
     for k in ("compress_MBps", "decompress_MBps", "decode_errors", "roundtrip_verified", "device", "gather", "gather_ms",

@@ -107,6 +107,29 @@ class Engine:
             self.L.gpumt_host_free(self.h, C.c_void_p(hb))
         return same
 
+    def replicas_equal(self, d_buf, base_n, reps, piece=1 << 20, stream=0):
+        """every one of `reps` back-to-back replicas of `base_n` bytes in d_buf equals replica 0: XXH32 of each `piece`
+        on the device (gpumt_xxh32_batch, one pass at HBM speed), the hash rows compared on the host -- bench.py's check
+        of the replicated decode legs beyond the first replica, which is compared with the text byte for byte"""
+        base_n, reps = int(base_n), int(reps)
+        if reps <= 1 or base_n == 0:
+            return True
+        per = (base_n + piece - 1) // piece
+        off1 = np.arange(per, dtype=np.uint64) * np.uint64(piece)
+        len1 = np.full(per, piece, np.uint32)
+        len1[-1] = base_n - (per - 1) * piece
+        off = np.concatenate([off1 + np.uint64(r * base_n) for r in range(reps)])
+        d_off, d_len = self.upload(off, stream), self.upload(np.tile(len1, reps), stream)
+        d_hash = self.alloc(per * reps * 4)
+        try:
+            self._ck(self.L.gpumt_xxh32_batch(self.h, d_buf.ptr, d_off.ptr, d_len.ptr, per * reps, d_hash.ptr, stream),
+                     "xxh32_batch")
+            hh = self.download(d_hash, per * reps * 4, np.uint32, stream=stream).reshape(reps, per)
+        finally:
+            for b in (d_off, d_len, d_hash):
+                b.free()
+        return bool((hh == hh[0]).all())
+
     def sync(self, stream=None):
         if stream is None:
             self._ck(self.L.gpumt_device_sync(self.h), "device_sync")
