@@ -141,6 +141,27 @@ def test_emu_encode_level_tiers_decompress_identical(name, level):
     assert E.zstd_compress(data, chunk, grid=1, level=level) == st
 
 
+def test_emu_many_small_chunks_matches_end_with_their_block():
+    """1 KiB chunks (tests/test_gpu_zstd.py::test_more_records_than_one_launch_slice on the CPU): a repeat-offset match
+    measured 16 bytes ahead must end with its block, not in the next chunk's bytes (round 5: it did not, the literal
+    copy behind the last match ran negative)"""
+    data = cases.text(300 * 1024 + 77, 33)
+    st = E.zstd_compress(data, 1024, grid=8)
+    assert H.oracle_zstdmt_decompress(st, len(data) + 64) == data
+    out, status = E.zstd_decompress(st)
+    assert (status == 0).all() and out == data
+    # structured input: the repeat offsets are used and decode (RFC 8878 3.1.1.5 history, unknown at a unit's start)
+    import json
+    js = ("".join(json.dumps({"id": i, "name": "user%d" % (i * 7919 % 1000), "tags": ["a", "b", "c"][:i % 4],
+                             "score": (i * 31) % 100 / 10, "active": i % 3 == 0}) + "\n" for i in range(9000))).encode()
+    for chunk in (1 << 20, 200000, 4096):
+        st = E.zstd_compress(js, chunk, grid=5)
+        assert H.oracle_zstdmt_decompress(st, len(js) + 64) == js
+        out, status = E.zstd_decompress(st)
+        assert (status == 0).all() and out == js
+    assert len(js) / len(E.zstd_compress(js, 1 << 20, grid=5)) > 9.0   # 7.9 without repeat offsets
+
+
 def test_emu_ratio_is_monotone_in_level():
     """the reference hands `level` to ZSTD_compress (lib/zstd-mt_compress.c:285): a higher level must not
     compress worse, and the tiers must be worth having on text"""

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 for so in zstdmt_amd/lib/variants/z*.so; do
   n=$(basename $so .so)
-  ZMT_LIB=$PWD/$so timeout 90 python bench.py --codec zstd --steps 3 --warmup 1 2>gpurun_out/zv_$n.err | python -c "
+  ZMT_LIB=$PWD/$so timeout 400 python bench.py --only --no-cpu --codec zstd --steps 3 --warmup 1 2>gpurun_out/zv_$n.err | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline())
 print('$n', 'enc_ms', d['kernels']['k_lz4_enc']['ms'], 'dec_ms', d['kernels']['k_lz4_dec']['ms'], 'ratio', d['config']['ratio'], 'verified', d['roundtrip_verified'], 'value', d['value'])

@@ -199,6 +199,13 @@ static inline u32 wv_shr1(u32 v, u32 fill)
 	u32 o = wv_shfl(v, l - 1);
 	return l ? o : fill;
 }
+/* lane l receives lane l+1's value, lane 63 `fill` */
+static inline u32 wv_shl1(u32 v, u32 fill)
+{
+	int l = wv_lane();
+	u32 o = wv_shfl(v, l + 1);
+	return l < 63 ? o : fill;
+}
 static inline u32 wv_alignbyte(u32 hi, u32 lo, u32 sh) { return (u32)((((u64)hi << 32) | lo) >> (8 * (sh & 3))); }
 #else
 static __device__ __forceinline__ u32 wv_umax(u32 a, u32 b) { return a > b ? a : b; }
@@ -216,6 +223,11 @@ static __device__ __forceinline__ u32 wv_scan_max_incl(u32 v)
 static __device__ __forceinline__ u32 wv_shr1(u32 v, u32 fill)
 {
 	return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false);
+}
+/* wave_shl:1 (gfx9 DPP): lane l receives lane l+1's value, lane 63 keeps `fill` */
+static __device__ __forceinline__ u32 wv_shl1(u32 v, u32 fill)
+{
+	return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false);
 }
 static __device__ __forceinline__ u32 wv_alignbyte(u32 hi, u32 lo, u32 sh)
 {

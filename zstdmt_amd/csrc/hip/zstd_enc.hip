@@ -822,7 +822,7 @@ static __device__ u32 ze_huf_encode(ZEncLds &L, u32 *stage, const ZHuf hf, const
 		}                                                                                  \
 	} while (0)
 
-template <bool PROF, int HB, u32 MM, int HLOG>
+template <bool PROF, int HB, u32 MM, int HLOG, bool REP = (ZE_REP != 0), u32 LAZYW = ZE_LAZYW>
 static __device__ __forceinline__ void
 zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_total, u32 blk_per_rec,
 	      u8 *__restrict__ slots, u64 stride, u32 *__restrict__ blk_len, u8 *__restrict__ scratch,
@@ -945,7 +945,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		{                                                                                  \
 			const bool v_ = (Cc) != 0xFFFFFFFFu;                                       \
 			const u8 *cp_ = src + (v_ ? (Cc) - 4u : 0u);                               \
-			const u8 *ip_ = src + ((ZE_REP ? ok_ : v_) ? p_ : 0u);                     \
+			const u8 *ip_ = src + ((REP ? ok_ : v_) ? p_ : 0u);                        \
 			(M).v = (V);                                                               \
 			(M).a = ld64u(cp_);                                                        \
 			(M).b = ld64u(cp_ + 8);                                                    \
@@ -988,12 +988,12 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 				/* the same bytes at the newest offset: 16 of them, consecutive addresses over the lanes */
 				u32 mr = 0;
 				const u32 repR = rp1;
-				if (ZE_REP && repR) {
+				if (REP && repR) {
 					const bool rv = p >= repR && p + MM <= bsize;
 					const u8 *rq = src + (rv ? p - repR : 0u);
 					const u64 y0 = v0 ^ ld64u(rq), y1 = m0.d ^ ld64u(rq + 8);
 					mr = y0 ? (u32)__builtin_ctzll(y0) >> 3 : y1 ? 8u + ((u32)__builtin_ctzll(y1) >> 3) : 16u;
-					mr = rv ? mr : 0u;
+					mr = rv ? (mr < bsize - p ? mr : bsize - p) : 0u; /* (a match ends with its block) */
 				}
 				const u64 x0 = v0 ^ (m0.a >> 32 | m0.b << 32), x1 = m0.d ^ (m0.b >> 32 | m0.c << 32);
 				const u32 x2 = m0.e ^ (u32)(m0.c >> 32);
@@ -1007,8 +1007,25 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 				const u32 xb = m0.pb ^ (u32)m0.a;
 				const u32 back = !cand ? 0u : xb ? (u32)__builtin_clz(xb) >> 3 : 4u; /* equal bytes right in front */
 				const u64 maskh = wv_ballot(cand && m >= MM);
-				const u64 maskr = ZE_REP ? wv_ballot(mr >= MM && p >= cursor) : 0ull;
+				const u64 maskr = REP ? wv_ballot(mr >= MM && p >= cursor) : 0ull;
 				u64 mask = maskh | maskr;
+				/* look-ahead (every lane's length is measured anyway), for all positions of the step at once: a match
+				 * that starts d <= LAZYW bytes further on wins when it is longer by more than the d literals it adds
+				 * -- bytes it reaches backwards over this position's side count for it.  Such a position is skipped;
+				 * the loop comes to that match (or to a better one in front of it) by itself.  Lane j reads lanes
+				 * j + 1 .. j + LAZYW through wave_shl:1 steps of one packed word (length | backward bytes << 8) */
+				u64 lazym = 0;
+				if (LAZYW) {
+					u32 w = (cand && m >= MM) ? (m | back << 8) : 0u;
+					bool lz = false;
+					ZMT_UNROLL
+					for (u32 d = 1; d <= LAZYW; d++) {
+						w = wv_shl1(w, 0u);
+						const u32 bq = (w >> 8) < d ? (w >> 8) : d;
+						lz = lz || (w != 0u && (w & 255u) + bq >= m + d + 1u);
+					}
+					lazym = wv_ballot(lz && m < ZE_FWD);
+				}
 				ZEP(7);
 				while (mask) {
 					const int j = wv_ffs(mask) - 1;
@@ -1019,7 +1036,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 					const bool hj = (maskh >> j) & 1;
 					u32 ml = hj ? wv_readlane(m, j) : 0u;
 					bool use_rep = false;
-					if (ZE_REP && ((maskr >> j) & 1)) {
+					if (REP && ((maskr >> j) & 1)) {
 						/* the repeat offset costs a few bits where a new one costs its logarithm: it wins unless the
 						 * table's candidate is clearly longer; it is still this step's repR even if other matches of
 						 * the step came in between (then it is the second or third entry of the history) */
@@ -1027,16 +1044,8 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 						use_rep = !hj || mrj + ZE_REPBONUS >= ml;
 						ml = use_rep ? mrj : ml;
 					}
-					if (ZE_LAZYW && !use_rep && ml < ZE_FWD) {
-						/* look-ahead (every lane's length is measured anyway): a match that starts d <= ZE_LAZYW bytes
-						 * further on wins when it is longer by more than the d literals it adds -- bytes it reaches
-						 * backwards over this position's side count for it.  This position is skipped; the loop
-						 * comes to that match (or to a better one in front of it) by itself */
-						const u32 d = (u32)lane - (u32)j;
-						const u32 bq = back < d ? back : d;
-						if (wv_any(d - 1u < ZE_LAZYW && cand && m >= MM && m + bq >= ml + d + 1u))
-							continue;
-					}
+					if (LAZYW && !use_rep && ((lazym >> j) & 1))
+						continue;
 					const u32 cj = use_rep ? pj - repR : wv_readlane(c0, j);
 					const u32 mcap = use_rep ? 16u : ZE_FWD;
 					if (__builtin_expect(ml == mcap, 0)) {
@@ -1074,7 +1083,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 						/* Offset_Value (RFC 8878 3.1.1.3.2.1.1): 1..3 = the history's entries (shifted by one when the
 						 * sequence has no literals), else offset + 3; and the history as the decoder will update it */
 						u32 ov = ofj + 3;
-						if (ZE_REP) {
+						if (REP) {
 							const u32 e1 = llj ? rp1 : rp2, e2 = llj ? rp2 : rp3;
 							if (ofj == e1)
 								ov = 1;
