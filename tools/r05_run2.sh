@@ -7,7 +7,7 @@ mkdir -p $O
 bash tools/zstd_enc_variants.sh > $O/r05_zstd_variants.txt 2>&1
 timeout 400 python bench.py --only --no-cpu --codec zstd --steps 3 --warmup 1 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.readline())
+d = [json.loads(l[7:]) for l in sys.stdin if l.startswith('DETAIL ')][0]
 print('shipped', 'enc_ms', d['kernels']['k_lz4_enc']['ms'], 'dec_ms', d['kernels']['k_lz4_dec']['ms'], 'ratio', d['config']['ratio'], 'verified', d['roundtrip_verified'], 'value', d['value'])
 " >> $O/r05_zstd_variants.txt
 cat $O/r05_zstd_variants.txt

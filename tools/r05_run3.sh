@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun), round 5 call 3: zstd encoder variants (look-ahead / repeat offsets) at levels 1 and 3.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out
+mkdir -p $O
+one() { # name, lib ("" = shipped), level
+  if [ -n "$2" ]; then export ZMT_LIB=$PWD/zstdmt_amd/lib/variants/$2.so; else unset ZMT_LIB; fi
+  timeout 400 python bench.py --only --no-cpu --codec zstd --zstd-level $3 --steps 3 --warmup 1 2>$O/zv_$1.err | python -c "
+import sys, json
+d = [json.loads(l[7:]) for l in sys.stdin if l.startswith('DETAIL ')][0]
+print('$1', 'level $3', 'enc_ms', d['kernels']['k_lz4_enc']['ms'], 'dec_ms', d['kernels']['k_lz4_dec']['ms'], 'ratio', d['config']['ratio'], 'verified', d['roundtrip_verified'], 'value', d['value'])
+"
+}
+( one base z_base 1; one lazy6 z_lazy 1; one lazy3 z_lazy3 1; one rep z_rep 1; one shipped "" 1
+  one base_l3 z_base 3; one shipped_l3 "" 3; one base_l10 z_base 10; one shipped_l10 "" 10 ) > $O/r05_zstd_variants.txt 2>&1
+cat $O/r05_zstd_variants.txt

@@ -971,6 +971,13 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		ZE_LOADV(2u, V[2]);
 		ZE_LOOKUP(0u, V[0], Cn[0], M[0]);
 		ZE_LOOKUP(1u, V[1], Cn[1], M[1]);
+		/* repeat-offset compare data: the 16 bytes `RR` in front of every position of the NEXT step, asked for a step
+		 * ahead with the newest offset known then (a load whose address waits for this step's parse would put a memory
+		 * round trip on every step's chain: 91 -> 129 ms per 8 GiB [MI355X]).  Where repeat offsets pay -- records,
+		 * tables, markup -- the offset stays the same from match to match and a step's delay loses nothing; where it
+		 * changes with every match (the bench text) there is nothing to find either way */
+		u64 RA[3] = {0, 0, 0}, RB[3] = {0, 0, 0};
+		u32 RR[3] = {0, 0, 0};
 		for (u32 t0 = 0; t0 < steps; t0 += 3) {
 		ZMT_UNROLL
 		for (int k = 0; k < 3; k++) {
@@ -979,6 +986,13 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 				break;
 			ZE_LOADV(t + 3, V[k]);
 			ZE_LOOKUP(t + 2, V[(k + 2) % 3], Cn[(k + 2) % 3], M[(k + 2) % 3]);
+			if (REP) {
+				const u32 pn = (t + 1) * 64u + (u32)lane, rn = rp1;
+				const u8 *rq = src + ((rn && pn >= rn && pn + MM <= bsize) ? pn - rn : 0u);
+				RR[(k + 1) % 3] = rn;
+				RA[(k + 1) % 3] = ld64u(rq);
+				RB[(k + 1) % 3] = ld64u(rq + 8);
+			}
 			ZEP(6);
 			const Cmp &m0 = M[k];
 			const u32 c0 = Cn[k];
@@ -987,11 +1001,11 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			if (p0 + 64 > cursor) { /* else the whole step lies inside the previous match */
 				/* the same bytes at the newest offset: 16 of them, consecutive addresses over the lanes */
 				u32 mr = 0;
-				const u32 repR = rp1;
-				if (REP && repR) {
+				const u32 repR = RR[k];
+				/* (an offset that has left the history meanwhile would cost as much as a new one: not looked at) */
+				if (REP && repR && (repR == rp1 || repR == rp2 || repR == rp3)) {
 					const bool rv = p >= repR && p + MM <= bsize;
-					const u8 *rq = src + (rv ? p - repR : 0u);
-					const u64 y0 = v0 ^ ld64u(rq), y1 = m0.d ^ ld64u(rq + 8);
+					const u64 y0 = v0 ^ RA[k], y1 = m0.d ^ RB[k];
 					mr = y0 ? (u32)__builtin_ctzll(y0) >> 3 : y1 ? 8u + ((u32)__builtin_ctzll(y1) >> 3) : 16u;
 					mr = rv ? (mr < bsize - p ? mr : bsize - p) : 0u; /* (a match ends with its block) */
 				}
