@@ -903,7 +903,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		 * that does not know what the units in front of it leave behind (the previous unit may even be a raw block), so an
 		 * entry is used only once this unit's own sequences have put it there.  Inside the unit the history runs through
 		 * all of its zstd blocks -- they are Compressed blocks, or the whole unit is one Raw block */
-		u32 rp1 = 0, rp2 = 0, rp3 = 0;
+		u32 rp1 = 0;
 		const u32 steps = bsize >= MM ? (bsize - MM) / 64 + 1 : 0;
 /* All loads of the pipeline are unconditional (addresses clamped, results of invalid lanes ignored):
  * a load under an exec mask needs its destination initialised first, and that write would have to
@@ -1003,7 +1003,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 				u32 mr = 0;
 				const u32 repR = RR[k];
 				/* (an offset that has left the history meanwhile would cost as much as a new one: not looked at) */
-				if (REP && repR && (repR == rp1 || repR == rp2 || repR == rp3)) {
+				if (REP && repR && repR == rp1) {
 					const bool rv = p >= repR && p + MM <= bsize;
 					const u64 y0 = v0 ^ RA[k], y1 = m0.d ^ RB[k];
 					mr = y0 ? (u32)__builtin_ctzll(y0) >> 3 : y1 ? 8u + ((u32)__builtin_ctzll(y1) >> 3) : 16u;
@@ -1020,17 +1020,24 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 					m = bsize - p;
 				const u32 xb = m0.pb ^ (u32)m0.a;
 				const u32 back = !cand ? 0u : xb ? (u32)__builtin_clz(xb) >> 3 : 4u; /* equal bytes right in front */
-				const u64 maskh = wv_ballot(cand && m >= MM);
-				const u64 maskr = REP ? wv_ballot(mr >= MM && p >= cursor) : 0ull;
-				u64 mask = maskh | maskr;
+				/* what this position offers, settled per lane so that the serial loop below reads it with three
+				 * v_readlane and nothing else: the repeat offset costs a few bits where a new one costs its logarithm, so
+				 * it wins unless the table's candidate is clearly longer.  mlx = length | "measured to the end of what was
+				 * loaded: the wave extends it" << 31 */
+				const bool hc = cand && m >= MM;
+				const bool ur = REP && mr >= MM && p >= cursor && (!hc || mr + ZE_REPBONUS >= m);
+				const u32 ml_v = ur ? mr : m;
+				const u32 mlx = ml_v | ((ml_v == (ur ? 16u : ZE_FWD)) ? 0x80000000u : 0u);
+				const u32 cj_v = ur ? p - repR : c0;
+				const u32 bk_v = ur ? 0u : back;
+				u64 mask = wv_ballot(hc || ur);
 				/* look-ahead (every lane's length is measured anyway), for all positions of the step at once: a match
 				 * that starts d <= LAZYW bytes further on wins when it is longer by more than the d literals it adds
 				 * -- bytes it reaches backwards over this position's side count for it.  Such a position is skipped;
 				 * the loop comes to that match (or to a better one in front of it) by itself.  Lane j reads lanes
 				 * j + 1 .. j + LAZYW through wave_shl:1 steps of one packed word (length | backward bytes << 8) */
-				u64 lazym = 0;
 				if (LAZYW) {
-					u32 w = (cand && m >= MM) ? (m | back << 8) : 0u;
+					u32 w = hc ? (m | back << 8) : 0u;
 					bool lz = false;
 					ZMT_UNROLL
 					for (u32 d = 1; d <= LAZYW; d++) {
@@ -1038,7 +1045,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 						const u32 bq = (w >> 8) < d ? (w >> 8) : d;
 						lz = lz || (w != 0u && (w & 255u) + bq >= m + d + 1u);
 					}
-					lazym = wv_ballot(lz && m < ZE_FWD);
+					mask &= ~wv_ballot(lz && m < ZE_FWD && !ur);
 				}
 				ZEP(7);
 				while (mask) {
@@ -1047,22 +1054,11 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 					const u32 pj = p0 + (u32)j;
 					if (__builtin_expect(pj < cursor, 0))
 						continue;
-					const bool hj = (maskh >> j) & 1;
-					u32 ml = hj ? wv_readlane(m, j) : 0u;
-					bool use_rep = false;
-					if (REP && ((maskr >> j) & 1)) {
-						/* the repeat offset costs a few bits where a new one costs its logarithm: it wins unless the
-						 * table's candidate is clearly longer; it is still this step's repR even if other matches of
-						 * the step came in between (then it is the second or third entry of the history) */
-						const u32 mrj = wv_readlane(mr, j);
-						use_rep = !hj || mrj + ZE_REPBONUS >= ml;
-						ml = use_rep ? mrj : ml;
-					}
-					if (LAZYW && !use_rep && ((lazym >> j) & 1))
-						continue;
-					const u32 cj = use_rep ? pj - repR : wv_readlane(c0, j);
-					const u32 mcap = use_rep ? 16u : ZE_FWD;
-					if (__builtin_expect(ml == mcap, 0)) {
+					const u32 mlw = wv_readlane(mlx, j);
+					u32 ml = mlw & 0x7FFFFFFFu;
+					const u32 cj = wv_readlane(cj_v, j);
+					const u32 mcap = ml;
+					if (__builtin_expect((mlw >> 31) != 0, 0)) {
 						const u64 tx_ = ZET();
 						/* extend: 64 lanes x 8 bytes per step */
 						for (u32 base = mcap;; base += 512) {
@@ -1091,30 +1087,21 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 					}
 					/* sequences collect in registers (lane = index mod 64) and leave 64 at a time */
 					{
-						u32 bk = use_rep ? 0u : wv_readlane(back, j); /* as far back as the literals since the last match reach */
+						u32 bk = wv_readlane(bk_v, j); /* as far back as the literals since the last match reach */
 						bk = bk < pj - anchor ? bk : pj - anchor;
 						const u32 llj = pj - bk - anchor, ofj = pj - cj;
 						/* Offset_Value (RFC 8878 3.1.1.3.2.1.1): 1..3 = the history's entries (shifted by one when the
 						 * sequence has no literals), else offset + 3; and the history as the decoder will update it */
 						u32 ov = ofj + 3;
 						if (REP) {
-							const u32 e1 = llj ? rp1 : rp2, e2 = llj ? rp2 : rp3;
-							if (ofj == e1)
+							/* only the first entry of the history is used -- Offset_Value 1 behind literals -- so the
+							 * history the decoder keeps matters in its first entry alone, and that is the offset of the
+							 * sequence before, whatever value coded it (a new offset goes in front; value 1 leaves the
+							 * front where it is).  Values 2 and 3 (the entries behind it) were tried: the scalar
+							 * bookkeeping per sequence costs more time than they save bytes */
+							if (llj && ofj == rp1)
 								ov = 1;
-							else if (ofj == e2)
-								ov = 2;
-							else if (llj && ofj == rp3)
-								ov = 3;
-							/* (value 3 without literals -- the newest offset minus one -- is not looked for.)  Which entry
-							 * that was: 0 = the newest, nothing moves; 1 = the two newest swap; 2, or a new offset: all
-							 * three move down and the offset goes in front */
-							const u32 idx = ov > 3 ? 3u : llj ? ov - 1u : ov;
-							if (idx >= 2)
-								rp3 = rp2;
-							if (idx >= 1) {
-								rp2 = rp1;
-								rp1 = ofj;
-							}
+							rp1 = ofj;
 						}
 						const bool me = (u32)lane == (ns & 63);
 						r_ll = me ? llj : r_ll;
