@@ -70,6 +70,9 @@
 #ifndef ZE_REP
 #define ZE_REP 1
 #endif
+#ifndef ZE_REPLIVE
+#define ZE_REPLIVE 8u
+#endif
 #ifndef ZE_REPBONUS
 #define ZE_REPBONUS 1u
 #endif
@@ -903,7 +906,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		 * that does not know what the units in front of it leave behind (the previous unit may even be a raw block), so an
 		 * entry is used only once this unit's own sequences have put it there.  Inside the unit the history runs through
 		 * all of its zstd blocks -- they are Compressed blocks, or the whole unit is one Raw block */
-		u32 rp1 = 0;
+		u32 rp1 = 0, replive = 0;
 		const u32 steps = bsize >= MM ? (bsize - MM) / 64 + 1 : 0;
 /* All loads of the pipeline are unconditional (addresses clamped, results of invalid lanes ignored):
  * a load under an exec mask needs its destination initialised first, and that write would have to
@@ -987,11 +990,19 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			ZE_LOADV(t + 3, V[k]);
 			ZE_LOOKUP(t + 2, V[(k + 2) % 3], Cn[(k + 2) % 3], M[(k + 2) % 3]);
 			if (REP) {
-				const u32 pn = (t + 1) * 64u + (u32)lane, rn = rp1;
-				const u8 *rq = src + ((rn && pn >= rn && pn + MM <= bsize) ? pn - rn : 0u);
-				RR[(k + 1) % 3] = rn;
-				RA[(k + 1) % 3] = ld64u(rq);
-				RB[(k + 1) % 3] = ld64u(rq + 8);
+				/* (the two loads are a third more work for the address unit than a step has without them: 94 -> 108 ms
+				 * per 8 GiB when every step asks.  They are asked for while the data shows that offsets repeat -- a
+				 * sequence at the offset of the one before it keeps the look-out open for ZE_REPLIVE steps -- which on
+				 * the bench text is one step in ten and on records or markup nearly all of them) */
+				RR[(k + 1) % 3] = 0;
+				if (replive) {
+					const u32 pn = (t + 1) * 64u + (u32)lane, rn = rp1;
+					const u8 *rq = src + ((rn && pn >= rn && pn + MM <= bsize) ? pn - rn : 0u);
+					RR[(k + 1) % 3] = rn;
+					RA[(k + 1) % 3] = ld64u(rq);
+					RB[(k + 1) % 3] = ld64u(rq + 8);
+					replive--;
+				}
 			}
 			ZEP(6);
 			const Cmp &m0 = M[k];
@@ -1099,6 +1110,8 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 							 * sequence before, whatever value coded it (a new offset goes in front; value 1 leaves the
 							 * front where it is).  Values 2 and 3 (the entries behind it) were tried: the scalar
 							 * bookkeeping per sequence costs more time than they save bytes */
+							if (ofj == rp1)
+								replive = ZE_REPLIVE;
 							if (llj && ofj == rp1)
 								ov = 1;
 							rp1 = ofj;
