@@ -1010,16 +1010,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			const u64 v0 = m0.v;
 			const u32 p0 = t * 64u, p = p0 + (u32)lane;
 			if (p0 + 64 > cursor) { /* else the whole step lies inside the previous match */
-				/* the same bytes at the newest offset: 16 of them, consecutive addresses over the lanes */
-				u32 mr = 0;
-				const u32 repR = RR[k];
-				/* (an offset that has left the history meanwhile would cost as much as a new one: not looked at) */
-				if (REP && repR && repR == rp1) {
-					const bool rv = p >= repR && p + MM <= bsize;
-					const u64 y0 = v0 ^ RA[k], y1 = m0.d ^ RB[k];
-					mr = y0 ? (u32)__builtin_ctzll(y0) >> 3 : y1 ? 8u + ((u32)__builtin_ctzll(y1) >> 3) : 16u;
-					mr = rv ? (mr < bsize - p ? mr : bsize - p) : 0u; /* (a match ends with its block) */
-				}
+				const u32 repR = RR[k]; /* the offset this step's repeat-offset compare data was asked for with; 0 = none */
 				const u64 x0 = v0 ^ (m0.a >> 32 | m0.b << 32), x1 = m0.d ^ (m0.b >> 32 | m0.c << 32);
 				const u32 x2 = m0.e ^ (u32)(m0.c >> 32);
 				u32 m = x0   ? (u32)__builtin_ctzll(x0) >> 3
@@ -1036,11 +1027,22 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 				 * it wins unless the table's candidate is clearly longer.  mlx = length | "measured to the end of what was
 				 * loaded: the wave extends it" << 31 */
 				const bool hc = cand && m >= MM;
-				const bool ur = REP && mr >= MM && p >= cursor && (!hc || mr + ZE_REPBONUS >= m);
-				const u32 ml_v = ur ? mr : m;
-				const u32 mlx = ml_v | ((ml_v == (ur ? 16u : ZE_FWD)) ? 0x80000000u : 0u);
-				const u32 cj_v = ur ? p - repR : c0;
-				const u32 bk_v = ur ? 0u : back;
+				bool ur = false;
+				u32 mlx = m | (m == ZE_FWD ? 0x80000000u : 0u), cj_v = c0, bk_v = back;
+				/* the same bytes at the newest offset (compare data of a step ago, see RA / RB); a wave-uniform branch:
+				 * a step without a look-out pays nothing for it.  (An offset that is no longer the newest would cost as
+				 * much as a new one: not looked at) */
+				if (REP && repR && repR == rp1) {
+					const bool rv = p >= repR && p + MM <= bsize && p >= cursor;
+					const u64 y0 = v0 ^ RA[k], y1 = m0.d ^ RB[k];
+					u32 mr = y0 ? (u32)__builtin_ctzll(y0) >> 3 : y1 ? 8u + ((u32)__builtin_ctzll(y1) >> 3) : 16u;
+					const bool full = mr == 16u;
+					mr = mr < bsize - p ? mr : bsize - p; /* (a match ends with its block) */
+					ur = rv && mr >= MM && (!hc || mr + ZE_REPBONUS >= m);
+					mlx = ur ? (mr | (full ? 0x80000000u : 0u)) : mlx;
+					cj_v = ur ? p - repR : cj_v;
+					bk_v = ur ? 0u : bk_v;
+				}
 				u64 mask = wv_ballot(hc || ur);
 				/* look-ahead (every lane's length is measured anyway), for all positions of the step at once: a match
 				 * that starts d <= LAZYW bytes further on wins when it is longer by more than the d literals it adds
