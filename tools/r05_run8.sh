@@ -10,8 +10,8 @@ d = [json.loads(l[7:]) for l in sys.stdin if l.startswith('DETAIL ')][0]
 print('$1', 'level $3', 'enc_ms', d['kernels']['k_lz4_enc']['ms'], 'dec_ms', d['kernels']['k_lz4_dec']['ms'], 'ratio', d['config']['ratio'], 'verified', d['roundtrip_verified'], 'value', d['value'])
 "
 }
-( one lazy6 z_lazy 1; one shipped "" 1; one shipped_l3 "" 3; one shipped_l10 "" 10 ) > $O/r05_zstd_variants5.txt 2>&1
+( one lazy6 z_lazy 1; one shipped "" 1; one shipped_l3 "" 3; one shipped_l10 "" 10 ) > $O/r05_zstd_variants6.txt 2>&1
 unset ZMT_LIB
-cat $O/r05_zstd_variants5.txt
-timeout 400 python tools/gpu_fuzz_api.py 240 5000 > $O/r05_gpu_fuzz_api.txt 2>&1; tail -n 3 $O/r05_gpu_fuzz_api.txt
+cat $O/r05_zstd_variants6.txt
+timeout 400 python tools/gpu_fuzz_api.py 200 6000 > $O/r05_gpu_fuzz_api.txt 2>&1; tail -n 3 $O/r05_gpu_fuzz_api.txt
 timeout 300 python -m pytest tests/test_gpu_zstd.py tests/test_gpu_zstdmt_api.py -x -q 2>&1 | tail -n 2

@@ -71,7 +71,7 @@
 #define ZE_REP 1
 #endif
 #ifndef ZE_REPLIVE
-#define ZE_REPLIVE 8u
+#define ZE_REPLIVE 40u /* steps the look-out stays open behind a group of 64 sequences with repeats in it */
 #endif
 #ifndef ZE_REPBONUS
 #define ZE_REPBONUS 1u
@@ -902,11 +902,36 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		wv_sync();
 		u32 ns = 0, anchor = 0, cursor = 0;
 		u32 r_ll = 0, r_ml = 0, r_of = 0;
-		/* repeat-offset history of RFC 8878 3.1.1.5 as the decoder will hold it; 0 = unknown: a unit is coded by a wave
-		 * that does not know what the units in front of it leave behind (the previous unit may even be a raw block), so an
-		 * entry is used only once this unit's own sequences have put it there.  Inside the unit the history runs through
-		 * all of its zstd blocks -- they are Compressed blocks, or the whole unit is one Raw block */
-		u32 rp1 = 0, replive = 0;
+		/* rp1: the offset of the newest sequence (0 = none yet in this unit); replive: steps the look-out for repeat matches
+		 * stays open; rcarry: the offset of the last sequence that left the registers (ZE_FLUSH_SEQS).  Inside a unit the
+		 * decoder's offset history runs through all of its zstd blocks -- they are Compressed blocks, or the whole unit is
+		 * one Raw block and has no sequences */
+		u32 rp1 = 0, replive = 0, rcarry = 0;
+/* 64 sequences leave the registers.  Offset_Value (RFC 8878 3.1.1.3.2.1.1) is settled here, for all of them at once: only
+ * the FIRST entry of the decoder's offset history is ever used -- value 1 behind literals -- so the history matters in its
+ * first entry alone, and that is the offset of the sequence before, whatever value coded it (a new offset goes in front;
+ * value 1 leaves the front where it is): a sequence with literals whose offset equals its predecessor's gets value 1,
+ * every other one offset + 3.  A unit starts with an unknown history (rcarry = 0 equals no offset): the wave does not know
+ * what the units in front of it leave behind, the previous unit may even be one Raw block.  (Values 2 and 3 -- the entries
+ * behind the first -- were tried with the bookkeeping in the serial loop: 6 scalar instructions per sequence on a pipe that
+ * is the kernel's bottleneck cost more time than they save bytes.)  Three or more repeats among the 64 keep the look-out for
+ * repeat matches open */
+#define ZE_FLUSH_SEQS(AT, LIVE)                                                                    \
+	do {                                                                                       \
+		u32 ov_ = r_of + 3u;                                                               \
+		if (REP) {                                                                         \
+			const u32 prev_ = wv_shr1(r_of, rcarry);                                   \
+			const bool same_ = (LIVE) && r_of == prev_;                                \
+			ov_ = (same_ && r_ll != 0u) ? 1u : ov_;                                    \
+			if (wv_popc(wv_ballot(same_)) >= 3)                                        \
+				replive = ZE_REPLIVE;                                              \
+		}                                                                                  \
+		if (LIVE) {                                                                        \
+			sq_ll[(AT) + (u32)lane] = r_ll;                                            \
+			sq_ml[(AT) + (u32)lane] = r_ml;                                            \
+			sq_of[(AT) + (u32)lane] = ov_;                                             \
+		}                                                                                  \
+	} while (0)
 		const u32 steps = bsize >= MM ? (bsize - MM) / 64 + 1 : 0;
 /* All loads of the pipeline are unconditional (addresses clamped, results of invalid lanes ignored):
  * a load under an exec mask needs its destination initialised first, and that write would have to
@@ -1103,31 +1128,16 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 						u32 bk = wv_readlane(bk_v, j); /* as far back as the literals since the last match reach */
 						bk = bk < pj - anchor ? bk : pj - anchor;
 						const u32 llj = pj - bk - anchor, ofj = pj - cj;
-						/* Offset_Value (RFC 8878 3.1.1.3.2.1.1): 1..3 = the history's entries (shifted by one when the
-						 * sequence has no literals), else offset + 3; and the history as the decoder will update it */
-						u32 ov = ofj + 3;
-						if (REP) {
-							/* only the first entry of the history is used -- Offset_Value 1 behind literals -- so the
-							 * history the decoder keeps matters in its first entry alone, and that is the offset of the
-							 * sequence before, whatever value coded it (a new offset goes in front; value 1 leaves the
-							 * front where it is).  Values 2 and 3 (the entries behind it) were tried: the scalar
-							 * bookkeeping per sequence costs more time than they save bytes */
-							if (ofj == rp1)
-								replive = ZE_REPLIVE;
-							if (llj && ofj == rp1)
-								ov = 1;
-							rp1 = ofj;
-						}
+						rp1 = ofj; /* the newest offset: what the next repeat-offset compare data are asked for with */
 						const bool me = (u32)lane == (ns & 63);
 						r_ll = me ? llj : r_ll;
 						r_ml = me ? ml + bk : r_ml;
-						r_of = me ? ov : r_of;
+						r_of = me ? ofj : r_of;
 					}
 					ns++;
 					if ((ns & 63) == 0) {
-						sq_ll[ns - 64 + (u32)lane] = r_ll;
-						sq_ml[ns - 64 + (u32)lane] = r_ml;
-						sq_of[ns - 64 + (u32)lane] = r_of;
+						ZE_FLUSH_SEQS(ns - 64, true);
+						rcarry = wv_readlane(r_of, 63);
 					}
 					anchor = cursor = pj + ml;
 					/* drop every candidate the match covers in one go */
@@ -1139,11 +1149,8 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		}
 #undef ZE_LOADV
 #undef ZE_LOOKUP
-		if ((u32)lane < (ns & 63)) { /* the sequences still in registers */
-			sq_ll[(ns & ~63u) + (u32)lane] = r_ll;
-			sq_ml[(ns & ~63u) + (u32)lane] = r_ml;
-			sq_of[(ns & ~63u) + (u32)lane] = r_of;
-		}
+		ZE_FLUSH_SEQS(ns & ~63u, (u32)lane < (ns & 63)); /* the sequences still in registers */
+#undef ZE_FLUSH_SEQS
 		wave_mem_fence();
 #ifdef ZMT_EMU
 		if (getenv("ZMT_EMU_DEBUG") && lane == 0) {
