@@ -9,13 +9,17 @@
  * sequential match finder:
  *
  *   zmt_zstd_enc_kernel      one wave per 128 KiB block (persistent waves, blocks round-robin).
- *     match finding          64 positions per step, one per lane: hash of 7 bytes, 4096-entry u16 LDS
+ *     match finding          64 positions per step, one per lane: hash of 6 bytes, 4096-entry u16 LDS
  *                            table (the newest position of a step wins, deterministically),
  *                            candidates verified with unaligned 8-byte compares per lane (20 bytes
  *                            forwards, 4 backwards), loads software-pipelined two steps ahead, long
- *                            matches extended 512 bytes per step by the whole wave;
- *     parse                  greedy, leftmost match first, resolved with ballots; a match grows
- *                            backwards into the literals in front of it;
+ *                            matches extended 512 bytes per step by the whole wave; while the data shows
+ *                            repeating offsets, every position is also compared at the newest offset
+ *                            (RFC 8878 repeat offsets: compare data asked for a step ahead);
+ *     parse                  greedy, leftmost match first, with a look-ahead of 6 positions (a clearly
+ *                            longer match a few bytes on wins), settled per lane for the whole step;
+ *                            the serial loop over the chosen matches only reads three values per
+ *                            match; a match grows backwards into the literals in front of it;
  *     literals               gathered lane-per-run, one Huffman code per 128 KiB unit (its first block
  *                            carries the tree, the others are treeless), coded in parallel (histogram with LDS
  *                            atomics, repaired ceil(log2) code lengths, canonical codes by ballots,
@@ -45,7 +49,7 @@
 #define ZE_HLOG 12
 #endif
 #ifndef ZE_MINMATCH
-#define ZE_MINMATCH 7u
+#define ZE_MINMATCH 6u /* 7 until round 5: with the look-ahead in the parse 6 / 6 costs 1.3 ms per 8 GiB and gives 1.2 % */
 #endif
 #define ZE_MAXSEQ (ZE_BLOCK / 4u) /* capacity of the per-wave sequence arrays (>= BLOCK / MINMATCH) */
 #define ZE_CAP 64u
@@ -55,10 +59,12 @@
  * Huffman coder plus the other entropy-phase arrays (ZEncLds), ZE_ENT_BYTES of them */
 #define ZE_ENT_BYTES (1024u + 512u + 256u + 136u + 8u + 1536u)
 #define ZE_STAGE_WORDS (((2u << ZE_HLOG) - ZE_ENT_BYTES) / 4u)
-/* bytes hashed: 7 = the shortest match taken; hashing 6 lets strings that differ in the 7th byte evict each
- * other from the small table (ratio 2.428 vs 2.446 on the bench text with ZE_MINMATCH 7) */
+/* bytes hashed = the shortest match taken.  (Rounds 2-4: 7 / 7 -- hashing 6 with minimum match 7 lets strings that differ
+ * in the 7th byte evict each other from the small table, 2.428 vs 2.446 on the bench text, and 6 / 6 made 26 % more
+ * sequences for the greedy parse.  With the look-ahead: 7 / 7 2.5590, 6 / 7 2.5426, 8 / 7 2.4924, 5 / 5 2.5849, 6 / 6
+ * 2.5877 on the emulator; [MI355X] 6 / 6 96.9 ms and 2.5851 against 95.6 ms and 2.5544 for 7 / 7) */
 #ifndef ZE_HBYTES
-#define ZE_HBYTES 7
+#define ZE_HBYTES 6
 #endif
 /* ZE_REP: matches at the previous match's offset are looked for at every position of a step (one coalesced load: the
  * lanes read consecutive addresses) and sequences carry RFC 8878 repeat-offset values.  Emulator, 1 MiB chunks, level 1:
@@ -87,9 +93,10 @@ template <int HB, int HLOG> static __device__ __forceinline__ u32 ze_hash(u64 v)
 }
 /* Level tiers (the reference hands `level` to ZSTD_compress, /root/reference/lib/zstd-mt_compress.c:285): what the
  * wave-parallel match finder can trade is table size (LDS, i.e. waves per CU) and hash width against ratio.
- * Bench text, 1 MiB chunks (emulator, deterministic): tier 1 = 7 bytes hashed / minimum match 7 / 4 Ki entries:
- * 2.503; tier 2 = 6 / 6 / 8 Ki: 2.610; tier 3 = 6 / 6 / 16 Ki: 2.672 (6 / 6 / 4 Ki: 2.517; 32 Ki: 2.704;
- * libzstd level 1: 2.84) */
+ * Bench text, 1 MiB chunks (emulator, deterministic), round 5 (look-ahead + repeat offsets; rounds 2-4 in brackets):
+ * tier 1 = 6 bytes hashed / minimum match 6 / 4 Ki entries: 2.588 [7 / 7 / 4 Ki: 2.503]; tier 2 = 6 / 6 / 8 Ki: 2.696
+ * [2.610]; tier 3 = 6 / 6 / 16 Ki: 2.771 [2.672]; libzstd 1.4.9 level 1 (hashLog 14, the whole 1 MiB chunk as window):
+ * 2.84, with this tier's table (hashLog 12, 128 KiB pieces): 2.57-2.60 (profiles/r05_sweeps/zstd_enc_steps.txt) */
 
 struct ZEncLds {
 	u16 st_ll[64], st_ml[64], st_of[32]; /* FSE state tables: predefined distributions, or fitted to the unit */
