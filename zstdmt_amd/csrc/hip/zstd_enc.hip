@@ -77,9 +77,6 @@
 #ifndef ZE_REP
 #define ZE_REP 1
 #endif
-#ifndef ZE_VPICK
-#define ZE_VPICK 1
-#endif
 #ifndef ZE_REPLIVE
 #define ZE_REPLIVE 40u /* steps the look-out stays open behind a group of 64 sequences with repeats in it */
 #endif
@@ -1097,60 +1094,13 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 					mask &= ~wv_ballot(lz && m < ZE_FWD && !ur);
 				}
 				ZEP(7);
-				/* ---- the step's matches, all at once (ZE_VPICK) ----
-				 * The greedy choice is a chain: the first candidate at or behind the cursor, then from each chosen match
-				 * the first candidate at or behind its end.  Every lane works out where the chain would go from ITS
-				 * match (`nxt`: one 64-bit shift of the candidate mask + find-first), the serial part only hops along
-				 * (one v_readlane per match) and notes which lane's match becomes sequence ns, ns + 1, ...; literal
-				 * lengths come from a prefix maximum of the chosen matches' ends, and three ds_bpermute move the fields
-				 * to the registers the sequences collect in.  A match measured to the end of what was loaded (bit 31 of
-				 * mlx) needs the wave's extension: the chain stops in front of it and the loop below takes over from
-				 * there; so does a step that would carry the collection across a multiple of 64.  Same matches, same
-				 * bytes as the loop alone (scalar instructions per match: ~40 -> ~10, on the pipe that bounds the kernel) */
-				if (ZE_VPICK && mask && (ns & 63u) <= 64u - (64u / MM + 2u)) {
-					const u32 mlen0 = mlx & 0x7FFFFFFFu;
-					const u32 endr = (u32)lane + mlen0; /* end of this lane's match, relative to the step */
-					const u64 behind = endr < 64u ? mask >> endr : 0ull;
-					const u32 nxt = behind ? endr + (u32)__builtin_ctzll(behind) : 64u;
-					const u64 capm = wv_ballot((mlx >> 31) != 0);
-					const u32 rel0 = cursor > p0 ? cursor - p0 : 0u;
-					const u64 from0 = rel0 < 64u ? (mask >> rel0) << rel0 : 0ull;
-					u32 cur = from0 ? (u32)wv_ffs(from0) - 1u : 64u;
-					u32 last = 64u, npick = 0;
-					u32 srcl = 0; /* lane (ns & 63) + r: the lane whose match is the r-th of this step */
-					u64 pickm = 0;
-					const u32 base = ns & 63u;
-					while (cur < 64u && !((capm >> cur) & 1ull)) {
-						pickm |= 1ull << cur;
-						srcl = (u32)lane == base + npick ? cur : srcl;
-						npick++;
-						last = cur;
-						cur = wv_readlane(nxt, (int)cur);
-					}
-					if (npick) {
-						const bool pk = (pickm >> lane) & 1ull;
-						const u32 smax = wv_scan_max_incl(pk ? p + mlen0 : 0u);
-						const u32 pe = wv_shr1(smax, 0u);
-						const u32 prev_end = pe > anchor ? pe : anchor; /* end of the match chosen in front of this one */
-						const u32 room = p - prev_end;                  /* (meaningful in the chosen lanes: p >= prev_end) */
-						const u32 bkl = bk_v < room ? bk_v : room;
-						const u32 f_ll = room - bkl, f_ml = mlen0 + bkl, f_of = p - cj_v;
-						const u32 g_ll = wv_shfl(f_ll, (int)srcl), g_ml = wv_shfl(f_ml, (int)srcl), g_of = wv_shfl(f_of, (int)srcl);
-						const bool mine = (u32)lane - base < npick;
-						r_ll = mine ? g_ll : r_ll;
-						r_ml = mine ? g_ml : r_ml;
-						r_of = mine ? g_of : r_of;
-						rp1 = wv_readlane(f_of, (int)last);
-						anchor = cursor = p0 + wv_readlane(endr, (int)last);
-						ns += npick;
-						if ((ns & 63u) == 0) {
-							ZE_FLUSH_SEQS(ns - 64, true);
-							rcarry = wv_readlane(r_of, 63);
-						}
-					}
-					/* what is left for the loop: nothing, or the step from the match that needs extending on */
-					mask = cur < 64u ? (mask >> cur) << cur : 0ull;
-				}
+				/* (Choosing the step's matches in vector code -- the chain of "first candidate at or behind this match's
+				 * end" per lane, one v_readlane per chosen match, literal lengths from a prefix maximum of the chosen ends,
+				 * three ds_bpermute into the collecting registers -- was built in round 5, byte-identical on 48 inputs, and
+				 * measured: 95.64 against 95.82 ms per 8 GiB.  The loop is not what a step waits for: its ~40 scalar
+				 * instructions per match run beside the other 15 waves' work, while the vector version puts a scan, three
+				 * bpermutes and the hops on the wave's own dependent chain.  Removed again;
+				 * profiles/r05_sweeps/zstd_enc_steps.txt) */
 				while (mask) {
 					const int j = wv_ffs(mask) - 1;
 					mask &= mask - 1;
