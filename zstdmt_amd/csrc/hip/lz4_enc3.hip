@@ -258,6 +258,76 @@ static __device__ __forceinline__ void copy_literals(const InRing &R, u8 *d, u32
 	}
 }
 
+/* ENC3_DEFER: sequences are not written out one by one -- the token, the literals, the offset and the length bytes of a
+ * sequence are four to six dependent steps of scalar code, an LDS read and single-lane stores on the chunk's chain -- but
+ * collect in registers (lane = sequence number mod 64: where its token goes, where its literals come from, the three
+ * numbers) and leave 64 at a time, every lane writing its own sequence.  The output position is still advanced and tested
+ * against the limit sequence by sequence, exactly as the reference does: a block that fails fails at the same sequence,
+ * with the same table insertions behind it. */
+#ifndef ENC3_DEFER
+#define ENC3_DEFER 1
+#endif
+struct Seq3 {
+	u32 tok, src, lit, mc, off; /* position of the token in dst, of the literals in the chunk; literal run, match code, offset */
+};
+/* length bytes of a run code (v >= 0): n255 bytes of 255 and the rest, written by the lane itself (the loop runs for runs of
+ * 270 and more: rare) */
+static __device__ __forceinline__ u32 seq3_len_ext(u8 *o, u32 v)
+{
+	const u32 n255 = v / 255;
+	for (u32 i = 0; i < n255; i++)
+		o[i] = 255;
+	o[n255] = (u8)(v - n255 * 255);
+	return n255 + 1;
+}
+static __device__ void seq3_flush(const Seq3 &q, u32 cnt, const u8 *chunk, u8 *dst, int lane)
+{
+	const bool act = (u32)lane < cnt;
+	const u32 lit = act ? q.lit : 0, mc = q.mc;
+	u8 *o = dst + q.tok;
+	if (act) {
+		o[0] = (u8)((lit >= 15 ? 15u : lit) << 4 | (mc >= 15 ? 15u : mc));
+		o++;
+		if (E_RARE(lit >= 15))
+			o += seq3_len_ext(o, lit - 15);
+	}
+	/* literals: exact, in pieces that may overlap each other (first and last piece of 8 or of 4, single bytes below
+	 * 4); runs above 64 bytes by the whole wave, one at a time */
+	const u8 *s_ = chunk + q.src;
+	if (act && lit <= 64) {
+		if (lit >= 8) {
+			for (u32 i = 8; i + 8 < lit; i += 8) {
+				const u64 v = ld64u(s_ + i);
+				__builtin_memcpy(o + i, &v, 8);
+			}
+			const u64 a = ld64u(s_), b = ld64u(s_ + lit - 8);
+			__builtin_memcpy(o, &a, 8);
+			__builtin_memcpy(o + lit - 8, &b, 8);
+		} else if (lit >= 4) {
+			const u32 a = ld32u(s_), b = ld32u(s_ + lit - 4);
+			st32u(o, a);
+			st32u(o + lit - 4, b);
+		} else {
+			for (u32 i = 0; i < lit; i++)
+				o[i] = s_[i];
+		}
+	}
+	u64 big = wv_ballot(act && lit > 64);
+	while (E_RARE(big != 0)) {
+		const int j = wv_ffs(big) - 1;
+		big &= big - 1;
+		const u32 oj = wv_readlane((u32)(o - dst), j), sj = wv_readlane(q.src, j), lj = wv_readlane(lit, j);
+		wave_copy(dst + oj, chunk + sj, lj, lane);
+	}
+	if (act) {
+		o += lit;
+		st16u(o, q.off);
+		o += 2;
+		if (E_RARE(mc >= 15))
+			(void)seq3_len_ext(o, mc - 15);
+	}
+}
+
 template <int TM, bool PROF>
 static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, u32 pos, u32 len, u8 *dst,
 				    u32 cap, int lane)
@@ -269,6 +339,8 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 	const u32 low = (TM == T_U16) ? pos : 0;
 	const bool second = (pos >> 16) != 0; /* T_P17: the 17th bit of every position of this block */
 	u32 ip = pos, anchor = pos, op = 0;
+	Seq3 sq = {0, 0, 0, 0, 0};
+	u32 nsq = 0; /* sequences of this block so far; those not written yet: nsq & 63 */
 	/* 1 after a match: the search opens with the reference's immediate re-match probe at ip.  That test is a
 	 * probe like the others (look T[h(ip)] up, insert ip, compare 4 bytes), the search it falls into when it
 	 * fails continues at ip + 1, ip + 2, ... -- so it rides in lane 0 of the search's first batch and the two
@@ -532,6 +604,31 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				if (op + lit + (2 + 1 + LASTLITERALS) + lit / 255 > cap)
 					return 0;
 			}
+			const u32 mc = fwd;
+			if (ENC3_DEFER) {
+				if (E_RARE(lit >= 15))
+					op += (lit - 15) / 255 + 1;
+				op += lit;
+				if (E_RARE(op + 2 + (1 + LASTLITERALS) + (mc >> 7) + 1 > cap)) {
+					if (op + 2 + (1 + LASTLITERALS) + (mc + 240) / 255 > cap)
+						return 0;
+				}
+				const bool me = (u32)lane == (nsq & 63u);
+				sq.tok = me ? token : sq.tok;
+				sq.src = me ? anchor : sq.src;
+				sq.lit = me ? lit : sq.lit;
+				sq.mc = me ? mc : sq.mc;
+				sq.off = me ? ip - match : sq.off;
+				nsq++;
+				op += 2;
+				ip += mc + MINMATCH;
+				if (E_RARE(mc >= 15))
+					op += (mc - 15) / 255 + 1;
+				anchor = ip;
+				if ((nsq & 63u) == 0)
+					seq3_flush(sq, 64, chunk, dst, lane);
+				EPC(R, 4);
+			} else {
 			const u32 tokhi = (lit >= 15 ? 15u : lit) << 4;
 			if (E_RARE(lit >= 15))
 				op += put_len_ext3(dst + op, lit - 15, lane);
@@ -546,7 +643,6 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			}
 			op += lit;
 			EPC(R, 3);
-			const u32 mc = fwd;
 			if (E_RARE(op + 2 + (1 + LASTLITERALS) + (mc >> 7) + 1 > cap)) {
 				if (op + 2 + (1 + LASTLITERALS) + (mc + 240) / 255 > cap)
 					return 0;
@@ -561,6 +657,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				op += put_len_ext3(dst + op, mc - 15, lane);
 			anchor = ip;
 			EPC(R, 4);
+			}
 		}
 		if (E_RARE(ip >= mflimit_p1))
 			goto block_done;
@@ -568,6 +665,8 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 	}
 block_done:
 last_literals:
+	if (ENC3_DEFER && (nsq & 63u) != 0) /* (a block that fails below is stored raw: writing what it had is harmless) */
+		seq3_flush(sq, nsq & 63u, chunk, dst, lane);
 	{
 		u32 run = iend - anchor;
 		if (op + run + 1 + (run + 255 - 15) / 255 > cap)
