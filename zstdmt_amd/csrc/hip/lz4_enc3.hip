@@ -258,15 +258,13 @@ static __device__ __forceinline__ void copy_literals(const InRing &R, u8 *d, u32
 	}
 }
 
-/* ENC3_DEFER: sequences are not written out one by one -- the token, the literals, the offset and the length bytes of a
- * sequence are four to six dependent steps of scalar code, an LDS read and single-lane stores on the chunk's chain -- but
- * collect in registers (lane = sequence number mod 64: where its token goes, where its literals come from, the three
- * numbers) and leave 64 at a time, every lane writing its own sequence.  The output position is still advanced and tested
- * against the limit sequence by sequence, exactly as the reference does: a block that fails fails at the same sequence,
- * with the same table insertions behind it. */
-#ifndef ENC3_DEFER
-#define ENC3_DEFER 1
-#endif
+/* Sequences are not written out one by one -- the token, the literals, the offset and the length bytes of a sequence are four
+ * to six dependent steps of scalar code, an LDS read and single-lane stores on the chunk's chain, and at 16 waves per CU every
+ * instruction of a wave costs it 20-30 cycles -- but collect in registers (lane = sequence number mod 64: where its token
+ * goes, where its literals come from, the three numbers) and leave 64 at a time, every lane writing its own sequence
+ * [MI355X, 8 GiB: 288.0 -> 269.6 ms, profiles/r05_sweeps/lz4_enc3_steps.txt].  The output position is still advanced and
+ * tested against the limit sequence by sequence, exactly as the reference does: a block that fails fails at the same
+ * sequence, with the same table insertions behind it. */
 struct Seq3 {
 	u32 tok, src, lit, mc, off; /* position of the token in dst, of the literals in the chunk; literal run, match code, offset */
 };
@@ -598,66 +596,39 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			/* ---------------- the sequence: token, literals, offset, length bytes ----------------
 			 * (the two output-limit tests first in a form without the division: lit >> 7 >= lit / 255 and
 			 * (mc >> 7) + 1 >= (mc + 240) / 255, so what passes these passes the reference's; else those decide) */
-			const u32 lit = ip - anchor;
-			const u32 token = op++;
-			if (E_RARE(op + lit + (2 + 1 + LASTLITERALS) + (lit >> 7) > cap)) {
-				if (op + lit + (2 + 1 + LASTLITERALS) + lit / 255 > cap)
+			const u32 lit = ip - anchor, mc = fwd;
+			const u32 token = op;
+			/* what the sequence adds to the output: token, literals, offset, and the length bytes of runs of 15 and more */
+			u32 adv = lit + 3u;
+			if (E_RARE((lit | mc) >= 15u))
+				adv += (lit >= 15 ? (lit - 15) / 255 + 1 : 0u) + (mc >= 15 ? (mc - 15) / 255 + 1 : 0u);
+			/* the reference's two output-limit tests (before the literals: op + 1 + lit + 8 + lit / 255 > cap; before the
+			 * offset: op' + 2 + 6 + (mc + 240) / 255 > cap) both pass when op + adv + 6 <= cap -- the second IS that, the
+			 * first asks less (lit / 255 <= the literal run's length bytes) -- so one compare covers the common case and
+			 * the two tests decide, in the reference's order, only near the limit */
+			if (E_RARE(op + adv + 6u > cap)) {
+				const u32 o1 = op + 1u;
+				if (o1 + lit + (2 + 1 + LASTLITERALS) + lit / 255 > cap)
+					return 0;
+				const u32 o2 = o1 + (lit >= 15 ? (lit - 15) / 255 + 1 : 0u) + lit;
+				if (o2 + 2 + (1 + LASTLITERALS) + (mc + 240) / 255 > cap)
 					return 0;
 			}
-			const u32 mc = fwd;
-			if (ENC3_DEFER) {
-				if (E_RARE(lit >= 15))
-					op += (lit - 15) / 255 + 1;
-				op += lit;
-				if (E_RARE(op + 2 + (1 + LASTLITERALS) + (mc >> 7) + 1 > cap)) {
-					if (op + 2 + (1 + LASTLITERALS) + (mc + 240) / 255 > cap)
-						return 0;
-				}
+			op += adv;
+			{
 				const bool me = (u32)lane == (nsq & 63u);
 				sq.tok = me ? token : sq.tok;
 				sq.src = me ? anchor : sq.src;
 				sq.lit = me ? lit : sq.lit;
 				sq.mc = me ? mc : sq.mc;
 				sq.off = me ? ip - match : sq.off;
-				nsq++;
-				op += 2;
-				ip += mc + MINMATCH;
-				if (E_RARE(mc >= 15))
-					op += (mc - 15) / 255 + 1;
-				anchor = ip;
-				if ((nsq & 63u) == 0)
-					seq3_flush(sq, 64, chunk, dst, lane);
-				EPC(R, 4);
-			} else {
-			const u32 tokhi = (lit >= 15 ? 15u : lit) << 4;
-			if (E_RARE(lit >= 15))
-				op += put_len_ext3(dst + op, lit - 15, lane);
-			if ((quick >> 31) && lit <= 64) {
-				/* the literals start at most 64 bytes in front of a position the search has just read: in the
-				 * ring (the slow extension may have moved it on, hence `quick`) */
-				E_ASSERT(lit == 0 || ring_has(R, anchor, lit));
-				if ((u32)lane < lit)
-					dst[op + (u32)lane] = R.ring[(anchor + (u32)lane) & (IRING - 1)];
-			} else {
-				copy_literals(R, dst + op, anchor, lit, lane);
 			}
-			op += lit;
-			EPC(R, 3);
-			if (E_RARE(op + 2 + (1 + LASTLITERALS) + (mc >> 7) + 1 > cap)) {
-				if (op + 2 + (1 + LASTLITERALS) + (mc + 240) / 255 > cap)
-					return 0;
-			}
-			if (lane == 0) {
-				st16u(dst + op, ip - match);
-				dst[token] = (u8)(tokhi | (mc >= 15 ? 15u : mc));
-			}
-			op += 2;
+			nsq++;
 			ip += mc + MINMATCH;
-			if (E_RARE(mc >= 15))
-				op += put_len_ext3(dst + op, mc - 15, lane);
 			anchor = ip;
+			if ((nsq & 63u) == 0)
+				seq3_flush(sq, 64, chunk, dst, lane);
 			EPC(R, 4);
-			}
 		}
 		if (E_RARE(ip >= mflimit_p1))
 			goto block_done;
@@ -665,7 +636,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 	}
 block_done:
 last_literals:
-	if (ENC3_DEFER && (nsq & 63u) != 0) /* (a block that fails below is stored raw: writing what it had is harmless) */
+	if ((nsq & 63u) != 0) /* (a block that fails below is stored raw: writing what it had is harmless) */
 		seq3_flush(sq, nsq & 63u, chunk, dst, lane);
 	{
 		u32 run = iend - anchor;
