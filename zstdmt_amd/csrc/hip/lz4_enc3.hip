@@ -81,12 +81,14 @@ template <int TM> static __device__ __forceinline__ u32 hash3(u64 x)
 }
 
 /* ---- hash table, three storage layouts; `lo` is the main array, `hi` the 17th bits (T_P17) ---- */
-template <int TM> static __device__ __forceinline__ u32 t_read(const u32 *lo, const u32 *hi, u32 h)
+/* (`second`, wave-uniform: the block starts at 64 KiB.  In a chunk's first block no entry has its 17th bit set -- the table
+ * starts zeroed and that block writes none, see t_write -- so the bit plane is not read there) */
+template <int TM> static __device__ __forceinline__ u32 t_read(const u32 *lo, const u32 *hi, u32 h, bool second)
 {
 	if (TM == T_U32)
 		return lo[h];
 	u32 v = ((const u16 *)lo)[h];
-	if (TM == T_P17)
+	if (TM == T_P17 && second)
 		v |= ((hi[h >> 5] >> (h & 31)) & 1) << 16;
 	return v;
 }
@@ -404,7 +406,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				if (ins2)
 					t_write<TM>(tlo, thi, h, cur, second);
 				wv_sync();
-				u32 cand = t_read<TM>(tlo, thi, h); /* (idle lanes read too: no exec-mask region) */
+				u32 cand = t_read<TM>(tlo, thi, h, second); /* (idle lanes read too: no exec-mask region) */
 				u32 prev_dup = 64, next_dup = 64;
 				{
 					EPC(R, 0);
