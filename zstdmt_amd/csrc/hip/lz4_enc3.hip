@@ -81,14 +81,15 @@ template <int TM> static __device__ __forceinline__ u32 hash3(u64 x)
 }
 
 /* ---- hash table, three storage layouts; `lo` is the main array, `hi` the 17th bits (T_P17) ---- */
-/* (`second`, wave-uniform: the block starts at 64 KiB.  In a chunk's first block no entry has its 17th bit set -- the table
- * starts zeroed and that block writes none, see t_write -- so the bit plane is not read there) */
-template <int TM> static __device__ __forceinline__ u32 t_read(const u32 *lo, const u32 *hi, u32 h, bool second)
+/* (measured and dropped in round 5, both bit-identical: not reading the 17th-bit plane in a chunk's first block, where no entry
+ * has it set -- 259.2 -> 263.4 ms per 8 GiB, the wave-uniform branch costs more than the read --, and one way out of the batch
+ * loop through a `found` flag instead of the jumps to last_literals: 263.4 -> 265.1) */
+template <int TM> static __device__ __forceinline__ u32 t_read(const u32 *lo, const u32 *hi, u32 h)
 {
 	if (TM == T_U32)
 		return lo[h];
 	u32 v = ((const u16 *)lo)[h];
-	if (TM == T_P17 && second)
+	if (TM == T_P17)
 		v |= ((hi[h >> 5] >> (h & 31)) & 1) << 16;
 	return v;
 }
@@ -406,7 +407,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				if (ins2)
 					t_write<TM>(tlo, thi, h, cur, second);
 				wv_sync();
-				u32 cand = t_read<TM>(tlo, thi, h, second); /* (idle lanes read too: no exec-mask region) */
+				u32 cand = t_read<TM>(tlo, thi, h); /* (idle lanes read too: no exec-mask region) */
 				u32 prev_dup = 64, next_dup = 64;
 				{
 					EPC(R, 0);
@@ -595,9 +596,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		}
 		EPC(R, 2);
 		{
-			/* ---------------- the sequence: token, literals, offset, length bytes ----------------
-			 * (the two output-limit tests first in a form without the division: lit >> 7 >= lit / 255 and
-			 * (mc >> 7) + 1 >= (mc + 240) / 255, so what passes these passes the reference's; else those decide) */
+			/* ---------------- the sequence: its place in the output, its numbers into the collecting registers ---------------- */
 			const u32 lit = ip - anchor, mc = fwd;
 			const u32 token = op;
 			/* what the sequence adds to the output: token, literals, offset, and the length bytes of runs of 15 and more */
