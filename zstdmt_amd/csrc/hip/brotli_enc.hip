@@ -35,15 +35,18 @@
 #ifndef BE_HLOG
 #define BE_HLOG 12
 #endif
+#ifndef BE_LAZYW
+#define BE_LAZYW 4u /* positions the greedy parse looks ahead for a longer match (0 = none) */
+#endif
 #ifndef BE_MINMATCH
-#define BE_MINMATCH 7u
+#define BE_MINMATCH 6u /* (7 until round 5: with the look-ahead 6 gives 2.512 against 2.463 on the bench text) */
 #endif
 #define BE_MAXSEQ (BE_BLOCK / 4u)
 #define BE_WSCRATCH (3u * BE_MAXSEQ * 4u) /* per persistent wave: the three sequence arrays */
 /* 6 bytes hashed; quality tiers (the reference hands `level` to BrotliEncoderCompress, /root/reference/lib/brotli-mt_compress.c:269-272):
  * as in zstd_enc.hip what the wave-parallel match finder can trade is table size (LDS, waves per CU) and minimum
- * match against ratio -- bench text, 1 MiB chunks (emulator): 4 Ki entries / minimum match 7: 2.450; 8 Ki / 6:
- * 2.584; 16 Ki / 6: 2.659 (libbrotli quality 1: 2.81) */
+ * match against ratio -- bench text, 1 MiB chunks (emulator), round 5 with the look-ahead [rounds 3-4]: 4 Ki entries /
+ * minimum match 6: 2.512 [4 Ki / 7: 2.450]; 8 Ki / 6: 2.616 [2.584]; 16 Ki / 6: 2.694 [2.659] (libbrotli quality 1: 2.81) */
 template <int HLOG> static __device__ __forceinline__ u32 be_hash(u64 v)
 {
 	return (u32)(((v << 16) * 0x9E3779B185EBCA87ull) >> (64 - HLOG));
@@ -465,6 +468,20 @@ brotli_enc_body(BEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nbl
 				if (cand && m > bsize - p)
 					m = bsize - p;
 				u64 mask = wv_ballot(cand && m >= MM);
+				/* look-ahead, as in zstd_enc.hip (round 5): a match that starts d <= BE_LAZYW bytes further on wins when
+				 * it is longer by more than the d literals it adds; settled for all positions of the step at once -- lane
+				 * j reads the lengths of lanes j + 1 .. j + BE_LAZYW through DPP wave_shl:1 steps -- and the skipped
+				 * positions leave the candidate mask */
+				if (BE_LAZYW) {
+					u32 w = (cand && m >= MM) ? m : 0u;
+					bool lz = false;
+					ZMT_UNROLL
+					for (u32 d = 1; d <= BE_LAZYW; d++) {
+						w = wv_shl1(w, 0u);
+						lz = lz || (w != 0u && w >= m + d + 1u);
+					}
+					mask &= ~wv_ballot(lz && m < 24u);
+				}
 				while (mask) {
 					const int j = wv_ffs(mask) - 1;
 					mask &= mask - 1;

@@ -41,6 +41,9 @@
 #ifndef SN_HBYTES
 #define SN_HBYTES 6
 #endif
+#ifndef SN_LAZYW
+#define SN_LAZYW 4u /* positions the greedy parse looks ahead for a longer match (0 = none) */
+#endif
 #define SN_FWD 20u /* bytes of a match measured by the lane that found it; longer ones by the whole wave */
 #define SN_CAP 64u /* longer literal runs are copied by the whole wave */
 #define SN_HDR 16u /* record header: skippable magic, 8, payload size, "SP", hint */
@@ -218,6 +221,19 @@ zmt_snappy_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nrec, u8 
 					const u32 xb = m0.pb ^ (u32)m0.a;
 					const u32 back = !cand ? 0u : xb ? (u32)__builtin_clz(xb) >> 3 : 4u;
 					u64 mask = wv_ballot(cand && m >= SN_MINMATCH);
+					/* look-ahead, as in zstd_enc.hip (round 5): a match that starts d <= SN_LAZYW bytes further on wins
+					 * when it is longer by more than the d literals it adds (bytes it reaches backwards count for it) */
+					if (SN_LAZYW) {
+						u32 w = (cand && m >= SN_MINMATCH) ? (m | back << 8) : 0u;
+						bool lz = false;
+						ZMT_UNROLL
+						for (u32 d = 1; d <= SN_LAZYW; d++) {
+							w = wv_shl1(w, 0u);
+							const u32 bq = (w >> 8) < d ? (w >> 8) : d;
+							lz = lz || (w != 0u && (w & 255u) + bq >= m + d + 1u);
+						}
+						mask &= ~wv_ballot(lz && m < SN_FWD);
+					}
 					while (mask) {
 						const int j = wv_ffs(mask) - 1;
 						mask &= mask - 1;
