@@ -332,6 +332,15 @@ static __device__ void seq3_flush(const Seq3 &q, u32 cnt, const u8 *chunk, u8 *d
 	}
 }
 
+/* 16 bytes at any address as two 8-byte halves: one global_load_dwordx4 */
+#define ENC3_LD16(P, LO, HI)                                                                        \
+	do {                                                                                        \
+		struct { u64 a, b; } q_;                                                            \
+		__builtin_memcpy(&q_, (P), 16);                                                     \
+		(LO) = q_.a;                                                                        \
+		(HI) = q_.b;                                                                        \
+	} while (0)
+
 template <int TM, bool PROF>
 static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, u32 pos, u32 len, u8 *dst,
 				    u32 cap, int lane)
@@ -428,7 +437,12 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					bool wide = probe && cand >= 8; /* else (chunk start) 8 bytes at cand only, no quick extension */
 					u32 a0 = !probe ? 0u : wide ? cand - 8 : cand;
 					const u8 *gp = chunk + a0;
-					u64 l0 = ld64u(gp), l1 = ld64u(wide ? gp + 8 : gp), l2 = ld64u(wide ? gp + 16 : gp);
+					/* (16 + 8 bytes: two vector-memory instructions instead of three.  A lane without a wide window reads
+					 * [cand, cand + 16) -- readable: cand + 16 <= iend + 3, the input carries 8 bytes of slack -- and uses
+					 * its first half; its third read repeats the first) */
+					u64 l0, l1, l2;
+					ENC3_LD16(gp, l0, l1);
+					l2 = ld64u(wide ? gp + 16 : gp);
 					/* in-batch duplicates of a hash: every probe sets its bit of the folded filter (only the probes: an LDS
 					 * atomic costs by active lanes) -- behind the loads, its wait would stand in front of them */
 					u32 dold = 0;
@@ -459,8 +473,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						wide = probe && cand >= 8;
 						a0 = !probe ? 0u : wide ? cand - 8 : cand;
 						gp = chunk + a0;
-						l0 = ld64u(gp);
-						l1 = ld64u(wide ? gp + 8 : gp);
+						ENC3_LD16(gp, l0, l1);
 						l2 = ld64u(wide ? gp + 16 : gp);
 					}
 					const u64 g0 = l0, g1 = wide ? l1 : l0, g2 = l2;
