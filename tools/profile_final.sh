@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (through gpurun), round 5: the profile round on the final tree -- default bench line, rocprofv3 stats and
+# Runs ON THE GPU BOX (through gpurun), the profile round on a final tree -- default bench line, rocprofv3 stats and
 # PMC passes of all codecs (tools/profile_round.sh), SQ counters (tools/profile_sq.sh), then the GPU test suite.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
