@@ -13,7 +13,8 @@
  *    length (forward) for the common case; longer runs continue 64 bytes at a time.
  *  - Sequences are not written out one by one: they collect in registers (lane = number mod 64) and leave 64 at a
  *    time, every lane writing its own (seq3_flush); the output position is advanced and tested per sequence, as the
- *    reference does.  288 -> 259 ms per 8 GiB (round 5).
+ *    reference does; the candidate's 24-byte window comes as one 16-byte and one 8-byte load.  288 -> 256 ms per
+ *    8 GiB (round 5).
  *  - For chunks <= 128 KiB the 4096-entry table stores 17-bit positions as u16 + one bit
  *    (8.5 KiB instead of 16 KiB).  A chunk-wave is a latency-bound dependent chain and the encoder's
  *    time follows 1 / (waves per CU) (14 waves 131.7 ms per 2 GiB, 12: 157, 9: 186, 5: 289), so LDS is
@@ -268,7 +269,7 @@ static __device__ __forceinline__ void copy_literals(const InRing &R, u8 *d, u32
  * to six dependent steps of scalar code, an LDS read and single-lane stores on the chunk's chain, and at 16 waves per CU every
  * instruction of a wave costs it 20-30 cycles -- but collect in registers (lane = sequence number mod 64: where its token
  * goes, where its literals come from, the three numbers) and leave 64 at a time, every lane writing its own sequence
- * [MI355X, 8 GiB: 288.0 -> 269.6 ms, profiles/r05_sweeps/lz4_enc3_steps.txt].  The output position is still advanced and
+ * [MI355X, 8 GiB: 288.0 -> 269.6 ms, with the merged limit test 259.2; profiles/r05_sweeps/lz4_enc3_steps.txt].  The output position is still advanced and
  * tested against the limit sequence by sequence, exactly as the reference does: a block that fails fails at the same
  * sequence, with the same table insertions behind it. */
 struct Seq3 {
