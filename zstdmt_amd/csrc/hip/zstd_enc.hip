@@ -1024,9 +1024,10 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			ZE_LOOKUP(t + 2, V[(k + 2) % 3], Cn[(k + 2) % 3], M[(k + 2) % 3]);
 			if (REP) {
 				/* (the two loads are a third more work for the address unit than a step has without them: 94 -> 108 ms
-				 * per 8 GiB when every step asks.  They are asked for while the data shows that offsets repeat -- a
-				 * sequence at the offset of the one before it keeps the look-out open for ZE_REPLIVE steps -- which on
-				 * the bench text is one step in ten and on records or markup nearly all of them) */
+				 * per 8 GiB when every step asks.  They are asked for while the data shows that offsets repeat -- three
+				 * or more sequences at their predecessor's offset among the 64 that last left the registers keep the
+				 * look-out open for ZE_REPLIVE steps (ZE_FLUSH_SEQS) -- which on the bench text is almost never and on
+				 * records or markup nearly always) */
 				RR[(k + 1) % 3] = 0;
 				if (replive) {
 					const u32 pn = (t + 1) * 64u + (u32)lane, rn = rp1;
