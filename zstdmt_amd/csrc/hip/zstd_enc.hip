@@ -1296,6 +1296,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 						const u32 lc = ll < 64 ? L.llcode[ll] : (u32)hb32(ll) + 19;
 						const u32 mc = mlb < 128 ? L.mlcode[mlb] : (u32)hb32(mlb) + 36;
 						const u32 oc = (u32)hb32(ofv);
+						u32 sbv = 0, sbn = 0; /* state bits of this sequence: value, count (none in front of a run's first) */
 						if (first) {
 							/* FSE_initCState2 x3: ML, OF, LL */
 							u32 nbo = (L.tt_ml[mc][0] + (1u << 15)) >> 16;
@@ -1306,19 +1307,32 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 							s_ll = L.st_ll[(((nbo << 16) - L.tt_ll[lc][0]) >> nbo) + L.tt_ll[lc][1]];
 							first = false;
 						} else {
-							u32 nbo = (s_of + L.tt_of[oc][0]) >> 16;
-							bw_add(w, s_of, nbo);
-							s_of = L.st_of[(s_of >> nbo) + L.tt_of[oc][1]];
-							nbo = (s_ml + L.tt_ml[mc][0]) >> 16;
-							bw_add(w, s_ml, nbo);
-							s_ml = L.st_ml[(s_ml >> nbo) + L.tt_ml[mc][1]];
-							nbo = (s_ll + L.tt_ll[lc][0]) >> 16;
-							bw_add(w, s_ll, nbo);
-							s_ll = L.st_ll[(s_ll >> nbo) + L.tt_ll[lc][1]];
+							/* the three state transitions are independent: their bits -- OF, ML, LL state bits, in
+							 * the stream's order -- go out as one field (at most 6 + 5 + 6 bits with these tables) */
+							const u32 n_of = (s_of + L.tt_of[oc][0]) >> 16, n_ml = (s_ml + L.tt_ml[mc][0]) >> 16;
+							const u32 n_ll = (s_ll + L.tt_ll[lc][0]) >> 16;
+							sbv = (s_of & ((1u << n_of) - 1u)) | (s_ml & ((1u << n_ml) - 1u)) << n_of |
+							      (s_ll & ((1u << n_ll) - 1u)) << (n_of + n_ml);
+							sbn = n_of + n_ml + n_ll;
+							s_of = L.st_of[(s_of >> n_of) + L.tt_of[oc][1]];
+							s_ml = L.st_ml[(s_ml >> n_ml) + L.tt_ml[mc][1]];
+							s_ll = L.st_ll[(s_ll >> n_ll) + L.tt_ll[lc][1]];
 						}
-						bw_add(w, ll - (L.llx[lc] & 0xFFFFFFu), L.llx[lc] >> 24);
-						bw_add(w, mlb + 3 - (L.mlx[mc] & 0xFFFFFFu), L.mlx[mc] >> 24);
-						bw_add(w, ofv - (1u << oc), oc);
+						{
+							/* ... followed by the extra bits of LL and ML in the same field when that stays below 32 bits
+							 * (nearly always: runs of 64 Ki have 16 extra bits each), then the offset's.  Two steps of
+							 * the bit writer per sequence instead of six */
+							const u32 nl = L.llx[lc] >> 24, nm = L.mlx[mc] >> 24;
+							const u32 lv = ll - (L.llx[lc] & 0xFFFFFFu), mv = mlb + 3 - (L.mlx[mc] & 0xFFFFFFu);
+							if (sbn + nl + nm <= 31u) {
+								bw_add(w, sbv | lv << sbn | mv << (sbn + nl), sbn + nl + nm);
+							} else {
+								bw_add(w, sbv, sbn);
+								bw_add(w, lv, nl);
+								bw_add(w, mv, nm);
+							}
+							bw_add(w, ofv - (1u << oc), oc);
+						}
 					}
 					L.sb_hi[lane] = hi - cnt;
 				}
