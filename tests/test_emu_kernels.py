@@ -208,6 +208,57 @@ def test_emu_fast_encoder_stored_block_after_an_attempt_that_wrote_matches():
             assert E.compress(data, chunk, 1)[0] == H.oracle_compress(data, chunk), (data[-20:], chunk)
 
 
+def _block_kinds(stream):
+    """(stored?, size) of every block of every record of an lz4-mt stream"""
+    import struct
+    out, i = [], 0
+    while i < len(stream):
+        c = struct.unpack_from("<I", stream, i + 8)[0]
+        p = i + 12 + 15
+        while True:
+            bh = struct.unpack_from("<I", stream, p)[0]
+            p += 4
+            if bh == 0:
+                break
+            out.append((bh >> 31, bh & 0x7FFFFFFF))
+            p += bh & 0x7FFFFFFF
+        i += 12 + c
+    return out
+
+
+def test_emu_fast_encoder_blocks_near_the_output_limit():
+    """Random blocks with a stretch of compressible bytes sized so that the savings land within a few bytes of what the
+    literal runs' length bytes cost: blocks that barely fit and blocks that barely do not (LZ4F stores those raw, SURVEY
+    Appendix B).  The encoder advances and tests its output position sequence by sequence as the reference does -- one
+    compare covers both of the reference's tests in the common case, the two tests decide near the limit (round 5) -- so
+    every stream must equal the oracle's, and both outcomes must occur."""
+    import random
+    stored = fit = 0
+    for seed in range(1000, 1030):
+        rng = random.Random(777000 + seed)
+        n = rng.choice([65536, 131072, 65536 + rng.randrange(20, 60000)])
+        base = bytearray(rng.getrandbits(8) for _ in range(n))
+        words = [bytes(rng.getrandbits(8) for _ in range(rng.randrange(3, 9))) for _ in range(40)]
+        for blk in range(0, n, 65536):
+            blen = min(65536, n - blk)
+            if blen < 400:
+                continue
+            target = blen // 255 + rng.randrange(-6, 30)
+            span = int(target * rng.uniform(2.0, 7.0)) + rng.randrange(0, 40)
+            at = blk + rng.randrange(0, max(1, blen - span - 8))
+            t = bytearray()
+            while len(t) < span:
+                t += rng.choice(words)
+            base[at:at + span] = t[:span]
+        data, chunk = bytes(base), rng.choice([65536, 131072, 1 << 20])
+        want = H.oracle_compress(data, chunk)
+        assert E.compress(data, chunk)[0] == want, seed
+        for st, _ in _block_kinds(want):
+            stored += st
+            fit += 1 - st
+    assert stored >= 10 and fit >= 10, (stored, fit)
+
+
 from cases import enc3_path_inputs as _enc3_path_inputs
 
 
