@@ -100,6 +100,33 @@ with open(os.path.join(H.GOLDEN_DIR, "lz4hc", "manifest.json")) as _f:
     HCMAN = json.load(_f)
 
 
+def test_fast_encoder_blocks_near_the_output_limit(eng):
+    """tests/test_emu_kernels.py::test_emu_fast_encoder_blocks_near_the_output_limit on the device: random blocks with a
+    compressible stretch sized so that they barely fit or barely do not (LZ4F stores those raw); the encoder's collected
+    emit advances and tests the output position sequence by sequence as the reference does, so every stream equals the
+    oracle's"""
+    import random
+    for seed in range(1000, 1040):
+        rng = random.Random(777000 + seed)
+        n = rng.choice([65536, 131072, 65536 + rng.randrange(20, 60000)])
+        base = bytearray(rng.getrandbits(8) for _ in range(n))
+        words = [bytes(rng.getrandbits(8) for _ in range(rng.randrange(3, 9))) for _ in range(40)]
+        for blk in range(0, n, 65536):
+            blen = min(65536, n - blk)
+            if blen < 400:
+                continue
+            target = blen // 255 + rng.randrange(-6, 30)
+            span = int(target * rng.uniform(2.0, 7.0)) + rng.randrange(0, 40)
+            at = blk + rng.randrange(0, max(1, blen - span - 8))
+            t = bytearray()
+            while len(t) < span:
+                t += rng.choice(words)
+            base[at:at + span] = t[:span]
+        data, chunk = bytes(base), rng.choice([65536, 131072, 1 << 20])
+        stream, _, _ = eng.compress_bytes(data, chunk)
+        assert stream == H.oracle_compress(data, chunk), seed
+
+
 @pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_hc_compress_golden(eng, level):
     """LZ4HC levels 3..12 against the digests the reference build wrote (tests/golden/gen_golden_lz4hc.py)."""

@@ -151,6 +151,25 @@ def test_fuzz_encode_is_decompress_identical(eng, seed):
         assert rv == 0 and back == data
 
 
+def test_repeat_offsets_on_structured_data(eng):
+    """RFC 8878 repeat offsets (round 5): records whose matches sit at one distance -- JSON lines -- are coded with
+    Offset_Value 1, at every chunk size incl. units that start with an unknown history; the oracle, the device decoder
+    and the reference library read them back, and they pay"""
+    import json
+    js = ("".join(json.dumps({"id": i, "name": "user%d" % (i * 7919 % 1000), "tags": ["a", "b", "c"][:i % 4],
+                             "score": (i * 31) % 100 / 10, "active": i % 3 == 0}) + "\n" for i in range(40000))).encode()
+    for chunk, level in ((1 << 20, 1), (200000, 1), (4096, 1), (1 << 20, 5)):
+        st, ro, rl = eng.compress_bytes(js, chunk, codec="zstd", level=level)
+        assert H.oracle_zstdmt_decompress(st, len(js) + 64) == js
+        out, status = eng.decompress_bytes(st, ro, rl, codec="zstd")
+        assert (status == 0).all() and out == js
+        if H.have_zref():
+            rv, back, _, _ = H.zstdmt_decompress_via(H.zref(), st, threads=2)
+            assert rv == 0 and back == js
+    st, _, _ = eng.compress_bytes(js, 1 << 20, codec="zstd", level=1)
+    assert len(js) / len(st) > 9.5   # 9.2 without repeat offsets (emulator, 7 / 7), 10.6 with (6 / 6)
+
+
 def test_level_tiers_ratio_monotone_and_decompress_identical(eng):
     """level reaches the encoder (the reference hands it to ZSTD_compress, lib/zstd-mt_compress.c:285): three tiers,
     each decompress-identical, ratio monotone in level"""
