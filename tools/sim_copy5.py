@@ -10,7 +10,8 @@ output, inside one lap of a 4 KiB ring):
     completed lines are visible to the next step (one ballot per step);
   - the dependency depth of the sequence DAG (what any exact scheme is bounded by).
 Kill criteria written before the run (VERDICT): > 400 wave-instructions per 680 output bytes or > 2.5 average passes.
-Instruction model (static counts of the prototype's loop bodies, tools/ubench/line_copy.hip): see COST below."""
+Instruction model: see COST below.  Its per-step figure (28) is kind: the piece loop written out and compiled for gfx950
+(tools/ubench/line_copy_step.hip) is 170 instructions per step (profiles/r05_sweeps/copy5_sim.txt)."""
 import ctypes as C, os, struct, sys
 import numpy as np
 sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden')
