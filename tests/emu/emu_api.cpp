@@ -16,6 +16,9 @@ void zmt_xxh32_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, const u3
 void zmt_lz4_enc3_u16_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
 void zmt_lz4_enc3_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
 void zmt_lz4_enc3_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
+void zmt_lz4_enc5_u16_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
+void zmt_lz4_enc5_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
+void zmt_lz4_enc5_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
 void zmt_lz4hc_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *, u8 *, int);
 void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u32 *, u32 *, u32 *, u32);
 void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
@@ -76,18 +79,21 @@ void emu_lz4_compress_batch(const u8 *in, u64 n, u32 chunk, u8 *slots, u64 strid
 	}
 	emu_xxh32_batch(in, off.data(), len.data(), nrec, chk.data());
 	const u32 *chkp = chk.data();
+	/* ZMT_EMU_LZ4_ENC=3 selects the probe-batch encoder (lz4_enc3.hip), anything else the window encoder (lz4_enc5.hip) */
+	const char *ev = getenv("ZMT_EMU_LZ4_ENC");
+	const bool v3 = ev && atoi(ev) == 3;
+	typedef void (*enc_fn)(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
+	const enc_fn k16 = v3 ? zmt_lz4_enc3_u16_kernel : zmt_lz4_enc5_u16_kernel;
+	const enc_fn k17 = v3 ? zmt_lz4_enc3_p17_kernel : zmt_lz4_enc5_p17_kernel;
+	const enc_fn k32 = v3 ? zmt_lz4_enc3_u32_kernel : zmt_lz4_enc5_u32_kernel;
 	if (chunk <= 65536) {
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
-			    [=]() { zmt_lz4_enc3_u16_kernel(in, n, chunk, 0, nrec, slots, stride, rec_len, chkp, nullptr); });
+			    [=]() { k16(in, n, chunk, 0, nrec, slots, stride, rec_len, chkp, nullptr); });
 	} else {
-		if (chunk <= 131072)
-			emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
-				    [=]() { zmt_lz4_enc3_p17_kernel(in, n, chunk, 0, nrec, slots, stride, rec_len, chkp, nullptr); });
-		else
-			emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
-				    [=]() { zmt_lz4_enc3_u32_kernel(in, n, chunk, 0, nrec, slots, stride, rec_len, chkp, nullptr); });
+		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1},
+			    [=]() { (chunk <= 131072 ? k17 : k32)(in, n, chunk, 0, nrec, slots, stride, rec_len, chkp, nullptr); });
 		emu::launch(dim3{1, 1, 1}, dim3{64, 1, 1},
-			    [=]() { zmt_lz4_enc3_u16_kernel(in, n, chunk, nrec - 1, nrec, slots, stride, rec_len, chkp, nullptr); });
+			    [=]() { k16(in, n, chunk, nrec - 1, nrec, slots, stride, rec_len, chkp, nullptr); });
 	}
 }
 

@@ -106,6 +106,8 @@ def test_fast_encoder_blocks_near_the_output_limit(eng):
     emit advances and tests the output position sequence by sequence as the reference does, so every stream equals the
     oracle's"""
     import random
+    import struct
+    stored = fit = 0
     for seed in range(1000, 1040):
         rng = random.Random(777000 + seed)
         n = rng.choice([65536, 131072, 65536 + rng.randrange(20, 60000)])
@@ -125,6 +127,21 @@ def test_fast_encoder_blocks_near_the_output_limit(eng):
         data, chunk = bytes(base), rng.choice([65536, 131072, 1 << 20])
         stream, _, _ = eng.compress_bytes(data, chunk)
         assert stream == H.oracle_compress(data, chunk), seed
+        # (stored?, size) of every block of the DEVICE's stream: both outcomes must occur
+        i = 0
+        while i < len(stream):
+            c = struct.unpack_from("<I", stream, i + 8)[0]
+            p = i + 12 + 15
+            while True:
+                bh = struct.unpack_from("<I", stream, p)[0]
+                p += 4
+                if bh == 0:
+                    break
+                stored += bh >> 31
+                fit += 1 - (bh >> 31)
+                p += bh & 0x7FFFFFFF
+            i += 12 + c
+    assert stored >= 10 and fit >= 10, (stored, fit)
 
 
 @pytest.mark.parametrize("level", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
@@ -221,6 +238,45 @@ def test_text_256m_roundtrip_and_checksum_of_checksums(eng):
     for i in (0, 1, 1000, len(rl) - 1):
         rec = stream[int(ro[i]):int(ro[i]) + int(rl[i])]
         assert rec == H.oracle_compress(data[i * 131072:(i + 1) * 131072], 131072)
+
+
+def test_text_1g_every_record_vs_oracle(eng):
+    """configs[1] at 1 GiB of the bench text (the C generator bench.py uses), 128 KiB chunks: EVERY record the device
+    writes is compared with the oracle's -- the oracle compresses 64 MiB slices on the host's threads (the C restatement
+    releases the GIL), records are independent, so the concatenation is the whole stream -- and the per-record XXH32 of
+    both streams must agree record by record; then the device decodes its own stream back."""
+    import ctypes as C
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    import xxhash
+    T = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zstdmt_amd", "lib", "libzmt_tools.so"))
+    T.zmt_gen_text.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_int]
+    n, chunk, piece = 1 << 30, 131072, 64 << 20
+    buf = np.empty(n, np.uint8)
+    T.zmt_gen_text(buf.ctypes.data, n, 20260926, 0, min(32, os.cpu_count() or 1))
+    data = buf.tobytes()
+    stream, ro, rl = eng.compress_bytes(data, chunk)
+    assert len(rl) == n // chunk
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        want = list(ex.map(lambda a: H.oracle_compress(data[a:a + piece], chunk), range(0, n, piece)))
+    per = piece // chunk
+    bad = []
+    for k, w in enumerate(want):
+        lo, hi = int(ro[k * per]), int(ro[(k + 1) * per])
+        got = stream[lo:hi]
+        if got != w:
+            # name the first differing record of the slice (XXH32 per record, as the streams carry no index)
+            off = 0
+            for i in range(per):
+                ln = int(rl[k * per + i])
+                if xxhash.xxh32(got[off:off + ln]).intdigest() != xxhash.xxh32(w[off:off + ln]).intdigest():
+                    bad.append(k * per + i)
+                    break
+                off += ln
+    assert not bad, "records that differ from the oracle: %r" % bad[:8]
+    assert sum(len(w) for w in want) == len(stream)
+    out, status = eng.decompress_bytes(stream, ro, rl)
+    assert not status.any() and out == data
 
 
 @pytest.mark.parametrize("mutate,code", [("magic", 2), ("hc", 2), ("blocksize", 3), ("checksum", 5),

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 
-HIP_SRCS = ["xxh32.hip", "snappy.hip", "lz4_enc3.hip", "lz4_enc_hc.hip", "lz4_dec.hip", "lz4_dec_split.hip", "lz4_dec_parse4.hip", "lz4_dec_copy3.hip", "zstd_dec.hip", "zstd_dec_seq.hip", "zstd_enc.hip", "brotli_dec.hip", "brotli_dec4.hip", "brotli_enc.hip", "pack.hip", "gpumt.hip"]
+HIP_SRCS = ["xxh32.hip", "snappy.hip", "lz4_enc3.hip", "lz4_enc5.hip", "lz4_enc_hc.hip", "lz4_dec.hip", "lz4_dec_split.hip", "lz4_dec_parse4.hip", "lz4_dec_copy3.hip", "zstd_dec.hip", "zstd_dec_seq.hip", "zstd_enc.hip", "brotli_dec.hip", "brotli_dec4.hip", "brotli_enc.hip", "pack.hip", "gpumt.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 HIPFLAGS += os.environ.get("ZMT_HIPFLAGS", "").split()   # developer: -D overrides for A/B builds

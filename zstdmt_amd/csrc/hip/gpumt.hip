@@ -28,6 +28,12 @@ __global__ void zmt_lz4_enc3_p17_prof_kernel(const u8 *, u64, u32, u32, u32, u8 
 					     unsigned long long *);
 __global__ void zmt_push_host_kernel(const u8 *, u8 *, u64, const u64 *);
 __global__ void zmt_lz4hc_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32 *, u8 *, int);
+__global__ void zmt_lz4_enc5_u16_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
+					unsigned long long *);
+__global__ void zmt_lz4_enc5_p17_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
+					unsigned long long *);
+__global__ void zmt_lz4_enc5_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
+					unsigned long long *);
 __global__ void zmt_lz4_enc3_u32_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *,
 					unsigned long long *);
 __global__ void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *,
@@ -103,6 +109,8 @@ struct gpumt_ctx {
 	unsigned long long *d_prof; /* 16 phase counters of the profiling decoder */
 	int xflags;  /* experiment switches of the parse kernel (developer) */
 	int lz4_ring; /* copy3: log2 of the LDS ring per wave (12, 13 or 14) */
+	int enc_variant; /* LZ4 fast levels: 0 = the window encoder (lz4_enc5.hip), 3 = the probe-batch encoder (lz4_enc3.hip) */
+	int dec_pad;  /* copy stage: dynamic-LDS padding per workgroup = resident-wave cap (developer A/B, GPUMT_LZ4_DEC_PAD) */
 	int debug_free; /* GPUMT_DEBUG_FREE: gpumt_free / gpumt_host_free check that the streams are idle */
 	int profile; /* record events in timer slots 8.. around individual kernels */
 	int num_cus;
@@ -255,6 +263,10 @@ int gpumt_open(int device, gpumt_ctx **out)
 		h->dec_variant = e && *e ? atoi(e) : 0;
 		e = getenv("GPUMT_LZ4_RING");
 		h->lz4_ring = e && *e ? atoi(e) : 12;
+		e = getenv("GPUMT_LZ4_ENC");
+		h->enc_variant = e && *e ? atoi(e) : 0;
+		e = getenv("GPUMT_LZ4_DEC_PAD");
+		h->dec_pad = e && *e ? atoi(e) : 0;
 		/* GPUMT_ZSTD_SEQ=1: no sequence pre-pass in front of the zstd frame decoder */
 		e = getenv("GPUMT_ZSTD_SEQ");
 		h->zseq_variant = e && *e ? atoi(e) : 0;
@@ -781,26 +793,28 @@ int gpumt_lz4_compress_batch_level(gpumt_ctx *h, const void *d_in, size_t n, siz
 				   (const u8 *)d_in, (u64)n, (u32)chunk, (u32)nrec, (u8 *)d_slots,
 				   (u64)slot_stride, d_rec_len, (const u32 *)chk,
 				   (u8 *)h->scratch[0][s] + hc_base, level);
-	} else if (chunk <= 65536) {
-		/* every record is a single independent block: byU16 table */
-		hipLaunchKernelGGL(zmt_lz4_enc3_u16_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
-				   (const u8 *)d_in, (u64)n, (u32)chunk, 0u, (u32)nrec, (u8 *)d_slots,
-				   (u64)slot_stride, d_rec_len, (const u32 *)chk, eprof);
 	} else {
-		/* linked-block records; the ragged last record may be <= 64 KiB and then belongs to the
-		 * byU16 kernel (each kernel skips records of the other kind) */
-		if (chunk <= 131072)
-			hipLaunchKernelGGL(eprof ? zmt_lz4_enc3_p17_prof_kernel : zmt_lz4_enc3_p17_kernel, dim3((unsigned)nrec), dim3(64),
-					   (size_t)h->xflags /* developer: dynamic-LDS padding = occupancy knob */, h->st[s],
-					   (const u8 *)d_in, (u64)n, (u32)chunk, 0u, (u32)nrec, (u8 *)d_slots,
+		/* chunk <= 64 KiB: every record is a single independent block (byU16 table).  Else linked-block records
+		 * (17-bit entries up to 128 KiB chunks, 32-bit beyond); the ragged last record may be <= 64 KiB and then
+		 * belongs to the byU16 kernel (each kernel skips records of the other kind) */
+		const bool v3 = h->enc_variant == 3 || eprof;
+		typedef void (*enc_fn)(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, const u32 *, unsigned long long *);
+		const enc_fn k16 = v3 ? zmt_lz4_enc3_u16_kernel : zmt_lz4_enc5_u16_kernel;
+		const enc_fn k17 = eprof ? zmt_lz4_enc3_p17_prof_kernel : v3 ? zmt_lz4_enc3_p17_kernel : zmt_lz4_enc5_p17_kernel;
+		const enc_fn k32 = v3 ? zmt_lz4_enc3_u32_kernel : zmt_lz4_enc5_u32_kernel;
+		if (chunk <= 65536) {
+			hipLaunchKernelGGL(k16, dim3((unsigned)nrec), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n,
+					   (u32)chunk, 0u, (u32)nrec, (u8 *)d_slots, (u64)slot_stride, d_rec_len,
+					   (const u32 *)chk, eprof);
+		} else {
+			hipLaunchKernelGGL(chunk <= 131072 ? k17 : k32, dim3((unsigned)nrec), dim3(64),
+					   chunk <= 131072 ? (size_t)h->xflags : 0 /* developer: dynamic-LDS padding = occupancy knob */,
+					   h->st[s], (const u8 *)d_in, (u64)n, (u32)chunk, 0u, (u32)nrec, (u8 *)d_slots,
 					   (u64)slot_stride, d_rec_len, (const u32 *)chk, eprof);
-		else
-			hipLaunchKernelGGL(zmt_lz4_enc3_u32_kernel, dim3((unsigned)nrec), dim3(64), 0, h->st[s],
-					   (const u8 *)d_in, (u64)n, (u32)chunk, 0u, (u32)nrec, (u8 *)d_slots,
-					   (u64)slot_stride, d_rec_len, (const u32 *)chk, eprof);
-		hipLaunchKernelGGL(zmt_lz4_enc3_u16_kernel, dim3(1), dim3(64), 0, h->st[s], (const u8 *)d_in,
-				   (u64)n, (u32)chunk, (u32)(nrec - 1), (u32)nrec, (u8 *)d_slots,
-				   (u64)slot_stride, d_rec_len, (const u32 *)chk, (unsigned long long *)NULL);
+			hipLaunchKernelGGL(k16, dim3(1), dim3(64), 0, h->st[s], (const u8 *)d_in, (u64)n, (u32)chunk,
+					   (u32)(nrec - 1), (u32)nrec, (u8 *)d_slots, (u64)slot_stride, d_rec_len,
+					   (const u32 *)chk, (unsigned long long *)NULL);
+		}
 	}
 	PROF1(9);
 	CK(hipGetLastError());
@@ -903,7 +917,7 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 		PROF1(14);
 		PROF0(15);
 #define C3_LAUNCH(NAME)                                                                                            \
-	hipLaunchKernelGGL(NAME, dim3((unsigned)nrec), dim3(64), 0, h->st[s], (const u8 *)d_stream,               \
+	hipLaunchKernelGGL(NAME, dim3((unsigned)nrec), dim3(64), (size_t)h->dec_pad, h->st[s], (const u8 *)d_stream, \
 			   (u64)stream_bytes, 0u, n, (u8 *)d_out, d_out_off, d_out_len, (const u64 *)blk0,         \
 			   (const u64 *)bco, (const u32 *)bcs, (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, \
 			   (const u32 *)bnt, (const u32 *)bol, d_status)
@@ -1324,6 +1338,12 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	} else if (!strcmp(what, "lz4_ring")) {
 		prev = h->lz4_ring;
 		h->lz4_ring = variant;
+	} else if (!strcmp(what, "lz4_enc")) {
+		prev = h->enc_variant;
+		h->enc_variant = variant;
+	} else if (!strcmp(what, "lz4_dec_pad")) {
+		prev = h->dec_pad;
+		h->dec_pad = variant;
 	} else if (!strcmp(what, "brotli_dec")) {
 		prev = h->bdec_variant;
 		h->bdec_variant = variant;

@@ -33,11 +33,13 @@
 #include "lz4_common.h"
 #include "lz4_frame.h"
 
-#define C3_CSTAGE 1024u
+/* ONE stage buffer (round 6): the next batch's bytes are requested once this batch's literals are copied -- nothing reads the
+ * stage after that, the sources fetched from before the ring stay in registers until they are stored -- so a second buffer
+ * bought no overlap, and without it the 4 KiB variant needs 4 096 + 16 + 1 008 = 5 120 bytes of LDS: 32 waves per CU instead of
+ * 26.  The stage follows its resident waves (profiles/r06_sweeps/copy3_wavecap.txt: 24 waves +10 %, 20 +20 %, 16 +31 %) */
+#define C3_CSTAGE 976u
 #define C3_CSLACK 32u
-#define C3_CBUF (C3_CSTAGE + C3_CSLACK) /* two of them: the next batch's bytes arrive while this one runs; once a
-					  * batch's literals are copied its buffer holds the 64 x 16 bytes fetched for
-					  * matches sourced before the ring */
+#define C3_CBUF (C3_CSTAGE + C3_CSLACK)
 #define C3_BLK_STORED 0x80000000u
 #define C3_XOUT 2048u /* most output bytes of one batch: two flush pieces of 1 KiB */
 #define C3_NEEDS_SERIAL 100u
@@ -81,7 +83,7 @@ static __device__ __forceinline__ u64 c3_tok_base(u64 coff, u32 gb) { return ((c
 /* 1 KiB of the stream into LDS, lane l moving bytes [16 l, 16 l + 16) of it; `g` is 16-byte aligned */
 static __device__ __forceinline__ void c3_stage(u8 *cb, const u8 *g, u32 nbytes, int lane)
 {
-	if (16u * (u32)lane < nbytes) {
+	if (16u * (u32)lane < (nbytes < C3_CBUF ? nbytes : C3_CBUF)) {
 #ifdef ZMT_EMU
 		__builtin_memcpy(cb + 16 * lane, g + 16 * lane, 16);
 #else
@@ -224,17 +226,13 @@ template <u32 WIN, bool PROF = false> struct C3 {
 	 * complete and does not overlap it.  Stores are 4-byte pieces placed so that ONE per-lane condition covers all
 	 * lengths up to 16 (every divergent `if` costs this kernel four scalar instructions, and the scalar pipe is what
 	 * it saturates): bytes 0-3 and the last 4 always, bytes 4-7 and the 4 before the last 4 when the match has 8 or
-	 * more; the middle of the rare long one in 8-byte steps */
-	template <bool BYTES> static __device__ __forceinline__ void match(u8 *ring, u32 mpos, u32 ml, const u8 *sb, u32 so, u32 sm)
+	 * more; the middle of the rare long one in 8-byte steps.  match_st: the stores, given the first 8 bytes `a` and the 8
+	 * bytes `b` at offset tl = ml - 8 (ml - 4 for a match shorter than 8) */
+	template <bool BYTES> static __device__ __forceinline__ void match_st(u8 *ring, u32 mpos, u32 ml, u64 a, u64 b)
 	{
 		u8 *const d = ring + (mpos & MASK); /* a batch lies inside one lap: no wrap on the destination side */
 		const bool wide = ml >= 8u;
 		const u32 tl = wide ? ml - 8u : ml - 4u;
-		const u64 a = ld64m(sb, so, sm), b = ld64m(sb, so + tl, sm);
-		if (ml > 16u) {
-			for (u32 i = 8; i + 8 < ml; i += 8)
-				c3_st64(d + i, ld64m(sb, so + i, sm));
-		}
 		if (BYTES) { /* the pass most lanes take */
 			c3_st32b(d, (u32)a);
 			c3_st32b(d + ml - 4u, wide ? (u32)(b >> 32) : (u32)b);
@@ -250,6 +248,17 @@ template <u32 WIN, bool PROF = false> struct C3 {
 				st32u(d + tl, (u32)b);
 			}
 		}
+	}
+	template <bool BYTES> static __device__ __forceinline__ void match(u8 *ring, u32 mpos, u32 ml, const u8 *sb, u32 so, u32 sm)
+	{
+		u8 *const d = ring + (mpos & MASK);
+		const u32 tl = ml >= 8u ? ml - 8u : ml - 4u;
+		const u64 a = ld64m(sb, so, sm), b = ld64m(sb, so + tl, sm);
+		if (ml > 16u) {
+			for (u32 i = 8; i + 8 < ml; i += 8)
+				c3_st64(d + i, ld64m(sb, so + i, sm));
+		}
+		match_st<BYTES>(ring, mpos, ml, a, b);
 	}
 
 	static __device__ __forceinline__ void
@@ -315,19 +324,18 @@ template <u32 WIN, bool PROF = false> struct C3 {
 	do {                                                                                                       \
 		const u8 *g_ = src + (C0);                                                                         \
 		const u32 a_ = (u32)((size_t)g_ & 15u);                                                            \
-		c3_stage(cbuf + (BUF) * C3_CBUF, g_ - a_, cs - (C0) + a_ + 16u, lane);                             \
+		c3_stage(cbuf, g_ - a_, cs - (C0) + a_ + 16u, lane);                                               \
 	} while (0)
-			u32 t0 = 0, cbi = 0;
+			u32 t0 = 0;
 			u32 q_cur = C3_TOK(0), q2_cur = C3_TOK2(0);
 			if (ntok)
-				C3_STAGE(wv_readlane(q_cur, 0), cbi);
+				C3_STAGE(wv_readlane(q_cur, 0), 0);
 			while (t0 < ntok && stc == ST_OK) {
 				C3PC(1);
 				c3_wait_vm(); /* the stage and the token positions of this batch */
 				C3PC(0);
 				const u32 q = q_cur, q2 = q2_cur;
-				u8 *const cb = cbuf + cbi * C3_CBUF;
-				cbi ^= 1u;
+				u8 *const cb = cbuf;
 				if (PROF)
 					pc[PROF ? 12 : 0]++;
 				/* ---------- fields of up to 64 sequences, lane = sequence ----------
@@ -398,7 +406,7 @@ template <u32 WIN, bool PROF = false> struct C3 {
 		q_cur = C3_TOK(t0n);                                                                               \
 		q2_cur = C3_TOK2(t0n);                                                                             \
 		if (t0n < ntok)                                                                                    \
-			C3_STAGE(r < 64u ? wv_readlane(q, (int)(r & 63u)) : wv_readlane(q2, (int)(r & 1u)), cbi);    \
+			C3_STAGE(r < 64u ? wv_readlane(q, (int)(r & 63u)) : wv_readlane(q2, (int)(r & 1u)), 0);      \
 	} while (0)
 				if (n == 0) {
 					C3_ISSUE();
@@ -465,10 +473,8 @@ template <u32 WIN, bool PROF = false> struct C3 {
 						wv_sync();
 						C3PC(5);
 						if (anyfar) {
-							/* the literals are out of the stage: it now holds the fetched sources, 16 bytes per lane */
+							/* the fetched sources (16 bytes per lane) stay in registers until the first match round stores them */
 							if (is_far) {
-								*(u64 *)(cb + 16u * (u32)lane) = f0;
-								*(u64 *)(cb + 16u * (u32)lane + 8) = f1;
 								/* the rare long one: the rest straight from memory into the ring (complete, unordered) */
 								for (u32 i = 16; i < ml; i += 8) {
 									const u32 o = i + 8 <= ml ? i : ml - 8;
@@ -493,8 +499,24 @@ template <u32 WIN, bool PROF = false> struct C3 {
 #else
 							if (r1) {
 #endif
-								const u8 *const sb = is_far ? cb + 16u * (u32)lane : ring;
-								match<true>(ring, mpos, (is_far && ml > 16u) ? 16u : ml, sb, is_far ? 0u : src_pos, is_far ? ~0u : MASK);
+								/* one store sequence for both kinds; a source in the ring is read here (three aligned dwords
+								 * per 8 bytes), a fetched one is shifted out of its two registers */
+								const u32 mlc = (is_far && ml > 16u) ? 16u : ml;
+								const u32 tl = mlc >= 8u ? mlc - 8u : mlc - 4u;
+								u64 a = f0, b = f1;
+								if (is_far) {
+									const u32 sh = 8u * (tl & 7u);
+									b = tl >= 8u ? f1 : (f0 >> sh) | ((f1 << 1) << (63u - sh));
+								} else {
+									a = ld64m(ring, src_pos, MASK);
+									b = ld64m(ring, src_pos + tl, MASK);
+									if (ml > 16u) {
+										u8 *const d = ring + (mpos & MASK);
+										for (u32 i = 8; i + 8 < ml; i += 8)
+											c3_st64(d + i, ld64m(ring, src_pos + i, MASK));
+									}
+								}
+								match_st<true>(ring, mpos, mlc, a, b);
 								fin = true;
 							}
 						}
@@ -620,7 +642,7 @@ template <u32 WIN, bool PROF = false> struct C3 {
 	     const u32 *__restrict__ blk_olen,                                                                     \
 	     u32 *__restrict__ status EXTRA)                                                                        \
 	{                                                                                                          \
-		__shared__ __attribute__((aligned(16))) u8 lds[WINSZ + 16u + 2u * C3_CBUF];                        \
+		__shared__ __attribute__((aligned(16))) u8 lds[WINSZ + 16u + C3_CBUF];                             \
 		C3<WINSZ, PROFILE>::body(stream, stream_bytes, rec0, nrec, out_base, out_off, out_len, blk0,       \
 					 blk_coff, blk_csize, rec_nblk, rec_flags, tok, blk_ntok, blk_olen,       \
 					 status, lds, lds + WINSZ + 16u, PROFP);                                   \

@@ -1,0 +1,517 @@
+/*
+ * lz4_enc5.hip -- LZ4 frame encoder v5 (round 6): the bit-exact greedy parse of lz4_enc3.hip (reference call site
+ * /root/reference/lib/lz4-mt_compress.c:281), one memory round trip per 64-POSITION WINDOW
+ * instead of one per sequence.
+ *
+ * What lz4_enc3.hip's counters said (profiles/r05_sq_counters.json): a chunk-wave is one dependent chain -- ring
+ * read, hash, table read, the candidates' loads from memory, vote, table writes, extension, emit, ~360 instructions and
+ * ~4 500 cycles per sequence -- and the LDS table (8.5 KiB per chunk) caps the chains at 16 per CU.  Its probe batch fetches
+ * the candidates of the next 10 positions; a sequence of the bench text is 12 bytes long, 4.6 of them probed.
+ *
+ * Here a wave looks at 64 consecutive positions at once (lane j = position w0 + j): every lane hashes its position, reads
+ * the table AS IT IS AT THE WINDOW'S START and fetches its candidate's neighbourhood -- the same loads the probe batch made,
+ * one round trip -- and then the wave walks the reference's parse through the window in registers: the first lane at or
+ * behind the search's start whose candidate verifies is the match, its extension comes from the lane's own 24 + 24 bytes
+ * (lz4_enc3.hip's "quick" extension), the next search starts behind the match -- at a lane that already holds its
+ * candidate.  5.3 sequences per window on the bench text, for about the candidates per sequence the probe batches fetched
+ * (a window probes every position, the batches 10-11 per search).
+ *
+ * Exactness.  The reference reads T[h(p)] and writes T[h(p)] = p at every probed position p, in position order, and inserts
+ * ip - 2 behind every match; positions inside a match are neither read nor written.  A lane's table value is therefore
+ * right unless a position of the same window with the same hash was INSERTED before it is probed: a probe of the search
+ * in progress (all lanes from the search's start up to it) or a position committed by an earlier search of the window.
+ * `prev` = the nearest earlier lane with the same hash (exact: a folded LDS filter finds the lanes that may have one, a
+ * readlane loop over those settles it; most windows have none); a probe whose chain of `prev` reaches an inserted lane has
+ * that position as its candidate -- its four bytes are the other lane's own, one ds_bpermute -- and its extension goes the
+ * general way (input ring).  Table writes of a window are made at its end, later positions over earlier ones, so that a
+ * block that fails the output limit leaves exactly the insertions the reference made up to the failing sequence.  A
+ * search that runs out of the window goes on in the next one while its probes are consecutive positions (the reference's
+ * first 65 probes of a search); one that is still running behind that (incompressible data: skip acceleration) takes
+ * lz4_enc3.hip's probe batches with the exact step schedule.
+ */
+#include "lz4_enc_shared.h"
+
+#ifndef ENC5_TAIL
+#define ENC5_TAIL 12u /* a search that would start in the last ENC5_TAIL lanes of its window opens a new window instead */
+#endif
+#ifndef ENC5_KMAX
+#define ENC5_KMAX 8u /* a search that leaves its window goes on in a new window if its next probe is number <= ENC5_KMAX, else in probe batches */
+#endif
+#define E5_NONE 64u
+static_assert(BM_BITS >= 2048u, "two folded filters of 1024 bits");
+
+enum { E5_NEXT = 0, E5_LAST = 1, E5_DONE = 2, E5_FAIL = 3, E5_SLOW = 4 };
+
+/* the parse state of a block */
+struct Enc5St {
+	u32 ip, anchor, op, nsq;
+	Seq3 sq;
+};
+
+/* ---------------- extend the match both ways, then the sequence into the collecting registers (lz4_enc3.hip's code) ----
+ * in: st.ip = the position whose four bytes matched those at `match`; quick (bit 31) = catch-up and length settled by the
+ * probe's own loads.  out: st.ip = st.anchor = the position behind the match.  false: the block does not fit (stored raw) */
+template <int TM>
+static __device__ __forceinline__ bool e5_finish(Enc5St &st, InRing &R, u32 match, u32 quick, u32 low, u32 matchlimit,
+						  u32 cap, const u8 *chunk, u8 *dst, int lane)
+{
+	u32 ip = st.ip;
+	const u32 anchor = st.anchor;
+	u32 fwd; /* equal bytes following the 4 that matched at ip */
+	if (quick >> 31) {
+		const u32 back = (quick >> 8) & 0xFFu;
+		fwd = (quick & 0xFFu) + back;
+		ip -= back;
+		match -= back;
+	} else {
+		ring_want(R, ip, lane); /* [ip, ip + 68) resident */
+		mside_prepare(R, match, lane);
+		u32 room = ip - anchor;
+		if (match - low < room)
+			room = match - low;
+		const u32 nb = room < 64 ? room : 64;
+		const u32 flimit = matchlimit - (ip + MINMATCH);
+		bool eqb = false, stopf = true;
+		if ((u32)lane < nb) {
+			const u32 a = ip >= R.rlo + nb ? (u32)R.ring[(ip - 1 - (u32)lane) & (IRING - 1)] : in_ld8(R, ip - 1 - (u32)lane);
+			const u32 b = R.mbase == 0xFFFFFFFFu ? (u32)R.ring[(match - 1 - (u32)lane) & (IRING - 1)]
+				      : (nb <= 32 && match >= 32) ? (u32)R.mwin[match - 1 - (u32)lane - R.mbase]
+								  : m_ld8(R, match - 1 - (u32)lane);
+			eqb = a == b;
+		}
+		if ((u32)lane < flimit)
+			stopf = in_fwd8(R, ip + MINMATCH + (u32)lane) != m_fwd8(R, match + MINMATCH + (u32)lane);
+		const u64 neb = ~wv_ballot(eqb);
+		const u64 smf = wv_ballot(stopf);
+		u32 back = neb ? (u32)wv_ffs(neb) - 1 : 64;
+		if (back > nb)
+			back = nb;
+		fwd = smf ? (u32)wv_ffs(smf) - 1 : 64;
+		if (E_RARE(back == 64)) { /* rare: catch-up continues beyond 64 bytes */
+			u32 ip2 = ip - 64, m2 = match - 64;
+			for (;;) {
+				u32 r2 = ip2 - anchor;
+				if (m2 - low < r2)
+					r2 = m2 - low;
+				if (r2 == 0)
+					break;
+				const u32 n2 = r2 < 64 ? r2 : 64;
+				bool e2 = false;
+				if ((u32)lane < n2)
+					e2 = in_ld8(R, ip2 - 1 - (u32)lane) == m_ld8(R, m2 - 1 - (u32)lane);
+				const u64 ne2 = ~wv_ballot(e2);
+				u32 t2 = ne2 ? (u32)wv_ffs(ne2) - 1 : 64;
+				if (t2 > n2)
+					t2 = n2;
+				ip2 -= t2;
+				m2 -= t2;
+				back += t2;
+				if (t2 < 64)
+					break;
+			}
+		}
+		if (E_RARE(!smf)) { /* rare: the match runs on beyond 64 bytes */
+			u32 base = 64;
+			for (;;) {
+				ring_want(R, ip + MINMATCH + base, lane);
+				const u32 i2 = base + (u32)lane;
+				bool st2 = true;
+				if (i2 < flimit)
+					st2 = in_ld8(R, ip + MINMATCH + i2) != m_ld8(R, match + MINMATCH + i2);
+				const u64 sm2 = wv_ballot(st2);
+				if (sm2) {
+					fwd = base + (u32)wv_ffs(sm2) - 1;
+					break;
+				}
+				base += 64;
+			}
+		}
+		ip -= back;
+		match -= back;
+		fwd += back;
+	}
+	/* ---------------- the sequence: its place in the output, its numbers into the collecting registers ---------------- */
+	const u32 lit = ip - anchor, mc = fwd;
+	const u32 op = st.op;
+	u32 adv = lit + 3u;
+	if (E_RARE((lit | mc) >= 15u))
+		adv += (lit >= 15 ? (lit - 15) / 255 + 1 : 0u) + (mc >= 15 ? (mc - 15) / 255 + 1 : 0u);
+	/* the reference's two output-limit tests, one compare in the common case (lz4_enc3.hip) */
+	if (E_RARE(op + adv + 6u > cap)) {
+		const u32 o1 = op + 1u;
+		if (o1 + lit + (2 + 1 + LASTLITERALS) + lit / 255 > cap)
+			return false;
+		const u32 o2 = o1 + (lit >= 15 ? (lit - 15) / 255 + 1 : 0u) + lit;
+		if (o2 + 2 + (1 + LASTLITERALS) + (mc + 240) / 255 > cap)
+			return false;
+	}
+	st.op = op + adv;
+	{
+		const bool me = (u32)lane == (st.nsq & 63u);
+		st.sq.tok = me ? op : st.sq.tok;
+		st.sq.src = me ? anchor : st.sq.src;
+		st.sq.lit = me ? lit : st.sq.lit;
+		st.sq.mc = me ? mc : st.sq.mc;
+		st.sq.off = me ? ip - match : st.sq.off;
+	}
+	st.nsq++;
+	ip += mc + MINMATCH;
+	st.ip = ip;
+	st.anchor = ip;
+	if ((st.nsq & 63u) == 0)
+		seq3_flush(st.sq, 64, chunk, dst, lane);
+	return true;
+}
+
+/* ---------------- a search that has left the consecutive part of its schedule: probe batches of 64 (lz4_enc3.hip's loop
+ * without the quick extension).  Probe k of the search is at probe_pos3(ip0, k); kbase = the next probe's number.
+ * true: *ipm / *match = the first probe that verifies and its candidate (insertions up to it are committed);
+ * false: the search ran into the block's end (every valid probe is inserted) */
+template <int TM>
+static __device__ bool e5_search_batches(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, u32 ip0, u32 kbase, u32 mflimit_p1,
+					 bool second, u32 *ipm, u32 *match, int lane)
+{
+	const u8 *chunk = R.chunk;
+	for (;;) {
+		u32 gap = 1;
+		const u32 cur = probe_pos3(ip0, kbase + (u32)lane, &gap);
+		const bool valid = cur + gap <= mflimit_p1;
+		const u64 vm = wv_ballot(valid);
+		if (vm == 0)
+			return false;
+		ring_want(R, wv_readlane(cur, 0), lane);
+		const u64 x = valid ? in_ld64(R, cur) : 0;
+		const u32 h = hash3<TM>(TM == T_U16 ? (u64)(u32)x : x);
+		u32 cand = t_read<TM>(tlo, thi, h);
+		u32 prev_dup = 64, next_dup = 64;
+		u32 dold = 0;
+		if (valid)
+			dold = lds_or(&bitmap[(h & (BM_BITS - 1)) >> 5], 1u << (h & 31));
+		const bool any_dup = wv_any(((dold >> (h & 31)) & 1) != 0);
+		wv_sync();
+		if (valid)
+			bitmap[(h & (BM_BITS - 1)) >> 5] = 0;
+		if (any_dup) {
+			for (u32 i = 0; i < 64; i++) {
+				const u32 hi_ = wv_readlane(h, (int)i);
+				const bool vi = (vm >> i) & 1;
+				if (vi && valid && hi_ == h) {
+					if (i < (u32)lane)
+						prev_dup = i;
+					else if (i > (u32)lane && next_dup == 64)
+						next_dup = i;
+				}
+			}
+			const u32 pc = wv_shfl(cur, (int)(prev_dup & 63));
+			if (prev_dup < 64)
+				cand = pc;
+		}
+		const bool probe = valid && ((TM == T_U16) || cand + DIST_MAX >= cur);
+		const u32 v4 = ld32u(chunk + (probe ? cand : 0u));
+		const u64 mm = wv_ballot(probe && v4 == (u32)x);
+		if (mm) {
+			const u32 jstar = (u32)wv_ffs(mm) - 1;
+			if ((u32)lane <= jstar && !(next_dup <= jstar))
+				t_write<TM>(tlo, thi, h, cur, second);
+			wv_sync();
+			*ipm = wv_readlane(cur, (int)jstar);
+			*match = wv_readlane(cand, (int)jstar);
+			return true;
+		}
+		if (valid && next_dup == 64)
+			t_write<TM>(tlo, thi, h, cur, second);
+		wv_sync();
+		if ((u32)wv_popc(vm) < 64)
+			return false;
+		kbase += 64;
+	}
+}
+
+template <int TM, bool PROF>
+static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, u32 pos, u32 len, u8 *dst,
+				    u32 cap, int lane)
+{
+	const u8 *chunk = R.chunk;
+	const u32 iend = pos + len;
+	const u32 mflimit_p1 = iend - MFLIMIT + 1;
+	const u32 matchlimit = iend - LASTLITERALS;
+	const u32 low = (TM == T_U16) ? pos : 0;
+	const bool second = (pos >> 16) != 0; /* T_P17: the 17th bit of every position of this block */
+	Enc5St st;
+	st.ip = pos;
+	st.anchor = pos;
+	st.op = 0;
+	st.nsq = 0;
+	st.sq = Seq3{0, 0, 0, 0, 0};
+	u32 rmode = 0; /* 1: the next probe is the re-match probe at ip, behind T[h(ip - 2)] = ip - 2 */
+	u32 ip0;       /* position of probe 0 of the search in progress */
+
+	if (len < MFLIMIT + 1)
+		goto last_literals;
+
+	ring_want(R, st.ip, lane);
+	{
+		const u64 x = wv_readfirst((u32)in_ld64(R, st.ip)) | (u64)wv_readfirst((u32)(in_ld64(R, st.ip) >> 32)) << 32;
+		if (lane == 0)
+			t_write<TM>(tlo, thi, hash3<TM>(TM == T_U16 ? (u64)(u32)x : x), st.ip, second);
+	}
+	st.ip++;
+	ip0 = st.ip;
+
+	for (;;) {
+		/* ======================= one window: lane j = position w0 + j ======================= */
+		const u32 w0 = st.ip;
+		if (w0 >= mflimit_p1) /* not even the first probe is allowed: the block's last literals */
+			goto last_literals;
+		if (rmode)
+			ip0 = w0 + 1; /* lane 0 is the re-match probe, probe 0 of the search behind it is at w0 + 1 */
+		const u32 jend = mflimit_p1 - w0 < 64u ? mflimit_p1 - w0 : 64u; /* lanes whose position may be probed: cur + 1 <= mflimit_p1 */
+		const u32 cur = w0 + (u32)lane;
+		const bool pvalid = (u32)lane < jend;
+		ring_want(R, w0, lane);
+		/* the position's neighbourhood [cur - 8, cur + 16) from the input ring: seven aligned dwords + funnel shifts
+		 * (lz4_enc3.hip); [w0 - 256, w0 + 256) is resident */
+		u64 x, xb, x1;
+		{
+			const u32 pb = cur - 8;
+			const u32 *const w = (const u32 *)(R.ring + (pb & (IRING - 1) & ~3u));
+			const u32 w0_ = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6];
+			xb = (u64)wv_alignbyte(w1, w0_, pb) | (u64)wv_alignbyte(w2, w1, pb) << 32;
+			x = (u64)wv_alignbyte(w3, w2, pb) | (u64)wv_alignbyte(w4, w3, pb) << 32;
+			x1 = (u64)wv_alignbyte(w5, w4, pb) | (u64)wv_alignbyte(w6, w5, pb) << 32;
+		}
+		const u32 h = hash3<TM>(TM == T_U16 ? (u64)(u32)x : x);
+		if (rmode) {
+			/* T[h(w0 - 2)] = w0 - 2 precedes the re-match lookup; its eight bytes are the last two of xb and six of x */
+			const u64 x2 = (xb >> 48) | (x << 16);
+			const u32 h2 = hash3<TM>(TM == T_U16 ? (u64)(u32)x2 : x2);
+			if (lane == 0)
+				t_write<TM>(tlo, thi, h2, w0 - 2, second);
+		}
+		wv_sync();
+		const u32 cand0 = t_read<TM>(tlo, thi, h); /* the table at the window's start */
+		/* the candidate's neighbourhood [cand - 8, cand + 16) from memory, 16 + 8 bytes (lz4_enc3.hip); lanes without a
+		 * candidate read chunk[0, 16) */
+		const bool dist_ok = (TM == T_U16) || cand0 + DIST_MAX >= cur;
+		const bool probe = pvalid && dist_ok;
+		const bool wide = probe && cand0 >= 8;
+		u64 l0, l1, l2;
+		{
+			const u32 a0 = !probe ? 0u : wide ? cand0 - 8 : cand0;
+			const u8 *gp = chunk + a0;
+			ENC3_LD16(gp, l0, l1);
+			l2 = ld64u(wide ? gp + 16 : gp);
+		}
+		/* ---- positions of the window with the same hash: prev = the nearest earlier one (E5_NONE: none).  Two folded
+		 * filters of 1 024 bits find the lanes that may have a twin (a bit set twice), behind the loads like lz4_enc3.hip's
+		 * filter; the exact pass runs over those lanes only ---- */
+		u32 prev = E5_NONE;
+		u64 dmask = 0;
+		{
+			const u32 fw = (h & 1023u) >> 5, fb = 1u << (h & 31u);
+			u32 o1 = 0;
+			if (pvalid)
+				o1 = lds_or(&bitmap[fw], fb);
+			if (pvalid && (o1 & fb))
+				(void)lds_or(&bitmap[32 + fw], fb);
+			wv_sync();
+			const bool maybe = pvalid && (bitmap[32 + fw] & fb);
+			wv_sync();
+			if (pvalid) {
+				bitmap[fw] = 0;
+				bitmap[32 + fw] = 0;
+			}
+			u64 dm = wv_ballot(maybe);
+			if (E_RARE(dm != 0)) {
+				while (dm) {
+					const int i = wv_ffs(dm) - 1;
+					dm &= dm - 1;
+					const u32 hi_ = wv_readlane(h, i);
+					if (maybe && (u32)lane > (u32)i && h == hi_)
+						prev = (u32)i;
+				}
+				dmask = wv_ballot(prev != E5_NONE);
+			}
+		}
+		/* ---- every lane: does its candidate verify, and how far do the 12 bytes behind / the 8 in front agree ---- */
+		const u64 g0 = l0, g1 = wide ? l1 : l0, g2 = l2;
+		const bool ver0 = probe && (u32)g1 == (u32)x;
+		u32 eqf, eqb_raw;
+		bool qstat;
+		{
+			const u32 flimit = matchlimit - (cur + MINMATCH);
+			const u64 df = ((x >> 32) | (x1 << 32)) ^ ((g1 >> 32) | (g2 << 32));
+			const u32 d2 = (u32)(x1 >> 32) ^ (u32)(g2 >> 32);
+			const u32 fbits_lo = (u32)wv_ffs(df) - 1u;
+			const u32 fbits_hi = 64u + (u32)__builtin_ctzll((u64)d2 | 1ull << 32);
+			eqf = (fbits_lo < fbits_hi ? fbits_lo : fbits_hi) >> 3;
+			const bool fdec = eqf < 12u || flimit <= 12u;
+			if (eqf > flimit)
+				eqf = flimit;
+			const u64 db = xb ^ g0;
+			eqb_raw = ((u32)__builtin_clzll(db | 1ull) + (db == 0)) >> 3;
+			qstat = wide && cur >= 8 && fdec;
+		}
+		const u32 room_m = cand0 - low;
+
+		/* ======================= the reference's parse through the window ======================= */
+		u64 I = 0; /* lanes whose position the parse inserted */
+		u32 s = 0; /* lane of the search's next probe */
+		u32 wend = E5_NEXT;
+		for (;;) {
+			/* the lanes this search may probe: up to the block's end, and while its probes are consecutive positions
+			 * (probe k at ip0 + k for k <= 64) */
+			u32 lim = ip0 + 65u - w0;
+			if (lim > jend)
+				lim = jend;
+			const u64 range = (lim >= 64u ? ~0ull : (1ull << lim) - 1ull) & ~((1ull << s) - 1ull);
+			bool ver = ver0;
+			u32 q = E5_NONE;
+			if (E_RARE((dmask & range) != 0)) {
+				/* a probe sees the latest insertion of its hash: inside the window the nearest earlier position with the
+				 * same hash that was inserted -- a probe of this search (every lane from s on) or a committed one */
+				q = prev;
+				for (;;) {
+					const bool skip = q != E5_NONE && q < s && !((I >> q) & 1ull);
+					if (!wv_any(skip))
+						break;
+					const u32 pq = wv_shfl(prev, (int)(q & 63u));
+					if (skip)
+						q = pq;
+				}
+				const u32 xq = wv_shfl((u32)x, (int)(q & 63u));
+				if (q != E5_NONE)
+					ver = pvalid && (u32)x == xq; /* (less than 64 bytes back: always inside the distance limit) */
+			}
+			const u64 mm = wv_ballot(ver) & range;
+			if (mm == 0) {
+				I |= range; /* every probe of the range was made, and inserted */
+				if (lim < 64u && lim == jend) {
+					wend = E5_LAST; /* the search ran into the block's end */
+					break;
+				}
+				st.ip = w0 + lim; /* the search's next probe */
+				rmode = 0;
+				if (lim < 64u || st.ip - ip0 > ENC5_KMAX)
+					wend = E5_SLOW;
+				break;
+			}
+			const u32 m = (u32)wv_ffs(mm) - 1u;
+			I |= range & ((2ull << m) - 1ull);
+			u32 match, quick = 0;
+			const u32 qm = wv_readlane(q, (int)m);
+			if (E_RARE(qm != E5_NONE)) {
+				match = w0 + qm; /* a position of this window: the general extension reads it from the ring */
+			} else {
+				/* catch-up is bounded by the literals in front (anchor) and by the candidate's room */
+				const u32 room_ip = cur - st.anchor;
+				const u32 nb = room_ip < room_m ? room_ip : room_m;
+				const bool bdec = nb == 0 || eqb_raw < 8u || nb <= 8u;
+				const u32 eqb = eqb_raw > nb ? nb : eqb_raw;
+				const u32 qi = (qstat && bdec) ? 0x80000000u | eqb << 8 | eqf : 0u;
+				match = wv_readlane(cand0, (int)m);
+				quick = wv_readlane(qi, (int)m);
+			}
+			st.ip = w0 + m;
+			if (E_RARE(!e5_finish<TM>(st, R, match, quick, low, matchlimit, cap, chunk, dst, lane))) {
+				wend = E5_FAIL;
+				break;
+			}
+			if (E_RARE(st.ip >= mflimit_p1)) {
+				wend = E5_DONE;
+				break;
+			}
+			/* next: T[h(ip - 2)] = ip - 2, the re-match probe at ip, the search behind it */
+			rmode = 1;
+			if (st.ip + ENC5_TAIL > w0 + 64u)
+				break; /* a new window at ip (its set-up makes the insertion) */
+			s = st.ip - w0;
+			I |= 1ull << (s - 2u);
+			ip0 = st.ip + 1u;
+		}
+		/* ---- the window's insertions, later positions over earlier ones: lanes without an earlier twin first (no two of
+		 * them share an entry), then those with one, in order ---- */
+		{
+			const bool ins = (I >> lane) & 1ull;
+			if (ins && !((dmask >> lane) & 1ull))
+				t_write<TM>(tlo, thi, h, cur, second);
+			u64 t = dmask & I;
+			while (E_RARE(t != 0)) {
+				const int i = wv_ffs(t) - 1;
+				t &= t - 1;
+				wv_sync();
+				if (lane == i)
+					t_write<TM>(tlo, thi, h, cur, second);
+			}
+			wv_sync();
+		}
+		if (E_RARE(wend != E5_NEXT)) {
+			if (wend == E5_FAIL)
+				return 0;
+			if (wend == E5_LAST)
+				goto last_literals;
+			if (wend == E5_DONE)
+				goto block_done;
+			/* E5_SLOW: the search goes on in probe batches */
+			u32 ipm, match;
+			if (!e5_search_batches<TM>(tlo, thi, bitmap, R, ip0, st.ip - ip0, mflimit_p1, second, &ipm, &match, lane))
+				goto last_literals;
+			st.ip = ipm;
+			if (!e5_finish<TM>(st, R, match, 0u, low, matchlimit, cap, chunk, dst, lane))
+				return 0;
+			if (st.ip >= mflimit_p1)
+				goto block_done;
+			rmode = 1;
+		}
+	}
+block_done:
+last_literals:
+	if ((st.nsq & 63u) != 0) /* (a block that fails below is stored raw: writing what it had is harmless) */
+		seq3_flush(st.sq, st.nsq & 63u, chunk, dst, lane);
+	{
+		u32 op = st.op;
+		const u32 run = iend - st.anchor;
+		if (op + run + 1 + (run + 255 - 15) / 255 > cap)
+			return 0;
+		if (run >= 15) {
+			if (lane == 0)
+				dst[op] = 15 << 4;
+			op++;
+			op += put_len_ext3(dst + op, run - 15, lane);
+		} else {
+			if (lane == 0)
+				dst[op] = (u8)(run << 4);
+			op++;
+		}
+		copy_literals(R, dst + op, st.anchor, run, lane);
+		op += run;
+		return op;
+	}
+}
+
+struct Enc5 {
+	template <int TM, bool PROF>
+	static __device__ __forceinline__ u32 block(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, u32 pos, u32 len, u8 *dst, u32 cap, int lane)
+	{
+		return encode_block5<TM, PROF>(tlo, thi, bitmap, R, pos, len, dst, cap, lane);
+	}
+};
+
+#define ENC5_KERNEL(NAME, TM, TABBYTES)                                                           \
+	extern "C" __global__ void __launch_bounds__(64)                                            \
+	NAME(const u8 *__restrict__ in, u64 n, u32 chunk, u32 rec0, u32 nrec,                       \
+	     u8 *__restrict__ slots, u64 slot_stride, u32 *__restrict__ rec_len,                   \
+	     const u32 *__restrict__ chk, unsigned long long *prof)                                \
+	{                                                                                          \
+		__shared__ __attribute__((aligned(16))) u32 tlo[(TABBYTES) / 4];                   \
+		__shared__ u32 thi[128];                                                           \
+		__shared__ u32 bitmap[BM_BITS / 32];                                               \
+		__shared__ __attribute__((aligned(16))) u8 ring[IRING + IMIRROR];                  \
+		__shared__ __attribute__((aligned(16))) u8 mwin[MWIN + 16];                        \
+		enc_frame_body<TM, false, Enc5>(tlo, thi, bitmap, ring, mwin, in, n, chunk, rec0, nrec, slots, \
+			      slot_stride, rec_len, chk, prof);                                                     \
+	}
+
+ENC5_KERNEL(zmt_lz4_enc5_u16_kernel, T_U16, 16384)
+ENC5_KERNEL(zmt_lz4_enc5_p17_kernel, T_P17, 8192)
+ENC5_KERNEL(zmt_lz4_enc5_u32_kernel, T_U32, 16384)
