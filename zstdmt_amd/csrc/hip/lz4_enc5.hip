@@ -35,16 +35,27 @@
 #define ENC5_TAIL 12u /* a search that would start in the last ENC5_TAIL lanes of its window opens a new window instead */
 #endif
 #ifndef ENC5_KMAX
-#define ENC5_KMAX 8u /* a search that leaves its window goes on in a new window if its next probe is number <= ENC5_KMAX, else in probe batches */
+#define ENC5_KMAX 40u /* a search that leaves its window goes on in a new window if its next probe is number <= ENC5_KMAX, else in probe batches */
 #endif
 #define E5_NONE 64u
 static_assert(BM_BITS >= 2048u, "two folded filters of 1024 bits");
+
+#ifdef ZMT_EMU
+/* developer statistics of the emulator build (tools/emu_enc5_stats.py): lane 0 counts */
+extern "C" { unsigned long long zmt_e5_stat[16]; }
+#define E5_STAT(i, n) do { if (lane == 0) zmt_e5_stat[i] += (n); } while (0)
+#define E5_DBG(...) do { if (lane == 0 && getenv("E5_DBG")) fprintf(stderr, __VA_ARGS__); } while (0)
+#else
+#define E5_DBG(...) do { } while (0)
+#define E5_STAT(i, n) do { } while (0)
+#endif
 
 enum { E5_NEXT = 0, E5_LAST = 1, E5_DONE = 2, E5_FAIL = 3, E5_SLOW = 4 };
 
 /* the parse state of a block */
 struct Enc5St {
 	u32 ip, anchor, op, nsq;
+	u32 cbase; /* number of the sequence in lane 0 of the collecting registers: sequence n waits in lane n - cbase */
 	Seq3 sq;
 };
 
@@ -147,7 +158,7 @@ static __device__ __forceinline__ bool e5_finish(Enc5St &st, InRing &R, u32 matc
 	}
 	st.op = op + adv;
 	{
-		const bool me = (u32)lane == (st.nsq & 63u);
+		const bool me = (u32)lane == st.nsq - st.cbase;
 		st.sq.tok = me ? op : st.sq.tok;
 		st.sq.src = me ? anchor : st.sq.src;
 		st.sq.lit = me ? lit : st.sq.lit;
@@ -158,8 +169,10 @@ static __device__ __forceinline__ bool e5_finish(Enc5St &st, InRing &R, u32 matc
 	ip += mc + MINMATCH;
 	st.ip = ip;
 	st.anchor = ip;
-	if ((st.nsq & 63u) == 0)
+	if (st.nsq - st.cbase == 64u) {
 		seq3_flush(st.sq, 64, chunk, dst, lane);
+		st.cbase = st.nsq;
+	}
 	return true;
 }
 
@@ -242,6 +255,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 	st.anchor = pos;
 	st.op = 0;
 	st.nsq = 0;
+	st.cbase = 0;
 	st.sq = Seq3{0, 0, 0, 0, 0};
 	u32 rmode = 0; /* 1: the next probe is the re-match probe at ip, behind T[h(ip - 2)] = ip - 2 */
 	u32 ip0;       /* position of probe 0 of the search in progress */
@@ -265,6 +279,11 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			goto last_literals;
 		if (rmode)
 			ip0 = w0 + 1; /* lane 0 is the re-match probe, probe 0 of the search behind it is at w0 + 1 */
+		/* a window yields at most 16 sequences: room for them in the collecting registers */
+		if (st.nsq - st.cbase > 48u) {
+			seq3_flush(st.sq, st.nsq - st.cbase, chunk, dst, lane);
+			st.cbase = st.nsq;
+		}
 		const u32 jend = mflimit_p1 - w0 < 64u ? mflimit_p1 - w0 : 64u; /* lanes whose position may be probed: cur + 1 <= mflimit_p1 */
 		const u32 cur = w0 + (u32)lane;
 		const bool pvalid = (u32)lane < jend;
@@ -355,24 +374,167 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		const u32 room_m = cand0 - low;
 
 		/* ======================= the reference's parse through the window ======================= */
+		E5_STAT(0, 1);
+		E5_STAT(1, dmask != 0);
+		E5_DBG("window w0=%u rmode=%u ip0=%u anchor=%u dmask=%llx\n", w0, rmode, ip0, st.anchor, (unsigned long long)dmask);
+		/* twins (two of 64 positions share one of 4 096 table entries in half of all windows): what a lane's probe finds
+		 * when its twin was inserted before it -- the twin's position; does it verify? -- is settled here, once */
+		bool tver = false, deep = false;
+		if (dmask != 0) {
+			const u32 xp = wv_shfl((u32)x, (int)(prev & 63u));
+			const u32 pp = wv_shfl(prev, (int)(prev & 63u));
+			tver = prev != E5_NONE && pvalid && (u32)x == xp; /* (less than 64 bytes back: inside the distance limit) */
+			deep = wv_any(prev != E5_NONE && pp != E5_NONE);  /* three positions with one hash: the general walk below */
+		}
+		const u64 V0 = wv_ballot(ver0);
+		const u64 vmask = jend >= 64u ? ~0ull : (1ull << jend) - 1ull; /* lanes whose position may be probed */
+		/* the lanes the search in progress may probe: while its probes are consecutive positions (probe k at ip0 + k for
+		 * k <= 64); a search that starts inside the window ends behind the window */
+		u64 lmask = vmask;
+		if (E_RARE(ip0 + 65u - w0 < 64u))
+			lmask &= (1ull << (ip0 + 65u - w0)) - 1ull;
+		/* ---- the chain of easy sequences, every lane as the start of a search (ENC5_VEC): the search from lane t finds its
+		 * match at lane mt = the first verifying lane from t on, which ends at lane t_next = mt + 4 + (its forward count).
+		 * Easy = the match lane's own loads settle both extensions and no twin that might verify lies in [t, mt] (those
+		 * searches, and the ones whose match needs the general extension, go one at a time through the code below).  Once
+		 * per window: mt, the match lane's numbers (one ds_bpermute each), t_next ---- */
+		/* twins whose candidate depends on the parse: those that verify against their twin or against the table's entry;
+		 * with three positions of one hash in the window the twin compared here need not be the one that counts: all of them */
+		const u64 smask = deep ? dmask : wv_ballot(prev != E5_NONE && (tver || ver0));
+		u32 v_m, v_pk, v_cd;
+		bool v_none, v_twin;
+		{
+			const u64 vr = (V0 & vmask) >> (u32)lane;
+			const u64 sr = smask >> (u32)lane;
+			const u32 mrel = vr ? (u32)__builtin_ctzll(vr) : 64u;
+			const u32 srel = sr ? (u32)__builtin_ctzll(sr) : 64u;
+			v_none = mrel == 64u;
+			v_twin = srel <= mrel;
+			v_m = ((u32)lane + mrel) & 63u;
+			/* what a search start needs of its match lane: forward count | backward count << 4 | min(room of the candidate,
+			 * 9) << 8 | "settled by its own loads" << 12 */
+			const u32 pk = eqf | eqb_raw << 4 | (room_m < 9u ? room_m : 9u) << 8 | (qstat ? 1u << 12 : 0u);
+			v_pk = wv_shfl(pk, (int)v_m);
+			v_cd = wv_shfl(cand0, (int)v_m);
+		}
 		u64 I = 0; /* lanes whose position the parse inserted */
 		u32 s = 0; /* lane of the search's next probe */
 		u32 wend = E5_NEXT;
 		for (;;) {
-			/* the lanes this search may probe: up to the block's end, and while its probes are consecutive positions
-			 * (probe k at ip0 + k for k <= 64) */
-			u32 lim = ip0 + 65u - w0;
-			if (lim > jend)
-				lim = jend;
-			const u64 range = (lim >= 64u ? ~0ull : (1ull << lim) - 1ull) & ~((1ull << s) - 1ull);
-			bool ver = ver0;
+#ifndef ENC5_NOVEC
+			/* ================= a run of easy sequences from lane s on, lane-parallel ================= */
+			if (lmask == vmask) {
+				/* the sequence of the search from lane t: catch-up is bounded by the literals in front -- the block's
+				 * anchor for the run's first search, its own start for the others -- and by the candidate's room */
+				const u32 anchor_t = (u32)lane == s ? st.anchor : cur;
+				const u32 mpos = w0 + v_m;
+				const u32 room_ip = mpos - anchor_t;
+				const u32 r9 = (v_pk >> 8) & 15u;
+				const u32 nb = room_ip < r9 ? room_ip : r9;
+				const u32 ebr = (v_pk >> 4) & 15u;
+				const bool bdec = nb == 0 || ebr < 8u || nb <= 8u;
+				const u32 eqb = ebr > nb ? nb : ebr;
+				const u32 t_next = v_m + 4u + (v_pk & 15u);
+				const bool hard = v_twin || !((v_pk >> 12) & 1u) || !bdec;
+				/* next start | 0x100: no match in the window | 0x200: not easy | 0x400: the match ends the block */
+				const u32 code = t_next | (v_none ? 0x100u : 0u) | (hard ? 0x200u : 0u) | (w0 + t_next >= mflimit_p1 ? 0x400u : 0u);
+				u64 A = 0;
+				u32 t = s, tl = s, c = 0;
+				for (;;) {
+					c = wv_readlane(code, (int)t);
+					if (c & 0x300u)
+						break;
+					A |= 1ull << t;
+					tl = t;
+					t = c & 0xFFu;
+					if ((c & 0x400u) || t + ENC5_TAIL > 64u)
+						break;
+				}
+				if (A != 0) {
+					const bool inA = (A >> (u32)lane) & 1ull;
+					const u32 lit = mpos - eqb - anchor_t, mc = (v_pk & 15u) + eqb;
+					const u32 el = lit >= 15u ? (lit - 15u) / 255u + 1u : 0u;
+					const u32 adv = inA ? lit + 3u + el + (mc >= 15u ? 1u : 0u) : 0u;
+					const u32 incl = wv_scan_incl(adv);
+					const u32 opt = st.op + incl - adv;
+					/* the output limit: one compare per sequence covers both of the reference's tests (e5_finish); a run
+					 * with a sequence near the limit is left to the code below, one search at a time */
+					if (E_RARE(wv_any(inA && opt + adv + 6u > cap))) {
+						A = 0;
+					} else {
+						const u32 nseq = (u32)wv_popc(A);
+						/* into the collecting registers: the run's r-th sequence goes to lane (number - cbase); the lanes
+						 * that start a search say where they are (window bytes of the match side as scratch) */
+						if (inA)
+							R.mwin[wv_mbcnt(A)] = (u8)lane;
+						wv_sync();
+						const u32 rd = (u32)lane - (st.nsq - st.cbase);
+						const bool take = rd < nseq;
+						const int from = (int)R.mwin[take ? rd : 0u];
+						const u32 g_tl = wv_shfl(opt | lit << 16, from);
+						const u32 g_om = wv_shfl((mpos - v_cd) | mc << 16, from);
+						const u32 g_src = wv_shfl(anchor_t, from);
+						st.sq.tok = take ? g_tl & 0xFFFFu : st.sq.tok;
+						st.sq.lit = take ? g_tl >> 16 : st.sq.lit;
+						st.sq.off = take ? g_om & 0xFFFFu : st.sq.off;
+						st.sq.mc = take ? g_om >> 16 : st.sq.mc;
+						st.sq.src = take ? g_src : st.sq.src;
+						wv_sync();
+						st.op += wv_readlane(incl, 63);
+						st.nsq += nseq;
+						if (E_RARE(st.nsq - st.cbase == 64u)) {
+							seq3_flush(st.sq, 64, chunk, dst, lane);
+							st.cbase = st.nsq;
+						}
+						/* the run's insertions: every lane from a search's start to its match, and the position two
+						 * in front of every search start but the run's first (ip - 2 behind a match) */
+						{
+							const u64 upto = A & ((2ull << (u32)lane) - 1ull);
+							const u32 ts = 63u - (u32)__builtin_clzll(upto | 1ull); /* the last start at or in front of this lane */
+							const u32 mts = wv_shfl(v_m, (int)ts);
+							I |= wv_ballot(upto != 0 && (u32)lane <= mts);
+							I |= (A & ~(1ull << s)) >> 2;
+						}
+						/* behind the run's last match */
+						const u32 e_last = wv_readlane(t_next, (int)tl);
+						st.ip = w0 + e_last;
+						st.anchor = st.ip;
+						E5_STAT(10, nseq);
+						E5_DBG(" run s=%u A=%llx nseq=%u e_last=%u I=%llx\n", s, (unsigned long long)A, nseq, e_last, (unsigned long long)I);
+						if (E_RARE(st.ip >= mflimit_p1)) {
+							wend = E5_DONE;
+							break;
+						}
+						rmode = 1;
+						if (st.ip + ENC5_TAIL > w0 + 64u)
+							break; /* a new window at ip (its set-up makes the insertion of ip - 2) */
+						s = e_last;
+						I |= 1ull << (s - 2u);
+						ip0 = st.ip + 1u;
+					}
+				}
+			}
+#endif
+			/* ================= one search from lane s, the general way ================= */
+			const u64 range = lmask & ~((1ull << s) - 1ull);
+			u64 mm;
 			u32 q = E5_NONE;
-			if (E_RARE((dmask & range) != 0)) {
-				/* a probe sees the latest insertion of its hash: inside the window the nearest earlier position with the
-				 * same hash that was inserted -- a probe of this search (every lane from s on) or a committed one */
+			E5_STAT(2, 1);
+			if ((dmask & range) == 0) {
+				mm = V0 & range;
+			} else if (!deep) {
+				/* a probe sees the latest insertion of its hash: its twin's position if that was inserted -- a probe of this
+				 * search (every lane from s on) or a committed one -- else what the table held at the window's start */
+				E5_STAT(3, 1);
+				const bool pin = prev != E5_NONE && (prev >= s || ((I >> (prev & 63u)) & 1ull));
+				q = pin ? prev : E5_NONE;
+				mm = wv_ballot(pin ? tver : ver0) & range;
+			} else {
+				E5_STAT(9, 1);
+				/* chains of three and more: walk to the nearest earlier position with the same hash that was inserted */
 				q = prev;
 				for (;;) {
-					const bool skip = q != E5_NONE && q < s && !((I >> q) & 1ull);
+					const bool skip = q != E5_NONE && q < s && !((I >> (q & 63u)) & 1ull);
 					if (!wv_any(skip))
 						break;
 					const u32 pq = wv_shfl(prev, (int)(q & 63u));
@@ -380,16 +542,16 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						q = pq;
 				}
 				const u32 xq = wv_shfl((u32)x, (int)(q & 63u));
-				if (q != E5_NONE)
-					ver = pvalid && (u32)x == xq; /* (less than 64 bytes back: always inside the distance limit) */
+				mm = wv_ballot(q != E5_NONE ? (pvalid && (u32)x == xq) : ver0) & range;
 			}
-			const u64 mm = wv_ballot(ver) & range;
 			if (mm == 0) {
+				E5_STAT(8, 1);
 				I |= range; /* every probe of the range was made, and inserted */
-				if (lim < 64u && lim == jend) {
+				if (lmask == vmask && jend < 64u) {
 					wend = E5_LAST; /* the search ran into the block's end */
 					break;
 				}
+				const u32 lim = lmask == ~0ull ? 64u : (u32)wv_ffs(~lmask) - 1u;
 				st.ip = w0 + lim; /* the search's next probe */
 				rmode = 0;
 				if (lim < 64u || st.ip - ip0 > ENC5_KMAX)
@@ -401,6 +563,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			u32 match, quick = 0;
 			const u32 qm = wv_readlane(q, (int)m);
 			if (E_RARE(qm != E5_NONE)) {
+				E5_STAT(4, 1);
 				match = w0 + qm; /* a position of this window: the general extension reads it from the ring */
 			} else {
 				/* catch-up is bounded by the literals in front (anchor) and by the candidate's room */
@@ -412,6 +575,9 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				match = wv_readlane(cand0, (int)m);
 				quick = wv_readlane(qi, (int)m);
 			}
+			E5_STAT(5, 1);
+			E5_STAT(6, (quick >> 31) == 0);
+			E5_DBG(" serial s=%u m=%u qm=%u match=%u quick=%x I=%llx\n", s, m, qm, match, quick, (unsigned long long)I);
 			st.ip = w0 + m;
 			if (E_RARE(!e5_finish<TM>(st, R, match, quick, low, matchlimit, cap, chunk, dst, lane))) {
 				wend = E5_FAIL;
@@ -428,6 +594,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			s = st.ip - w0;
 			I |= 1ull << (s - 2u);
 			ip0 = st.ip + 1u;
+			lmask = vmask;
 		}
 		/* ---- the window's insertions, later positions over earlier ones: lanes without an earlier twin first (no two of
 		 * them share an entry), then those with one, in order ---- */
@@ -452,6 +619,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				goto last_literals;
 			if (wend == E5_DONE)
 				goto block_done;
+			E5_STAT(7, 1);
 			/* E5_SLOW: the search goes on in probe batches */
 			u32 ipm, match;
 			if (!e5_search_batches<TM>(tlo, thi, bitmap, R, ip0, st.ip - ip0, mflimit_p1, second, &ipm, &match, lane))
@@ -466,8 +634,8 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 	}
 block_done:
 last_literals:
-	if ((st.nsq & 63u) != 0) /* (a block that fails below is stored raw: writing what it had is harmless) */
-		seq3_flush(st.sq, st.nsq & 63u, chunk, dst, lane);
+	if (st.nsq != st.cbase) /* (a block that fails below is stored raw: writing what it had is harmless) */
+		seq3_flush(st.sq, st.nsq - st.cbase, chunk, dst, lane);
 	{
 		u32 op = st.op;
 		const u32 run = iend - st.anchor;
