@@ -16,6 +16,6 @@ for i in range(16): st[i] = 0
 got, _, _ = E.compress(data, 131072, 0)
 assert got == H.oracle_compress(data, 131072)
 names = ["windows", "windows with twins", "searches", "searches through the twin code", "winners with a window candidate",
-         "sequences from windows", "  of them by the general extension", "searches continued in probe batches", "searches that left their window", "searches through the chain walk", "sequences from lane-parallel runs"]
+         "sequences from windows", "  of them by the general extension", "searches continued in probe batches", "searches that left their window", "searches through the chain walk", "sequences from lane-parallel runs", "serial: forward or window undecided (!qstat)", "serial: backward undecided", "serial: no wide window"]
 for i, nm in enumerate(names): print("%-45s %10d" % (nm, st[i]))
 print("sequences per window %.2f, bytes per window %.1f" % (st[5] / st[0], n / st[0]))

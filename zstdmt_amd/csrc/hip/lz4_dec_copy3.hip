@@ -43,6 +43,7 @@
 #define C3_BLK_STORED 0x80000000u
 #define C3_XOUT 2048u /* most output bytes of one batch: two flush pieces of 1 KiB */
 #define C3_NEEDS_SERIAL 100u
+#define E_C3_RARE(c) __builtin_expect(!!(c), 0)
 
 #ifndef ZMT_EMU
 #define C3KT() (PROF ? (u64)clock64() : 0ull)
@@ -522,26 +523,31 @@ template <u32 WIN, bool PROF = false> struct C3 {
 						}
 						wv_sync();
 						C3PC(7);
-						for (;;) {
 #ifdef C3X_NO_ROUNDS
-							break;
+						if (false) {
+#else
+						/* (the set of unfinished matches is kept as the wave's mask: one ballot per round, of the lanes that
+						 * went, instead of the compiler's round trip through a register for every test of `fin`; overlapping
+						 * matches -- 0.2 % -- are looked for once per batch, not once per round) */
+						u64 unf = wv_ballot(!fin);
+						if (unf != 0) {
 #endif
-							const u64 unf = wv_ballot(!fin);
-							if (!unf)
-								break;
-							if (PROF)
-								pc[PROF ? 13 : 0]++;
-							const u32 first = (u32)wv_ffs(unf) - 1;
-							const u32 W = wv_readlane(mpos, (int)first);
-							const bool go = (!fin) & (src_pos + eff <= W);
-							if (go & (!ovl))
-								match<false>(ring, mpos, ml, ring, src_pos, MASK);
-							if (wv_any(go & ovl)) { /* (offset < length: 0.2 % of the matches) */
-								if (go & ovl)
-									match_ovl(ring, mpos, off, ml);
-							}
-							fin = fin | go;
-							wv_sync();
+							const bool any_ovl = wv_any(!fin && ovl);
+							do {
+								if (PROF)
+									pc[PROF ? 13 : 0]++;
+								const u32 W = wv_readlane(mpos, wv_ffs(unf) - 1);
+								const bool go = (!fin) & (src_pos + eff <= W);
+								if (go & (!ovl))
+									match<false>(ring, mpos, ml, ring, src_pos, MASK);
+								if (E_C3_RARE(any_ovl)) { /* (offset < length: 0.2 % of the matches) */
+									if (go & ovl)
+										match_ovl(ring, mpos, off, ml);
+								}
+								fin = fin | go;
+								unf &= ~wv_ballot(go);
+								wv_sync();
+							} while (unf != 0);
 						}
 						C3PC(8);
 						st.opos = o_end;

@@ -32,12 +32,13 @@
 #include "lz4_enc_shared.h"
 
 #ifndef ENC5_TAIL
-#define ENC5_TAIL 12u /* a search that would start in the last ENC5_TAIL lanes of its window opens a new window instead */
+#define ENC5_TAIL 6u /* a search that would start in the last ENC5_TAIL lanes of its window opens a new window instead */
 #endif
 #ifndef ENC5_KMAX
-#define ENC5_KMAX 40u /* a search that leaves its window goes on in a new window if its next probe is number <= ENC5_KMAX, else in probe batches */
+#define ENC5_KMAX 64u /* a search that leaves its window goes on in a new window if its next probe is number <= ENC5_KMAX, else in probe batches */
 #endif
 #define E5_NONE 64u
+#define E5_FWD 20u /* bytes behind a match's first four that a lane compares by itself */
 static_assert(BM_BITS >= 2048u, "two folded filters of 1024 bits");
 
 #ifdef ZMT_EMU
@@ -290,36 +291,38 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		ring_want(R, w0, lane);
 		/* the position's neighbourhood [cur - 8, cur + 16) from the input ring: seven aligned dwords + funnel shifts
 		 * (lz4_enc3.hip); [w0 - 256, w0 + 256) is resident */
-		u64 x, xb, x1;
+		u64 x, xb, x1, x2; /* [cur - 8, cur), [cur, cur + 8), [cur + 8, cur + 16), [cur + 16, cur + 24) */
 		{
 			const u32 pb = cur - 8;
-			const u32 *const w = (const u32 *)(R.ring + (pb & (IRING - 1) & ~3u));
-			const u32 w0_ = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6];
+			const u32 *const w = (const u32 *)(R.ring + (pb & (IRING - 1) & ~3u)); /* + 36 <= IRING + IMIRROR */
+			const u32 w0_ = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5], w6 = w[6], w7 = w[7], w8 = w[8];
 			xb = (u64)wv_alignbyte(w1, w0_, pb) | (u64)wv_alignbyte(w2, w1, pb) << 32;
 			x = (u64)wv_alignbyte(w3, w2, pb) | (u64)wv_alignbyte(w4, w3, pb) << 32;
 			x1 = (u64)wv_alignbyte(w5, w4, pb) | (u64)wv_alignbyte(w6, w5, pb) << 32;
+			x2 = (u64)wv_alignbyte(w7, w6, pb) | (u64)wv_alignbyte(w8, w7, pb) << 32;
 		}
 		const u32 h = hash3<TM>(TM == T_U16 ? (u64)(u32)x : x);
 		if (rmode) {
 			/* T[h(w0 - 2)] = w0 - 2 precedes the re-match lookup; its eight bytes are the last two of xb and six of x */
-			const u64 x2 = (xb >> 48) | (x << 16);
-			const u32 h2 = hash3<TM>(TM == T_U16 ? (u64)(u32)x2 : x2);
+			const u64 xm2 = (xb >> 48) | (x << 16);
+			const u32 h2 = hash3<TM>(TM == T_U16 ? (u64)(u32)xm2 : xm2);
 			if (lane == 0)
 				t_write<TM>(tlo, thi, h2, w0 - 2, second);
 		}
 		wv_sync();
 		const u32 cand0 = t_read<TM>(tlo, thi, h); /* the table at the window's start */
-		/* the candidate's neighbourhood [cand - 8, cand + 16) from memory, 16 + 8 bytes (lz4_enc3.hip); lanes without a
-		 * candidate read chunk[0, 16) */
+		/* the candidate's neighbourhood [cand - 8, cand + 24) from memory, 16 + 16 bytes (lz4_enc3.hip fetched 16 + 8: the same
+		 * two instructions and, seven times of eight, the same line; 20 bytes behind the match's first four settle 60 % of the
+		 * matches the 12 left open); lanes without a candidate read chunk[0, 16) */
 		const bool dist_ok = (TM == T_U16) || cand0 + DIST_MAX >= cur;
 		const bool probe = pvalid && dist_ok;
 		const bool wide = probe && cand0 >= 8;
-		u64 l0, l1, l2;
+		u64 l0, l1, l2, l3;
 		{
 			const u32 a0 = !probe ? 0u : wide ? cand0 - 8 : cand0;
 			const u8 *gp = chunk + a0;
 			ENC3_LD16(gp, l0, l1);
-			l2 = ld64u(wide ? gp + 16 : gp);
+			ENC3_LD16(wide ? gp + 16 : gp, l2, l3);
 		}
 		/* ---- positions of the window with the same hash: prev = the nearest earlier one (E5_NONE: none).  Two folded
 		 * filters of 1 024 bits find the lanes that may have a twin (a bit set twice), behind the loads like lz4_enc3.hip's
@@ -353,18 +356,19 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			}
 		}
 		/* ---- every lane: does its candidate verify, and how far do the 12 bytes behind / the 8 in front agree ---- */
-		const u64 g0 = l0, g1 = wide ? l1 : l0, g2 = l2;
+		const u64 g0 = l0, g1 = wide ? l1 : l0, g2 = l2, g3 = l3;
 		const bool ver0 = probe && (u32)g1 == (u32)x;
 		u32 eqf, eqb_raw;
 		bool qstat;
 		{
+			/* fwd: equal bytes behind the 4, E5_FWD = 20 looked at; back: equal bytes in front, 8 looked at.  Settled when a
+			 * difference (or the limit) lies inside them */
 			const u32 flimit = matchlimit - (cur + MINMATCH);
-			const u64 df = ((x >> 32) | (x1 << 32)) ^ ((g1 >> 32) | (g2 << 32));
-			const u32 d2 = (u32)(x1 >> 32) ^ (u32)(g2 >> 32);
-			const u32 fbits_lo = (u32)wv_ffs(df) - 1u;
-			const u32 fbits_hi = 64u + (u32)__builtin_ctzll((u64)d2 | 1ull << 32);
-			eqf = (fbits_lo < fbits_hi ? fbits_lo : fbits_hi) >> 3;
-			const bool fdec = eqf < 12u || flimit <= 12u;
+			const u32 da = (u32)(x >> 32) ^ (u32)(g1 >> 32);
+			const u64 db_ = x1 ^ g2, dc = x2 ^ g3;
+			const u32 ea = (u32)__builtin_ctz(da | 0x80000000u) >> 3; /* (the or keeps the count defined when da is 0: not used then) */
+			eqf = da ? ea : db_ ? 4u + ((u32)__builtin_ctzll(db_) >> 3) : dc ? 12u + ((u32)__builtin_ctzll(dc) >> 3) : E5_FWD;
+			const bool fdec = eqf < E5_FWD || flimit <= E5_FWD;
 			if (eqf > flimit)
 				eqf = flimit;
 			const u64 db = xb ^ g0;
@@ -411,9 +415,9 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			v_none = mrel == 64u;
 			v_twin = srel <= mrel;
 			v_m = ((u32)lane + mrel) & 63u;
-			/* what a search start needs of its match lane: forward count | backward count << 4 | min(room of the candidate,
-			 * 9) << 8 | "settled by its own loads" << 12 */
-			const u32 pk = eqf | eqb_raw << 4 | (room_m < 9u ? room_m : 9u) << 8 | (qstat ? 1u << 12 : 0u);
+			/* what a search start needs of its match lane: forward count (5 bits) | backward count << 5 | min(room of the
+			 * candidate, 9) << 9 | "settled by its own loads" << 13 */
+			const u32 pk = eqf | eqb_raw << 5 | (room_m < 9u ? room_m : 9u) << 9 | (qstat ? 1u << 13 : 0u);
 			v_pk = wv_shfl(pk, (int)v_m);
 			v_cd = wv_shfl(cand0, (int)v_m);
 		}
@@ -429,30 +433,30 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				const u32 anchor_t = (u32)lane == s ? st.anchor : cur;
 				const u32 mpos = w0 + v_m;
 				const u32 room_ip = mpos - anchor_t;
-				const u32 r9 = (v_pk >> 8) & 15u;
+				const u32 r9 = (v_pk >> 9) & 15u;
 				const u32 nb = room_ip < r9 ? room_ip : r9;
-				const u32 ebr = (v_pk >> 4) & 15u;
+				const u32 ebr = (v_pk >> 5) & 15u;
 				const bool bdec = nb == 0 || ebr < 8u || nb <= 8u;
 				const u32 eqb = ebr > nb ? nb : ebr;
-				const u32 t_next = v_m + 4u + (v_pk & 15u);
-				const bool hard = v_twin || !((v_pk >> 12) & 1u) || !bdec;
-				/* next start | 0x100: no match in the window | 0x200: not easy | 0x400: the match ends the block */
-				const u32 code = t_next | (v_none ? 0x100u : 0u) | (hard ? 0x200u : 0u) | (w0 + t_next >= mflimit_p1 ? 0x400u : 0u);
+				const u32 t_next = v_m + 4u + (v_pk & 31u);
+				const bool hard = v_twin || !((v_pk >> 13) & 1u) || !bdec;
+				/* next start | 0x100: the match ends the block | 0x200: no match in the window, or not easy */
+				const u32 code = t_next | (w0 + t_next >= mflimit_p1 ? 0x100u : 0u) | ((v_none || hard) ? 0x200u : 0u);
 				u64 A = 0;
-				u32 t = s, tl = s, c = 0;
+				u32 t = s, tl = s;
 				for (;;) {
-					c = wv_readlane(code, (int)t);
-					if (c & 0x300u)
+					const u32 c = wv_readlane(code, (int)t);
+					if (c >= 0x200u)
 						break;
 					A |= 1ull << t;
 					tl = t;
-					t = c & 0xFFu;
-					if ((c & 0x400u) || t + ENC5_TAIL > 64u)
+					t = c;
+					if (c + ENC5_TAIL > 64u) /* (the flag of a match that ends the block is above every lane number) */
 						break;
 				}
 				if (A != 0) {
 					const bool inA = (A >> (u32)lane) & 1ull;
-					const u32 lit = mpos - eqb - anchor_t, mc = (v_pk & 15u) + eqb;
+					const u32 lit = mpos - eqb - anchor_t, mc = (v_pk & 31u) + eqb;
 					const u32 el = lit >= 15u ? (lit - 15u) / 255u + 1u : 0u;
 					const u32 adv = inA ? lit + 3u + el + (mc >= 15u ? 1u : 0u) : 0u;
 					const u32 incl = wv_scan_incl(adv);
@@ -574,6 +578,15 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				const u32 qi = (qstat && bdec) ? 0x80000000u | eqb << 8 | eqf : 0u;
 				match = wv_readlane(cand0, (int)m);
 				quick = wv_readlane(qi, (int)m);
+#ifdef ZMT_EMU
+				{
+					const u32 s11 = wv_readlane((u32)(!qstat), (int)m), s12 = wv_readlane((u32)(qstat && !bdec), (int)m);
+					const u32 s13 = wv_readlane((u32)(!wide || cur < 8), (int)m);
+					E5_STAT(11, s11);
+					E5_STAT(12, s12);
+					E5_STAT(13, s13);
+				}
+#endif
 			}
 			E5_STAT(5, 1);
 			E5_STAT(6, (quick >> 31) == 0);
