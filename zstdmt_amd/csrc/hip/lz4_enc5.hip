@@ -331,26 +331,36 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		u64 dmask = 0;
 		{
 			const u32 fw = (h & 1023u) >> 5, fb = 1u << (h & 31u);
-			u32 o1 = 0;
-			if (pvalid)
-				o1 = lds_or(&bitmap[fw], fb);
-			if (pvalid && (o1 & fb))
-				(void)lds_or(&bitmap[32 + fw], fb);
-			wv_sync();
-			const bool maybe = pvalid && (bitmap[32 + fw] & fb);
-			wv_sync();
-			if (pvalid) {
-				bitmap[fw] = 0;
-				bitmap[32 + fw] = 0;
-			}
+			bool maybe;
+			/* (every lane of a window is a position that may be probed except at a block's end: the common case has no
+			 * exec-mask region around the filter's four steps) */
+#define E5_FILTER(PV)                                                                                              \
+	do {                                                                                                       \
+		u32 o1_ = 0;                                                                                       \
+		if (PV)                                                                                            \
+			o1_ = lds_or(&bitmap[fw], fb);                                                             \
+		if ((PV) && (o1_ & fb))                                                                            \
+			(void)lds_or(&bitmap[32 + fw], fb);                                                        \
+		wv_sync();                                                                                         \
+		maybe = (PV) && (bitmap[32 + fw] & fb);                                                            \
+		wv_sync();                                                                                         \
+		if (PV) {                                                                                          \
+			bitmap[fw] = 0;                                                                            \
+			bitmap[32 + fw] = 0;                                                                       \
+		}                                                                                                  \
+	} while (0)
+			if (E_RARE(jend < 64u))
+				E5_FILTER(pvalid);
+			else
+				E5_FILTER(true);
+#undef E5_FILTER
 			u64 dm = wv_ballot(maybe);
-			if (E_RARE(dm != 0)) {
+			if (dm != 0) { /* (two of three windows) */
 				while (dm) {
 					const int i = wv_ffs(dm) - 1;
 					dm &= dm - 1;
 					const u32 hi_ = wv_readlane(h, i);
-					if (maybe && (u32)lane > (u32)i && h == hi_)
-						prev = (u32)i;
+					prev = ((u32)lane > (u32)i && h == hi_) ? (u32)i : prev; /* (equal hashes share the filter's bit: both lanes are in dm) */
 				}
 				dmask = wv_ballot(prev != E5_NONE);
 			}
@@ -395,8 +405,9 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		/* the lanes the search in progress may probe: while its probes are consecutive positions (probe k at ip0 + k for
 		 * k <= 64); a search that starts inside the window ends behind the window */
 		u64 lmask = vmask;
-		if (E_RARE(ip0 + 65u - w0 < 64u))
-			lmask &= (1ull << (ip0 + 65u - w0)) - 1ull;
+		u32 klim = ip0 + 65u - w0;
+		if (E_RARE(klim < 64u))
+			lmask &= (1ull << klim) - 1ull;
 		/* ---- the chain of easy sequences, every lane as the start of a search (ENC5_VEC): the search from lane t finds its
 		 * match at lane mt = the first verifying lane from t on, which ends at lane t_next = mt + 4 + (its forward count).
 		 * Easy = the match lane's own loads settle both extensions and no twin that might verify lies in [t, mt] (those
@@ -427,7 +438,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		for (;;) {
 #ifndef ENC5_NOVEC
 			/* ================= a run of easy sequences from lane s on, lane-parallel ================= */
-			if (lmask == vmask) {
+			{
 				/* the sequence of the search from lane t: catch-up is bounded by the literals in front -- the block's
 				 * anchor for the run's first search, its own start for the others -- and by the candidate's room */
 				const u32 anchor_t = (u32)lane == s ? st.anchor : cur;
@@ -439,7 +450,9 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				const bool bdec = nb == 0 || ebr < 8u || nb <= 8u;
 				const u32 eqb = ebr > nb ? nb : ebr;
 				const u32 t_next = v_m + 4u + (v_pk & 31u);
-				const bool hard = v_twin || !((v_pk >> 13) & 1u) || !bdec;
+				/* (a search that began in front of the window must find its match while its probes are consecutive
+				 * positions: the lane behind them is klim, 64 and more for every other search) */
+				const bool hard = v_twin || !((v_pk >> 13) & 1u) || !bdec || ((u32)lane == s && v_m >= klim);
 				/* next start | 0x100: the match ends the block | 0x200: no match in the window, or not easy */
 				const u32 code = t_next | (w0 + t_next >= mflimit_p1 ? 0x100u : 0u) | ((v_none || hard) ? 0x200u : 0u);
 				u64 A = 0;
@@ -515,6 +528,8 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						s = e_last;
 						I |= 1ull << (s - 2u);
 						ip0 = st.ip + 1u;
+						lmask = vmask;
+						klim = 128u;
 					}
 				}
 			}
@@ -608,6 +623,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			I |= 1ull << (s - 2u);
 			ip0 = st.ip + 1u;
 			lmask = vmask;
+			klim = 128u;
 		}
 		/* ---- the window's insertions, later positions over earlier ones: lanes without an earlier twin first (no two of
 		 * them share an entry), then those with one, in order ---- */
