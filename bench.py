@@ -384,8 +384,10 @@ def bench_lz4_zstd(ctx, codec, gib_args=None, steps=None, warmup=None, cpu=True,
                      ms["k_lz4_dec"], alg, ("zmt_zstd_seq_kernel", "zmt_zstd_dec_small_kernel", "zmt_zstd_dec_kernel"))
     else:
         name, what = "lz4-mt", "lz4-mt -1"
-        ek = ("zmt_lz4_enc3_p17_kernel" if 65536 < chunk <= 131072 else
-              ("zmt_lz4_enc3_u16_kernel" if chunk <= 65536 else "zmt_lz4_enc3_u32_kernel"))
+        # (GPUMT_LZ4_ENC=3 selects round 5's probe-batch encoder, lz4_enc3.hip; the default is the window encoder, lz4_enc5.hip)
+        ev = "3" if os.environ.get("GPUMT_LZ4_ENC", "") == "3" else "5"
+        ek = (f"zmt_lz4_enc{ev}_p17_kernel" if 65536 < chunk <= 131072 else
+              (f"zmt_lz4_enc{ev}_u16_kernel" if chunk <= 65536 else f"zmt_lz4_enc{ev}_u32_kernel"))
         r_enc = None if dec_only else roof(ek, ms["k_lz4_enc"], alg, (ek,))
         k_parse = "zmt_dec_parse4_kernel"
         k_copy = "zmt_dec_copy3_w%d_kernel" % (1 << (args.lz4_ring - 10))

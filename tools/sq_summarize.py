@@ -8,7 +8,7 @@ from collections import defaultdict
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 go = os.path.join(root, "gpurun_out")
-KEEP = ("zmt_lz4_enc3_p17_kernel", "zmt_dec_parse3_kernel", "zmt_dec_parse4_kernel", "zmt_brotli_dec4_kernel", "zmt_dec_copy3_w4_kernel", "zmt_dec_copy3_w8_kernel", "zmt_dec_copy3_w16_kernel", "zmt_zstd_enc_kernel",
+KEEP = ("zmt_lz4_enc3_p17_kernel", "zmt_lz4_enc5_p17_kernel", "zmt_dec_parse3_kernel", "zmt_dec_parse4_kernel", "zmt_brotli_dec4_kernel", "zmt_dec_copy3_w4_kernel", "zmt_dec_copy3_w8_kernel", "zmt_dec_copy3_w16_kernel", "zmt_zstd_enc_kernel",
         "zmt_zstd_dec_small_kernel", "zmt_zstd_seq_kernel", "zmt_brotli_dec_kernel", "zmt_brotli_enc_kernel")
 out = {"_what": "rocprofv3 --pmc passes (tools/profile_sq.sh) over the bench commands, 8 GiB per launch; counter "
                 "values are summed over the device per launch, averaged over the launches of a run",

@@ -45,9 +45,7 @@ static_assert(BM_BITS >= 2048u, "two folded filters of 1024 bits");
 /* developer statistics of the emulator build (tools/emu_enc5_stats.py): lane 0 counts */
 extern "C" { unsigned long long zmt_e5_stat[16]; }
 #define E5_STAT(i, n) do { if (lane == 0) zmt_e5_stat[i] += (n); } while (0)
-#define E5_DBG(...) do { if (lane == 0 && getenv("E5_DBG")) fprintf(stderr, __VA_ARGS__); } while (0)
 #else
-#define E5_DBG(...) do { } while (0)
 #define E5_STAT(i, n) do { } while (0)
 #endif
 
@@ -390,7 +388,6 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		/* ======================= the reference's parse through the window ======================= */
 		E5_STAT(0, 1);
 		E5_STAT(1, dmask != 0);
-		E5_DBG("window w0=%u rmode=%u ip0=%u anchor=%u dmask=%llx\n", w0, rmode, ip0, st.anchor, (unsigned long long)dmask);
 		/* twins (two of 64 positions share one of 4 096 table entries in half of all windows): what a lane's probe finds
 		 * when its twin was inserted before it -- the twin's position; does it verify? -- is settled here, once */
 		bool tver = false, deep = false;
@@ -517,7 +514,6 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						st.ip = w0 + e_last;
 						st.anchor = st.ip;
 						E5_STAT(10, nseq);
-						E5_DBG(" run s=%u A=%llx nseq=%u e_last=%u I=%llx\n", s, (unsigned long long)A, nseq, e_last, (unsigned long long)I);
 						if (E_RARE(st.ip >= mflimit_p1)) {
 							wend = E5_DONE;
 							break;
@@ -605,7 +601,6 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			}
 			E5_STAT(5, 1);
 			E5_STAT(6, (quick >> 31) == 0);
-			E5_DBG(" serial s=%u m=%u qm=%u match=%u quick=%x I=%llx\n", s, m, qm, match, quick, (unsigned long long)I);
 			st.ip = w0 + m;
 			if (E_RARE(!e5_finish<TM>(st, R, match, quick, low, matchlimit, cap, chunk, dst, lane))) {
 				wend = E5_FAIL;
