@@ -46,6 +46,7 @@ struct HcState {
 	u16 *chain;
 	const u8 *src;
 	u32 next_to_update;
+	u32 *filter; /* 64 words of LDS: two folded bitmaps of the window scan (hc_win_build) */
 	/* levels 10..12: the price table of the optimal parser, one column per field */
 	int *o_price, *o_off, *o_mlen, *o_litlen;
 };
@@ -324,6 +325,194 @@ static __device__ __forceinline__ int hc_wider(HcState &H, u32 ip, u32 low_limit
 	return hc_wider_core(H, ip, low_limit, high_limit, longest, mpos, spos, max_attempts, max_attempts > 128, false, lane);
 }
 
+/* ---- the first search of a sequence, 64 positions at a time (levels 3..8; round 6) ------------------------------------
+ * LZ4HC_compress_hashChain looks for the next match with `ml = InsertAndFindBestMatch(ip); if (ml < MINMATCH) ip++;` -- 4.6
+ * searches per sequence of the bench text, each a chain walk of dependent memory round trips (insert + lookup, then one per
+ * candidate).  Unlike the fast levels' table, HC's tables do not depend on the parse: EVERY position is inserted, in order,
+ * before a later one is searched.  So what the search at position p returns -- longest = MINMATCH - 1, no backward extension --
+ * is a function of the data alone, and the searches of 64 consecutive positions can be made side by side, one per lane, against
+ * the tables as they are once every position in front of the window is inserted: the same hash head and chain links the serial
+ * search would follow, unless a position of the same window has the same hash (then the serial head would be that position:
+ * the lane is left to the serial search), the same candidates, the same "strictly longer wins".  A lane compares 28 bytes behind
+ * the first four by itself; a candidate that is equal throughout leaves the lane to the serial search too.  The results stay
+ * valid for the whole window whatever the lazy evaluation between two scans inserts (only positions of the window, never seen
+ * by a lane that has no twin), so one build serves the ~5 sequences of a window: 4 round trips per window where the serial scan
+ * took ~25 per sequence.  Levels 9..12 (pattern analysis, chain swap, the optimal parser) keep the serial search. */
+#define HCW_FWD 28u
+#define HCW_SLOTS 4 /* candidates of a position the window keeps for the wider searches (level 3 walks at most 4) */
+struct HcWin {
+	u32 w0;    /* first position (chunk-relative) of the window; HCW_NONE: no window */
+	u32 ml, ref; /* this lane's position: the search's result (ml >= MINMATCH: a match at chunk position ref) */
+	bool hard; /* the serial search decides (a twin in the window, or a candidate longer than the lane can count) */
+	/* the first HCW_SLOTS candidates of the position's chain whose four bytes equal the position's: chunk position (HCW_NONE:
+	 * the candidate in that place of the chain has other bytes, or the chain ended) and equal bytes behind the four */
+	u32 cm[HCW_SLOTS], cf[HCW_SLOTS];
+};
+#define HCW_NONE 0xFFFFFFFFu
+
+static __device__ void hc_win_build(HcState &H, HcWin &W, u32 ip, u32 mflimit, u32 matchlimit, int max_attempts, int lane)
+{
+	const u8 *const s = H.src;
+	u32 dummy_p, dummy_h;
+	hc_insert_lookup(H, ip + HC_BASE, &dummy_p, &dummy_h, lane); /* every position in front of the window is in the chains */
+	const u32 p = ip + (u32)lane;
+	const bool valid = p <= mflimit;
+	/* the position's 32 bytes and its table entry (invalid lanes read the window's first position: no exec-mask regions) */
+	const u8 *const own = s + (valid ? p : ip);
+	u64 o0, o1, o2, o3;
+	{
+		struct { u64 a, b; } q;
+		__builtin_memcpy(&q, own, 16);
+		o0 = q.a;
+		o1 = q.b;
+		__builtin_memcpy(&q, own + 16, 16);
+		o2 = q.a;
+		o3 = q.b;
+	}
+	const u32 pattern = (u32)o0;
+	const u32 hv = hc_hash(pattern);
+	u32 match_index = H.hash[hv];
+	/* twins: an earlier position of the window with the same hash would be the head of this position's chain */
+	bool twin = false;
+	{
+		const u32 fw = (hv & 1023u) >> 5, fb = 1u << (hv & 31u);
+		u32 o_ = 0;
+		if (valid)
+			o_ = atomicOr(&H.filter[fw], fb);
+		if (valid && (o_ & fb))
+			(void)atomicOr(&H.filter[32 + fw], fb);
+		wv_sync();
+		const bool maybe = valid && (H.filter[32 + fw] & fb);
+		wv_sync();
+		if (valid) {
+			H.filter[fw] = 0;
+			H.filter[32 + fw] = 0;
+		}
+		u64 dm = wv_ballot(maybe);
+		while (dm) {
+			const int i = wv_ffs(dm) - 1;
+			dm &= dm - 1;
+			const u32 hi_ = wv_readlane(hv, i);
+			twin = twin || ((u32)lane > (u32)i && hv == hi_);
+		}
+	}
+	const u32 p_index = p + HC_BASE;
+	const u32 lowest = (HC_BASE + HC_DIST_MAX + 1 > p_index) ? HC_BASE : p_index - HC_DIST_MAX;
+	const u32 limit = matchlimit - (p + HC_MINMATCH); /* (valid: p <= mflimit < matchlimit - 4) */
+	u32 longest = HC_MINMATCH - 1, ref = 0;
+	bool undecided = false;
+	int attempts = max_attempts;
+	bool active = valid && !twin;
+	for (int k = 0; k < HCW_SLOTS; k++) {
+		W.cm[k] = HCW_NONE;
+		W.cf[k] = 0;
+	}
+	for (int step = 0;; step++) {
+		active = active && match_index >= lowest && attempts > 0;
+		if (!wv_any(active))
+			break;
+		attempts--;
+		const u32 m = active ? match_index - HC_BASE : ip;
+		u64 c0, c1, c2, c3;
+		{
+			struct { u64 a, b; } q;
+			__builtin_memcpy(&q, s + m, 16);
+			c0 = q.a;
+			c1 = q.b;
+			__builtin_memcpy(&q, s + m + 16, 16);
+			c2 = q.a;
+			c3 = q.b;
+		}
+		const u32 delta = H.chain[(active ? match_index : HC_BASE) & (HC_MAXD - 1)];
+		if (active && (u32)c0 == pattern) {
+			/* equal bytes behind the four: 28 looked at */
+			const u32 da = (u32)(o0 >> 32) ^ (u32)(c0 >> 32);
+			const u64 db = o1 ^ c1, dc = o2 ^ c2, dd = o3 ^ c3;
+			u32 cnt = da   ? (u32)__builtin_ctz(da) >> 3
+				  : db ? 4u + ((u32)__builtin_ctzll(db) >> 3)
+				  : dc ? 12u + ((u32)__builtin_ctzll(dc) >> 3)
+				  : dd ? 20u + ((u32)__builtin_ctzll(dd) >> 3)
+				       : HCW_FWD;
+			if (cnt == HCW_FWD && limit > HCW_FWD)
+				undecided = true; /* runs on: its length is the serial search's to count */
+			if (cnt > limit)
+				cnt = limit;
+			const u32 ml = HC_MINMATCH + cnt;
+			if (ml > longest) {
+				longest = ml;
+				ref = m;
+			}
+			ZMT_UNROLL
+			for (int k = 0; k < HCW_SLOTS; k++) {
+				if (step == k) { /* (step is wave-uniform: one of the four pairs is written) */
+					W.cm[k] = m;
+					W.cf[k] = cnt;
+				}
+			}
+		}
+		match_index -= delta;
+	}
+	W.w0 = ip;
+	W.ml = valid ? longest : 0u;
+	W.ref = ref;
+	W.hard = valid && (twin || undecided);
+}
+
+/* a wider search (LZ4HC_InsertAndGetWiderMatch with longest = the match in hand, backward extension down to low_limit) from
+ * the window's record of its position q: the candidates are the lane's, their forward counts too; what is new is how far
+ * each reaches backwards -- at most q - low_limit bytes -- which 16 lanes per candidate compare in one round trip.  The
+ * reference's two-byte test in front of each candidate is implied whenever the candidate beats the length in hand (its bytes
+ * lie inside the forward part that is already known equal: q - low_limit is the length in hand minus 2 or 3), so the result
+ * is the first candidate with the greatest 4 + forward + backward above `longest`, as the serial walk's.  false: not
+ * available (no window over q, a lane the serial search decides, more than 16 bytes to look back, a level that walks more
+ * candidates than the window keeps) */
+static __device__ bool hc_wider_fast(const HcState &H, const HcWin &W, u32 q, u32 low_limit, u32 mflimit, int max_attempts,
+				     int *longest, u32 *mpos, u32 *spos, int lane)
+{
+	if (max_attempts > HCW_SLOTS || W.w0 == HCW_NONE || q < W.w0 || q >= W.w0 + 64u || q > mflimit)
+		return false;
+	const int j = (int)(q - W.w0);
+	const u32 look_back = q - low_limit;
+	if (look_back > 16u || wv_readlane((u32)W.hard, j))
+		return false;
+	const u8 *const s = H.src;
+	/* group g = lanes 16 g .. 16 g + 15 looks back from candidate g */
+	const u32 g = (u32)lane >> 4, i = (u32)lane & 15u;
+	u32 mg = HCW_NONE;
+	u32 m_[HCW_SLOTS], f_[HCW_SLOTS];
+	ZMT_UNROLL
+	for (int k = 0; k < HCW_SLOTS; k++) {
+		m_[k] = wv_readlane(W.cm[k], j);
+		f_[k] = wv_readlane(W.cf[k], j);
+		if (g == (u32)k)
+			mg = m_[k];
+	}
+	const u32 room = mg == HCW_NONE ? 0u : (look_back < mg ? look_back : mg);
+	bool eq = false;
+	if (i < room)
+		eq = s[q - 1 - i] == s[mg - 1 - i];
+	const u64 ne = ~wv_ballot(eq);
+	int best = *longest;
+	ZMT_UNROLL
+	for (int k = 0; k < HCW_SLOTS; k++) {
+		if (m_[k] == HCW_NONE)
+			continue;
+		const u32 sl = (u32)(ne >> (16 * k)) & 0xFFFFu;
+		u32 back = sl ? (u32)__builtin_ctz(sl) : 16u;
+		const u32 rk = look_back < m_[k] ? look_back : m_[k];
+		if (back > rk)
+			back = rk;
+		const int ml = (int)(HC_MINMATCH + f_[k] + back);
+		if (ml > best) {
+			best = ml;
+			*mpos = m_[k] - back;
+			*spos = q - back;
+		}
+	}
+	*longest = best;
+	return true;
+}
+
 /* LZ4HC_encodeSequence: 1 when the output limit is hit.  op / oend are offsets into dst. */
 static __device__ int hc_encode(const u8 *s, u8 *dst, u32 *ip, u32 *op, u32 *anchor, int ml, u32 mpos, u32 oend,
 				int lane)
@@ -386,25 +575,68 @@ static __device__ u32 hc_block(HcState &H, u32 start, u32 n, u8 *dst, u32 cap, i
 	int ml0, ml, ml2, ml3;
 	u32 start0, ref0, ref = 0, start2 = 0, ref2 = 0, start3 = 0, ref3 = 0;
 
+	HcWin W;
+	W.w0 = HCW_NONE;
+	W.ml = 0;
+	W.ref = 0;
+	W.hard = false;
+	for (int k = 0; k < HCW_SLOTS; k++) {
+		W.cm[k] = HCW_NONE;
+		W.cf[k] = 0;
+	}
+	const bool use_win = max_attempts <= 128; /* levels 3..8: no pattern analysis in the search */
+
+	/* the wider searches of the lazy evaluation walk the same chain as the first search of their position, with the same
+	 * attempts, and take a candidate only if its four bytes equal the position's: a position of the window whose lane met no
+	 * such candidate (and has no twin) has nothing to offer them either -- the search is skipped, its insertions are made by
+	 * the next one that runs (they do not depend on who asks) */
+#define HCW_NOTHING(Q)                                                                                             \
+	(use_win && W.w0 != HCW_NONE && (Q) >= W.w0 && (Q) < W.w0 + 64u && (Q) <= mflimit &&                        \
+	 wv_readlane((u32)(!W.hard && W.ml < HC_MINMATCH), (int)((Q) - W.w0)) != 0)
+
 	if (n < HC_MFLIMIT + 1)
 		goto last_literals;
 	while (ip <= mflimit) {
-		{
+		if (use_win && H.next_to_update <= ip + HC_BASE) {
+			/* the next position whose search returns a match: from the window's lanes; a lane that cannot tell asks the
+			 * serial search */
+			if (W.w0 == HCW_NONE || ip < W.w0 || ip >= W.w0 + 64u)
+				hc_win_build(H, W, ip, mflimit, matchlimit, max_attempts, lane);
+			const u64 cand = wv_ballot((W.hard || W.ml >= HC_MINMATCH) && W.w0 + (u32)lane >= ip);
+			if (cand == 0) {
+				ip = W.w0 + 64u;
+				continue;
+			}
+			const int j = wv_ffs(cand) - 1;
+			ip = W.w0 + (u32)j;
+			if (wv_readlane((u32)W.hard, j)) {
+				u32 dummy = ip;
+				ml = hc_wider(H, ip, ip, matchlimit, (int)HC_MINMATCH - 1, &ref, &dummy, max_attempts, lane);
+				if (ml < (int)HC_MINMATCH) {
+					ip++;
+					continue;
+				}
+			} else {
+				ml = (int)wv_readlane(W.ml, j);
+				ref = wv_readlane(W.ref, j);
+			}
+		} else {
 			u32 dummy = ip;
 			ml = hc_wider(H, ip, ip, matchlimit, (int)HC_MINMATCH - 1, &ref, &dummy, max_attempts, lane);
-		}
-		if (ml < (int)HC_MINMATCH) {
-			ip++;
-			continue;
+			if (ml < (int)HC_MINMATCH) {
+				ip++;
+				continue;
+			}
 		}
 		start0 = ip;
 		ref0 = ref;
 		ml0 = ml;
 search2:
-		if (ip + (u32)ml <= mflimit)
-			ml2 = hc_wider(H, ip + (u32)ml - 2, ip, matchlimit, ml, &ref2, &start2, max_attempts, lane);
-		else
-			ml2 = ml;
+		ml2 = ml;
+		if (ip + (u32)ml <= mflimit && !HCW_NOTHING(ip + (u32)ml - 2)) {
+			if (!use_win || !hc_wider_fast(H, W, ip + (u32)ml - 2, ip, mflimit, max_attempts, &ml2, &ref2, &start2, lane))
+				ml2 = hc_wider(H, ip + (u32)ml - 2, ip, matchlimit, ml, &ref2, &start2, max_attempts, lane);
+		}
 		if (ml2 == ml) {
 			if (hc_encode(s, dst, &ip, &op, &anchor, ml, ref, oend, lane))
 				return 0;
@@ -437,10 +669,11 @@ search3:
 				ml2 -= correction;
 			}
 		}
-		if (start2 + (u32)ml2 <= mflimit)
-			ml3 = hc_wider(H, start2 + (u32)ml2 - 3, start2, matchlimit, ml2, &ref3, &start3, max_attempts, lane);
-		else
-			ml3 = ml2;
+		ml3 = ml2;
+		if (start2 + (u32)ml2 <= mflimit && !HCW_NOTHING(start2 + (u32)ml2 - 3)) {
+			if (!use_win || !hc_wider_fast(H, W, start2 + (u32)ml2 - 3, start2, mflimit, max_attempts, &ml3, &ref3, &start3, lane))
+				ml3 = hc_wider(H, start2 + (u32)ml2 - 3, start2, matchlimit, ml2, &ref3, &start3, max_attempts, lane);
+		}
 		if (ml3 == ml2) {
 			if (start2 < ip + (u32)ml)
 				ml = (int)(start2 - ip);
@@ -505,6 +738,7 @@ search3:
 		ml2 = ml3;
 		goto search3;
 	}
+#undef HCW_NOTHING
 last_literals:
 	{
 		const u32 run = iend - anchor;
@@ -779,7 +1013,10 @@ zmt_lz4hc_enc_kernel(const u8 *__restrict__ in, u64 n, u32 chunk, u32 nrec, u8 *
 	const int max_attempts = level <= 9 ? 1 << (level - 1) : level == 10 ? 96 : level == 11 ? 512 : 16384;
 	const int sufficient_len = level == 10 ? 64 : level == 11 ? 128 : HC_OPT_NUM;
 	const int lane = wv_lane();
+	__shared__ u32 hc_filter[64];
 	HcState H;
+	hc_filter[lane] = 0;
+	H.filter = hc_filter;
 	H.hash = (u32 *)(scratch + (u64)blockIdx.x * HC_SCRATCH);
 	H.chain = (u16 *)(scratch + (u64)blockIdx.x * HC_SCRATCH + 32768u * 4u);
 	H.o_price = (int *)(scratch + (u64)blockIdx.x * HC_SCRATCH + 32768u * 4u + HC_MAXD * 2u);
