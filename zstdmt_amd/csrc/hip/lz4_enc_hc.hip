@@ -82,21 +82,39 @@ static __device__ void hc_insert_lookup(HcState &H, u32 target, u32 *pattern, u3
 		const u32 w = (act || probe) ? ld32u(H.src + (idx - HC_BASE)) : 0u;
 		const u32 hv = (act || probe) ? hc_hash(w) : 0x10000u + (u32)lane;
 		const u32 prev = (act || probe) ? H.hash[hv] : 0u;
-		/* lanes of the batch that share a hash: chained in lane order, the last inserting one owns the table */
-		const u64 actm = wv_ballot(act);
+		/* lanes of the batch that share a hash: chained in lane order, the last inserting one owns the table.  Two folded LDS
+		 * bitmaps find the lanes that may share one (a bit set twice), an exact pass runs over those -- two or three of a
+		 * batch, where a pass over every distinct hash took 64 rounds (round 6) */
 		u32 pred = 64;
 		bool last = true;
-		u64 todo = wv_ballot(act || probe);
-		while (todo) {
-			const int f = wv_ffs(todo) - 1;
-			const u32 hvf = wv_readlane(hv, f);
-			const u64 same = wv_ballot((act || probe) && hv == hvf);
-			if ((act || probe) && hv == hvf) {
-				const u64 below = same & actm & ((1ull << lane) - 1ull);
-				pred = below ? 63u - (u32)__builtin_clzll(below) : 64u;
-				last = (lane == 63) || (((same & actm) >> (lane + 1)) == 0);
+		{
+			const bool in = act || probe;
+			const u32 fw = (hv & 1023u) >> 5, fb = 1u << (hv & 31u);
+			u32 o_ = 0;
+			if (in)
+				o_ = atomicOr(&H.filter[fw], fb);
+			if (in && (o_ & fb))
+				(void)atomicOr(&H.filter[32 + fw], fb);
+			wv_sync();
+			const bool maybe = in && (H.filter[32 + fw] & fb);
+			wv_sync();
+			if (in) {
+				H.filter[fw] = 0;
+				H.filter[32 + fw] = 0;
 			}
-			todo &= ~same;
+			u64 dm = wv_ballot(maybe);
+			while (dm) {
+				const int f = wv_ffs(dm) - 1;
+				dm &= dm - 1;
+				const u32 hvf = wv_readlane(hv, f);
+				const bool f_act = (wv_ballot(act) >> f) & 1ull; /* (the lookup's lane chains nothing behind it) */
+				const bool same = in && hv == hvf;
+				if (same && (u32)lane > (u32)f && f_act)
+					pred = (u32)f; /* ascending passes: the nearest earlier inserting lane stays */
+				const u64 later = wv_ballot(same && act && (u32)lane > (u32)f);
+				if (lane == f && later != 0)
+					last = false;
+			}
 		}
 		const u32 from = pred < 64u ? base + pred : prev;
 		if (act) {
@@ -339,6 +357,13 @@ static __device__ __forceinline__ int hc_wider(HcState &H, u32 ip, u32 low_limit
  * by a lane that has no twin), so one build serves the ~5 sequences of a window: 4 round trips per window where the serial scan
  * took ~25 per sequence.  Levels 9..12 (pattern analysis, chain swap, the optimal parser) keep the serial search. */
 #define HCW_FWD 28u
+#ifdef ZMT_EMU
+/* developer statistics of the emulator build (tools/emu_hc_stats.py): lane 0 counts */
+extern "C" { unsigned long long zmt_hc_stat[16]; }
+#define HC_STAT(i) do { if (lane == 0) zmt_hc_stat[i]++; } while (0)
+#else
+#define HC_STAT(i) do { } while (0)
+#endif
 #define HCW_SLOTS 4 /* candidates of a position the window keeps for the wider searches (level 3 walks at most 4) */
 struct HcWin {
 	u32 w0;    /* first position (chunk-relative) of the window; HCW_NONE: no window */
@@ -354,6 +379,7 @@ static __device__ void hc_win_build(HcState &H, HcWin &W, u32 ip, u32 mflimit, u
 {
 	const u8 *const s = H.src;
 	u32 dummy_p, dummy_h;
+	HC_STAT(0);
 	hc_insert_lookup(H, ip + HC_BASE, &dummy_p, &dummy_h, lane); /* every position in front of the window is in the chains */
 	const u32 p = ip + (u32)lane;
 	const bool valid = p <= mflimit;
@@ -372,8 +398,11 @@ static __device__ void hc_win_build(HcState &H, HcWin &W, u32 ip, u32 mflimit, u
 	const u32 pattern = (u32)o0;
 	const u32 hv = hc_hash(pattern);
 	u32 match_index = H.hash[hv];
-	/* twins: an earlier position of the window with the same hash would be the head of this position's chain */
-	bool twin = false;
+	/* twins: an earlier position of the window with the same hash is the head of this position's chain when its turn comes
+	 * (every position in front of it is inserted by then), and that position's own head follows it: the link the insertion
+	 * would write.  prev = the nearest earlier lane with this lane's hash (two folded LDS bitmaps find the lanes that may
+	 * have one, an exact pass over those settles it) */
+	u32 prev = 64u;
 	{
 		const u32 fw = (hv & 1023u) >> 5, fb = 1u << (hv & 31u);
 		u32 o_ = 0;
@@ -393,16 +422,22 @@ static __device__ void hc_win_build(HcState &H, HcWin &W, u32 ip, u32 mflimit, u
 			const int i = wv_ffs(dm) - 1;
 			dm &= dm - 1;
 			const u32 hi_ = wv_readlane(hv, i);
-			twin = twin || ((u32)lane > (u32)i && hv == hi_);
+			prev = ((u32)lane > (u32)i && hv == hi_) ? (u32)i : prev;
 		}
 	}
+	const bool twin = prev != 64u;
+	if (twin)
+		match_index = ip + prev + HC_BASE;
+	/* (a chain link is a 16-bit distance: a head farther back than that is out of reach either way) */
+	const u32 head0 = match_index;
+	const bool any_twin = wv_any(twin);
 	const u32 p_index = p + HC_BASE;
 	const u32 lowest = (HC_BASE + HC_DIST_MAX + 1 > p_index) ? HC_BASE : p_index - HC_DIST_MAX;
 	const u32 limit = matchlimit - (p + HC_MINMATCH); /* (valid: p <= mflimit < matchlimit - 4) */
 	u32 longest = HC_MINMATCH - 1, ref = 0;
 	bool undecided = false;
 	int attempts = max_attempts;
-	bool active = valid && !twin;
+	bool active = valid;
 	for (int k = 0; k < HCW_SLOTS; k++) {
 		W.cm[k] = HCW_NONE;
 		W.cf[k] = 0;
@@ -450,12 +485,20 @@ static __device__ void hc_win_build(HcState &H, HcWin &W, u32 ip, u32 mflimit, u
 				}
 			}
 		}
-		match_index -= delta;
+		/* the link behind a position of the window is not in the table yet: it leads to that position's head */
+		u32 next = match_index - delta;
+		if (any_twin) {
+			const bool inwin = active && match_index >= ip + HC_BASE;
+			const u32 hw = wv_shfl(head0, (int)((match_index - ip - HC_BASE) & 63u));
+			if (inwin)
+				next = hw;
+		}
+		match_index = next;
 	}
 	W.w0 = ip;
 	W.ml = valid ? longest : 0u;
 	W.ref = ref;
-	W.hard = valid && (twin || undecided);
+	W.hard = valid && undecided;
 }
 
 /* a wider search (LZ4HC_InsertAndGetWiderMatch with longest = the match in hand, backward extension down to low_limit) from
@@ -466,39 +509,50 @@ static __device__ void hc_win_build(HcState &H, HcWin &W, u32 ip, u32 mflimit, u
  * is the first candidate with the greatest 4 + forward + backward above `longest`, as the serial walk's.  false: not
  * available (no window over q, a lane the serial search decides, more than 16 bytes to look back, a level that walks more
  * candidates than the window keeps) */
-static __device__ bool hc_wider_fast(const HcState &H, const HcWin &W, u32 q, u32 low_limit, u32 mflimit, int max_attempts,
+static __device__ bool hc_wider_fast(HcState &H, HcWin &W, u32 q, u32 low_limit, u32 mflimit, u32 matchlimit, int max_attempts,
 				     int *longest, u32 *mpos, u32 *spos, int lane)
 {
-	if (max_attempts > HCW_SLOTS || W.w0 == HCW_NONE || q < W.w0 || q >= W.w0 + 64u || q > mflimit)
+	if (max_attempts > HCW_SLOTS || q > mflimit)
 		return false;
+	if (W.w0 == HCW_NONE || q < W.w0 || q >= W.w0 + 64u) {
+		/* the match in hand runs out of the window: the next window now, from q on (the positions in front of q lie inside
+		 * the match: no first search will ask for them, and their insertion does not depend on who asks) */
+		if (q < W.w0 || H.next_to_update > q + HC_BASE) {
+			HC_STAT(4);
+			return false;
+		}
+		hc_win_build(H, W, q, mflimit, matchlimit, max_attempts, lane);
+	}
 	const int j = (int)(q - W.w0);
 	const u32 look_back = q - low_limit;
-	if (look_back > 16u || wv_readlane((u32)W.hard, j))
+	if (look_back > 32u || wv_readlane((u32)W.hard, j)) {
+		HC_STAT(look_back > 32u ? 5 : 6);
 		return false;
+	}
+	HC_STAT(3);
 	const u8 *const s = H.src;
-	/* group g = lanes 16 g .. 16 g + 15 looks back from candidate g */
-	const u32 g = (u32)lane >> 4, i = (u32)lane & 15u;
-	u32 mg = HCW_NONE;
+	/* half a wave looks back from one candidate: candidates 0 and 1, then 2 and 3 -- all four byte pairs are requested before
+	 * the first is looked at: one round trip */
+	const u32 g = (u32)lane >> 5, i = (u32)lane & 31u;
 	u32 m_[HCW_SLOTS], f_[HCW_SLOTS];
 	ZMT_UNROLL
 	for (int k = 0; k < HCW_SLOTS; k++) {
 		m_[k] = wv_readlane(W.cm[k], j);
 		f_[k] = wv_readlane(W.cf[k], j);
-		if (g == (u32)k)
-			mg = m_[k];
 	}
-	const u32 room = mg == HCW_NONE ? 0u : (look_back < mg ? look_back : mg);
-	bool eq = false;
-	if (i < room)
-		eq = s[q - 1 - i] == s[mg - 1 - i];
-	const u64 ne = ~wv_ballot(eq);
+	const u32 ma = g ? m_[1] : m_[0], mb = g ? m_[3] : m_[2];
+	const u32 ra = ma == HCW_NONE ? 0u : (look_back < ma ? look_back : ma);
+	const u32 rb = mb == HCW_NONE ? 0u : (look_back < mb ? look_back : mb);
+	const u32 own = (i < ra || i < rb) ? (u32)s[q - 1 - i] : 0u;
+	const u32 ca = i < ra ? (u32)s[ma - 1 - i] : 0x100u, cb = i < rb ? (u32)s[mb - 1 - i] : 0x100u;
+	const u64 nea = ~wv_ballot(own == ca), neb = ~wv_ballot(own == cb);
 	int best = *longest;
 	ZMT_UNROLL
 	for (int k = 0; k < HCW_SLOTS; k++) {
 		if (m_[k] == HCW_NONE)
 			continue;
-		const u32 sl = (u32)(ne >> (16 * k)) & 0xFFFFu;
-		u32 back = sl ? (u32)__builtin_ctz(sl) : 16u;
+		const u32 sl = (u32)((k < 2 ? nea : neb) >> (32 * (k & 1)));
+		u32 back = sl ? (u32)__builtin_ctz(sl) : 32u;
 		const u32 rk = look_back < m_[k] ? look_back : m_[k];
 		if (back > rk)
 			back = rk;
@@ -610,6 +664,7 @@ static __device__ u32 hc_block(HcState &H, u32 start, u32 n, u8 *dst, u32 cap, i
 			const int j = wv_ffs(cand) - 1;
 			ip = W.w0 + (u32)j;
 			if (wv_readlane((u32)W.hard, j)) {
+				HC_STAT(2);
 				u32 dummy = ip;
 				ml = hc_wider(H, ip, ip, matchlimit, (int)HC_MINMATCH - 1, &ref, &dummy, max_attempts, lane);
 				if (ml < (int)HC_MINMATCH) {
@@ -628,13 +683,14 @@ static __device__ u32 hc_block(HcState &H, u32 start, u32 n, u8 *dst, u32 cap, i
 				continue;
 			}
 		}
+		HC_STAT(1);
 		start0 = ip;
 		ref0 = ref;
 		ml0 = ml;
 search2:
 		ml2 = ml;
 		if (ip + (u32)ml <= mflimit && !HCW_NOTHING(ip + (u32)ml - 2)) {
-			if (!use_win || !hc_wider_fast(H, W, ip + (u32)ml - 2, ip, mflimit, max_attempts, &ml2, &ref2, &start2, lane))
+			if (!use_win || !hc_wider_fast(H, W, ip + (u32)ml - 2, ip, mflimit, matchlimit, max_attempts, &ml2, &ref2, &start2, lane))
 				ml2 = hc_wider(H, ip + (u32)ml - 2, ip, matchlimit, ml, &ref2, &start2, max_attempts, lane);
 		}
 		if (ml2 == ml) {
@@ -671,7 +727,7 @@ search3:
 		}
 		ml3 = ml2;
 		if (start2 + (u32)ml2 <= mflimit && !HCW_NOTHING(start2 + (u32)ml2 - 3)) {
-			if (!use_win || !hc_wider_fast(H, W, start2 + (u32)ml2 - 3, start2, mflimit, max_attempts, &ml3, &ref3, &start3, lane))
+			if (!use_win || !hc_wider_fast(H, W, start2 + (u32)ml2 - 3, start2, mflimit, matchlimit, max_attempts, &ml3, &ref3, &start3, lane))
 				ml3 = hc_wider(H, start2 + (u32)ml2 - 3, start2, matchlimit, ml2, &ref3, &start3, max_attempts, lane);
 		}
 		if (ml3 == ml2) {
