@@ -579,10 +579,12 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 				const bool la = todo != 0;
 				B4_ENSURE(la, 12u);
 				const bool two = todo >= 2u;
-				const u32 e0 = la ? (u32)tab_lit[(u32)acc & 255u] : 0x1000u;
+				/* (both table reads unconditional -- a group without literals left reads an entry it does not use -- and the
+				 * pair stored by the group's first two lanes in one instruction: no exec-mask region on the pass's chain) */
+				const u32 e0 = (u32)tab_lit[(u32)acc & 255u];
 				const u32 l0 = ((e0 >> 12) - 1u) & 15u;
-				const u32 e1 = two ? (u32)tab_lit[(u32)(acc >> l0) & 255u] : 0x1000u;
-				if (wv_any(la && ((e0 >> 12) == 0 || (e1 >> 12) == 0))) {
+				const u32 e1 = (u32)tab_lit[(u32)(acc >> l0) & 255u];
+				if (wv_any(la && ((e0 >> 12) == 0 || (two && (e1 >> 12) == 0)))) {
 					u32 sym;
 					B4_SYMBOL(la, tab_lit, lit_rec, lva, lvi, false, sym);
 					if (la) {
@@ -594,13 +596,10 @@ zmt_brotli_dec4_kernel(const u8 *__restrict__ stream, const u64 *__restrict__ re
 							todo = 0;
 					}
 				} else if (la) {
-					const u32 l1 = (e1 >> 12) - 1u; /* 0 bits when there is no second one */
-					if (l16 == 0) {
-						out[pos] = (u8)e0;
-						if (two)
-							out[pos + 1] = (u8)e1;
-					}
 					const u32 adv = two ? 2u : 1u;
+					const u32 l1 = two ? (e1 >> 12) - 1u : 0u;
+					if (l16 < adv)
+						out[pos + l16] = (u8)(l16 ? e1 : e0);
 					pos += adv;
 					todo -= adv;
 					B4_CONSUME(l0 + l1);

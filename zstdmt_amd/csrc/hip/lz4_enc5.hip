@@ -1,33 +1,48 @@
 /*
- * lz4_enc5.hip -- LZ4 frame encoder v5 (round 6): the bit-exact greedy parse of lz4_enc3.hip (reference call site
- * /root/reference/lib/lz4-mt_compress.c:281), one memory round trip per 64-POSITION WINDOW
- * instead of one per sequence.
+ * lz4_enc5.hip -- LZ4 frame encoder v5 (round 6, the default for levels 1-2): the bit-exact greedy parse of lz4_enc3.hip
+ * (reference call site /root/reference/lib/lz4-mt_compress.c:281), one memory round trip per
+ * 64-POSITION WINDOW instead of one per sequence, and the parse through a window in vector code.
  *
- * What lz4_enc3.hip's counters said (profiles/r05_sq_counters.json): a chunk-wave is one dependent chain -- ring
- * read, hash, table read, the candidates' loads from memory, vote, table writes, extension, emit, ~360 instructions and
- * ~4 500 cycles per sequence -- and the LDS table (8.5 KiB per chunk) caps the chains at 16 per CU.  Its probe batch fetches
- * the candidates of the next 10 positions; a sequence of the bench text is 12 bytes long, 4.6 of them probed.
+ * What lz4_enc3.hip's counters said (profiles/r05_sq_counters.json): a chunk-wave is one dependent chain -- ring read, hash,
+ * table read, the candidates' loads from memory, vote, table writes, extension, emit: ~360 instructions and ~4 500 cycles per
+ * sequence -- and the LDS table (8.5 KiB per chunk) caps the chains at 16 per CU.  Its probe batch fetched the candidates of
+ * the next 10 positions; a sequence of the bench text is 12 bytes long.
  *
- * Here a wave looks at 64 consecutive positions at once (lane j = position w0 + j): every lane hashes its position, reads
- * the table AS IT IS AT THE WINDOW'S START and fetches its candidate's neighbourhood -- the same loads the probe batch made,
- * one round trip -- and then the wave walks the reference's parse through the window in registers: the first lane at or
- * behind the search's start whose candidate verifies is the match, its extension comes from the lane's own 24 + 24 bytes
- * (lz4_enc3.hip's "quick" extension), the next search starts behind the match -- at a lane that already holds its
- * candidate.  5.3 sequences per window on the bench text, for about the candidates per sequence the probe batches fetched
- * (a window probes every position, the batches 10-11 per search).
+ * Here a wave looks at 64 consecutive positions at once (lane j = position w0 + j).  Every lane hashes its position, reads
+ * the table AS IT IS AT THE WINDOW'S START and fetches its candidate's neighbourhood [cand - 8, cand + 24) -- the loads the
+ * probe batch made, one round trip -- and knows by itself whether its candidate verifies and how far the match would reach
+ * (20 bytes forwards, 8 backwards: lz4_enc3.hip's "quick" extension).  Then the reference's parse is walked through the
+ * window:
+ *   - every lane also plays "a search starts here": its match lane = the first verifying lane at or behind it (one 64-bit
+ *     shift + count-trailing-zeros of the ballot), that lane's numbers by two ds_bpermute, hence the lane where the NEXT
+ *     search starts.  A scalar loop of ONE v_readlane per sequence follows these links from the window's first search and
+ *     marks the starts (a run of "easy" sequences); everything else about the run's sequences -- literal run, catch-up,
+ *     lengths, offset, their output positions (one wave prefix sum, the output limit tested per sequence as the reference
+ *     does), the move into the collecting registers (rank by mbcnt, one LDS byte per sequence, three ds_bpermute), the set of
+ *     inserted positions -- is lane-parallel: 89 % of the bench text's sequences;
+ *   - a search that is not easy (its match needs more bytes than the lane fetched, its candidate lies inside the window, a
+ *     twin that might verify sits in its range, it leaves the window) is done by the wave the general way, one at a time
+ *     (the code of lz4_enc3.hip: input ring, 128-byte match window), and the run goes on behind it.
+ * 5 sequences per window on the bench text, for about the candidates per sequence the probe batches fetched.
  *
  * Exactness.  The reference reads T[h(p)] and writes T[h(p)] = p at every probed position p, in position order, and inserts
  * ip - 2 behind every match; positions inside a match are neither read nor written.  A lane's table value is therefore
  * right unless a position of the same window with the same hash was INSERTED before it is probed: a probe of the search
  * in progress (all lanes from the search's start up to it) or a position committed by an earlier search of the window.
- * `prev` = the nearest earlier lane with the same hash (exact: a folded LDS filter finds the lanes that may have one, a
- * readlane loop over those settles it; most windows have none); a probe whose chain of `prev` reaches an inserted lane has
- * that position as its candidate -- its four bytes are the other lane's own, one ds_bpermute -- and its extension goes the
- * general way (input ring).  Table writes of a window are made at its end, later positions over earlier ones, so that a
- * block that fails the output limit leaves exactly the insertions the reference made up to the failing sequence.  A
- * search that runs out of the window goes on in the next one while its probes are consecutive positions (the reference's
- * first 65 probes of a search); one that is still running behind that (incompressible data: skip acceleration) takes
- * lz4_enc3.hip's probe batches with the exact step schedule.
+ * `prev` = the nearest earlier lane with the same hash ("twin": two folded LDS bitmaps find the lanes that may have one, a
+ * readlane loop over those settles it exactly; 64 positions on 4 096 entries: two of three windows have a pair).  Whether a
+ * lane verifies against its twin is settled once per window (one ds_bpermute); which of the two candidates counts depends on
+ * the parse, so a twin that might verify ends a lane-parallel run and is resolved by the general path, where the set of
+ * inserted lanes is known (chains of three and more by a walk).  Table writes of a window are made at its end, later
+ * positions over earlier ones, so that a block that fails the output limit leaves exactly the insertions the reference
+ * made up to the failing sequence.  A search that runs out of the window goes on in the next one while its probes are
+ * consecutive positions (the reference's first 65 probes of a search); one that is still running behind that
+ * (incompressible data: skip acceleration) takes lz4_enc3.hip's probe batches with the exact step schedule.
+ *
+ * [MI355X, 8 GiB of the bench text, 128 KiB chunks] 255.9 ms (lz4_enc3) -> 105 ms, bit-identical; on PRNG bytes and at
+ * 64 KiB / 1 MiB / 4 MiB chunks it is 1.2 - 2.9 x lz4_enc3 (profiles/r06_sweeps/lz4_enc5_steps.txt).  What bounds it now:
+ * the scalar pipe (0.78 scalar instructions per cycle per CU of a ceiling of ~0.8 at 16 waves) and 4.4 TB/s of candidate
+ * lines (485 GB fetched per launch).  GPUMT_LZ4_ENC=3 / gpumt_set_variant("lz4_enc", 3) selects lz4_enc3.hip.
  */
 #include "lz4_enc_shared.h"
 
