@@ -3,8 +3,8 @@
 # PMC passes of all codecs (tools/profile_round.sh), SQ counters (tools/profile_sq.sh), then the GPU test suite.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-bash tools/profile_round.sh all > $O/r05_profile_round.log 2>&1
+bash tools/profile_round.sh all > $O/r06_profile_round.log 2>&1
 tail -c 1500 $O/bench_default.json
-bash tools/profile_sq.sh "lz4 zstd brotli" > $O/r05_profile_sq.log 2>&1
-timeout 900 python -m pytest tests -m gpu -x -q > $O/r05_gputests_final.txt 2>&1; echo "pytest rc $?" >> $O/r05_gputests_final.txt
-tail -3 $O/r05_gputests_final.txt
+bash tools/profile_sq.sh "lz4 zstd brotli" > $O/r06_profile_sq.log 2>&1
+timeout 2400 python -m pytest tests -m gpu -x -q > $O/r06_gputests_final.txt 2>&1; echo "pytest rc $?" >> $O/r06_gputests_final.txt
+tail -3 $O/r06_gputests_final.txt

@@ -125,7 +125,7 @@ static __device__ u32 encode_block3(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					u32 a0 = !probe ? 0u : wide ? cand - 8 : cand;
 					const u8 *gp = chunk + a0;
 					/* (16 + 8 bytes: two vector-memory instructions instead of three.  A lane without a wide window reads
-					 * [cand, cand + 16) -- readable: cand + 16 <= iend + 3, the input carries 8 bytes of slack -- and uses
+					 * [cand, cand + 16) -- readable: cand + 16 <= iend + 3, and d_in extends 64 readable bytes past n (include/gpumt.h; the host engines ask for n + 512) -- and uses
 					 * its first half; its third read repeats the first) */
 					u64 l0, l1, l2;
 					ENC3_LD16(gp, l0, l1);

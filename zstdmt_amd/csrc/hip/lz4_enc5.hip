@@ -44,6 +44,9 @@
  * the scalar pipe (0.78 scalar instructions per cycle per CU of a ceiling of ~0.8 at 16 waves) and 4.4 TB/s of candidate
  * lines (485 GB fetched per launch).  GPUMT_LZ4_ENC=3 / gpumt_set_variant("lz4_enc", 3) selects lz4_enc3.hip.
  */
+/* (measured and not kept: a 512-byte input ring refilled 256 bytes at a time -- IRING 512, IPIECE 256, IAHEAD 160, the match
+ * window without its slack: 9 632 bytes of LDS = 17 chunk-waves per CU instead of 16 -- 107.1 ms against 105.4: the refills
+ * and the match-window fetches of the smaller ring cost more than the 17th wave returns) */
 #include "lz4_enc_shared.h"
 
 #ifndef ENC5_TAIL

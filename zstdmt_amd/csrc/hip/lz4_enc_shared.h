@@ -28,11 +28,15 @@
 #define ENC3_B1 16u
 #endif
 
-#define IPIECE 512u /* refill granule: 8 bytes per lane */
+#ifndef IPIECE
+#define IPIECE 512u /* refill granule: 8 bytes per lane (lz4_enc5.hip: 256 = the lower half of the wave) */
+#endif
 /* bytes ring_want() makes resident ahead of a position: >= 72 (a batch of 64 consecutive probes reads
  * 8 bytes each) and small enough that IRING - IAHEAD - IPIECE >= 64 bytes of history stay behind it
  * (catch-up compares 64 bytes backwards, the re-match step reads ip - 2) */
+#ifndef IAHEAD
 #define IAHEAD (IRING >= 2048u ? 512u : 256u)
+#endif
 static_assert(IRING >= IAHEAD + IPIECE + 64u, "the input ring must keep 64 bytes of history");
 #define IMIRROR 32u /* the search reads 24 bytes from one wrapped address */
 /* uniform branches are what a single wave pays most for: keep the common path falling through */
@@ -167,9 +171,11 @@ static __device__ __forceinline__ void ring_want(InRing &R, u32 pos, int lane)
 		a = sh < 8 ? a >> (8 * (sh & 7)) : 0;
 		wv_sync();
 		u8 *d = R.ring + (p & (IRING - 1));
-		*(u64 *)d = a;
-		if ((p & (IRING - 1)) < IMIRROR) /* mirror: multi-byte reads never wrap */
-			*(u64 *)(d + IRING) = a;
+		if (IPIECE == 512u || 8u * (u32)lane < IPIECE) { /* (a piece of 256 bytes: 32 lanes) */
+			*(u64 *)d = a;
+			if ((p & (IRING - 1)) < IMIRROR) /* mirror: multi-byte reads never wrap */
+				*(u64 *)(d + IRING) = a;
+		}
 		wv_sync();
 		rhi += IPIECE;
 	}
@@ -386,7 +392,8 @@ static __device__ __forceinline__ void enc_frame_body(u32 *tlo, u32 *thi, u32 *b
 #else
 	R.tq = 0;
 #endif
-	/* the input buffer carries >= 8 readable bytes after its end (hash reads); never go further */
+	/* the ring never loads beyond 8 bytes behind the input (hash reads); the candidate loads of the encoders may reach up to
+	 * 24 bytes behind it, inside the 64 readable bytes include/gpumt.h requires after d_in + n */
 	R.limit = (u32)((n - start) < (u64)chunk + 8 ? (n - start) + 8 : (u64)chunk + 8);
 
 	for (u32 pos = 0; pos < len; pos += ZMT_BLOCK) {

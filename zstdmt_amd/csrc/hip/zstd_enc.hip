@@ -54,6 +54,12 @@
 #define ZE_MAXSEQ (ZE_BLOCK / 4u) /* capacity of the per-wave sequence arrays (>= BLOCK / MINMATCH) */
 #define ZE_CAP 64u
 #define ZE_FWD 20u /* bytes of a match measured by the lane that found it; longer ones by the whole wave */
+/* accuracy logs of the three sequence tables (the predefined tables' sizes: the decoder's small-table variant applies).  The
+ * table builder, the merged state-bit field of the sequence coder and its end flush all use these */
+#define ZE_LL_LOG 6
+#define ZE_OF_LOG 5
+#define ZE_ML_LOG 6
+static_assert(ZE_LL_LOG + ZE_OF_LOG + ZE_ML_LOG <= 31, "the three state-bit counts of a sequence leave as one bit-writer field of at most 31 bits");
 #define ZE_HUF_MAXLOG 10 /* longest literal code: 10 bits keep the decoder's table at 2 KiB (format max 11) */
 /* While a block is assembled the hash table is idle: its LDS doubles as the bit-packing stage of the
  * Huffman coder plus the other entropy-phase arrays (ZEncLds), ZE_ENT_BYTES of them */
@@ -869,11 +875,11 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		}
 		u8 *scr = (u8 *)L.table + 64 * lane; /* the hash table is not live yet */
 		if (lane == 0)
-			fse_ctable(L.st_ll, L.tt_ll, ZE_LL_DEF, 36, 6, scr);
+			fse_ctable(L.st_ll, L.tt_ll, ZE_LL_DEF, 36, ZE_LL_LOG, scr);
 		else if (lane == 1)
-			fse_ctable(L.st_ml, L.tt_ml, ZE_ML_DEF, 53, 6, scr);
+			fse_ctable(L.st_ml, L.tt_ml, ZE_ML_DEF, 53, ZE_ML_LOG, scr);
 		else if (lane == 2)
-			fse_ctable(L.st_of, L.tt_of, ZE_OF_DEF, 29, 5, scr);
+			fse_ctable(L.st_of, L.tt_of, ZE_OF_DEF, 29, ZE_OF_LOG, scr);
 	}
 	wv_sync();
 	bool tabs_pre = true; /* st_* / tt_* hold the predefined distributions */
@@ -911,9 +917,10 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		u32 ns = 0, anchor = 0, cursor = 0;
 		u32 r_ll = 0, r_ml = 0, r_of = 0;
 		/* rp1: the offset of the newest sequence (0 = none yet in this unit); replive: steps the look-out for repeat matches
-		 * stays open; rcarry: the offset of the last sequence that left the registers (ZE_FLUSH_SEQS).  Inside a unit the
-		 * decoder's offset history runs through all of its zstd blocks -- they are Compressed blocks, or the whole unit is
-		 * one Raw block and has no sequences */
+		 * stays open; rcarry: the offset of the last sequence that left the registers (ZE_FLUSH_SEQS).  All three are reset
+		 * here, i.e. per 128 KiB block this wave encodes: the decoder's history does run on through the
+		 * blocks of a unit, but Offset_Value 1 is only written when the predecessor IN THE SAME BLOCK has the same offset, so
+		 * a reset costs the repeat code of a block's first sequence and nothing else */
 		u32 rp1 = 0, replive = 0, rcarry = 0;
 /* 64 sequences leave the registers.  Offset_Value (RFC 8878 3.1.1.3.2.1.1) is settled here, for all of them at once: only
  * the FIRST entry of the decoder's offset history is ever used -- value 1 behind literals -- so the history matters in its
@@ -1196,7 +1203,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			short *snorm = (short *)(L.bitstage + 128); /* same layout */
 			u8 *sscr = (u8 *)(L.bitstage + 192);        /* 64 bytes per table: spread scratch, then its description */
 			const int t_off = lane == 0 ? 0 : lane == 1 ? 89 : 36;
-			const int t_alpha = lane == 0 ? 36 : lane == 1 ? 29 : 53, t_log = lane == 1 ? 5 : 6;
+			const int t_alpha = lane == 0 ? 36 : lane == 1 ? 29 : 53, t_log = lane == 0 ? ZE_LL_LOG : lane == 1 ? ZE_OF_LOG : ZE_ML_LOG;
 			u16 *t_st = lane == 0 ? L.st_ll : lane == 1 ? L.st_of : L.st_ml;
 			u32(*t_tt)[2] = lane == 0 ? L.tt_ll : lane == 1 ? L.tt_of : L.tt_ml;
 			if (ns >= ZE_ADAPT_MIN) {
@@ -1240,11 +1247,11 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 				tabs_pre = false;
 			} else if (!tabs_pre) {
 				if (lane == 0)
-					fse_ctable(L.st_ll, L.tt_ll, ZE_LL_DEF, 36, 6, sscr);
+					fse_ctable(L.st_ll, L.tt_ll, ZE_LL_DEF, 36, ZE_LL_LOG, sscr);
 				else if (lane == 1)
-					fse_ctable(L.st_of, L.tt_of, ZE_OF_DEF, 29, 5, sscr + 64);
+					fse_ctable(L.st_of, L.tt_of, ZE_OF_DEF, 29, ZE_OF_LOG, sscr + 64);
 				else if (lane == 2)
-					fse_ctable(L.st_ml, L.tt_ml, ZE_ML_DEF, 53, 6, sscr + 128);
+					fse_ctable(L.st_ml, L.tt_ml, ZE_ML_DEF, 53, ZE_ML_LOG, sscr + 128);
 				tabs_pre = true;
 			}
 			wv_sync();
@@ -1308,7 +1315,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 							first = false;
 						} else {
 							/* the three state transitions are independent: their bits -- OF, ML, LL state bits, in
-							 * the stream's order -- go out as one field (at most 6 + 5 + 6 bits with these tables) */
+							 * the stream's order -- go out as one field (at most ZE_OF_LOG + ZE_ML_LOG + ZE_LL_LOG = 17 bits) */
 							const u32 n_of = (s_of + L.tt_of[oc][0]) >> 16, n_ml = (s_ml + L.tt_ml[mc][0]) >> 16;
 							const u32 n_ll = (s_ll + L.tt_ll[lc][0]) >> 16;
 							sbv = (s_of & ((1u << n_of) - 1u)) | (s_ml & ((1u << n_ml) - 1u)) << n_of |
@@ -1339,9 +1346,9 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 				wv_sync();
 			}
 			if (coder) {
-				bw_add(w, s_ml, 6);
-				bw_add(w, s_of, 5);
-				bw_add(w, s_ll, 6);
+				bw_add(w, s_ml, ZE_ML_LOG);
+				bw_add(w, s_of, ZE_OF_LOG);
+				bw_add(w, s_ll, ZE_LL_LOG);
 				bw_add(w, 1, 1); /* end mark */
 				const u32 tail = (w.nb + 7) >> 3;
 				if (w.p + tail > w.limit) {
