@@ -67,6 +67,10 @@ int  gpumt_open(int device, gpumt_ctx **out);
 void gpumt_close(gpumt_ctx *h);
 const char *gpumt_last_error(gpumt_ctx *h);
 const char *gpumt_device_name(gpumt_ctx *h);
+/* NUMA node of the host the device's PCIe function hangs off (sysfs numa_node), -1 when the host does not say.  Pinned
+ * memory from gpumt_host_alloc lives on that node: a host thread that fills or drains it copies 25-30 % faster from
+ * there (profiles/r06_sweeps/api_numa.txt), which is why the host engines' reader / writer threads bind themselves to it */
+int gpumt_host_node(gpumt_ctx *h);
 
 /* ---- memory / transfers / sync ------------------------------------------------------------ */
 /* Freed buffers go to process-wide caches (device: GPUMT_DEVICE_CACHE_MB, pinned host:

@@ -94,6 +94,7 @@ int gpumt_open(int device, gpumt_ctx **out)
 void gpumt_close(gpumt_ctx *h) { free(h); }
 const char *gpumt_last_error(gpumt_ctx *) { return "emulated device"; }
 const char *gpumt_device_name(gpumt_ctx *) { return "fiber emulator"; }
+int gpumt_host_node(gpumt_ctx *) { return -1; }
 
 /* test hooks: contexts opened so far, launches per emulated device */
 unsigned long long emu_gpumt_opened(void) { return g_opened; }

@@ -69,3 +69,28 @@ def test_no_device_fails_loudly(native):
     import zstdmt_amd as z
     with pytest.raises(z.NativeError):
         z.Engine(0)
+
+
+def test_bind_to_node_only_narrows_the_threads_mask(native):
+    """mt_pipe.c's mt_bind_to_node (the reader / writer threads of the host engines move next to the device's pinned memory):
+    never widens the calling thread's CPU mask, does nothing for an unknown node or with GPUMT_NUMA=0"""
+    import os, threading
+    out = {}
+
+    def run():
+        before = os.sched_getaffinity(0)
+        native.mt_bind_to_node.restype = C.c_int
+        native.mt_bind_to_node.argtypes = [C.c_int]
+        out["none"] = native.mt_bind_to_node(-1), native.mt_bind_to_node(4095)
+        os.environ["GPUMT_NUMA"] = "0"
+        out["off"] = native.mt_bind_to_node(0)
+        del os.environ["GPUMT_NUMA"]
+        out["rv"] = native.mt_bind_to_node(0)
+        out["before"], out["after"] = before, os.sched_getaffinity(0)
+
+    t = threading.Thread(target=run)
+    t.start()
+    t.join()
+    assert out["none"] == (0, 0) and out["off"] == 0
+    assert out["after"] <= out["before"] and len(out["after"]) > 0
+    assert (out["rv"] == 1) == (out["after"] != out["before"])

@@ -270,3 +270,21 @@ def test_emu_enc3_paths_bit_exact(name, chunk):
     assert got == H.oracle_compress(data, chunk)
     out, status = E.decompress(got)
     assert status.tolist() == [0] * len(status) and out == data
+
+
+@pytest.mark.parametrize("chunk", [65536, 131072, 262144])
+def test_emu_probe_batch_encoder_variant_is_still_bit_exact(chunk, monkeypatch):
+    """lz4_enc3.hip (round 5's probe batches) stays in the tree as a variant of the window encoder lz4_enc5.hip
+    (GPUMT_LZ4_ENC=3 / ZMT_EMU_LZ4_ENC=3): both must write the oracle's bytes on the path inputs and on windows full of
+    twins (few distinct 5-byte strings: every window holds positions with equal hashes, chains of three and more)"""
+    import random
+    rng = random.Random(4242)
+    words = [bytes(rng.randrange(97, 101) for _ in range(rng.randrange(2, 7))) for _ in range(12)]
+    twins = b"".join(rng.choice(words) for _ in range(30000))
+    inputs = dict(_enc3_path_inputs(), twins=twins, zeros_and_text=bytes(5000) + twins[:20000] + bytes(70000))
+    for name, data in sorted(inputs.items()):
+        want = H.oracle_compress(data, chunk)
+        monkeypatch.setenv("ZMT_EMU_LZ4_ENC", "3")
+        assert E.compress(data, chunk)[0] == want, ("enc3", name)
+        monkeypatch.setenv("ZMT_EMU_LZ4_ENC", "5")
+        assert E.compress(data, chunk)[0] == want, ("enc5", name)

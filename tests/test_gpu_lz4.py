@@ -96,6 +96,26 @@ def test_fast_encoder_paths_vs_oracle(eng, chunk):
         assert not status.any() and out == data, name
 
 
+def test_probe_batch_encoder_variant_equals_window_encoder(eng):
+    """gpumt_set_variant("lz4_enc", 3) selects round 5's probe-batch encoder (lz4_enc3.hip); the default is the window
+    encoder (lz4_enc5.hip).  Both are the reference's parse: same bytes on text, on windows full of equal hashes and on
+    incompressible input, at the three table modes (chunks of 64 KiB, 128 KiB, 1 MiB)"""
+    import random
+    rng = random.Random(4242)
+    words = [bytes(rng.randrange(97, 101) for _ in range(rng.randrange(2, 7))) for _ in range(12)]
+    twins = b"".join(rng.choice(words) for _ in range(60000))
+    data = text(700000, 11) + twins + rnd(200000, 5) + bytes(100000) + text(300000, 12)
+    try:
+        for chunk in (65536, 131072, 1 << 20):
+            want = H.oracle_compress(data, chunk)
+            for v in (3, 0):
+                eng.set_variant("lz4_enc", v)
+                stream, _, _ = eng.compress_bytes(data, chunk)
+                assert stream == want, (v, chunk)
+    finally:
+        eng.set_variant("lz4_enc", 0)
+
+
 with open(os.path.join(H.GOLDEN_DIR, "lz4hc", "manifest.json")) as _f:
     HCMAN = json.load(_f)
 

@@ -43,6 +43,38 @@ static double now(void)
 	clock_gettime(CLOCK_MONOTONIC, &ts);
 	return ts.tv_sec + ts.tv_nsec * 1e-9;
 }
+/* The callbacks alone: the calls the engine makes (one fn_read of `chunk` bytes per chunk into a 256 MiB batch buffer that is reused
+ * every 256 MiB, as the engine's slots are; one fn_write per record out of such a buffer), with no engine behind them -- the rate a
+ * caller with these callbacks can be served at by ANY library that keeps the contract of one fn_read / one fn_write at a time
+ * (/root/reference/lib/lz4-mt_compress.c:256-277).  ZMT_API_BOUND=1 prints it next to the legs */
+static void callbacks_alone(const uint8_t *src, size_t n, size_t chunk, uint8_t *sink, size_t n_out)
+{
+	const size_t batch = (size_t)256 << 20;
+	uint8_t *slot = malloc(batch);
+	memset(slot, 1, batch);
+	for (int rep = 0; rep < 2; rep++) {
+		struct mem in = { (uint8_t *)src, n, 0 }, out = { sink, n_out, 0 };
+		double t0 = now();
+		for (size_t off = 0; in.pos < n;) {
+			Buf b = { slot + off, chunk, chunk };
+			rd(&in, &b);
+			off = off + chunk + chunk > batch ? 0 : off + chunk;
+		}
+		const double tr = now() - t0;
+		t0 = now();
+		const size_t rec = chunk / 2 + 12; /* a record of a text chunk */
+		for (size_t off = 0; out.pos + rec <= n_out;) {
+			Buf b = { slot + off, rec, rec };
+			wr(&out, &b);
+			off = off + 2 * rec > batch ? 0 : off + rec;
+		}
+		const double tw = now() - t0;
+		if (rep)
+			fprintf(stderr, "callbacks alone: fn_read of %zu bytes x %zu calls %.1f MB/s; fn_write of %zu bytes x %zu calls %.1f MB/s\n",
+				chunk, n / chunk, n / 1e6 / tr, rec, n_out / rec, out.pos / 1e6 / tw);
+	}
+	free(slot);
+}
 static void *sym(void *so, const char *pfx, const char *name)
 {
 	char buf[64];
@@ -79,6 +111,8 @@ int main(int argc, char **argv)
 	zmt_gen_text(src, n, 20260926, 0, 32);
 	memset(cmp, 0, cap);
 	memset(back, 0, n);
+	if (getenv("ZMT_API_BOUND"))
+		callbacks_alone(src, n, chunk ? (size_t)chunk : 131072, cmp, n / 2);
 	for (int rep = 0; rep < 2; rep++) { /* rep 0 warms up (allocations, first touch) */
 		struct mem in = { src, n, 0 }, out = { cmp, cap, 0 };
 		RdWr io = { rd, &in, wr, &out };

@@ -23,6 +23,7 @@ GPUMT_SYMBOLS = {
     "gpumt_close": (None, [_vp]),
     "gpumt_last_error": (C.c_char_p, [_vp]),
     "gpumt_device_name": (C.c_char_p, [_vp]),
+    "gpumt_host_node": (C.c_int, [_vp]),
     "gpumt_malloc": (_vp, [_vp, _sz]),
     "gpumt_free": (None, [_vp, _vp]),
     "gpumt_host_alloc": (_vp, [_vp, _sz]),

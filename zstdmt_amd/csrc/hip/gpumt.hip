@@ -308,6 +308,25 @@ void gpumt_close(gpumt_ctx *h)
 const char *gpumt_last_error(gpumt_ctx *h) { return h ? h->err : "no handle"; }
 const char *gpumt_device_name(gpumt_ctx *h) { return h ? h->name : ""; }
 
+int gpumt_host_node(gpumt_ctx *h)
+{
+	char bus[64] = "", path[128];
+	int node = -1;
+	if (!h || hipDeviceGetPCIBusId(bus, (int)sizeof bus, h->device) != hipSuccess)
+		return -1;
+	for (char *c = bus; *c; c++)
+		if (*c >= 'A' && *c <= 'F')
+			*c = (char)(*c - 'A' + 'a'); /* sysfs spells the address in lower case */
+	snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+	FILE *f = fopen(path, "r");
+	if (!f)
+		return -1;
+	if (fscanf(f, "%d", &node) != 1)
+		node = -1;
+	fclose(f);
+	return node;
+}
+
 /*
  * Device buffers of a context (batch slots, per-wave scratch) are GiB-sized and hipMalloc / hipFree of
  * that size cost tens of milliseconds each -- 0.86 s of a 1.3 s BROTLIMT_decompressDCtx call on 8 GiB

@@ -188,6 +188,7 @@ static size_t c_launch(LZ4MT_CCtx *ctx, struct cslot *s)
 }
 
 /* ---- the three roles (mt_pipe.h) ---- */
+static void cp_role_start(void *a) { mt_bind_near(&((LZ4MT_CCtx *)a)->gpus); }
 static size_t cp_fill(void *a, int si, int *has_data, int *eof)
 {
 	LZ4MT_CCtx *ctx = (LZ4MT_CCtx *)a;
@@ -259,7 +260,7 @@ static size_t cp_drain(void *a, int si)
 
 size_t LZ4MT_compressCCtx(LZ4MT_CCtx *ctx, LZ4MT_RdWr_t *rdwr)
 {
-	static const mt_pipe_ops ops = {cp_fill, cp_launch, cp_complete, cp_drain};
+	static const mt_pipe_ops ops = {cp_fill, cp_launch, cp_complete, cp_drain, cp_role_start};
 	size_t err;
 
 	if (!ctx)
@@ -479,6 +480,7 @@ static size_t d_launch(LZ4MT_DCtx *ctx, struct dslot *s)
 	return rc ? ERROR(compression_library) : 0;
 }
 
+static void dp_role_start(void *a) { mt_bind_near(&((LZ4MT_DCtx *)a)->gpus); }
 static size_t dp_fill(void *a, int si, int *has_data, int *eof)
 {
 	LZ4MT_DCtx *ctx = (LZ4MT_DCtx *)a;
@@ -789,7 +791,7 @@ static size_t plain_decompress(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *io, const uint8_t 
 
 size_t LZ4MT_decompressDCtx(LZ4MT_DCtx *ctx, LZ4MT_RdWr_t *rdwr)
 {
-	static const mt_pipe_ops ops = {dp_fill, dp_launch, dp_complete, dp_drain};
+	static const mt_pipe_ops ops = {dp_fill, dp_launch, dp_complete, dp_drain, dp_role_start};
 	uint8_t magic[4];
 	LZ4MT_Buffer b;
 	size_t err;

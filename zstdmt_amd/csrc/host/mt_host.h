@@ -63,6 +63,18 @@ typedef struct {
 	int trace; /* GPUMT_TRACE, read once in mt_gpus_open (the pipeline threads only test the field) */
 } mt_gpus;
 
+int mt_bind_to_node(int node); /* mt_pipe.c */
+/* the reader / writer thread of a context next to its pinned buffers: the host node of its devices when they share one */
+static inline void mt_bind_near(const mt_gpus *m)
+{
+	int node = m->n > 0 ? gpumt_host_node(m->g[0]) : -1;
+	for (int i = 1; i < m->n; i++)
+		if (gpumt_host_node(m->g[i]) != node)
+			node = -1;
+	if (mt_bind_to_node(node) && m->trace)
+		fprintf(stderr, "[mt_pipe] reader / writer thread bound to host node %d (the device's)\n", node);
+}
+
 static inline void mt_gpus_close(mt_gpus *m)
 {
 	for (int i = 0; i < m->n; i++)

@@ -1,7 +1,9 @@
 /* mt_pipe.c -- see mt_pipe.h */
+#define _GNU_SOURCE /* cpu_set_t, pthread_setaffinity_np */
 #include "mt_pipe.h"
 
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
@@ -11,6 +13,62 @@ static double now_s(void)
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC, &ts);
 	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/*
+ * The reader's and the writer's work is a memcpy between the caller's memory and the pinned batch buffers, which the HIP runtime
+ * places on the NUMA node of the device.  [MI355X box, 2 nodes] bound to that node the LZ4MT legs run at 20.9 / 25.5 GB/s, bound to
+ * the other one at 16.5 / 19.5 (profiles/r06_sweeps/api_numa.txt) -- the two are the library's own threads (as the reference's
+ * workers are, lib/lz4-mt_compress.c:207), so they go where their buffers are.
+ */
+int mt_bind_to_node(int node)
+{
+	const char *e = getenv("GPUMT_NUMA");
+	char path[96], list[4096];
+	cpu_set_t have, want;
+	FILE *f;
+	int any = 0, differs = 0;
+	if (node < 0 || (e && *e == '0'))
+		return 0;
+	snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+	f = fopen(path, "r");
+	if (!f)
+		return 0;
+	if (!fgets(list, sizeof list, f))
+		list[0] = 0;
+	fclose(f);
+	if (pthread_getaffinity_np(pthread_self(), sizeof have, &have))
+		return 0;
+	CPU_ZERO(&want);
+	for (const char *c = list; *c;) { /* "0-63,128-191" */
+		char *end;
+		long a = strtol(c, &end, 10), b;
+		if (end == c)
+			break;
+		b = a;
+		if (*end == '-') {
+			c = end + 1;
+			b = strtol(c, &end, 10);
+			if (end == c)
+				break;
+		}
+		for (long i = a; i <= b && i < CPU_SETSIZE; i++)
+			if (i >= 0 && CPU_ISSET((int)i, &have)) {
+				CPU_SET((int)i, &want);
+				any = 1;
+			}
+		c = *end == ',' ? end + 1 : end;
+		if (*end != ',')
+			break;
+	}
+	if (!any)
+		return 0;
+	for (int i = 0; i < CPU_SETSIZE; i++)
+		if (CPU_ISSET(i, &have) != CPU_ISSET(i, &want))
+			differs = 1;
+	if (!differs)
+		return 0;
+	return pthread_setaffinity_np(pthread_self(), sizeof want, &want) == 0;
 }
 
 int mt_nslot_for(int ndevices)
@@ -55,6 +113,8 @@ static void fail(pipe_t *p, size_t err)
 static void *reader_main(void *a)
 {
 	pipe_t *p = (pipe_t *)a;
+	if (p->ops->role_start)
+		p->ops->role_start(p->arg);
 	for (long b = 0;; b++) {
 		const int s = (int)(b % p->nslot);
 		int has_data = 0, eof = 0;
@@ -97,6 +157,8 @@ static void *reader_main(void *a)
 static void *writer_main(void *a)
 {
 	pipe_t *p = (pipe_t *)a;
+	if (p->ops->role_start)
+		p->ops->role_start(p->arg);
 	for (long b = 0;; b++) {
 		const int s = (int)(b % p->nslot);
 		size_t err;

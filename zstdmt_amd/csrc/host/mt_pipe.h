@@ -36,10 +36,17 @@ typedef struct {
 	size_t (*launch)(void *arg, int slot);
 	size_t (*complete)(void *arg, int slot);
 	size_t (*drain)(void *arg, int slot);
+	/* called once on the reader thread and once on the writer thread before their first batch (may be NULL): the
+	 * engines bind the two threads to the CPUs next to the device's pinned memory (mt_bind_near, mt_host.h) */
+	void (*role_start)(void *arg);
 } mt_pipe_ops;
 
 size_t mt_pipe_run(const mt_pipe_ops *ops, void *arg);             /* mt_nslot() slots */
 size_t mt_pipe_run_n(const mt_pipe_ops *ops, void *arg, int nslot); /* nslot in 2..MT_NSLOT */
+
+/* Binds the calling thread to the CPUs of NUMA node `node` of the host (those of them its affinity mask already allows; nothing
+ * happens when there are none, when node < 0, or with GPUMT_NUMA=0 in the environment).  Returns 1 when the mask changed. */
+int mt_bind_to_node(int node);
 
 /* The same batches, every role on the calling thread, one batch at a time: what the reference does
  * for a decompress context with threads == 1 (lib/lz4-mt_decompress.c:528-534 calls pt_decompress

@@ -221,6 +221,7 @@ static size_t c_launch(ZSTDCB_CCtx *ctx, struct cslot *s)
 }
 
 /* ---- the three roles (mt_pipe.h) ---- */
+static void cp_role_start(void *a) { mt_bind_near(&((ZSTDCB_CCtx *)a)->gpus); }
 static size_t cp_fill(void *a, int si, int *has_data, int *eof)
 {
 	ZSTDCB_CCtx *ctx = (ZSTDCB_CCtx *)a;
@@ -290,7 +291,7 @@ static size_t cp_drain(void *a, int si)
 
 size_t ZSTDCB_compressCCtx(ZSTDCB_CCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 {
-	static const mt_pipe_ops ops = {cp_fill, cp_launch, cp_complete, cp_drain};
+	static const mt_pipe_ops ops = {cp_fill, cp_launch, cp_complete, cp_drain, cp_role_start};
 	size_t err;
 
 	if (!ctx)
@@ -520,6 +521,7 @@ static size_t d_launch(ZSTDCB_DCtx *ctx, struct dslot *s)
 	return rc ? ZSTDCB_ERROR(compression_library) : 0;
 }
 
+static void dp_role_start(void *a) { mt_bind_near(&((ZSTDCB_DCtx *)a)->gpus); }
 static size_t dp_fill(void *a, int si, int *has_data, int *eof)
 {
 	ZSTDCB_DCtx *ctx = (ZSTDCB_DCtx *)a;
@@ -854,7 +856,7 @@ size_t ZSTDCB_decompressDCtx(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 {
 	uint8_t sniff[16];
 	ZSTDCB_Buffer b;
-	static const mt_pipe_ops ops = {dp_fill, dp_launch, dp_complete, dp_drain};
+	static const mt_pipe_ops ops = {dp_fill, dp_launch, dp_complete, dp_drain, dp_role_start};
 	size_t err;
 	int rv;
 
