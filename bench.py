@@ -555,6 +555,21 @@ def bench_zstd_ref(ctx, gib, steps, warmup):
         acc["k_zstd_dec"] += eng.timer_ms(11)
     wall = time.perf_counter() - t0
     ms = {k: v / steps for k, v in acc.items()}
+    if os.environ.get("ZMT_ZREF_PROF"):
+        # developer: per-phase cycles of the frame decoder (its profiling build: the general kernel, 12 waves per CU) on these streams
+        import ctypes as C
+        cnt = (C.c_ulonglong * 16)()
+        eng.set_variant("profile", 5)
+        L.gpumt_debug_counters(h, cnt, 16)
+        step()
+        eng.sync(0)
+        L.gpumt_debug_counters(h, cnt, 16)
+        eng.set_variant("profile", 1)
+        c = list(cnt)
+        w = max(c[9], 1)
+        nm = ["hdr+huftab", "huffman", "seqhdr+tables", "stage+fse", "exec-lit", "exec-match", "other"]
+        print("zref frame decoder, Mcycles per record: " + ", ".join(f"{nm[i]}={c[i] / w / 1e6:.2f}" for i in range(7))
+              + f" total={c[8] / w / 1e6:.2f}; leg {eng.timer_ms(11):.2f} ms", file=sys.stderr)
     status = eng.download(d_st, nrec * 4, np.uint32)
     bad = int((status != 0).sum())
     # replica 0 against the text byte for byte, every other replica against replica 0 (device-side XXH32 per MiB)
