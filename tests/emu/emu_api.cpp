@@ -23,7 +23,7 @@ void zmt_lz4hc_enc_kernel(const u8 *, u64, u32, u32, u8 *, u64, u32 *, const u32
 void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u32 *, u32 *, u32 *, u32);
 void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
-void zmt_dec_parse4_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, const u64 *, uint16_t *, u32 *, u32 *);
+void zmt_dec_parse4_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, uint16_t *, u32 *, u32 *);
 #define C3_DECL(NAME) void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *, const u32 *, const u32 *, const u32 *, const uint16_t *, const u32 *, const u32 *, u32 *);
 C3_DECL(zmt_dec_copy3_w4_kernel)
 C3_DECL(zmt_dec_copy3_w8_kernel)
@@ -160,37 +160,26 @@ void emu_lz4_decompress_batch(int variant, const u8 *stream, u64 stream_bytes, c
 		emu::launch(dim3{(nrec + 255) / 256, 1, 1}, dim3{256, 1, 1}, [=]() {
 			zmt_dec_frames_kernel(stream, rec_off, rec_len, nrec, out_len, blk0p, bcop, bcsp, rnbp, rflp, status, cep, cvp);
 		});
-		/* the records in slices, as gpumt_lz4_decompress_batch runs them on two streams (ZMT_EMU_LZ4_SLICES; here one after the
-		 * other): parse -> copy -> serial leftovers -> checksum verify per slice of records */
-		const char *se = getenv("ZMT_EMU_LZ4_SLICES");
-		u32 S = se && *se ? (u32)atoi(se) : 1u;
-		S = S < 1 ? 1 : S > nrec ? nrec : S;
-		for (u32 k = 0; k < S; k++) {
-			const u32 r0 = (u32)((u64)nrec * k / S), r1 = (u32)((u64)nrec * (k + 1) / S), m = r1 - r0;
-			emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
-				zmt_dec_parse4_kernel(stream, stream_bytes, bcop, bcsp, blk0p + r0, blk0p + r1, tokp, bntp, bolp);
-			});
-			if (k == 0 && getenv("ZMT_EMU_DEBUG")) {
-				for (size_t b = 0; b < blk0[r1]; b++)
-					fprintf(stderr, "blk %zu coff=%llu csize=%x ntok=%u olen=%u\n", b, (unsigned long long)bco[b], bcs[b], bnt[b], bol[b]);
-				for (u32 r = 0; r < nrec; r++)
-					fprintf(stderr, "rec %u status=%u nblk=%u\n", r, status[r], rnb[r]);
-			}
-			emu::launch(dim3{m, 1, 1}, dim3{64, 1, 1}, [=]() {
-				if (ring == 12)
-					zmt_dec_copy3_w4_kernel(stream, stream_bytes, r0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
-				else if (ring == 13)
-					zmt_dec_copy3_w8_kernel(stream, stream_bytes, r0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
-				else
-					zmt_dec_copy3_w16_kernel(stream, stream_bytes, r0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
-			});
-			emu::launch(dim3{m, 1, 1}, dim3{64, 1, 1}, [=]() {
-				zmt_lz4_dec_serial(stream, rec_off + r0, rec_len + r0, m, out, out_off + r0, out_len + r0, status + r0, cep + r0, cvp + r0, 100u);
-			});
-			emu::launch(dim3{(m * 4 + 255) / 256, 1, 1}, dim3{256, 1, 1},
-				    [=]() { zmt_xxh32_kernel(out, out_off + r0, out_len + r0, m, nullptr, cep + r0, cvp + r0, status + r0); });
+		emu::launch(dim3{(u32)((nblk_max + 63) / 64), 1, 1}, dim3{64, 1, 1}, [=]() {
+			zmt_dec_parse4_kernel(stream, stream_bytes, bcop, bcsp, blk0p + nrec, tokp, bntp, bolp);
+		});
+		if (getenv("ZMT_EMU_DEBUG")) {
+			for (size_t b = 0; b < blk0[nrec]; b++)
+				fprintf(stderr, "blk %zu coff=%llu csize=%x ntok=%u olen=%u\n", b, (unsigned long long)bco[b], bcs[b], bnt[b], bol[b]);
+			for (u32 r = 0; r < nrec; r++)
+				fprintf(stderr, "rec %u status=%u nblk=%u\n", r, status[r], rnb[r]);
 		}
-		return;
+		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
+				if (ring == 12)
+					zmt_dec_copy3_w4_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
+				else if (ring == 13)
+					zmt_dec_copy3_w8_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
+				else
+					zmt_dec_copy3_w16_kernel(stream, stream_bytes, 0, nrec, out, out_off, out_len, blk0p, bcop, bcsp, rnbp, rflp, tokp, bntp, bolp, status);
+		});
+		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
+			zmt_lz4_dec_serial(stream, rec_off, rec_len, nrec, out, out_off, out_len, status, cep, cvp, 100u);
+		});
 	}
 	emu::launch(dim3{(nrec * 4 + 255) / 256, 1, 1}, dim3{256, 1, 1},
 		    [=]() { zmt_xxh32_kernel(out, out_off, out_len, nrec, nullptr, cep, cvp, status); });

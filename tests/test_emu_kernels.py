@@ -289,44 +289,3 @@ def test_emu_probe_batch_encoder_variant_is_still_bit_exact(chunk, monkeypatch):
         monkeypatch.setenv("ZMT_EMU_LZ4_ENC", "5")
         assert E.compress(data, chunk)[0] == want, ("enc5", name)
 
-
-@pytest.mark.parametrize("slices", [2, 3, 7])
-def test_emu_decompress_in_slices(slices, monkeypatch):
-    """gpumt_lz4_decompress_batch runs a big batch as slices of records (parse -> copy -> leftovers -> verify per slice, two streams):
-    the slice arithmetic -- block ranges out of the records' first-block table, pointer offsets of the per-record arrays -- on a
-    batch of ragged records with a corrupt one, one with block checksums (left to the wave-per-record decoder) and stored blocks"""
-    import random
-    rng = random.Random(99)
-    parts, recs = [], []
-    for i in range(11):
-        n = rng.choice([1, 700, 65536, 65537, 131072, 100000, 200000])
-        data = rnd(n, i) if i % 4 == 3 else text(n, seed=i)
-        parts.append(data)
-        recs.append(H.oracle_compress(data, 262144))
-    d = os.path.join(H.GOLDEN_DIR, "lz4f_flags")
-    man = json.load(open(os.path.join(d, "manifest.json")))["cases"]
-    name = sorted(k for k, e in man.items() if e["flg"] & 0x10)[0]
-    recs.insert(5, open(os.path.join(d, name + ".rec"), "rb").read())
-    parts.insert(5, None)
-    good = b"".join(recs)
-    rec = E.walk_records(good)
-    bad = bytearray(good)
-    off8 = sum(len(r) for r in recs[:8])
-    bad[off8 + 12 + 15 + 2] ^= 0x40   # record 8: a block size that cannot be
-    monkeypatch.setenv("ZMT_EMU_LZ4_SLICES", str(slices))
-    out, status = E.decompress(bytes(bad), 0, rec=rec)
-    monkeypatch.setenv("ZMT_EMU_LZ4_SLICES", "1")
-    out1, status1 = E.decompress(bytes(bad), 0, rec=rec)
-    assert status.tolist() == status1.tolist() and status.tolist()[8] != 0
-    assert [s for i, s in enumerate(status.tolist()) if i != 8] == [0] * 11
-    assert out == out1
-    pos = 0
-    for i, p in enumerate(parts):
-        if p is None:
-            pos += man[name]["content_size"] if "content_size" in man[name] else 0
-            if "content_size" not in man[name]:
-                break
-            continue
-        if i != 8:
-            assert out[pos:pos + len(p)] == p, i
-        pos += len(p)

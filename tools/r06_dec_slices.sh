@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the slicing this drives was removed again after the measurement: profiles/r06_sweeps/lz4_dec_slices.txt; the script
+# works on the commit "LZ4 decode in slices on internal streams")
 # Runs ON THE GPU BOX: the decompress-only leg (8 GiB, configs[2]) with the batch's records in S slices on the decode path's two
 # internal streams (GPUMT_LZ4_DEC_SLICES): parse under copy, verify under copy.  decompress_leg = probe + decode + verify (HIP events)
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out; mkdir -p $O

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the slicing this drives was removed again after the measurement: profiles/r06_sweeps/lz4_dec_slices.txt; the script
+# works on the commit "LZ4 decode in slices on internal streams")
 # Runs ON THE GPU BOX: kernel timeline (rocprofv3 --kernel-trace) of the decompress-only leg with S slices
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; O=gpurun_out; S=${1:-4}
 rm -rf $O/tl_dec_$S

@@ -41,9 +41,7 @@ __global__ void zmt_lz4_dec_serial(const u8 *, const u64 *, const u32 *, u32, u8
 __global__ void zmt_dec_nblk_kernel(const u32 *, u32, u32 *);
 __global__ void zmt_dec_frames_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *,
 				      const u64 *, u64 *, u32 *, u32 *, u32 *, u32 *, u32 *, u32 *);
-__global__ void zmt_dec_parse4_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, const u64 *, u16 *, u32 *, u32 *);
-#define DEC_SLICES_DEFAULT 1u /* (set by the measurement) */
-#define DEC_SLICES_MAX 32u
+__global__ void zmt_dec_parse4_kernel(const u8 *, u64, const u64 *, const u32 *, const u64 *, u16 *, u32 *, u32 *);
 #define C3_DECL(NAME)                                                                                              \
 	__global__ void NAME(const u8 *, u64, u32, u32, u8 *, const u64 *, const u32 *, const u64 *, const u64 *,  \
 			     const u32 *, const u32 *, const u32 *, const u16 *, const u32 *, const u32 *, u32 *);
@@ -112,10 +110,6 @@ struct gpumt_ctx {
 	int xflags;  /* experiment switches of the parse kernel (developer) */
 	int lz4_ring; /* copy3: log2 of the LDS ring per wave (12, 13 or 14) */
 	int enc_variant; /* LZ4 fast levels: 0 = the window encoder (lz4_enc5.hip), 3 = the probe-batch encoder (lz4_enc3.hip) */
-	int dec_slices; /* LZ4 decode: slices of a batch's records run as parse -> copy -> verify chains on two internal streams (0 = by size) */
-	hipStream_t aux[3]; /* those streams (two for the copies, one for the verifies), created with the first sliced batch */
-	hipEvent_t aux_ev[4 + DEC_SLICES_MAX];
-	int aux_ok;
 	int dec_pad;  /* copy stage: dynamic-LDS padding per workgroup = resident-wave cap (developer A/B, GPUMT_LZ4_DEC_PAD) */
 	int debug_free; /* GPUMT_DEBUG_FREE: gpumt_free / gpumt_host_free check that the streams are idle */
 	int profile; /* record events in timer slots 8.. around individual kernels */
@@ -273,9 +267,6 @@ int gpumt_open(int device, gpumt_ctx **out)
 		h->enc_variant = e && *e ? atoi(e) : 0;
 		e = getenv("GPUMT_LZ4_DEC_PAD");
 		h->dec_pad = e && *e ? atoi(e) : 0;
-		/* GPUMT_LZ4_DEC_SLICES: slices of a batch's records on the decode path's two internal streams (0 = by size, 1 = none) */
-		e = getenv("GPUMT_LZ4_DEC_SLICES");
-		h->dec_slices = e && *e ? atoi(e) : 0;
 		/* GPUMT_ZSTD_SEQ=1: no sequence pre-pass in front of the zstd frame decoder */
 		e = getenv("GPUMT_ZSTD_SEQ");
 		h->zseq_variant = e && *e ? atoi(e) : 0;
@@ -307,12 +298,6 @@ void gpumt_close(gpumt_ctx *h)
 		(void)hipEventDestroy(h->t1[i]);
 	}
 	(void)hipEventDestroy(h->xev);
-	if (h->aux_ok) {
-		for (int i = 0; i < 3; i++)
-			(void)hipStreamDestroy(h->aux[i]);
-		for (int i = 0; i < 4 + (int)DEC_SLICES_MAX; i++)
-			(void)hipEventDestroy(h->aux_ev[i]);
-	}
 	for (int i = 0; i < GPUMT_NMARKS; i++)
 		(void)hipEventDestroy(h->mark[i]);
 	for (int i = 0; i < GPUMT_NSTREAMS; i++)
@@ -944,28 +929,15 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 				   (const u64 *)blk0, bco, bcs, rnb, rfl, d_status, ce, cv);
 		PROF1(13);
 		const int ring = h->lz4_ring < 12 ? 12 : h->lz4_ring > 14 ? 14 : h->lz4_ring;
-		/* Slices.  The parse kernel (lane per block) and the copy kernel (wave per record) are bound by different things and
-		 * each ends in a partial round of waves; the checksum pass streams the output once more.  With the records in S
-		 * slices, slice k's parse -> copy -> leftovers -> verify chain on one of two internal streams and slice k + 1's on
-		 * the other, the parse of a slice runs under the copy of the one before it and its verify under the copy of the next
-		 * (profiles/r06_sweeps/lz4_dec_slices.txt).  Per-kernel timers (profile >= 2) keep the one-stream order. */
-		u32 S = h->dec_slices > 0 ? (u32)h->dec_slices : (nrec >= 16384 ? DEC_SLICES_DEFAULT : 1u);
-		if (S > nrec / 2048)
-			S = (u32)(nrec / 2048);
-		if (S > DEC_SLICES_MAX)
-			S = DEC_SLICES_MAX;
-		if (h->profile >= 2 || S < 2)
-			S = 1;
-		if (S > 1 && !h->aux_ok) {
-			for (int i = 0; i < 3; i++)
-				CK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
-			for (int i = 0; i < 4 + (int)DEC_SLICES_MAX; i++)
-				CK(hipEventCreateWithFlags(&h->aux_ev[i], hipEventDisableTiming));
-			h->aux_ok = 1;
-		}
-#define C3_LAUNCH(NAME, R0, M, ST)                                                                                 \
-	hipLaunchKernelGGL(NAME, dim3((unsigned)(M)), dim3(64), (size_t)h->dec_pad, ST, (const u8 *)d_stream,       \
-			   (u64)stream_bytes, (u32)(R0), n, (u8 *)d_out, d_out_off, d_out_len, (const u64 *)blk0,  \
+		PROF0(14);
+		hipLaunchKernelGGL(zmt_dec_parse4_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
+				   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
+				   (const u32 *)bcs, (const u64 *)(blk0 + nrec), tok, bnt, bol);
+		PROF1(14);
+		PROF0(15);
+#define C3_LAUNCH(NAME)                                                                                            \
+	hipLaunchKernelGGL(NAME, dim3((unsigned)nrec), dim3(64), (size_t)h->dec_pad, h->st[s], (const u8 *)d_stream, \
+			   (u64)stream_bytes, 0u, n, (u8 *)d_out, d_out_off, d_out_len, (const u64 *)blk0,         \
 			   (const u64 *)bco, (const u32 *)bcs, (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, \
 			   (const u32 *)bnt, (const u32 *)bol, d_status)
 #define C3_LAUNCHP(NAME)                                                                                           \
@@ -973,55 +945,10 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 			   (u64)stream_bytes, 0u, n, (u8 *)d_out, d_out_off, d_out_len, (const u64 *)blk0,         \
 			   (const u64 *)bco, (const u32 *)bcs, (const u32 *)rnb, (const u32 *)rfl, (const u16 *)tok, \
 			   (const u32 *)bnt, (const u32 *)bol, d_status, h->d_prof)
-		if (S > 1) {
-			/* one parse of the whole batch (its duration is a block's chain, not the number of blocks), then the copies of the
-			 * slices on two streams with nothing ordered between them -- a slice's last waves drain while the other stream's
-			 * slice fills the device -- and every slice's verify on a third stream behind its copy */
-			hipLaunchKernelGGL(zmt_dec_parse4_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0, h->st[s],
-					   (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco, (const u32 *)bcs,
-					   (const u64 *)blk0, (const u64 *)(blk0 + nrec), tok, bnt, bol);
-			CK(hipEventRecord(h->aux_ev[0], h->st[s]));
-			for (int i = 0; i < 3; i++)
-				CK(hipStreamWaitEvent(h->aux[i], h->aux_ev[0], 0));
-			for (u32 k = 0; k < S; k++) {
-				const u32 r0 = (u32)((u64)nrec * k / S), r1 = (u32)((u64)nrec * (k + 1) / S), m = r1 - r0;
-				hipStream_t q = h->aux[k & 1];
-				if (ring == 12)
-					C3_LAUNCH(zmt_dec_copy3_w4_kernel, r0, m, q);
-				else if (ring == 13)
-					C3_LAUNCH(zmt_dec_copy3_w8_kernel, r0, m, q);
-				else
-					C3_LAUNCH(zmt_dec_copy3_w16_kernel, r0, m, q);
-				hipLaunchKernelGGL(zmt_lz4_dec_serial, dim3(m), dim3(64), 0, q, (const u8 *)d_stream, d_rec_off + r0,
-						   d_rec_len + r0, m, (u8 *)d_out, d_out_off + r0, d_out_len + r0, d_status + r0,
-						   ce + r0, cv + r0, 100u);
-				CK(hipEventRecord(h->aux_ev[4 + k], q));
-				CK(hipStreamWaitEvent(h->aux[2], h->aux_ev[4 + k], 0));
-				hipLaunchKernelGGL(zmt_xxh32_kernel, dim3((unsigned)(((size_t)m * 4 + 255) / 256)), dim3(256), 0, h->aux[2],
-						   (const u8 *)d_out, d_out_off + r0, d_out_len + r0, m, (u32 *)NULL,
-						   (const u32 *)(ce + r0), (const u32 *)(cv + r0), d_status + r0);
-			}
-			for (int i = 0; i < 3; i++) {
-				CK(hipEventRecord(h->aux_ev[1 + i], h->aux[i]));
-				CK(hipStreamWaitEvent(h->st[s], h->aux_ev[1 + i], 0));
-			}
-			/* (timer 11 holds the whole path here, the verify included; the per-kernel slots read as empty) */
-			PROF0(14);
-			PROF1(14);
-			PROF0(15);
-			PROF1(15);
-			PROF0(12);
-			PROF1(12);
-			PROF1(11);
-			CK(hipGetLastError());
-			return GPUMT_OK;
-		}
-		PROF0(14);
-		hipLaunchKernelGGL(zmt_dec_parse4_kernel, dim3((unsigned)((nblk_max + 63) / 64)), dim3(64), 0,
-				   h->st[s], (const u8 *)d_stream, (u64)stream_bytes, (const u64 *)bco,
-				   (const u32 *)bcs, (const u64 *)blk0, (const u64 *)(blk0 + nrec), tok, bnt, bol);
-		PROF1(14);
-		PROF0(15);
+		/* (one stream, one launch per stage.  Slices of the records on internal streams -- a slice's parse under the copy of
+		 * the one before it, its XXH32 verify under the copy of the next -- were built and measured in rounds 2 and 6: a kernel
+		 * that arrives while the device is full of copy waves is starved, not interleaved, and a slice's parse lasts as long as
+		 * the whole batch's; 13.4-32.9 ms against 13.55, profiles/r06_sweeps/lz4_dec_slices.txt) */
 		if (h->profile == 8) {
 			if (ring == 12)
 				C3_LAUNCHP(zmt_dec_copy3_w4_kernel_prof);
@@ -1031,11 +958,11 @@ int gpumt_lz4_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream
 				C3_LAUNCHP(zmt_dec_copy3_w16_kernel_prof);
 		} else {
 			if (ring == 12)
-				C3_LAUNCH(zmt_dec_copy3_w4_kernel, 0u, nrec, h->st[s]);
+				C3_LAUNCH(zmt_dec_copy3_w4_kernel);
 			else if (ring == 13)
-				C3_LAUNCH(zmt_dec_copy3_w8_kernel, 0u, nrec, h->st[s]);
+				C3_LAUNCH(zmt_dec_copy3_w8_kernel);
 			else
-				C3_LAUNCH(zmt_dec_copy3_w16_kernel, 0u, nrec, h->st[s]);
+				C3_LAUNCH(zmt_dec_copy3_w16_kernel);
 		}
 		PROF1(15);
 		/* records the fast path does not cover (block size > 64 KiB, odd block counts) */
@@ -1435,9 +1362,6 @@ int gpumt_set_variant(gpumt_ctx *h, const char *what, int variant)
 	} else if (!strcmp(what, "lz4_enc")) {
 		prev = h->enc_variant;
 		h->enc_variant = variant;
-	} else if (!strcmp(what, "lz4_dec_slices")) {
-		prev = h->dec_slices;
-		h->dec_slices = variant;
 	} else if (!strcmp(what, "lz4_dec_pad")) {
 		prev = h->dec_pad;
 		h->dec_pad = variant;

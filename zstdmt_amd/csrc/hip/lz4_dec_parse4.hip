@@ -51,19 +51,17 @@ static __device__ __forceinline__ u64 p4_tok_base(u64 coff, u32 gb) { return ((c
 
 extern "C" __global__ void __launch_bounds__(64)
 zmt_dec_parse4_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ blk_coff,
-		      const u32 *__restrict__ blk_csize, const u64 *__restrict__ blk_lo_ptr, const u64 *__restrict__ nblk_ptr,
-		      u16 *__restrict__ tok, u32 *__restrict__ blk_ntok, u32 *__restrict__ blk_olen)
+		      const u32 *__restrict__ blk_csize, const u64 *__restrict__ nblk_ptr, u16 *__restrict__ tok,
+		      u32 *__restrict__ blk_ntok, u32 *__restrict__ blk_olen)
 {
 	__shared__ __attribute__((aligned(16))) u8 ring_lds[64 * P4_RSTRIDE];
 	__shared__ __attribute__((aligned(16))) u8 tile_lds[64 * 32];
 	__shared__ __attribute__((aligned(16))) u8 dump_lds[64];
 	const int lane = wv_lane();
-	/* blocks [*blk_lo_ptr, *nblk_ptr): all of a batch's, or those of a slice of its records (two entries of the records'
-	 * first-block table; the grid is sized for the batch either way) */
-	const u64 blk_lo = *blk_lo_ptr, nblk = *nblk_ptr;
-	if (blk_lo + (u64)blockIdx.x * 64 >= nblk)
+	const u32 gb = blockIdx.x * 64 + (u32)lane;
+	const u64 nblk = *nblk_ptr;
+	if ((u64)blockIdx.x * 64 >= nblk)
 		return;
-	const u32 gb = (u32)blk_lo + blockIdx.x * 64 + (u32)lane;
 	const bool exists = (u64)gb < nblk;
 	const u32 cs_raw = exists ? blk_csize[gb] : P4_BLK_EMPTY;
 	const bool parse = exists && cs_raw != P4_BLK_EMPTY && !(cs_raw & P4_BLK_STORED);
