@@ -19,4 +19,5 @@ assert got == H.oracle_compress_level(data, 131072, level)
 names = ["windows built", "first matches (sequences started)", "first searches left to the serial search", "wider searches from the window",
          "wider: no window over the position", "wider: more than 16 bytes to look back", "wider: lane left to the serial search"]
 for i, nm in enumerate(names): print("%-45s %10d" % (nm, st[i]))
+print("window scan: candidates visited %d, of them with the position's four bytes %d (%.1f %%)" % (st[8], st[9], 100.0 * st[9] / max(st[8], 1)))
 print("bytes per window %.1f" % (n / max(st[0], 1)))

@@ -361,7 +361,9 @@ static __device__ __forceinline__ int hc_wider(HcState &H, u32 ip, u32 low_limit
 /* developer statistics of the emulator build (tools/emu_hc_stats.py): lane 0 counts */
 extern "C" { unsigned long long zmt_hc_stat[16]; }
 #define HC_STAT(i) do { if (lane == 0) zmt_hc_stat[i]++; } while (0)
+#define HC_STAT_ALL(i, c) do { if (c) __atomic_fetch_add(&zmt_hc_stat[i], 1ull, __ATOMIC_RELAXED); } while (0)
 #else
+#define HC_STAT_ALL(i, c) do { } while (0)
 #define HC_STAT(i) do { } while (0)
 #endif
 #define HCW_SLOTS 4 /* candidates of a position the window keeps for the wider searches (level 3 walks at most 4) */
@@ -459,6 +461,8 @@ static __device__ void hc_win_build(HcState &H, HcWin &W, u32 ip, u32 mflimit, u
 			c3 = q.b;
 		}
 		const u32 delta = H.chain[(active ? match_index : HC_BASE) & (HC_MAXD - 1)];
+		HC_STAT_ALL(8, active);
+		HC_STAT_ALL(9, active && (u32)c0 == pattern);
 		if (active && (u32)c0 == pattern) {
 			/* equal bytes behind the four: 28 looked at */
 			const u32 da = (u32)(o0 >> 32) ^ (u32)(c0 >> 32);
