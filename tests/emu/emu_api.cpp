@@ -31,15 +31,15 @@ C3_DECL(zmt_dec_copy3_w16_kernel)
 void zmt_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *);
 void zmt_scan_kernel(const u32 *, u32, u64 *);
 void zmt_compact_kernel(const u8 *, u64, const u32 *, const u64 *, u32, u8 *);
-void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *, u32, u8 *);
-void zmt_zstd_seq_kernel(const u8 *, u64, const u64 *, const u32 *, u32, const u64 *, const u32 *, const u32 *, u8 *);
+void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *, u32, u8 *, u64);
+void zmt_zstd_seq_kernel(const u8 *, u64, const u64 *, const u32 *, u32, const u64 *, const u32 *, const u32 *, u8 *, u64);
 void zmt_brotli_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 void zmt_brotli_enc_t2_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 void zmt_brotli_enc_t3_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
 void zmt_brotli_assemble_kernel(u64, u32, u32, u32, u8 *, u64, const u32 *, u32 *);
 void zmt_brotli_dec_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *, u8 *, const u8 *, u32);
 void zmt_brotli_dec4_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *, u32 *, u32 *);
-void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *, u8 *);
+void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *, u32 *, u8 *, u32 *, u32 *, u32 *, u8 *, u64);
 void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *, u32 *);
 void zmt_zstd_probe_kernel(const u8 *, const u64 *, const u32 *, u32, u32 *, u32 *);
 void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
@@ -211,11 +211,10 @@ void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *re
 	const bool seq_on = !(e && atoi(e) == 1);
 	std::vector<u8> seqv(seq_on ? (size_t)total + 32 : 0, 0xA5);
 	u8 *seqbuf = seq_on ? seqv.data() + 16 : nullptr;
-	if (seq_on)
-		memcpy(seqbuf - 16, &total, 8); /* the capacity word of zstd_dec_seq.h */
+	const u64 seqcap = total; /* the capacity argument of zstd_dec_seq.h */
 	if (seq_on)
 		emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
-			zmt_zstd_seq_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out_off, out_len, status, seqbuf);
+			zmt_zstd_seq_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out_off, out_len, status, seqbuf, seqcap);
 		});
 	/* (test hook: how many blocks the pre-pass marked, read back from the record headers of zstd_dec_seq.h) */
 	g_zstd_marks = 0;
@@ -231,13 +230,13 @@ void emu_zstd_decompress_batch(const u8 *stream, u64 stream_bytes, const u64 *re
 		}
 	/* small-table variant first, then the general one for the records it handed over (status 101) */
 	emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
-		zmt_zstd_dec_small_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status, cep, cvp, seqbuf);
+		zmt_zstd_dec_small_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status, cep, cvp, seqbuf, seqcap);
 	});
 	if (getenv("ZMT_EMU_DEBUG"))
 		for (u32 r = 0; r < nrec; r++)
 			fprintf(stderr, "zstd rec %u after small kernel: status %u\n", r, status[r]);
 	emu::launch(dim3{nrec, 1, 1}, dim3{64, 1, 1}, [=]() {
-		zmt_zstd_dec_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status, cep, cvp, 101u, seqbuf);
+		zmt_zstd_dec_kernel(stream, stream_bytes, rec_off, rec_len, nrec, out, out_off, out_len, litp, status, cep, cvp, 101u, seqbuf, seqcap);
 	});
 	emu::launch(dim3{(nrec * 4 + 255) / 256, 1, 1}, dim3{256, 1, 1},
 		    [=]() { zmt_xxh64_verify_kernel(out, out_off, out_len, nrec, cep, cvp, status); });

@@ -72,13 +72,13 @@ __global__ void zmt_brotli_dec_kernel_prof(const u8 *, const u64 *, const u32 *,
 __global__ void zmt_brotli_dec4_kernel(const u8 *, const u64 *, const u32 *, u32, u8 *, const u64 *, const u32 *,
 				       u32 *, u32 *);
 __global__ void zmt_zstd_dec_small_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-					  u32 *, u8 *, u32 *, u32 *, u32 *, u8 *);
+					  u32 *, u8 *, u32 *, u32 *, u32 *, u8 *, u64);
 __global__ void zmt_zstd_dec_kernel(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-				    u32 *, u8 *, u32 *, u32 *, u32 *, u32, u8 *);
+				    u32 *, u8 *, u32 *, u32 *, u32 *, u32, u8 *, u64);
 __global__ void zmt_zstd_dec_kernel_prof(const u8 *, u64, const u64 *, const u32 *, u32, u8 *, const u64 *,
-					 u32 *, u8 *, u32 *, u32 *, u32 *, u32, unsigned long long *, u8 *);
+					 u32 *, u8 *, u32 *, u32 *, u32 *, u32, unsigned long long *, u8 *, u64);
 __global__ void zmt_zstd_seq_kernel(const u8 *, u64, const u64 *, const u32 *, u32, const u64 *, const u32 *,
-				    const u32 *, u8 *);
+				    const u32 *, u8 *, u64);
 __global__ void zmt_xxh64_verify_kernel(const u8 *, const u64 *, const u32 *, u32, const u32 *, const u32 *,
 					u32 *);
 __global__ void zmt_zstd_enc_kernel(const u8 *, u64, u32, u32, u32, u8 *, u64, u32 *, u8 *);
@@ -1104,13 +1104,10 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 	if (want_scratch(h, 1, s, lit_bytes + chk_bytes + seq_bytes))
 		return GPUMT_E_HIP;
 	u32 *chk_e = (u32 *)((u8 *)h->scratch[1][s] + lit_bytes), *chk_v = chk_e + nrec;
-	/* the region's capacity sits 16 bytes in front of it (zstd_dec_seq.h): records whose [out_off, out_off + out_len)
-	 * does not fit out_bytes are decoded without the pre-pass instead of writing past the scratch */
+	/* the region's capacity goes to both kernels (zstd_dec_seq.h): records whose [out_off, out_off + out_len) does not fit
+	 * out_bytes are decoded without the pre-pass instead of writing past the scratch */
 	u8 *seqbuf = seq_on ? (u8 *)h->scratch[1][s] + lit_bytes + chk_bytes + 16 : NULL;
-	if (seqbuf) {
-		CK(hipMemsetD32Async((hipDeviceptr_t)(seqbuf - 16), (int)(u32)out_bytes, 1, h->st[s]));
-		CK(hipMemsetD32Async((hipDeviceptr_t)(seqbuf - 12), (int)(u32)((u64)out_bytes >> 32), 1, h->st[s]));
-	}
+	const u64 seqcap = (u64)out_bytes;
 	if (h->profile == 5 && !h->d_prof) {
 		CK(hipMalloc((void **)&h->d_prof, 16 * sizeof(unsigned long long)));
 		CK(hipMemset(h->d_prof, 0, 16 * sizeof(unsigned long long)));
@@ -1121,12 +1118,12 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 		if (seqbuf)
 			hipLaunchKernelGGL(zmt_zstd_seq_kernel, dim3((unsigned)m), dim3(64), 0, h->st[s],
 					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
-					   d_out_off + b, (const u32 *)(d_out_len + b), (const u32 *)(d_status + b), seqbuf);
+					   d_out_off + b, (const u32 *)(d_out_len + b), (const u32 *)(d_status + b), seqbuf, seqcap);
 		if (h->profile == 5) {
 			hipLaunchKernelGGL(zmt_zstd_dec_kernel_prof, dim3((unsigned)m), dim3(64), 0, h->st[s],
 					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
 					   (u8 *)d_out, d_out_off + b, d_out_len + b, (u8 *)h->scratch[1][s], d_status + b,
-					   chk_e + b, chk_v + b, 0u, h->d_prof, seqbuf);
+					   chk_e + b, chk_v + b, 0u, h->d_prof, seqbuf, seqcap);
 		} else {
 			/* small-table variant first (16 waves per CU); records that need the full-size tables
 			 * come back with status 101 and are decoded by the general variant (12 waves per CU) */
@@ -1135,11 +1132,11 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 				hipLaunchKernelGGL(zmt_zstd_dec_small_kernel, dim3((unsigned)m), dim3(64), 0, h->st[s],
 						   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
 						   (u8 *)d_out, d_out_off + b, d_out_len + b, (u8 *)h->scratch[1][s],
-						   d_status + b, chk_e + b, chk_v + b, seqbuf);
+						   d_status + b, chk_e + b, chk_v + b, seqbuf, seqcap);
 			hipLaunchKernelGGL(zmt_zstd_dec_kernel, dim3((unsigned)m), dim3(64), 0, h->st[s],
 					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
 					   (u8 *)d_out, d_out_off + b, d_out_len + b, (u8 *)h->scratch[1][s], d_status + b,
-					   chk_e + b, chk_v + b, want, seqbuf);
+					   chk_e + b, chk_v + b, want, seqbuf, seqcap);
 		}
 	}
 	/* XXH64 content checksums, for the frames that carry one */

@@ -86,7 +86,7 @@ static __device__ __forceinline__ void
 zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
 	      const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base, const u64 *__restrict__ out_off,
 	      u32 *__restrict__ out_len, u8 *__restrict__ litbuf, u32 *__restrict__ status,
-	      u32 *__restrict__ chk_expect, u32 *__restrict__ chk_valid, unsigned long long *prof, u8 *seqbuf)
+	      u32 *__restrict__ chk_expect, u32 *__restrict__ chk_valid, unsigned long long *prof, u8 *seqbuf, u64 seqcap)
 {
 	const int lane = wv_lane();
 	u64 pc[PROF ? 8 : 1] = {0}, tq = ZT();
@@ -184,7 +184,7 @@ zstd_dec_body(LDS &L, u32 want_status, const u8 *__restrict__ stream, u64 stream
 	int my_tab_log = 0;
 	u32 opos = 0, ip = hp;
 	/* sequences decoded ahead by zmt_zstd_seq_kernel (zstd_dec_seq.hip): hdr[i] != 0 says block i's are at seq[hdr[i] - 1] */
-	const bool pre_on = seqbuf != nullptr && zs_eligible(seqbuf, out_off[rec], cap);
+	const bool pre_on = seqbuf != nullptr && zs_eligible(seqcap, out_off[rec], cap);
 	const u32 *pre_hdr = pre_on ? (const u32 *)zs_region(seqbuf, out_off[rec]) : nullptr;
 	const u64 *pre_seq = pre_on ? zs_region(seqbuf, out_off[rec]) + zs_nhdr(cap) / 2 : nullptr;
 	const u32 pre_nhdr = pre_on ? zs_nhdr(cap) : 0;
@@ -1316,11 +1316,11 @@ zmt_zstd_dec_small_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const
 			  const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
 			  const u64 *__restrict__ out_off, u32 *__restrict__ out_len,
 			  u8 *__restrict__ litbuf, u32 *__restrict__ status, u32 *__restrict__ chk_expect,
-			  u32 *__restrict__ chk_valid, u8 *seqbuf)
+			  u32 *__restrict__ chk_valid, u8 *seqbuf, u64 seqcap)
 {
 	__shared__ __attribute__((aligned(16))) ZLdsSmall L;
 	zstd_dec_body<false>(L, (u32)ST_OK, stream, stream_bytes, rec_off, rec_len, nrec, out_base, out_off, out_len,
-			     litbuf, status, chk_expect, chk_valid, nullptr, seqbuf);
+			     litbuf, status, chk_expect, chk_valid, nullptr, seqbuf, seqcap);
 }
 
 extern "C" __global__ void __launch_bounds__(64)
@@ -1328,11 +1328,11 @@ zmt_zstd_dec_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 		    const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
 		    const u64 *__restrict__ out_off, u32 *__restrict__ out_len,
 		    u8 *__restrict__ litbuf, u32 *__restrict__ status, u32 *__restrict__ chk_expect,
-		    u32 *__restrict__ chk_valid, u32 want, u8 *seqbuf)
+		    u32 *__restrict__ chk_valid, u32 want, u8 *seqbuf, u64 seqcap)
 {
 	__shared__ __attribute__((aligned(16))) ZLds L;
 	zstd_dec_body<false>(L, want, stream, stream_bytes, rec_off, rec_len, nrec, out_base, out_off, out_len, litbuf,
-			     status, chk_expect, chk_valid, nullptr, seqbuf);
+			     status, chk_expect, chk_valid, nullptr, seqbuf, seqcap);
 }
 
 #ifndef ZMT_EMU
@@ -1342,11 +1342,11 @@ zmt_zstd_dec_kernel_prof(const u8 *__restrict__ stream, u64 stream_bytes, const 
 			 const u32 *__restrict__ rec_len, u32 nrec, u8 *out_base,
 			 const u64 *__restrict__ out_off, u32 *__restrict__ out_len,
 			 u8 *__restrict__ litbuf, u32 *__restrict__ status, u32 *__restrict__ chk_expect,
-			 u32 *__restrict__ chk_valid, u32 want, unsigned long long *prof, u8 *seqbuf)
+			 u32 *__restrict__ chk_valid, u32 want, unsigned long long *prof, u8 *seqbuf, u64 seqcap)
 {
 	__shared__ __attribute__((aligned(16))) ZLds L;
 	zstd_dec_body<true>(L, want, stream, stream_bytes, rec_off, rec_len, nrec, out_base, out_off, out_len, litbuf,
-			    status, chk_expect, chk_valid, prof, seqbuf);
+			    status, chk_expect, chk_valid, prof, seqbuf, seqcap);
 }
 #endif
 

@@ -7,9 +7,9 @@
  *                     else 1 + index of the block's first sequence in seq[]
  *   u64 seq[]         ll | ml << 18 | offset value << 36, in stream order
  * Records that cannot hold more than one block have no region (neither kernel touches the buffer for them), and
- * neither have records whose region would end behind the buffer: its capacity in bytes is the u64 the launcher
- * writes 16 bytes in front of `seqbuf` (a caller whose out_bytes understates the real extent loses the pre-pass
- * for the records beyond it, nothing else -- ADVICE round 4).
+ * neither have records whose region would end behind the buffer: its capacity in bytes, `seqcap`, is an argument of
+ * both kernels (a caller whose out_bytes understates the real extent loses the pre-pass for the records beyond it,
+ * nothing else).
  */
 #pragma once
 
@@ -17,9 +17,9 @@
 #define ZS_NB 8u /* blocks of a frame decoded side by side, four lanes each */
 #endif
 
-static __device__ __forceinline__ bool zs_eligible(const u8 *seqbuf, u64 out_off, u32 out_len)
+static __device__ __forceinline__ bool zs_eligible(u64 seqcap, u64 out_off, u32 out_len)
 {
-	return out_len > 131072u && out_off + out_len <= *(const u64 *)(seqbuf - 16);
+	return out_len > 131072u && out_off + out_len <= seqcap;
 }
 static __device__ __forceinline__ u32 zs_nhdr(u32 out_len)
 {

@@ -141,7 +141,7 @@ static __device__ __forceinline__ u32 zs_extra_bits(u32 sym, u32 lo, u32 hi, u32
 extern "C" __global__ void __launch_bounds__(64)
 zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *__restrict__ rec_off,
 		    const u32 *__restrict__ rec_len, u32 nrec, const u64 *__restrict__ out_off,
-		    const u32 *__restrict__ out_len, const u32 *__restrict__ status, u8 *__restrict__ seqbuf)
+		    const u32 *__restrict__ out_len, const u32 *__restrict__ status, u8 *__restrict__ seqbuf, u64 seqbuf_bytes)
 {
 	__shared__ __attribute__((aligned(16))) ZSeqLds L;
 	const int lane = wv_lane();
@@ -149,7 +149,7 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 	if (rec >= nrec)
 		return;
 	const u32 cap = wv_readfirst(out_len[rec]);
-	if (!zs_eligible(seqbuf, out_off[rec], cap))
+	if (!zs_eligible(seqbuf_bytes, out_off[rec], cap))
 		return;
 	u64 *const reg = zs_region(seqbuf, out_off[rec]);
 	u32 *const hdr = (u32 *)reg;
