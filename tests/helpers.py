@@ -227,6 +227,8 @@ class MemIO:
         self.writes = []
         self.read_threads = set()    # threading.get_ident() of every fn_read / fn_write call
         self.write_threads = set()
+        self.read_cpus = set()       # os.sched_getaffinity of the calling thread, as frozensets (what mt_bind_near left)
+        self.write_cpus = set()
         self.lock = threading.Lock()
         self.fail_read_at = fail_read_at
         self.fail_write_at = fail_write_at
@@ -240,6 +242,7 @@ class MemIO:
         b = bufp.contents
         with self.lock:
             self.read_threads.add(threading.get_ident())
+            self.read_cpus.add(frozenset(os.sched_getaffinity(0)))
             if self.fail_read_at is not None and len(self.reads) >= self.fail_read_at:
                 return self.read_rv
             want = b.size
@@ -255,6 +258,7 @@ class MemIO:
         b = bufp.contents
         with self.lock:
             self.write_threads.add(threading.get_ident())
+            self.write_cpus.add(frozenset(os.sched_getaffinity(0)))
             if self.fail_write_at is not None and len(self.writes) >= self.fail_write_at:
                 return self.write_rv
             self.out.append(C.string_at(b.buf, b.size))

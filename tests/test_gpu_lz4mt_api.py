@@ -255,3 +255,41 @@ def test_callback_threads(lib):
     rv, out, io, _ = H.lz4mt_decompress_via(lib, stream, threads=4)
     assert not lib.LZ4MT_isError(rv) and out == data
     assert len(io.write_threads) == 1 and me not in io.write_threads
+
+
+def _cpulist(text_):
+    cpus = set()
+    for part in text_.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def test_reader_and_writer_threads_run_next_to_the_device(lib, monkeypatch):
+    """mt_bind_near: the library's reader / writer threads (never the caller's) bind themselves to the CPUs of the host NUMA
+    node the device hangs off -- where its pinned batch buffers live -- within the mask the process has; GPUMT_NUMA=0 leaves
+    them alone.  The callbacks report the affinity mask they run under."""
+    import zstdmt_amd as z
+    eng = z.Engine(0)
+    node = eng.L.gpumt_host_node(eng.h)
+    me = frozenset(os.sched_getaffinity(0))
+    data = text(5 * 131072 + 99)
+    monkeypatch.setenv("GPUMT_NUMA", "0")
+    rv, stream, io, _ = H.lz4mt_compress_via(lib, data, 131072, threads=2)
+    assert not lib.LZ4MT_isError(rv) and io.read_cpus == {me} and io.write_cpus == {me}
+    monkeypatch.delenv("GPUMT_NUMA")
+    rv, stream2, io, _ = H.lz4mt_compress_via(lib, data, 131072, threads=2)
+    assert not lib.LZ4MT_isError(rv) and stream2 == stream
+    rv, out, iod, _ = H.lz4mt_decompress_via(lib, stream, threads=4)
+    assert not lib.LZ4MT_isError(rv) and out == data
+    path = "/sys/devices/system/node/node%d/cpulist" % node
+    want = me
+    if node >= 0 and os.path.exists(path):
+        near = frozenset(_cpulist(open(path).read())) & me
+        want = near if near else me
+    for got in (io.read_cpus, io.write_cpus, iod.write_cpus):
+        assert got == {want}, (node, sorted(want)[:4], [sorted(g)[:4] for g in got])
+    # (the decompressor sniffs the stream's first four bytes on the caller's thread before its pipeline starts)
+    assert iod.read_cpus - {me} == {want} - {me} and want in iod.read_cpus | {me}
+    assert frozenset(os.sched_getaffinity(0)) == me   # the caller's own thread is never touched
