@@ -331,6 +331,10 @@ int main(int argc, char **argv)
 	struct rusage ru;
 	int opt, level_set = 0;
 	prog = prog ? prog + 1 : argv[0];
+	/* A command line run is a fresh process: every pinned buffer it uses is allocated cold (~0.3 s per GiB), which the library's
+	 * chunk-aware batch size -- built for contexts that live on -- does not earn back on one file (4 GiB at the default 4 MiB chunk:
+	 * 2.2 s with 256 MiB batches, 3.7 s with the library's 1 GiB; profiles/r06_sweeps/api_chunk_sizes.txt).  GPUMT_BATCH_MB overrides. */
+	setenv("GPUMT_BATCH_MB", "256", 0);
 	if (!strcmp(prog, UNZIP)) {
 		o_mode = M_DECOMPRESS;
 	} else if (!strcmp(prog, ZCAT)) {

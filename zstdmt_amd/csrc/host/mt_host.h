@@ -38,6 +38,23 @@ static inline size_t zmt_batch_bytes(void)
 	return v;
 }
 #define BATCH_MAXREC 8192
+/*
+ * The kernels run one wave per chunk / record, and a wave moves ~20 MB/s whatever else runs: the device needs about a thousand
+ * chunks in flight to keep up with the reader (measured, profiles/r06_sweeps/api_chunk_sizes.txt: LZ4MT at the reference's
+ * default 4 MiB chunk -- lib/lz4-mt_compress.c:114 -- 3.9 GB/s with 3 x 64 chunks in flight, 9.8 with 3 x 256).  So unless the
+ * batch size is set by hand a batch grows to hold 256 chunks of the size in use, up to 1 GiB.
+ */
+static inline size_t zmt_batch_bytes_for(size_t unit)
+{
+	const char *e = getenv("GPUMT_BATCH_MB"), *k = getenv("GPUMT_BATCH_KB");
+	const size_t base = zmt_batch_bytes();
+	size_t want = unit > ((size_t)1 << 22) ? (size_t)1 << 30 : unit * 256;
+	if ((e && *e) || (k && *k))
+		return base;
+	if (want > ((size_t)1 << 30))
+		want = (size_t)1 << 30;
+	return want > base ? want : base;
+}
 
 static inline uint32_t rd32(const uint8_t *p)
 {

@@ -227,7 +227,7 @@ static size_t cp_fill(void *a, int si, int *has_data, int *eof)
 	ZSTDCB_CCtx *ctx = (ZSTDCB_CCtx *)a;
 	struct cslot *s = &ctx->s[si];
 	const size_t chunk = (size_t)ctx->inputsize, stride = gpumt_zstd_slot_stride(chunk);
-	size_t lim = BATCH_BYTES / chunk, err;
+	size_t lim = zmt_batch_bytes_for(chunk) / chunk, err;
 	if (lim < 1)
 		lim = 1;
 	if (lim > BATCH_MAXREC)
@@ -320,7 +320,8 @@ struct dslot {
 
 struct ZSTDCB_DCtx_s {
 	int threads, inputsize;
-	size_t budget;
+	size_t budget; /* output bytes per device batch, grows from BATCH_MIN to zmt_batch_bytes_for(the largest record seen) */
+	size_t big_out;
 	size_t insize, outsize, curframe, frames;
 	mt_gpus gpus; /* the devices the batch slots are dealt out to (mt_host.h) */
 	struct dslot s[MT_NSLOT];
@@ -483,6 +484,8 @@ static size_t d_read_batch(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *io, struct dslot *s,
 			zstdmt_errcode = GPUMT_ST_UNSUPPORTED;
 			return ZSTDCB_ERROR(compression_library);
 		}
+		if ((size_t)osz > ctx->big_out)
+			ctx->big_out = (size_t)osz;
 		m_rec_off(s, 0)[s->nrec] = s->in_bytes;
 		m_rec_len(s, 0)[s->nrec] = 12 + csize;
 		m_out_off(s, 0)[s->nrec] = s->out_bytes;
@@ -532,7 +535,7 @@ static size_t dp_fill(void *a, int si, int *has_data, int *eof)
 		return ZSTDCB_ERROR(memory_allocation);
 	err = d_read_batch(ctx, ctx->io, s, eof);
 	*has_data = s->nrec > 0;
-	if (ctx->budget < BATCH_BYTES)
+	if (ctx->budget < zmt_batch_bytes_for(ctx->big_out))
 		ctx->budget *= 4;
 	return err;
 }
@@ -908,6 +911,7 @@ size_t ZSTDCB_decompressDCtx(ZSTDCB_DCtx *ctx, ZSTDCB_RdWr_t *rdwr)
 		return ZSTDCB_ERROR(data_error);
 	}
 	ctx->budget = BATCH_MIN;
+	ctx->big_out = 0;
 	ctx->io = rdwr;
 	/* threads == 1: every callback on the calling thread, as the reference (its single-thread path) */
 	err = ctx->threads == 1 ? mt_pipe_run_inline(&ops, ctx) : mt_pipe_run_n(&ops, ctx, mt_nslot_for(ctx->gpus.n));
