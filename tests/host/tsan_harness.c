@@ -20,6 +20,7 @@
 struct gpumt_ctx { int device; };
 
 int gpumt_device_count(void) { return 2; }
+int gpumt_host_node(gpumt_ctx *h) { (void)h; return -1; }
 int gpumt_open(int device, gpumt_ctx **out)
 {
 	gpumt_ctx *h = calloc(1, sizeof *h);
