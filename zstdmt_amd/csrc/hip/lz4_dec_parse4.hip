@@ -183,7 +183,13 @@ zmt_dec_parse4_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64
 			const u32 lit = L4 + x1;
 			const u32 idx = lit + (lx ? 4u : 3u); /* the match-length byte, if there is one, sits at g + idx */
 			const u32 gi = g + idx;
+#ifdef P4_EXTRA_TRIP
+			/* developer A/B: one more dependent LDS round trip on the step's chain (what is a round trip worth?) */
+			const u32 b2x = myring[gi & (P4_RING - 1)];
+			const u32 b2 = myring[(gi + b2x * (gridDim.y - 1u)) & (P4_RING - 1)];
+#else
 			const u32 b2 = myring[gi & (P4_RING - 1)];
+#endif
 			const u32 x2 = mx ? b2 : 0u;
 			const u32 ml = M4 + 4u + x2;
 			const u32 nxt = gi + (mx ? 1u : 0u);
