@@ -194,7 +194,10 @@ static size_t cp_fill(void *a, int si, int *has_data, int *eof)
 	LZ4MT_CCtx *ctx = (LZ4MT_CCtx *)a;
 	struct cslot *s = &ctx->s[si];
 	const size_t chunk = (size_t)ctx->inputsize, stride = gpumt_lz4_slot_stride(chunk);
-	size_t lim = zmt_batch_bytes_for(chunk) / chunk, err;
+	/* (twice the chunk: the LZ4 encoder is one wave per chunk at ~20 MB/s -- 512 chunks per batch, 3 batches in flight, is
+	 * where the device comes near the reader: 12.3 -> 16.8 GB/s at 1 MiB chunks; the other codecs' encoders put several waves
+	 * on a chunk, and the decompress leg lost 2 GB/s to the coarser pipeline with the same rule) */
+	size_t lim = zmt_batch_bytes_for(2 * chunk) / chunk, err;
 	if (lim < 1)
 		lim = 1;
 	if (lim > BATCH_MAXREC)
