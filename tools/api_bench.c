@@ -47,6 +47,7 @@ static double now(void)
  * every 256 MiB, as the engine's slots are; one fn_write per record out of such a buffer), with no engine behind them -- the rate a
  * caller with these callbacks can be served at by ANY library that keeps the contract of one fn_read / one fn_write at a time
  * (/root/reference/lib/lz4-mt_compress.c:256-277).  ZMT_API_BOUND=1 prints it next to the legs */
+static double g_alone_rd, g_alone_wr; /* MB/s of the callbacks alone (ZMT_API_BOUND=1), 0 = not measured */
 static void callbacks_alone(const uint8_t *src, size_t n, size_t chunk, uint8_t *sink, size_t n_out)
 {
 	const size_t batch = (size_t)256 << 20;
@@ -69,6 +70,10 @@ static void callbacks_alone(const uint8_t *src, size_t n, size_t chunk, uint8_t 
 			off = off + 2 * rec > batch ? 0 : off + rec;
 		}
 		const double tw = now() - t0;
+		if (rep) {
+			g_alone_rd = n / 1e6 / tr;
+			g_alone_wr = out.pos / 1e6 / tw;
+		}
 		if (rep)
 			fprintf(stderr, "callbacks alone: fn_read of %zu bytes x %zu calls %.1f MB/s; fn_write of %zu bytes x %zu calls %.1f MB/s\n",
 				chunk, n / chunk, n / 1e6 / tr, rec, n_out / rec, out.pos / 1e6 / tw);
@@ -138,9 +143,15 @@ int main(int argc, char **argv)
 		freeD(d);
 		if (isErr(rv)) { fprintf(stderr, "decompress: %s\n", errStr(rv)); return 4; }
 		if (out2.pos != n || memcmp(src, back, n)) { fprintf(stderr, "round trip mismatch\n"); return 5; }
-		if (rep)
+		if (rep) {
 			printf("{\"api\": \"%s*\", \"level\": %d, \"bytes\": %zu, \"chunk\": %d, \"compressed\": %zu, \"compress_MBps\": %.1f, "
-			       "\"decompress_MBps\": %.1f}\n", pfx, level, n, chunk, out.pos, n / 1e6 / tc, n / 1e6 / td);
+			       "\"decompress_MBps\": %.1f", pfx, level, n, chunk, out.pos, n / 1e6 / tc, n / 1e6 / td);
+			if (g_alone_rd > 0)
+				printf(", \"callbacks_alone_MBps\": {\"fn_read\": %.1f, \"fn_write\": %.1f, \"what\": \"the same callbacks driven with "
+				       "the engine's call pattern and no engine behind them: the bound of any library under the one-fn_read-at-a-time contract\"}",
+				       g_alone_rd, g_alone_wr);
+			printf("}\n");
+		}
 	}
 	return 0;
 }
