@@ -1082,6 +1082,17 @@ int gpumt_zstd_probe_sizes(gpumt_ctx *h, const void *d_stream, const uint64_t *d
 	return GPUMT_OK;
 }
 
+/* developer A/B: dynamic-LDS padding of the sequence pre-pass = a cap on its resident waves (GPUMT_ZSEQ_PAD, bytes) */
+static size_t zseq_pad(void)
+{
+	static long v = -1;
+	if (v < 0) {
+		const char *e = getenv("GPUMT_ZSEQ_PAD");
+		v = e && *e ? atol(e) : 0;
+	}
+	return (size_t)v;
+}
+
 int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t stream_bytes,
 				const uint64_t *d_rec_off, const uint32_t *d_rec_len, size_t nrec,
 				void *d_out, size_t out_bytes, const uint64_t *d_out_off,
@@ -1116,7 +1127,7 @@ int gpumt_zstd_decompress_batch(gpumt_ctx *h, const void *d_stream, size_t strea
 	for (size_t b = 0; b < nrec; b += slice) {
 		const size_t m = nrec - b < slice ? nrec - b : slice;
 		if (seqbuf)
-			hipLaunchKernelGGL(zmt_zstd_seq_kernel, dim3((unsigned)m), dim3(64), 0, h->st[s],
+			hipLaunchKernelGGL(zmt_zstd_seq_kernel, dim3((unsigned)m), dim3(64), zseq_pad(), h->st[s],
 					   (const u8 *)d_stream, (u64)stream_bytes, d_rec_off + b, d_rec_len + b, (u32)m,
 					   d_out_off + b, (const u32 *)(d_out_len + b), (const u32 *)(d_status + b), seqbuf, seqcap);
 		if (h->profile == 5) {
