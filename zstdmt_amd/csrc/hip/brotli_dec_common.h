@@ -9,6 +9,7 @@
 #define ZMT_BROTLI_DEC_COMMON_H
 #include "lz4_common.h"
 #include "lz4_frame.h"
+#define ZMT_GCOPY_ONE_TRIP /* the copies of a batch in one memory round trip (match_copy.h) */
 #include "match_copy.h"
 
 #define BR_NLIT_LDS 8u

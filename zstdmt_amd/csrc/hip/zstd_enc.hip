@@ -341,19 +341,49 @@ static __device__ __forceinline__ void bw_add(BitW &w, u32 v, u32 n) /* n <= 31,
 	}
 }
 
-static __device__ __forceinline__ void ze_copy(u8 *d, const u8 *s, u32 len)
+/* The literals of one sequence (len <= ZE_CAP) copied by its lane, 64 sequences side by side, in two halves: all loads of a batch, then all
+ * its stores.  Every load of the batch is issued
+ * before its first store: the memory counter is in order, so a load behind a store waits for the store, and the three shapes of
+ * the old routine (8-byte loop / two 4-byte pieces / bytes) each ran their own load -> store chain, one after the other, for the
+ * lanes that took them -- ~8 memory round trips per batch, 11 % of the encoder (profiles/r06_sweeps/zstd_enc_gather.txt).  Reads up
+ * to 7 bytes behind a run shorter than 8 (inside the input's slack, include/gpumt.h). */
+struct ZeLits {
+	u64 head, tail, v[ZE_CAP / 8 - 1];
+};
+static __device__ __forceinline__ void ze_lits_load(ZeLits &q, const u8 *s, u32 len)
 {
-	if (len >= 8) {
-		for (u32 i = 0; i + 8 < len; i += 8)
-			st64g(d + i, ld64u(s + i));
-		st64g(d + len - 8, ld64u(s + len - 8));
-	} else if (len >= 4) {
-		const u32 a = ld32u(s), b = ld32u(s + len - 4);
-		st32u(d, a);
-		st32u(d + len - 4, b);
-	} else {
-		for (u32 i = 0; i < len; i++)
-			d[i] = s[i];
+	const bool big = len >= 8u;
+	q.head = (len != 0 && !big) ? ld64u(s) : 0ull;    /* a run of 1..7 bytes */
+	q.tail = big ? ld64u(s + len - 8) : 0ull;         /* the last 8 bytes of a longer one (may overlap) */
+	ZMT_UNROLL
+	for (u32 k = 0; k < ZE_CAP / 8 - 1; k++) {
+		q.v[k] = 0;
+		if (wv_any(len > 8u * k + 8u)) { /* qword k lies inside the run and the tail's 8 bytes do not reach back over all of it */
+			if (len > 8u * k + 8u)
+				q.v[k] = ld64u(s + 8u * k);
+		}
+	}
+}
+static __device__ __forceinline__ void ze_lits_store(const ZeLits &q, u8 *d, u32 len)
+{
+	ZMT_UNROLL
+	for (u32 k = 0; k < ZE_CAP / 8 - 1; k++) {
+		if (wv_any(len > 8u * k + 8u)) {
+			if (len > 8u * k + 8u)
+				st64g(d + 8u * k, q.v[k]);
+		}
+	}
+	if (len >= 8u) {
+		st64g(d + len - 8, q.tail);
+	} else if (len >= 4u) {
+		st32u(d, (u32)q.head);
+		st32u(d + len - 4, (u32)(q.head >> (8u * (len - 4u))));
+	} else if (len != 0) {
+		d[0] = (u8)q.head;
+		if (len > 1u)
+			d[1] = (u8)(q.head >> 8);
+		if (len > 2u)
+			d[2] = (u8)(q.head >> 16);
 	}
 }
 
@@ -725,15 +755,21 @@ static __device__ u32 ze_huf_encode(ZEncLds &L, u32 *stage, const ZHuf hf, const
 			u64 lo64 = 0;
 			u32 hi32 = 0, nb = 0;
 			if (mine_n) {
-				const u8 *p = lit + s_lo + mine_hi - mine_n;
-				for (u32 j = mine_n; j-- > 0;) { /* last symbol first */
-					const u32 e = L.hcode[p[j]];
-					const u32 l = e >> 11, c = e & 2047;
-					if (nb < 64)
-						lo64 |= (u64)c << nb;
-					if (nb + l > 64)
-						hi32 |= nb >= 64 ? c << (nb - 64) : c >> (64 - nb);
-					nb += l;
+				/* the lane's (up to) eight symbols with ONE load -- eight byte loads in a loop were eight dependent memory round
+				 * trips per round; a short first piece reads on into symbols that are not its own (or the buffer's 64-byte slack) */
+				const u64 w8 = ld64u(lit + s_lo + mine_hi - mine_n);
+				ZMT_UNROLL
+				for (u32 jj = 0; jj < 8; jj++) { /* last symbol first */
+					const u32 j = 7u - jj;
+					if (j < mine_n) {
+						const u32 e = L.hcode[(u32)(w8 >> (8u * j)) & 255u];
+						const u32 l = e >> 11, c = e & 2047;
+						if (nb < 64)
+							lo64 |= (u64)c << nb;
+						if (nb + l > 64)
+							hi32 |= nb >= 64 ? c << (nb - 64) : c >> (64 - nb);
+						nb += l;
+					}
 				}
 			}
 			const u32 incl = wv_scan_incl(nb);
@@ -1370,21 +1406,44 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 			u32 lit_total = 0;
 			{
 				u32 ip = 0, lpos = 0;
-				for (u32 b = 0; b < ns; b += 64) {
-					const u32 i = b + (u32)lane;
-					const u32 ll = i < ns ? sq_ll[i] : 0, ml = i < ns ? sq_ml[i] : 0;
-					const u32 incl = wv_scan_incl(ll + ml), lincl = wv_scan_incl(ll);
-					const u32 s0 = ip + incl - ll - ml, d0 = lpos + lincl - ll;
-					if (ll && ll <= ZE_CAP)
-						ze_copy(litbuf + d0, src + s0, ll);
-					u64 lm = wv_ballot(ll > ZE_CAP);
+				/* 128 sequences per pass, two per lane (the loads of both before the stores of either); the lengths of the next
+				 * pass are asked for before this pass's copies */
+				u32 n_ll0 = (u32)lane < ns ? sq_ll[lane] : 0, n_ml0 = (u32)lane < ns ? sq_ml[lane] : 0;
+				u32 n_ll1 = 64u + (u32)lane < ns ? sq_ll[64u + (u32)lane] : 0, n_ml1 = 64u + (u32)lane < ns ? sq_ml[64u + (u32)lane] : 0;
+				for (u32 b = 0; b < ns; b += 128) {
+					const u32 ll0 = n_ll0, ml0 = n_ml0, ll1 = n_ll1, ml1 = n_ml1;
+					{
+						const u32 i2 = b + 128u + (u32)lane, i3 = i2 + 64u;
+						n_ll0 = i2 < ns ? sq_ll[i2] : 0;
+						n_ml0 = i2 < ns ? sq_ml[i2] : 0;
+						n_ll1 = i3 < ns ? sq_ll[i3] : 0;
+						n_ml1 = i3 < ns ? sq_ml[i3] : 0;
+					}
+					const u32 incl0 = wv_scan_incl(ll0 + ml0), lincl0 = wv_scan_incl(ll0);
+					const u32 ip1 = ip + wv_readlane(incl0, 63), lpos1 = lpos + wv_readlane(lincl0, 63);
+					const u32 incl1 = wv_scan_incl(ll1 + ml1), lincl1 = wv_scan_incl(ll1);
+					const u32 s0 = ip + incl0 - ll0 - ml0, d0 = lpos + lincl0 - ll0;
+					const u32 s1 = ip1 + incl1 - ll1 - ml1, d1 = lpos1 + lincl1 - ll1;
+					const u32 c0 = ll0 <= ZE_CAP ? ll0 : 0u, c1 = ll1 <= ZE_CAP ? ll1 : 0u;
+					ZeLits q0, q1;
+					ze_lits_load(q0, src + s0, c0); /* (every lane: the routines vote) */
+					ze_lits_load(q1, src + s1, c1);
+					ze_lits_store(q0, litbuf + d0, c0);
+					ze_lits_store(q1, litbuf + d1, c1);
+					u64 lm = wv_ballot(ll0 > ZE_CAP);
 					while (lm) {
 						const int j = wv_ffs(lm) - 1;
 						lm &= lm - 1;
-						wave_copy(litbuf + wv_readlane(d0, j), src + wv_readlane(s0, j), wv_readlane(ll, j), lane);
+						wave_copy(litbuf + wv_readlane(d0, j), src + wv_readlane(s0, j), wv_readlane(ll0, j), lane);
 					}
-					ip += wv_readlane(incl, 63);
-					lpos += wv_readlane(lincl, 63);
+					lm = wv_ballot(ll1 > ZE_CAP);
+					while (lm) {
+						const int j = wv_ffs(lm) - 1;
+						lm &= lm - 1;
+						wave_copy(litbuf + wv_readlane(d1, j), src + wv_readlane(s1, j), wv_readlane(ll1, j), lane);
+					}
+					ip = ip1 + wv_readlane(incl1, 63);
+					lpos = lpos1 + wv_readlane(lincl1, 63);
 				}
 				wave_copy(litbuf + lpos, src + ip, bsize - ip, lane); /* after the last match */
 				lit_total = lpos + (bsize - ip);
