@@ -33,11 +33,19 @@
 
 #define ZS_PB 2u /* blocks whose tables are read and built at a time */
 #define ZS_WSTRIDE 288u
+/* a block's bitstream window in its stage row, and the bits that may lie behind the cursor before it is refilled (a refill is a memory
+ * round trip in front of the steps, with six waves per CU to hide it: at 160 bytes / 544 bits -- rounds 4-5 -- there were 2.4 x as
+ * many; the row is 288 bytes either way, it holds the 256-byte table descriptions first) */
+#ifndef ZS_WIN
+#define ZS_WIN 256u
+#define ZS_REFILL 1320u
+#endif
+static_assert(ZS_WIN + 20u <= ZS_WSTRIDE + 0u && ZS_WIN % 32u == 0, "the window and its 16-byte reads stay inside the stage row");
 struct ZSeqLds {
 	u16 ll[ZS_NB][512], of[ZS_NB][256], ml[ZS_NB][512]; /* FSE cells (16 bits, see zs_build16), slot s of every kind */
 	u16 pre_ll[64], pre_of[32], pre_ml[64];               /* the predefined tables, built once */
 	u8 below[16];
-	u8 stage[ZS_NB][ZS_WSTRIDE]; /* table descriptions of the group's blocks (256 bytes); afterwards their 160-byte bitstream
+	u8 stage[ZS_NB][ZS_WSTRIDE]; /* table descriptions of the group's blocks (256 bytes); afterwards their 256-byte bitstream
 	                              * windows.  The stride puts block g's window 8 banks behind block g - 1's: the eight blocks
 	                              * read five dwords each at nearly the same offset of their windows (their streams advance at
 	                              * the same pace), and a stride of 256 bytes is all 64 banks */
@@ -493,29 +501,33 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 		if (ngrp) {
 			const u32 e_of = sl == 1 ? 0u : ~0u, e_ml = sl == 0 ? ~0u : 0u;
 			const u32 s_ll = sl == 0 ? 0u : ~0u, s_ml = sl == 1 ? ~0u : 0u;
-			u8 *gwin = &L.stage[0][0] + ZS_WSTRIDE * (g < ZS_NB ? g : 0u); /* 160-byte window per block, 40 per lane */
+			u8 *gwin = &L.stage[0][0] + ZS_WSTRIDE * (g < ZS_NB ? g : 0u); /* ZS_WIN-byte window per block, a quarter per lane */
 			const u32 *myval = L.valx[sl];
 			u32 state = 0, done = 0;
 			bool first = true;
 			while (wv_any(act && done < g_n)) {
-				const int whi = (bp + 7) >> 3, wlo = whi - 160;
+				const int whi = (bp + 7) >> 3, wlo = whi - (int)ZS_WIN;
 				wv_sync();
 				if (act && done < g_n) {
-					const int rel = (int)g_off + wlo + 40 * (int)sl;
-					u64 w[5] = {0, 0, 0, 0, 0};
+					const int rel = (int)g_off + wlo + (int)(ZS_WIN / 4u) * (int)sl;
+					constexpr int NW = (int)(ZS_WIN / 32u); /* 8-byte words of a lane's quarter */
+					u64 w[NW];
+					ZMT_UNROLL
+					for (int j = 0; j < NW; j++)
+						w[j] = 0;
 					if (rel >= 0) {
 						ZMT_UNROLL
-						for (int j = 0; j < 5; j++)
+						for (int j = 0; j < NW; j++)
 							w[j] = ld64u(f + rel + 8 * j);
 					} else {
-						for (int j = 0; j < 5; j++)
+						for (int j = 0; j < NW; j++)
 							for (int k2 = 0; k2 < 8; k2++)
 								if (rel + 8 * j + k2 >= 0)
 									w[j] |= (u64)f[rel + 8 * j + k2] << (8 * k2);
 					}
 					ZMT_UNROLL
-					for (int j = 0; j < 5; j++)
-						*(u64 *)(gwin + 40u * sl + 8u * (u32)j) = w[j];
+					for (int j = 0; j < NW; j++)
+						*(u64 *)(gwin + (ZS_WIN / 4u) * sl + 8u * (u32)j) = w[j];
 				}
 				wv_sync();
 				const u8 *winb = gwin - wlo - 15; /* winb[b + 15] = byte b of my stream */
@@ -599,10 +611,10 @@ zmt_zstd_seq_kernel(const u8 *__restrict__ stream, u64 stream_bytes, const u64 *
 						act = false;
 					const bool more = act && done < g_n;
 					/* a sequence consumes at most 27 + 16 + 16 offset / match / literal extra bits + 9 + 9 + 8 state
-					 * bits = 85; with 544 bits already behind the cursor, the 8th sequence's 16-byte read -- issued with
-					 * 544 + 7 x 85 bits consumed -- still lies inside the 160-byte window (13 bits of margin) */
-					static_assert(544 + 7 * 85 + 8 * 16 <= 8 * 160, "the 16-byte read of the 8th sequence leaves the window");
-					if (!wv_any(more) || wv_any(more && 8 * whi - bp > 544))
+					 * bits = 85; with ZS_REFILL bits already behind the cursor, the 8th sequence's 16-byte read -- issued
+					 * with ZS_REFILL + 7 x 85 bits consumed -- still lies inside the window */
+					static_assert(ZS_REFILL + 7 * 85 + 8 * 16 <= 8 * ZS_WIN, "the 16-byte read of the 8th sequence leaves the window");
+					if (!wv_any(more) || wv_any(more && 8 * whi - bp > (int)ZS_REFILL))
 						break;
 				}
 			}
