@@ -12,41 +12,28 @@
 static __device__ __forceinline__ void st64g(u8 *p, u64 v) { __builtin_memcpy(p, &v, 8); }
 
 /* Two bodies of the single-lane copy.  ZMT_GCOPY_ONE_TRIP (defined by the translation unit before this header: the brotli
- * decoders) takes the one whose three length classes load together -- one memory round trip per batch of copies, nine more live
- * registers; the zstd decoders, compiled against a 128-register budget with spills, measured slower with it (reference-written
- * streams 52.4 ms against 51.2; 54.5 with the classes sharing registers) and keep the class-by-class body.  brotli dec4: 260.1 -> 254.1 ms.
- * (profiles/r06_sweeps/gcopy_one_trip.txt) */
+ * decoders) takes the one whose loads all come first -- one memory round trip per batch of copies; the zstd decoders measured
+ * slower with every variant of it (reference-written streams 51.5-54.5 ms against 50.8) and keep the class-by-class body.
+ * brotli dec4: 260.1 -> 252.3 ms.  (profiles/r06_sweeps/gcopy_one_trip.txt) */
 #ifdef ZMT_GCOPY_ONE_TRIP
 static __device__ __forceinline__ void g_copy(u8 *d, const u8 *s, u32 len)
 {
 	/* Lanes that take different branches run one after the other, and with in-order memory returns a branch that loads and
-	 * stores pays its own load -> store round trip.  So the three length classes (8.., 4..7, 1..3) issue ALL their loads
-	 * first -- three branches that only load, their requests in flight together -- and store afterwards: one round trip for
-	 * the 64 copies of a batch whatever their lengths.  (The classes keep registers of their own: sharing them between the
-	 * classes -- a lane is in one -- measured slower, 257.5 against 254.1 ms.) */
-	const bool big = len >= 8, mid = !big && len >= 4, small = len != 0 && len < 4;
+	 * stores pays its own load -> store round trip.  So ALL loads come first: every copy reads its first 8 bytes with the same
+	 * instruction (a run shorter than 8 reads on behind itself: into output not written yet or the buffers' 64-byte slack),
+	 * runs of 8 and more add three pieces, and the stores follow -- one round trip for the 64 copies of a batch whatever their
+	 * lengths, in the registers the longest class needs anyway. */
+	const bool big = len >= 8;
 	const u32 o1 = len - 8 < 8 ? len - 8 : 8, o2 = (len > 16 ? len : 16) - 16, o3 = len - 8; /* (big only) */
-	const u32 h = len >> 1;                                                                  /* (small only) */
 	u64 a = 0, b = 0, c = 0, e = 0;
-	u32 m0 = 0, m1 = 0;
-	u8 s0 = 0, s1 = 0, s2 = 0;
+	if (len)
+		a = ld64u(s);
 	if (big) {
 		/* 8..32 bytes: four 8-byte pieces at 0, min(8, len-8), max(len,16)-16, len-8 (they overlap for the shorter
 		 * lengths); the middle of longer runs (rare: the caps are 64) piece by piece below */
-		a = ld64u(s);
 		b = ld64u(s + o1);
 		c = ld64u(s + o2);
 		e = ld64u(s + o3);
-	}
-	if (mid) {
-		m0 = ld32u(s);
-		m1 = ld32u(s + len - 4);
-	}
-	if (small) {
-		/* 1..3 bytes: first, middle, last */
-		s0 = s[0];
-		s1 = s[h];
-		s2 = s[len - 1];
 	}
 	if (big) {
 		if (len > 32) {
@@ -57,15 +44,15 @@ static __device__ __forceinline__ void g_copy(u8 *d, const u8 *s, u32 len)
 		st64g(d + o1, b);
 		st64g(d + o2, c);
 		st64g(d + o3, e);
-	}
-	if (mid) {
-		st32u(d, m0);
-		st32u(d + len - 4, m1);
-	}
-	if (small) {
-		d[0] = s0;
-		d[h] = s1;
-		d[len - 1] = s2;
+	} else if (len >= 4) {
+		st32u(d, (u32)a);
+		st32u(d + len - 4, (u32)(a >> (8u * (len - 4u))));
+	} else if (len) {
+		d[0] = (u8)a;
+		if (len > 1)
+			d[1] = (u8)(a >> 8);
+		if (len > 2)
+			d[2] = (u8)(a >> 16);
 	}
 }
 
