@@ -36,7 +36,9 @@
 #define B4_HANDOFF 102u /* internal status: zmt_brotli_dec_kernel decodes the record afterwards (gpumt.hip) */
 #define B4_WIN 256u
 #define B4_WSTRIDE (B4_WIN + 16u)
-#define B4_NB 16u
+#ifndef B4_NB
+#define B4_NB 16u /* copies a group holds back before it executes them (one per lane) */
+#endif
 #ifndef B4_NG
 #define B4_NG 4u /* streams per wave (16-lane groups in use); gpumt.hip sizes the grid with the same number */
 #endif
