@@ -371,6 +371,18 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				E5_FILTER(true);
 #undef E5_FILTER
 			u64 dm = wv_ballot(maybe);
+#ifndef ENC5_BRANCHY
+			const u64 dm2 = dm & (dm - 1ull);
+			if (dm2 != 0 && (dm2 & (dm2 - 1ull)) == 0) {
+				/* exactly two lanes may have a twin (the common case of the two windows in three that have any): they are
+				 * twins of each other or a chance meeting in the folded filter -- no loop, and the mask is a scalar */
+				const int i0 = wv_ffs(dm) - 1, i1 = wv_ffs(dm2) - 1;
+				if (wv_readlane(h, i0) == wv_readlane(h, i1)) {
+					prev = (u32)lane == (u32)i1 ? (u32)i0 : prev;
+					dmask = dm2;
+				}
+			} else
+#endif
 			if (dm != 0) { /* (two of three windows) */
 				while (dm) {
 					const int i = wv_ffs(dm) - 1;
@@ -392,8 +404,21 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			const u32 flimit = matchlimit - (cur + MINMATCH);
 			const u32 da = (u32)(x >> 32) ^ (u32)(g1 >> 32);
 			const u64 db_ = x1 ^ g2, dc = x2 ^ g3;
+#ifdef ENC5_BRANCHY
 			const u32 ea = (u32)__builtin_ctz(da | 0x80000000u) >> 3; /* (the or keeps the count defined when da is 0: not used then) */
 			eqf = da ? ea : db_ ? 4u + ((u32)__builtin_ctzll(db_) >> 3) : dc ? 12u + ((u32)__builtin_ctzll(dc) >> 3) : E5_FWD;
+#else
+			/* the first differing bit of the 4 + 8 + 8 bytes as a chain of minima: the three-way choice compiled to two nested
+			 * exec-mask regions -- a dozen scalar instructions per window on the pipe this kernel saturates */
+			{
+				const u32 za = da ? (u32)__builtin_ctz(da) : 255u; /* (255: "none here", above every sum below) */
+				const u32 zb = db_ ? (u32)__builtin_ctzll(db_) : 255u;
+				const u32 zc = dc ? (u32)__builtin_ctzll(dc) : 64u;
+				const u32 zc2 = 64u + zc, zbc = 32u + (zb < zc2 ? zb : zc2);
+				const u32 z = za < zbc ? za : zbc;
+				eqf = z >> 3; /* 4 + 8 + 8 equal bytes: 160 >> 3 = E5_FWD */
+			}
+#endif
 			const bool fdec = eqf < E5_FWD || flimit <= E5_FWD;
 			if (eqf > flimit)
 				eqf = flimit;
@@ -447,6 +472,17 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			v_pk = wv_shfl(pk, (int)v_m);
 			v_cd = wv_shfl(cand0, (int)v_m);
 		}
+#ifndef ENC5_BRANCHY
+		/* a search start's link for the marking loop, as far as the window knows it: the lane behind its match | 0x40: the run's
+		 * last (the match ends the block, or the next search would start in the window's tail) | 0x80: not in a run */
+		u32 code_w;
+		{
+			const u32 tn = v_m + 4u + (v_pk & 31u);
+			const bool out = v_none | v_twin | (((v_pk >> 13) & 1u) == 0u);
+			const bool fin = (tn + ENC5_TAIL > 64u) | (w0 + tn >= mflimit_p1);
+			code_w = out ? 0x80u : fin ? 0x40u : tn;
+		}
+#endif
 		u64 I = 0; /* lanes whose position the parse inserted */
 		u32 s = 0; /* lane of the search's next probe */
 		u32 wend = E5_NEXT;
@@ -467,6 +503,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				const u32 t_next = v_m + 4u + (v_pk & 31u);
 				/* (a search that began in front of the window must find its match while its probes are consecutive
 				 * positions: the lane behind them is klim, 64 and more for every other search) */
+#ifdef ENC5_BRANCHY
 				const bool hard = v_twin || !((v_pk >> 13) & 1u) || !bdec || ((u32)lane == s && v_m >= klim);
 				/* next start | 0x100: the match ends the block | 0x200: no match in the window, or not easy */
 				const u32 code = t_next | (w0 + t_next >= mflimit_p1 ? 0x100u : 0u) | ((v_none || hard) ? 0x200u : 0u);
@@ -482,16 +519,41 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					if (c + ENC5_TAIL > 64u) /* (the flag of a match that ends the block is above every lane number) */
 						break;
 				}
+#else
+				/* below 64: the run goes on at that lane; 0x40: this search is the run's last (its match ends the block, or the
+				 * next search would start in the window's tail); 0x80: not in the run (no match in the window, or not easy).  One
+				 * test per sequence in the loop; starts come in lane order, so the last one is A's highest bit */
+				/* (what does not depend on the run's first lane is the window's: code_w; the catch-up is undecided iff all 8 bytes
+				 * in front agree and 9 may be taken -- nb <= 9, ebr <= 8 -- one add and one compare instead of mask algebra on the
+				 * scalar pipe) */
+				(void)bdec;
+				const bool hardx = (nb + ebr >= 17u) | (((u32)lane == s) & (v_m >= klim));
+				const u32 code = hardx ? 0x80u : code_w;
+				u64 A = 0;
+				u32 tl = s;
+				{
+					u32 t = s, c = wv_readlane(code, (int)s);
+					while (c < 0x40u) {
+						A |= 1ull << t;
+						t = c;
+						c = wv_readlane(code, (int)t);
+					}
+					if (c == 0x40u)
+						A |= 1ull << t;
+					if (A != 0)
+						tl = 63u - (u32)__builtin_clzll(A);
+				}
+#endif
 				if (A != 0) {
 					const bool inA = (A >> (u32)lane) & 1ull;
 					const u32 lit = mpos - eqb - anchor_t, mc = (v_pk & 31u) + eqb;
-					const u32 el = lit >= 15u ? (lit - 15u) / 255u + 1u : 0u;
+					const u32 el = (lit + 240u) / 255u; /* = lit >= 15 ? (lit - 15) / 255 + 1 : 0, without the exec-mask region */
 					const u32 adv = inA ? lit + 3u + el + (mc >= 15u ? 1u : 0u) : 0u;
 					const u32 incl = wv_scan_incl(adv);
 					const u32 opt = st.op + incl - adv;
 					/* the output limit: one compare per sequence covers both of the reference's tests (e5_finish); a run
 					 * with a sequence near the limit is left to the code below, one search at a time */
-					if (E_RARE(wv_any(inA && opt + adv + 6u > cap))) {
+					if (E_RARE(wv_any((inA ? opt + adv + 6u : 0u) > cap))) {
 						A = 0;
 					} else {
 						const u32 nseq = (u32)wv_popc(A);
