@@ -478,6 +478,9 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		u32 code_w;
 		{
 			const u32 tn = v_m + 4u + (v_pk & 31u);
+			/* (measured and not kept: runs marked as if no twin mattered and cut at the first search a twin's insertion proves wrong
+			 * -- 24 % fewer one-at-a-time sequences, 103.3-103.8 ms against 101.9: the check costs more than the quick serial
+			 * sequences it saves; profiles/r06_sweeps/lz4_enc5_steps.txt) */
 			const bool out = v_none | v_twin | (((v_pk >> 13) & 1u) == 0u);
 			const bool fin = (tn + ENC5_TAIL > 64u) | (w0 + tn >= mflimit_p1);
 			code_w = out ? 0x80u : fin ? 0x40u : tn;
@@ -540,8 +543,15 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					}
 					if (c == 0x40u)
 						A |= 1ull << t;
-					if (A != 0)
-						tl = 63u - (u32)__builtin_clzll(A);
+				}
+				/* the lanes the run's searches probe: from every start to its match */
+				u64 P = 0;
+				if (A != 0) {
+					const u64 upto = A & ((2ull << (u32)lane) - 1ull);
+					const u32 ts = 63u - (u32)__builtin_clzll(upto | 1ull); /* the last start at or in front of this lane */
+					const u32 mts = wv_shfl(v_m, (int)ts);
+					P = wv_ballot(upto != 0 && (u32)lane <= mts);
+					tl = 63u - (u32)__builtin_clzll(A);
 				}
 #endif
 				if (A != 0) {
@@ -582,6 +592,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						}
 						/* the run's insertions: every lane from a search's start to its match, and the position two
 						 * in front of every search start but the run's first (ip - 2 behind a match) */
+#ifdef ENC5_BRANCHY
 						{
 							const u64 upto = A & ((2ull << (u32)lane) - 1ull);
 							const u32 ts = 63u - (u32)__builtin_clzll(upto | 1ull); /* the last start at or in front of this lane */
@@ -589,6 +600,9 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 							I |= wv_ballot(upto != 0 && (u32)lane <= mts);
 							I |= (A & ~(1ull << s)) >> 2;
 						}
+#else
+						I |= P | ((A & ~(1ull << s)) >> 2);
+#endif
 						/* behind the run's last match */
 						const u32 e_last = wv_readlane(t_next, (int)tl);
 						st.ip = w0 + e_last;
