@@ -340,6 +340,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			ENC3_LD16(gp, l0, l1);
 			ENC3_LD16(wide ? gp + 16 : gp, l2, l3);
 		}
+#ifdef ENC5_FILTER2
 		/* ---- positions of the window with the same hash: prev = the nearest earlier one (E5_NONE: none).  Two folded
 		 * filters of 1 024 bits find the lanes that may have a twin (a bit set twice), behind the loads like lz4_enc3.hip's
 		 * filter; the exact pass runs over those lanes only ---- */
@@ -393,6 +394,44 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				dmask = wv_ballot(prev != E5_NONE);
 			}
 		}
+#else
+		/* ---- positions of the window with the same hash: prev = the nearest earlier one (E5_NONE: none).  ONE filter of 2 048 bits
+		 * on the hash's low 11 bits, behind the loads: the returning atomic tells every lane but the first of a bit that the bit
+		 * was taken ("late": one lane per window on average, half of them chance meetings on 11 bits); for a late lane the set of
+		 * lanes with its hash is one ballot, and every lane of the set finds its nearest earlier member by itself -- pairs and
+		 * longer chains alike.  (Before: two folded filters of 1 024 bits -- a second atomic, a read, a barrier -- and a scalar
+		 * pass over both lanes of every pair the fold threw together: four lanes per window on average) ---- */
+		u32 prev = E5_NONE;
+		u64 dmask = 0;
+		{
+			const u32 fw = (h & 2047u) >> 5, fb = 1u << (h & 31u);
+			u64 late;
+			/* (every lane of a window is a position that may be probed except at a block's end: the common case has no
+			 * exec-mask region around the filter's steps) */
+			if (E_RARE(jend < 64u)) {
+				u32 o1_ = 0;
+				if (pvalid)
+					o1_ = lds_or(&bitmap[fw], fb);
+				late = wv_ballot(pvalid && (o1_ & fb)); /* (the emulator's lanes meet here: every atomic is made before a bit is cleared) */
+				if (pvalid)
+					bitmap[fw] = 0;
+			} else {
+				const u32 o1_ = lds_or(&bitmap[fw], fb);
+				late = wv_ballot((o1_ & fb) != 0);
+				bitmap[fw] = 0;
+			}
+			while (late) {
+				const int i = wv_ffs(late) - 1;
+				const u32 hi_ = wv_readlane(h, i);
+				const u64 E = wv_ballot(pvalid && h == hi_);
+				late &= ~E;
+				const u64 below = E & ((1ull << (u32)lane) - 1ull);
+				if (((E >> (u32)lane) & 1ull) && below != 0)
+					prev = 63u - (u32)__builtin_clzll(below);
+			}
+			dmask = wv_ballot(prev != E5_NONE);
+		}
+#endif
 		/* ---- every lane: does its candidate verify, and how far do the 12 bytes behind / the 8 in front agree ---- */
 		const u64 g0 = l0, g1 = wide ? l1 : l0, g2 = l2, g3 = l3;
 		const bool ver0 = probe && (u32)g1 == (u32)x;
