@@ -296,11 +296,9 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			goto last_literals;
 		if (rmode)
 			ip0 = w0 + 1; /* lane 0 is the re-match probe, probe 0 of the search behind it is at w0 + 1 */
-		/* a window yields at most 16 sequences: room for them in the collecting registers */
-		if (st.nsq - st.cbase > 48u) {
-			seq3_flush(st.sq, st.nsq - st.cbase, chunk, dst, lane);
-			st.cbase = st.nsq;
-		}
+		/* a window yields at most 16 sequences: room for them in the collecting registers.  The flush rides on the window's
+		 * memory round trip: its literals are asked for with the candidates, its stores leave once those have landed */
+		const bool fl = st.nsq - st.cbase > 48u;
 		const u32 jend = mflimit_p1 - w0 < 64u ? mflimit_p1 - w0 : 64u; /* lanes whose position may be probed: cur + 1 <= mflimit_p1 */
 		const u32 cur = w0 + (u32)lane;
 		const bool pvalid = (u32)lane < jend;
@@ -340,61 +338,9 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			ENC3_LD16(gp, l0, l1);
 			ENC3_LD16(wide ? gp + 16 : gp, l2, l3);
 		}
-#ifdef ENC5_FILTER2
-		/* ---- positions of the window with the same hash: prev = the nearest earlier one (E5_NONE: none).  Two folded
-		 * filters of 1 024 bits find the lanes that may have a twin (a bit set twice), behind the loads like lz4_enc3.hip's
-		 * filter; the exact pass runs over those lanes only ---- */
-		u32 prev = E5_NONE;
-		u64 dmask = 0;
-		{
-			const u32 fw = (h & 1023u) >> 5, fb = 1u << (h & 31u);
-			bool maybe;
-			/* (every lane of a window is a position that may be probed except at a block's end: the common case has no
-			 * exec-mask region around the filter's four steps) */
-#define E5_FILTER(PV)                                                                                              \
-	do {                                                                                                       \
-		u32 o1_ = 0;                                                                                       \
-		if (PV)                                                                                            \
-			o1_ = lds_or(&bitmap[fw], fb);                                                             \
-		if ((PV) && (o1_ & fb))                                                                            \
-			(void)lds_or(&bitmap[32 + fw], fb);                                                        \
-		wv_sync();                                                                                         \
-		maybe = (PV) && (bitmap[32 + fw] & fb);                                                            \
-		wv_sync();                                                                                         \
-		if (PV) {                                                                                          \
-			bitmap[fw] = 0;                                                                            \
-			bitmap[32 + fw] = 0;                                                                       \
-		}                                                                                                  \
-	} while (0)
-			if (E_RARE(jend < 64u))
-				E5_FILTER(pvalid);
-			else
-				E5_FILTER(true);
-#undef E5_FILTER
-			u64 dm = wv_ballot(maybe);
-#ifndef ENC5_BRANCHY
-			const u64 dm2 = dm & (dm - 1ull);
-			if (dm2 != 0 && (dm2 & (dm2 - 1ull)) == 0) {
-				/* exactly two lanes may have a twin (the common case of the two windows in three that have any): they are
-				 * twins of each other or a chance meeting in the folded filter -- no loop, and the mask is a scalar */
-				const int i0 = wv_ffs(dm) - 1, i1 = wv_ffs(dm2) - 1;
-				if (wv_readlane(h, i0) == wv_readlane(h, i1)) {
-					prev = (u32)lane == (u32)i1 ? (u32)i0 : prev;
-					dmask = dm2;
-				}
-			} else
-#endif
-			if (dm != 0) { /* (two of three windows) */
-				while (dm) {
-					const int i = wv_ffs(dm) - 1;
-					dm &= dm - 1;
-					const u32 hi_ = wv_readlane(h, i);
-					prev = ((u32)lane > (u32)i && h == hi_) ? (u32)i : prev; /* (equal hashes share the filter's bit: both lanes are in dm) */
-				}
-				dmask = wv_ballot(prev != E5_NONE);
-			}
-		}
-#else
+		u64 fq0 = 0, fq1 = 0;
+		if (fl)
+			seq3_flush_ask(st.sq, st.nsq - st.cbase, chunk, lane, fq0, fq1);
 		/* ---- positions of the window with the same hash: prev = the nearest earlier one (E5_NONE: none).  ONE filter of 2 048 bits
 		 * on the hash's low 11 bits, behind the loads: the returning atomic tells every lane but the first of a bit that the bit
 		 * was taken ("late": one lane per window on average, half of them chance meetings on 11 bits); for a late lane the set of
@@ -431,7 +377,14 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			}
 			dmask = wv_ballot(prev != E5_NONE);
 		}
-#endif
+		/* (every load of the window has landed before the flush's first store leaves: see vm_landed) */
+		vm_landed<false>(l0, l1);
+		vm_landed<false>(l2, l3);
+		if (fl) {
+			vm_landed<true>(fq0, fq1);
+			seq3_flush_put(st.sq, st.nsq - st.cbase, chunk, dst, lane, fq0, fq1);
+			st.cbase = st.nsq;
+		}
 		/* ---- every lane: does its candidate verify, and how far do the 12 bytes behind / the 8 in front agree ---- */
 		const u64 g0 = l0, g1 = wide ? l1 : l0, g2 = l2, g3 = l3;
 		const bool ver0 = probe && (u32)g1 == (u32)x;
@@ -443,10 +396,6 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			const u32 flimit = matchlimit - (cur + MINMATCH);
 			const u32 da = (u32)(x >> 32) ^ (u32)(g1 >> 32);
 			const u64 db_ = x1 ^ g2, dc = x2 ^ g3;
-#ifdef ENC5_BRANCHY
-			const u32 ea = (u32)__builtin_ctz(da | 0x80000000u) >> 3; /* (the or keeps the count defined when da is 0: not used then) */
-			eqf = da ? ea : db_ ? 4u + ((u32)__builtin_ctzll(db_) >> 3) : dc ? 12u + ((u32)__builtin_ctzll(dc) >> 3) : E5_FWD;
-#else
 			/* the first differing bit of the 4 + 8 + 8 bytes as a chain of minima: the three-way choice compiled to two nested
 			 * exec-mask regions -- a dozen scalar instructions per window on the pipe this kernel saturates */
 			{
@@ -457,7 +406,6 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				const u32 z = za < zbc ? za : zbc;
 				eqf = z >> 3; /* 4 + 8 + 8 equal bytes: 160 >> 3 = E5_FWD */
 			}
-#endif
 			const bool fdec = eqf < E5_FWD || flimit <= E5_FWD;
 			if (eqf > flimit)
 				eqf = flimit;
@@ -511,7 +459,6 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			v_pk = wv_shfl(pk, (int)v_m);
 			v_cd = wv_shfl(cand0, (int)v_m);
 		}
-#ifndef ENC5_BRANCHY
 		/* a search start's link for the marking loop, as far as the window knows it: the lane behind its match | 0x40: the run's
 		 * last (the match ends the block, or the next search would start in the window's tail) | 0x80: not in a run */
 		u32 code_w;
@@ -524,7 +471,6 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			const bool fin = (tn + ENC5_TAIL > 64u) | (w0 + tn >= mflimit_p1);
 			code_w = out ? 0x80u : fin ? 0x40u : tn;
 		}
-#endif
 		u64 I = 0; /* lanes whose position the parse inserted */
 		u32 s = 0; /* lane of the search's next probe */
 		u32 wend = E5_NEXT;
@@ -545,23 +491,6 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				const u32 t_next = v_m + 4u + (v_pk & 31u);
 				/* (a search that began in front of the window must find its match while its probes are consecutive
 				 * positions: the lane behind them is klim, 64 and more for every other search) */
-#ifdef ENC5_BRANCHY
-				const bool hard = v_twin || !((v_pk >> 13) & 1u) || !bdec || ((u32)lane == s && v_m >= klim);
-				/* next start | 0x100: the match ends the block | 0x200: no match in the window, or not easy */
-				const u32 code = t_next | (w0 + t_next >= mflimit_p1 ? 0x100u : 0u) | ((v_none || hard) ? 0x200u : 0u);
-				u64 A = 0;
-				u32 t = s, tl = s;
-				for (;;) {
-					const u32 c = wv_readlane(code, (int)t);
-					if (c >= 0x200u)
-						break;
-					A |= 1ull << t;
-					tl = t;
-					t = c;
-					if (c + ENC5_TAIL > 64u) /* (the flag of a match that ends the block is above every lane number) */
-						break;
-				}
-#else
 				/* below 64: the run goes on at that lane; 0x40: this search is the run's last (its match ends the block, or the
 				 * next search would start in the window's tail); 0x80: not in the run (no match in the window, or not easy).  One
 				 * test per sequence in the loop; starts come in lane order, so the last one is A's highest bit */
@@ -592,7 +521,6 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					P = wv_ballot(upto != 0 && (u32)lane <= mts);
 					tl = 63u - (u32)__builtin_clzll(A);
 				}
-#endif
 				if (A != 0) {
 					const bool inA = (A >> (u32)lane) & 1ull;
 					const u32 lit = mpos - eqb - anchor_t, mc = (v_pk & 31u) + eqb;
@@ -631,17 +559,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						}
 						/* the run's insertions: every lane from a search's start to its match, and the position two
 						 * in front of every search start but the run's first (ip - 2 behind a match) */
-#ifdef ENC5_BRANCHY
-						{
-							const u64 upto = A & ((2ull << (u32)lane) - 1ull);
-							const u32 ts = 63u - (u32)__builtin_clzll(upto | 1ull); /* the last start at or in front of this lane */
-							const u32 mts = wv_shfl(v_m, (int)ts);
-							I |= wv_ballot(upto != 0 && (u32)lane <= mts);
-							I |= (A & ~(1ull << s)) >> 2;
-						}
-#else
 						I |= P | ((A & ~(1ull << s)) >> 2);
-#endif
 						/* behind the run's last match */
 						const u32 e_last = wv_readlane(t_next, (int)tl);
 						st.ip = w0 + e_last;
@@ -840,3 +758,4 @@ struct Enc5 {
 ENC5_KERNEL(zmt_lz4_enc5_u16_kernel, T_U16, 16384)
 ENC5_KERNEL(zmt_lz4_enc5_p17_kernel, T_P17, 8192)
 ENC5_KERNEL(zmt_lz4_enc5_u32_kernel, T_U32, 16384)
+

@@ -328,6 +328,97 @@ static __device__ void seq3_flush(const Seq3 &q, u32 cnt, const u8 *chunk, u8 *d
 		(HI) = q_.b;                                                                        \
 	} while (0)
 
+/* The same flush in two halves, for a caller that has other loads in flight (lz4_enc5.hip's window: its candidates): the first
+ * 16 literal bytes of every collected sequence are ASKED FOR with those loads (seq3_flush_ask), and once they have all landed
+ * seq3_flush_put writes every sequence out of its two registers -- a run of up to 15 literals as its 8 / 4 / 2 / 1-byte pieces,
+ * exact (the byte behind a run is another lane's token) -- with no load -> store round trip of its own: gfx9 counts loads and
+ * stores in one in-order counter, so seq3_flush's three length classes are three serial round trips on the chunk's chain, and its
+ * stores sit in front of the next window's candidate loads.  Longer runs (rare) take seq3_flush's code. */
+/* "these loaded values are needed HERE": an empty statement that reads them, so that the compiler's wait for the loads stands at
+ * this point of the program and not at their first use further down -- behind stores whose completion the wait would then
+ * include (one in-order counter for loads and stores), or behind a join where it can no longer tell what is outstanding */
+template <bool FENCE> static __device__ __forceinline__ void vm_landed(u64 &a, u64 &b)
+{
+#ifndef ZMT_EMU
+	u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+	if (FENCE) /* (no memory operation of the program moves across: the stores behind it stay behind it) */
+		asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1) : : "memory");
+	else
+		asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+	a = (u64)a0 | (u64)a1 << 32;
+	b = (u64)b0 | (u64)b1 << 32;
+#else
+	(void)a;
+	(void)b;
+#endif
+}
+static __device__ __forceinline__ void seq3_flush_ask(const Seq3 &q, u32 cnt, const u8 *chunk, int lane, u64 &f0, u64 &f1)
+{
+	/* (up to 16 bytes behind an anchor: inside the chunk or the 64 bytes of slack behind the input, include/gpumt.h) */
+	const u8 *s_ = chunk + ((u32)lane < cnt ? q.src : 0u);
+	ENC3_LD16(s_, f0, f1);
+}
+static __device__ __forceinline__ void seq3_flush_put(const Seq3 &q, u32 cnt, const u8 *chunk, u8 *dst, int lane, u64 f0, u64 f1)
+{
+	const bool act = (u32)lane < cnt;
+	const u32 lit = act ? q.lit : 0, mc = q.mc;
+	u8 *o = dst + q.tok;
+	if (act) {
+		o[0] = (u8)((lit >= 15 ? 15u : lit) << 4 | (mc >= 15 ? 15u : mc));
+		o++;
+		if (E_RARE(lit >= 15))
+			o += seq3_len_ext(o, lit - 15);
+	}
+	/* (both registers are looked at before the first store leaves, by every lane: the one wait for the loads stands in front of
+	 * straight-line code, and no later join of the exec-mask regions below makes the compiler wait again -- with the stores) */
+	const u64 r8 = (lit & 8u) ? f1 : f0;
+	const u32 r4 = (lit & 4u) ? (u32)(r8 >> 32) : (u32)r8;
+	const u32 r2 = (lit & 2u) ? r4 >> 16 : r4;
+	const u32 lit15 = lit <= 15u ? lit : 0u; /* (lit = 0 for lanes without a sequence: no piece) */
+	{
+		u8 *d = o;
+		if (lit15 & 8u)
+			__builtin_memcpy(d, &f0, 8);
+		d += lit15 & 8u;
+		if (lit15 & 4u)
+			st32u(d, (u32)r8);
+		d += lit15 & 4u;
+		if (lit15 & 2u)
+			st16u(d, r4 & 0xFFFFu);
+		d += lit15 & 2u;
+		if (lit15 & 1u)
+			d[0] = (u8)r2;
+	}
+	if (E_RARE(wv_any(lit > 15u))) {
+		/* longer runs (rare): 16 .. 64 bytes by the lane in 8-byte pieces, above that by the whole wave, one at a time */
+		if (lit > 15u && lit <= 64u) {
+			const u8 *s_ = chunk + q.src;
+			for (u32 i = 8; i + 8 < lit; i += 8) {
+				const u64 v = ld64u(s_ + i);
+				__builtin_memcpy(o + i, &v, 8);
+			}
+			const u64 b = ld64u(s_ + lit - 8);
+			__builtin_memcpy(o, &f0, 8);
+			__builtin_memcpy(o + lit - 8, &b, 8);
+		}
+		u64 big = wv_ballot(act && lit > 64);
+		while (big != 0) {
+			const int j = wv_ffs(big) - 1;
+			big &= big - 1;
+			const u32 oj = wv_readlane((u32)(o - dst), j), sj = wv_readlane(q.src, j), lj = wv_readlane(lit, j);
+			wave_copy(dst + oj, chunk + sj, lj, lane);
+		}
+	}
+	if (act) {
+		o += lit;
+		st16u(o, q.off);
+		o += 2;
+		if (E_RARE(mc >= 15))
+			(void)seq3_len_ext(o, mc - 15);
+	}
+}
+
+
 /* ---- the record around the blocks: skippable header, LZ4F frame header, block headers (stored when a block does not fit),
  * end mark and content checksum; ENC::block<TM, PROF>() is the block encoder (lz4_enc3.hip, lz4_enc5.hip) ---- */
 template <int TM, bool PROF, class ENC>
