@@ -382,8 +382,8 @@ template <u32 WIN, bool PROF = false> struct C3 {
 					ml = (tokb & 15u) + 4u + (mx ? (w2 >> 16) & 255u : 0u);
 					/* a 255 length byte makes the run 270 / 274: "above 64" covers it; the block's last sequence counts as big */
 					const u32 big = (u32)lane + 1u == rem ? 0xFFFFu : (lit > (v2 ? ml : 0u) ? lit : (v2 ? ml : 0u));
-					sm0 = wv_ballot((v2 ? big : 0xFFFFu) <= 64u);  /* small: fully staged, no run above 64, not the last */
-					hard_m = wv_ballot((v1 ? big : 0u) > 64u);      /* needs the generic path whatever batch it would be in */
+					sm0 = wv_ballot(wv_opaque(v2 ? big : 0xFFFFu) <= 64u);  /* small: fully staged, no run above 64, not the last */
+					hard_m = wv_ballot(wv_opaque(v1 ? big : 0u) > 64u);      /* needs the generic path whatever batch it would be in */
 				}
 				C3PC(2);
 				/* ---------- cut: the run of small sequences, then output positions, then span and lap ---------- */
@@ -395,7 +395,7 @@ template <u32 WIN, bool PROF = false> struct C3 {
 				const u32 op = o0 + incl - len;
 				const u32 lap_end = (o0 | MASK) + 1u;
 				const u32 olim = o0 + C3_XOUT < lap_end ? o0 + C3_XOUT : lap_end;
-				const u64 fit = wv_ballot((in_run ? op + len : 0xFFFFFFFFu) <= olim);
+				const u64 fit = wv_ballot(wv_opaque(in_run ? op + len : 0xFFFFFFFFu) <= olim);
 				const u32 n = ~fit ? (u32)wv_ffs(~fit) - 1u : 64u; /* (the conditions are monotone in the lane) */
 				/* the sequence behind the run is executed generically if it is "hard", or if it is small but crosses the
 				 * lap boundary on its own (it could not open a batch either) */
@@ -436,7 +436,8 @@ template <u32 WIN, bool PROF = false> struct C3 {
 					const u32 src_pos = mpos - off;
 					const u32 eff = ml < off ? ml : off;
 					const u32 o_end = o0 + total;
-					if (wv_any(act & ((off == 0) | (off > mpos - low))) | (total > cap - o0)) {
+					/* (offset 0 or beyond the output so far, one compare: 0 - 1 is above everything; a lane without a sequence has offset 1 and output in front of it) */
+					if (wv_any(off - 1u >= mpos - low) | (total > cap - o0)) {
 						stc = ST_BAD_BLOCK;
 						break;
 					}
@@ -460,7 +461,7 @@ template <u32 WIN, bool PROF = false> struct C3 {
 						/* ---- sources before the ring: 16 bytes of the output in memory, loads first ---- */
 						u64 f0 = 0, f1 = 0;
 						if (anyfar) {
-							if (wv_any(is_far & (src_pos + eff > st.fenced))) {
+							if (wv_any(wv_opaque(is_far ? src_pos + eff : 0u) > st.fenced)) {
 								wave_mem_fence();
 								st.fenced = st.flushed;
 							}
@@ -551,7 +552,7 @@ template <u32 WIN, bool PROF = false> struct C3 {
 						u64 unf = wv_ballot(!fin);
 						if (unf != 0) {
 #endif
-							const bool any_ovl = wv_any(!fin && ovl);
+							const bool any_ovl = (unf & wv_ballot(off < ml)) != 0;
 							do {
 								if (PROF)
 									pc[PROF ? 13 : 0]++;
@@ -564,7 +565,7 @@ template <u32 WIN, bool PROF = false> struct C3 {
 										match_ovl(ring, mpos, off, ml);
 								}
 								fin = fin | go;
-								unf &= ~wv_ballot(go);
+								unf &= ~wv_ballot(src_pos + eff <= W); /* (= the lanes that went: the ballot of one compare) */
 								wv_sync();
 							} while (unf != 0);
 						}

@@ -347,6 +347,9 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		 * lanes with its hash is one ballot, and every lane of the set finds its nearest earlier member by itself -- pairs and
 		 * longer chains alike.  (Before: two folded filters of 1 024 bits -- a second atomic, a read, a barrier -- and a scalar
 		 * pass over both lanes of every pair the fold threw together: four lanes per window on average) ---- */
+		/* (ballots below are taken of ONE compare each and combined as scalar masks: a ballot of `a && b` compiles to mask algebra
+		 * plus a select and a second compare that re-materialise the mask it already has) */
+		const u64 vmask = jend >= 64u ? ~0ull : (1ull << jend) - 1ull; /* lanes whose position may be probed */
 		u32 prev = E5_NONE;
 		u64 dmask = 0;
 		{
@@ -358,7 +361,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 				u32 o1_ = 0;
 				if (pvalid)
 					o1_ = lds_or(&bitmap[fw], fb);
-				late = wv_ballot(pvalid && (o1_ & fb)); /* (the emulator's lanes meet here: every atomic is made before a bit is cleared) */
+				late = wv_ballot((o1_ & fb) != 0); /* (0 for a lane without a position; the emulator's lanes meet here: every atomic is made before a bit is cleared) */
 				if (pvalid)
 					bitmap[fw] = 0;
 			} else {
@@ -369,7 +372,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 			while (late) {
 				const int i = wv_ffs(late) - 1;
 				const u32 hi_ = wv_readlane(h, i);
-				const u64 E = wv_ballot(pvalid && h == hi_);
+				const u64 E = wv_ballot(h == hi_) & vmask;
 				late &= ~E;
 				const u64 below = E & ((1ull << (u32)lane) - 1ull);
 				if (((E >> (u32)lane) & 1ull) && below != 0)
@@ -421,14 +424,16 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		/* twins (two of 64 positions share one of 4 096 table entries in half of all windows): what a lane's probe finds
 		 * when its twin was inserted before it -- the twin's position; does it verify? -- is settled here, once */
 		bool tver = false, deep = false;
+		u64 TV = 0; /* lanes that verify against their twin */
 		if (dmask != 0) {
 			const u32 xp = wv_shfl((u32)x, (int)(prev & 63u));
 			const u32 pp = wv_shfl(prev, (int)(prev & 63u));
 			tver = prev != E5_NONE && pvalid && (u32)x == xp; /* (less than 64 bytes back: inside the distance limit) */
-			deep = wv_any(prev != E5_NONE && pp != E5_NONE);  /* three positions with one hash: the general walk below */
+			TV = wv_ballot((u32)x == xp) & dmask & vmask;
+			deep = wv_any(pp != E5_NONE); /* three positions with one hash: the general walk below (a lane without a twin reads lane 0's, which has none) */
 		}
-		const u64 V0 = wv_ballot(ver0);
-		const u64 vmask = jend >= 64u ? ~0ull : (1ull << jend) - 1ull; /* lanes whose position may be probed */
+		/* the lanes whose candidate verifies: the four bytes agree, the position may be probed, the candidate is within reach */
+		const u64 V0 = wv_ballot((u32)g1 == (u32)x) & vmask & (TM == T_U16 ? ~0ull : wv_ballot(cand0 + DIST_MAX >= cur));
 		/* the lanes the search in progress may probe: while its probes are consecutive positions (probe k at ip0 + k for
 		 * k <= 64); a search that starts inside the window ends behind the window */
 		u64 lmask = vmask;
@@ -442,7 +447,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 		 * per window: mt, the match lane's numbers (one ds_bpermute each), t_next ---- */
 		/* twins whose candidate depends on the parse: those that verify against their twin or against the table's entry;
 		 * with three positions of one hash in the window the twin compared here need not be the one that counts: all of them */
-		const u64 smask = deep ? dmask : wv_ballot(prev != E5_NONE && (tver || ver0));
+		const u64 smask = deep ? dmask : dmask & (TV | V0);
 		u32 v_m, v_pk, v_cd;
 		bool v_none, v_twin;
 		{
@@ -518,7 +523,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					const u64 upto = A & ((2ull << (u32)lane) - 1ull);
 					const u32 ts = 63u - (u32)__builtin_clzll(upto | 1ull); /* the last start at or in front of this lane */
 					const u32 mts = wv_shfl(v_m, (int)ts);
-					P = wv_ballot(upto != 0 && (u32)lane <= mts);
+					P = wv_ballot((u32)lane <= mts) & ~((A & (0ull - A)) - 1ull); /* (from the run's first start on) */
 					tl = 63u - (u32)__builtin_clzll(A);
 				}
 				if (A != 0) {
@@ -528,9 +533,11 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 					const u32 adv = inA ? lit + 3u + el + (mc >= 15u ? 1u : 0u) : 0u;
 					const u32 incl = wv_scan_incl(adv);
 					const u32 opt = st.op + incl - adv;
-					/* the output limit: one compare per sequence covers both of the reference's tests (e5_finish); a run
-					 * with a sequence near the limit is left to the code below, one search at a time */
-					if (E_RARE(wv_any((inA ? opt + adv + 6u : 0u) > cap))) {
+					const u32 run_out = wv_readlane(incl, 63);
+					/* the output limit: one compare per sequence covers both of the reference's tests (e5_finish), and the run's
+					 * last sequence stands for all of them (the positions only grow); a run with a sequence near the limit is
+					 * left to the code below, one search at a time */
+					if (E_RARE(st.op + run_out + 6u > cap)) {
 						A = 0;
 					} else {
 						const u32 nseq = (u32)wv_popc(A);
@@ -551,7 +558,7 @@ static __device__ u32 encode_block5(u32 *tlo, u32 *thi, u32 *bitmap, InRing &R, 
 						st.sq.mc = take ? g_om >> 16 : st.sq.mc;
 						st.sq.src = take ? g_src : st.sq.src;
 						wv_sync();
-						st.op += wv_readlane(incl, 63);
+						st.op += run_out;
 						st.nsq += nseq;
 						if (E_RARE(st.nsq - st.cbase == 64u)) {
 							seq3_flush(st.sq, 64, chunk, dst, lane);

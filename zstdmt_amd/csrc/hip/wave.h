@@ -152,6 +152,19 @@ static __device__ __forceinline__ void grp_sync() { wv_sync(); }
 static __device__ __forceinline__ bool wv_any(bool p) { return wv_ballot(p) != 0; }
 static __device__ __forceinline__ bool wv_all(bool p) { return wv_ballot(!p) == 0; }
 
+/* a value the optimiser must take as it is.  A ballot of `c && v > k` compiles to mask algebra on SGPR pairs plus a select and a
+ * second compare that re-materialise the mask; the condition folded into the compared value -- wv_ballot(wv_opaque(c ? v : 0) > k)
+ * -- is one select and one compare, but the fold only survives instruction combining behind this */
+#ifdef ZMT_EMU
+static inline u32 wv_opaque(u32 v) { return v; }
+#else
+static __device__ __forceinline__ u32 wv_opaque(u32 v)
+{
+	asm volatile("" : "+v"(v));
+	return v;
+}
+#endif
+
 /* inclusive prefix sum over the 64 lanes */
 #ifdef ZMT_EMU
 static inline u32 wv_scan_incl(u32 v)
