@@ -1004,7 +1004,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 		wv_sync();                                                                         \
 		/* equal hashes inside one step: the highest position must stay, whatever order the   \
 		 * LDS served the conflicting lanes in (a step never straddles a 64 Ki boundary) */    \
-		while (wv_any(ok_ && tab[h_] < (u16)p_)) {                                         \
+		while (wv_any(wv_opaque(ok_ ? (u32)tab[h_] : 0xFFFFu) < (u32)(u16)p_)) { /* (one compare: wave.h) */ \
 			if (ok_ && tab[h_] < (u16)p_)                                              \
 				tab[h_] = (u16)p_;                                                 \
 			wv_sync();                                                                 \
@@ -1090,10 +1090,23 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 				const u32 repR = RR[k]; /* the offset this step's repeat-offset compare data was asked for with; 0 = none */
 				const u64 x0 = v0 ^ (m0.a >> 32 | m0.b << 32), x1 = m0.d ^ (m0.b >> 32 | m0.c << 32);
 				const u32 x2 = m0.e ^ (u32)(m0.c >> 32);
+#ifdef ZE_BRANCHY
 				u32 m = x0   ? (u32)__builtin_ctzll(x0) >> 3
 					: x1 ? 8u + ((u32)__builtin_ctzll(x1) >> 3)
 					: x2 ? 16u + ((u32)__builtin_ctz(x2) >> 3)
 					     : ZE_FWD;
+#else
+				/* the first differing bit of the 8 + 8 + 4 bytes as a chain of minima (the three-way choice compiles to nested
+				 * exec-mask regions: scalar instructions on every step of a kernel that lives on its scalar pipe; lz4_enc5.hip) */
+				u32 m;
+				{
+					const u32 z0 = x0 ? (u32)__builtin_ctzll(x0) : 255u; /* (255: "none here", above every sum below) */
+					const u32 z1 = x1 ? (u32)__builtin_ctzll(x1) : 255u;
+					const u32 z2 = x2 ? (u32)__builtin_ctz(x2) : 32u;
+					const u32 z12 = 64u + (z1 < 64u + z2 ? z1 : 64u + z2);
+					m = (z0 < z12 ? z0 : z12) >> 3; /* 8 + 8 + 4 equal bytes: 160 >> 3 = ZE_FWD */
+				}
+#endif
 				const bool cand = c0 != 0xFFFFFFFFu && p >= cursor;
 				if (cand && m > bsize - p)
 					m = bsize - p;
@@ -1120,7 +1133,15 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 					cj_v = ur ? p - repR : cj_v;
 					bk_v = ur ? 0u : bk_v;
 				}
+#ifdef ZE_BRANCHY
 				u64 mask = wv_ballot(hc || ur);
+#else
+				/* (ballots of one compare each, combined as scalar masks: a ballot of `a && b` compiles to mask algebra plus a
+				 * select and a second compare that re-materialise the mask) */
+				u64 mask = wv_ballot(m >= MM) & wv_ballot(c0 != 0xFFFFFFFFu) & wv_ballot(p >= cursor);
+				if (REP)
+					mask |= wv_ballot(ur);
+#endif
 				/* look-ahead (every lane's length is measured anyway), for all positions of the step at once: a match
 				 * that starts d <= LAZYW bytes further on wins when it is longer by more than the d literals it adds
 				 * -- bytes it reaches backwards over this position's side count for it.  Such a position is skipped;
@@ -1128,6 +1149,7 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 				 * j + 1 .. j + LAZYW through wave_shl:1 steps of one packed word (length | backward bytes << 8) */
 				if (LAZYW) {
 					u32 w = hc ? (m | back << 8) : 0u;
+#ifdef ZE_BRANCHY
 					bool lz = false;
 					ZMT_UNROLL
 					for (u32 d = 1; d <= LAZYW; d++) {
@@ -1136,6 +1158,20 @@ zstd_enc_body(ZEncLds &L, const u8 *__restrict__ in, u64 n, u32 chunk, u32 nblk_
 						lz = lz || (w != 0u && (w & 255u) + bq >= m + d + 1u);
 					}
 					mask &= ~wv_ballot(lz && m < ZE_FWD && !ur);
+#else
+					/* the best offer of the LAZYW positions behind as one signed maximum of (length + reach - d) -- a position
+					 * without a match offers -d -- and ONE compare against what this position needs to be beaten */
+					int best = -1;
+					ZMT_UNROLL
+					for (u32 d = 1; d <= LAZYW; d++) {
+						w = wv_shl1(w, 0u);
+						const u32 bq = (w >> 8) < d ? (w >> 8) : d;
+						const int offer = (int)((w & 255u) + bq) - (int)d;
+						best = offer > best ? offer : best;
+					}
+					const u32 need = (m < ZE_FWD && !ur) ? m + 1u : 0x7FFFFFFFu;
+					mask &= ~wv_ballot(best >= (int)wv_opaque(need));
+#endif
 				}
 				ZEP(7);
 				/* (Choosing the step's matches in vector code -- the chain of "first candidate at or behind this match's
