@@ -50,7 +50,7 @@
 #include "lz4_enc_shared.h"
 
 #ifndef ENC5_TAIL
-#define ENC5_TAIL 6u /* a search that would start in the last ENC5_TAIL lanes of its window opens a new window instead */
+#define ENC5_TAIL 3u /* a search that would start in the last ENC5_TAIL lanes of its window opens a new window instead */
 #endif
 #ifndef ENC5_KMAX
 #define ENC5_KMAX 64u /* a search that leaves its window goes on in a new window if its next probe is number <= ENC5_KMAX, else in probe batches */
