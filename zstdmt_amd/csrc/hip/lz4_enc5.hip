@@ -29,8 +29,8 @@
  * ip - 2 behind every match; positions inside a match are neither read nor written.  A lane's table value is therefore
  * right unless a position of the same window with the same hash was INSERTED before it is probed: a probe of the search
  * in progress (all lanes from the search's start up to it) or a position committed by an earlier search of the window.
- * `prev` = the nearest earlier lane with the same hash ("twin": two folded LDS bitmaps find the lanes that may have one, a
- * readlane loop over those settles it exactly; 64 positions on 4 096 entries: two of three windows have a pair).  Whether a
+ * `prev` = the nearest earlier lane with the same hash ("twin": one LDS bitmap whose returning atomic names the lanes that found
+ * their bit taken, one ballot per such lane settles it exactly; 64 positions on 4 096 entries: two of three windows have a pair).  Whether a
  * lane verifies against its twin is settled once per window (one ds_bpermute); which of the two candidates counts depends on
  * the parse, so a twin that might verify ends a lane-parallel run and is resolved by the general path, where the set of
  * inserted lanes is known (chains of three and more by a walk).  Table writes of a window are made at its end, later
@@ -39,10 +39,10 @@
  * consecutive positions (the reference's first 65 probes of a search); one that is still running behind that
  * (incompressible data: skip acceleration) takes lz4_enc3.hip's probe batches with the exact step schedule.
  *
- * [MI355X, 8 GiB of the bench text, 128 KiB chunks] 255.9 ms (lz4_enc3) -> 105 ms, bit-identical; on PRNG bytes and at
- * 64 KiB / 1 MiB / 4 MiB chunks it is 1.2 - 2.9 x lz4_enc3 (profiles/r06_sweeps/lz4_enc5_steps.txt).  What bounds it now:
- * the scalar pipe (0.78 scalar instructions per cycle per CU of a ceiling of ~0.8 at 16 waves) and 4.4 TB/s of candidate
- * lines (485 GB fetched per launch).  GPUMT_LZ4_ENC=3 / gpumt_set_variant("lz4_enc", 3) selects lz4_enc3.hip.
+ * [MI355X, 8 GiB of the bench text, 128 KiB chunks] 255.9 ms (lz4_enc3) -> 105 ms -> 93 ms (the instruction count taken down:
+ * profiles/r06_sweeps/lz4_enc5_steps.txt), bit-identical; on PRNG bytes and at 64 KiB / 1 MiB / 4 MiB chunks it is 1.2 - 2.9 x
+ * lz4_enc3.  What bounds it now: its instruction count, scalar and vector alike (~0.16 ms per instruction per window; 0.71 scalar
+ * instructions per cycle per CU of a ceiling of ~0.8 at 16 waves) and 5.2 TB/s of candidate lines (487 GB per launch).  GPUMT_LZ4_ENC=3 / gpumt_set_variant("lz4_enc", 3) selects lz4_enc3.hip.
  */
 /* (measured and not kept: a 512-byte input ring refilled 256 bytes at a time -- IRING 512, IPIECE 256, IAHEAD 160, the match
  * window without its slack: 9 632 bytes of LDS = 17 chunk-waves per CU instead of 16 -- 107.1 ms against 105.4: the refills
