@@ -88,32 +88,32 @@ static __device__ void hc_insert_lookup(HcState &H, u32 target, u32 *pattern, u3
 		u32 pred = 64;
 		bool last = true;
 		{
+			/* (one 2 048-bit filter on the hash's low 11 bits: the returning atomic names the lanes that found their bit taken --
+			 * about one of a batch, most of them chance meetings --, one ballot per such lane gives the lanes with its hash and
+			 * every member finds its neighbours among the inserting ones by itself; lz4_enc5.hip.  Before: two folded 1 024-bit
+			 * filters and a pass with two ballots over both lanes of every pair the fold threw together) */
 			const bool in = act || probe;
-			const u32 fw = (hv & 1023u) >> 5, fb = 1u << (hv & 31u);
+			const u32 fw = (hv & 2047u) >> 5, fb = in ? 1u << (hv & 31u) : 0u;
 			u32 o_ = 0;
 			if (in)
 				o_ = atomicOr(&H.filter[fw], fb);
-			if (in && (o_ & fb))
-				(void)atomicOr(&H.filter[32 + fw], fb);
-			wv_sync();
-			const bool maybe = in && (H.filter[32 + fw] & fb);
-			wv_sync();
-			if (in) {
+			u64 late = wv_ballot((o_ & fb) != 0); /* (the emulator's lanes meet here: every atomic is made before a word is cleared) */
+			if (in)
 				H.filter[fw] = 0;
-				H.filter[32 + fw] = 0;
-			}
-			u64 dm = wv_ballot(maybe);
-			while (dm) {
-				const int f = wv_ffs(dm) - 1;
-				dm &= dm - 1;
+			const u64 actm = wv_ballot(act);
+			while (late) {
+				const int f = wv_ffs(late) - 1;
 				const u32 hvf = wv_readlane(hv, f);
-				const bool f_act = (wv_ballot(act) >> f) & 1ull; /* (the lookup's lane chains nothing behind it) */
-				const bool same = in && hv == hvf;
-				if (same && (u32)lane > (u32)f && f_act)
-					pred = (u32)f; /* ascending passes: the nearest earlier inserting lane stays */
-				const u64 later = wv_ballot(same && act && (u32)lane > (u32)f);
-				if (lane == f && later != 0)
-					last = false;
+				const u64 E = wv_ballot(hv == hvf); /* (a lane that takes no part has a hash value of its own) */
+				late &= ~E;
+				const u64 EA = E & actm; /* (the lookup's lane chains nothing behind it) */
+				if ((E >> (u32)lane) & 1ull) {
+					const u64 below = EA & ((1ull << (u32)lane) - 1ull);
+					if (below != 0)
+						pred = 63u - (u32)__builtin_clzll(below); /* the nearest earlier inserting lane */
+					if (act && (EA >> (u32)lane) > 1ull)
+						last = false; /* a later inserting lane owns the table */
+				}
 			}
 		}
 		const u32 from = pred < 64u ? base + pred : prev;
@@ -406,25 +406,23 @@ static __device__ void hc_win_build(HcState &H, HcWin &W, u32 ip, u32 mflimit, u
 	 * have one, an exact pass over those settles it) */
 	u32 prev = 64u;
 	{
-		const u32 fw = (hv & 1023u) >> 5, fb = 1u << (hv & 31u);
+		/* (the filter of hc_insert_lookup: one bitmap, the lanes its returning atomic names, one ballot each) */
+		const u32 fw = (hv & 2047u) >> 5, fb = valid ? 1u << (hv & 31u) : 0u;
 		u32 o_ = 0;
 		if (valid)
 			o_ = atomicOr(&H.filter[fw], fb);
-		if (valid && (o_ & fb))
-			(void)atomicOr(&H.filter[32 + fw], fb);
-		wv_sync();
-		const bool maybe = valid && (H.filter[32 + fw] & fb);
-		wv_sync();
-		if (valid) {
+		u64 late = wv_ballot((o_ & fb) != 0);
+		if (valid)
 			H.filter[fw] = 0;
-			H.filter[32 + fw] = 0;
-		}
-		u64 dm = wv_ballot(maybe);
-		while (dm) {
-			const int i = wv_ffs(dm) - 1;
-			dm &= dm - 1;
+		const u64 validm = wv_ballot(valid);
+		while (late) {
+			const int i = wv_ffs(late) - 1;
 			const u32 hi_ = wv_readlane(hv, i);
-			prev = ((u32)lane > (u32)i && hv == hi_) ? (u32)i : prev;
+			const u64 E = wv_ballot(hv == hi_) & validm;
+			late &= ~E;
+			const u64 below = E & ((1ull << (u32)lane) - 1ull);
+			if (((E >> (u32)lane) & 1ull) && below != 0)
+				prev = 63u - (u32)__builtin_clzll(below);
 		}
 	}
 	const bool twin = prev != 64u;
